@@ -1,0 +1,504 @@
+/* oracle/ -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * The "ZA codec": this repo's deterministic DEFLATE encoder specification, restated in scalar C.
+ * It stands where the reference calls zng_deflateReset / zng_deflateSetDictionary /
+ * zng_deflate(Z_SYNC_FLUSH) (zlib_ngmodule.c:1725, :1735, :1742).  zlib-ng's source is absent from
+ * /root/reference (un-vendored submodule) and no reference test pins compressed bytes, so the
+ * encoder choices below are ours; what is pinned is that the output is valid RFC 1951 that inflates
+ * to the input (tests/test_oracle_*.py cross-decode with the system zlib).  The HIP kernels in
+ * python-zlib-ng_amd/csrc/ are an independent implementation of the same five stages and must match
+ * this file byte for byte, stage by stage.
+ *
+ *   stage 1  hash chains        prevdist[p] = distance to the nearest earlier position whose
+ *                               4-byte hash lands in the same 15-bit bucket (u16 head table)
+ *   stage 2  match search       best[p] = longest match among the first `chain` chain entries,
+ *                               nearest wins ties, truncated at the 2 KiB segment end
+ *   stage 3  parse              per 2 KiB segment, greedy (levels 1-3) or one-step lazy (4-9)
+ *   stage 4  entropy plan       histograms -> length-limited canonical Huffman (Moffat-Katajainen
+ *                               in-place lengths + count-based limiting), stored/fixed/dynamic pick
+ *   stage 5  bit packing        header, tokens, EOB, then sync-flush marker or final padding
+ */
+#include "oracle.h"
+#include <string.h>
+#include <stdlib.h>
+#include <pthread.h>
+#include <time.h>
+
+typedef struct { int chain, nice, lazy; } za_level;
+/* (max_chain, nice_length, max_lazy) per level -- the classic zlib configuration table values */
+static const za_level LEVELS[10] = {
+    {0, 0, 0}, {4, 8, 0}, {8, 16, 0}, {32, 32, 0}, {16, 16, 4}, {32, 32, 16},
+    {128, 128, 16}, {256, 128, 32}, {1024, 258, 128}, {4096, 258, 258}
+};
+
+static inline uint32_t ld32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static inline uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - ZA_HASH_BITS); }
+
+/* ---------------- stage 1 ---------------- */
+static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *prevdist)
+{
+    static __thread uint16_t head[1 << ZA_HASH_BITS];
+    memset(head, 0, sizeof head);
+    int pmin = ZA_WIN - dict_len;
+    for (int p = -dict_len; p < n; p++) {
+        int i = p + dict_len;
+        if (p + ZA_MIN_MATCH > n) { prevdist[i] = 0; continue; }
+        uint32_t P = (uint32_t)(ZA_WIN + p);
+        uint32_t h = hash4(ld32(data + p));
+        uint32_t d = (P - head[h]) & 0xFFFFu;
+        prevdist[i] = (uint16_t)((d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin) ? d : 0);
+        head[h] = (uint16_t)(P & 0xFFFFu);
+    }
+}
+
+/* ---------------- stage 2 ---------------- */
+static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const uint16_t *prevdist,
+                              int p, const za_level *L)
+{
+    int seg_end = (p / ZA_SEG + 1) * ZA_SEG;
+    if (seg_end > n) seg_end = n;
+    int maxlen = seg_end - p;
+    if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
+    if (maxlen < ZA_MIN_MATCH) return 0;
+    int nice = L->nice < maxlen ? L->nice : maxlen;
+    int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
+    int q = p, depth = L->chain;
+    while (depth-- > 0) {
+        int d = prevdist[q + dict_len];
+        if (d == 0) break;
+        q -= d;
+        int dist = p - q;
+        if (dist > ZA_WIN) break;
+        if (data[q + best_len] != data[p + best_len]) continue;
+        int len = 0;
+        while (len < maxlen && data[q + len] == data[p + len]) len++;
+        if (len > best_len) {
+            best_len = len; best_dist = dist;
+            if (len >= nice) break;
+        }
+    }
+    if (best_len < ZA_MIN_MATCH) return 0;
+    if (best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR) return 0;
+    return ((uint32_t)best_len << 16) | (uint32_t)best_dist;
+}
+
+/* ---------------- symbol maps ---------------- */
+static const uint16_t len_base[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+static const uint8_t  len_extra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+static const uint16_t dist_base[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
+static const uint8_t  dist_extra[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+
+static int len_code(int len)     /* 0..28 */
+{
+    int c = 28;
+    while (len_base[c] > len) c--;
+    return c;
+}
+static int dist_code(int dist)   /* 0..29 */
+{
+    int c = 29;
+    while (dist_base[c] > dist) c--;
+    return c;
+}
+
+/* ---------------- stage 4 helpers ---------------- */
+static int cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* Length-limited code lengths.  Moffat & Katajainen, "In-place calculation of minimum-redundancy
+ * codes" (1995) on the symbols sorted by (freq, index); depths above `limit` are folded by the
+ * classic count-based adjustment (one code leaves length `limit`, one shorter code splits), then
+ * lengths are dealt out longest-first to the rarest symbols. */
+static void huff_lengths(const uint32_t *freq, int n, int limit, uint8_t *lens)
+{
+    uint32_t key[288];
+    uint32_t A[288];
+    int m = 0;
+    memset(lens, 0, (size_t)n);
+    for (int i = 0; i < n; i++) if (freq[i]) key[m++] = (freq[i] << 9) | (uint32_t)i;
+    if (m == 0) return;
+    if (m == 1) { lens[key[0] & 511] = 1; return; }
+    qsort(key, (size_t)m, sizeof key[0], cmp_u32);
+    for (int i = 0; i < m; i++) A[i] = key[i] >> 9;
+    {
+        int root, leaf, next, avbl, used, dpth;
+        A[0] += A[1]; root = 0; leaf = 2;
+        for (next = 1; next < m - 1; next++) {
+            if (leaf >= m || A[root] < A[leaf]) { A[next] = A[root]; A[root++] = (uint32_t)next; }
+            else A[next] = A[leaf++];
+            if (leaf >= m || (root < next && A[root] < A[leaf])) { A[next] += A[root]; A[root++] = (uint32_t)next; }
+            else A[next] += A[leaf++];
+        }
+        A[m - 2] = 0;
+        for (next = m - 3; next >= 0; next--) A[next] = A[A[next]] + 1;
+        avbl = 1; used = dpth = 0; root = m - 2; next = m - 1;
+        while (avbl > 0) {
+            while (root >= 0 && (int)A[root] == dpth) { used++; root--; }
+            while (avbl > used) { A[next--] = (uint32_t)dpth; avbl--; }
+            avbl = 2 * used; dpth++; used = 0;
+        }
+    }
+    int cnt[17];
+    memset(cnt, 0, sizeof cnt);
+    int over = 0;
+    for (int i = 0; i < m; i++) {
+        int d = (int)A[i];
+        if (d > limit) { d = limit; over = 1; }
+        cnt[d]++;
+    }
+    if (over) {
+        uint32_t total = 0;
+        for (int i = 1; i <= limit; i++) total += (uint32_t)cnt[i] << (limit - i);
+        while (total != (1u << limit)) {
+            cnt[limit]--;
+            for (int i = limit - 1; i > 0; i--)
+                if (cnt[i]) { cnt[i]--; cnt[i + 1] += 2; break; }
+            total--;
+        }
+    }
+    int idx = 0;
+    for (int l = limit; l >= 1; l--)
+        for (int k = 0; k < cnt[l]; k++) lens[key[idx++] & 511] = (uint8_t)l;
+}
+
+/* canonical codes (RFC 1951 3.2.2), returned bit-reversed so they can be emitted LSB first */
+static void canon_codes(const uint8_t *lens, int n, uint16_t *codes)
+{
+    int bl_count[16] = {0};
+    uint32_t next_code[16];
+    for (int i = 0; i < n; i++) bl_count[lens[i]]++;
+    bl_count[0] = 0;
+    uint32_t code = 0;
+    for (int b = 1; b <= 15; b++) { code = (code + (uint32_t)bl_count[b - 1]) << 1; next_code[b] = code; }
+    for (int i = 0; i < n; i++) {
+        int l = lens[i];
+        codes[i] = 0;
+        if (!l) continue;
+        uint32_t c = next_code[l]++, r = 0;
+        for (int b = 0; b < l; b++) if (c & (1u << b)) r |= 1u << (l - 1 - b);
+        codes[i] = (uint16_t)r;
+    }
+}
+
+/* ---------------- bit writer ---------------- */
+typedef struct { uint8_t *out; size_t cap; size_t pos; uint64_t acc; int nb; int overflow; } bitwr;
+static inline void putbits(bitwr *w, uint32_t v, int n)
+{
+    w->acc |= (uint64_t)v << w->nb;
+    w->nb += n;
+    while (w->nb >= 8) {
+        if (w->pos < w->cap) w->out[w->pos] = (uint8_t)w->acc; else w->overflow = 1;
+        w->pos++; w->acc >>= 8; w->nb -= 8;
+    }
+}
+static inline void flushbyte(bitwr *w) { if (w->nb) putbits(w, 0, 8 - w->nb); }
+static inline uint64_t bitpos(const bitwr *w) { return (uint64_t)w->pos * 8 + (uint64_t)w->nb; }
+
+static const uint8_t cl_order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+
+/* run-length encode the concatenated code-length sequence; out tokens: sym | extra<<8 */
+static int rle_lengths(const uint8_t *seq, int n, uint16_t *tok)
+{
+    int nt = 0, i = 0;
+    while (i < n) {
+        int v = seq[i], run = 1;
+        while (i + run < n && seq[i + run] == v) run++;
+        i += run;
+        if (v == 0) {
+            while (run >= 3) {
+                if (run >= 11) { int r = run > 138 ? 138 : run; tok[nt++] = (uint16_t)(18 | ((r - 11) << 8)); run -= r; }
+                else { tok[nt++] = (uint16_t)(17 | ((run - 3) << 8)); run = 0; }
+            }
+            while (run-- > 0) tok[nt++] = 0;
+        } else {
+            tok[nt++] = (uint16_t)v; run--;
+            while (run >= 3) { int r = run > 6 ? 6 : run; tok[nt++] = (uint16_t)(16 | ((r - 3) << 8)); run -= r; }
+            while (run-- > 0) tok[nt++] = (uint16_t)v;
+        }
+    }
+    return nt;
+}
+
+long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int flags,
+                       uint8_t *out, size_t cap, uint32_t *crc, za_o_debug *dbg)
+{
+    if (level == -1) level = 6;
+    if (level < 0 || level > 9 || n < 0 || n > ZA_MAX_UNIT || dict_len < 0 || dict_len > ZA_WIN)
+        return ZA_STREAM_ERROR;
+    const za_level *L = &LEVELS[level];
+    int final = (flags & ZA_FLAG_FINAL) != 0;
+    bitwr w = { out, cap, 0, 0, 0, 0 };
+    if (crc) *crc = za_o_crc32(0, data, (size_t)n);
+    int nseg = (n + ZA_SEG - 1) / ZA_SEG;
+    if (dbg && dbg->btype) *dbg->btype = -1;
+
+    if (n == 0) {
+        if (final) { putbits(&w, 3, 3); putbits(&w, 0, 7); flushbyte(&w); }       /* 03 00 */
+        else { putbits(&w, 0, 3); flushbyte(&w); putbits(&w, 0, 16); putbits(&w, 0xFFFF, 16); }
+        return w.overflow ? ZA_BUF_ERROR : (long)w.pos;
+    }
+
+    int use_stored = (level == 0);
+    uint32_t hist[320];
+    uint8_t lens[320];
+    uint16_t codes[320];
+    uint32_t *tokens = NULL, *best = NULL;
+    uint16_t *prevdist = NULL;
+    uint32_t seg_ntok[ZA_MAX_SEGS];
+    uint32_t seg_bits[ZA_MAX_SEGS + 1];
+    int btype = 0;
+    uint8_t cl_lens[19]; uint16_t cl_codes[19];
+    uint16_t cltok[320]; int ncltok = 0, hlit = 257, hdist = 1, hclen = 4;
+    memset(hist, 0, sizeof hist);
+    memset(lens, 0, sizeof lens);
+    memset(seg_ntok, 0, sizeof seg_ntok);
+    memset(seg_bits, 0, sizeof seg_bits);
+
+    if (!use_stored) {
+        prevdist = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(dict_len + n));
+        best = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+        tokens = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
+        if (!prevdist || !best || !tokens) { free(prevdist); free(best); free(tokens); return ZA_MEM_ERROR; }
+        stage1_chains(data, dict_len, n, prevdist);
+        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, p, L);
+        /* stage 3: parse every segment on its own */
+        for (int s = 0; s < nseg; s++) {
+            int p = s * ZA_SEG, end = p + ZA_SEG;
+            uint32_t *t = tokens + (size_t)s * ZA_SEG;
+            int nt = 0;
+            if (end > n) end = n;
+            while (p < end) {
+                uint32_t b = best[p];
+                int len = (int)(b >> 16);
+                if (len >= ZA_MIN_MATCH) {
+                    if (L->lazy && len < L->lazy && p + 1 < end && (int)(best[p + 1] >> 16) > len) {
+                        t[nt++] = data[p]; hist[data[p]]++; p++;
+                        continue;
+                    }
+                    int dist = (int)(b & 0xFFFF);
+                    t[nt++] = 0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1);
+                    hist[257 + len_code(len)]++;
+                    hist[288 + dist_code(dist)]++;
+                    p += len;
+                } else {
+                    t[nt++] = data[p]; hist[data[p]]++; p++;
+                }
+            }
+            seg_ntok[s] = (uint32_t)nt;
+        }
+        hist[256] = 1;
+        if (dbg) {
+            if (dbg->prevdist) memcpy(dbg->prevdist, prevdist, sizeof(uint16_t) * (size_t)(dict_len + n));
+            if (dbg->best) memcpy(dbg->best, best, sizeof(uint32_t) * (size_t)n);
+            if (dbg->tokens) memcpy(dbg->tokens, tokens, sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
+            if (dbg->seg_ntok) memcpy(dbg->seg_ntok, seg_ntok, sizeof seg_ntok);
+            if (dbg->hist) memcpy(dbg->hist, hist, sizeof hist);
+        }
+        /* stage 4: entropy plan */
+        uint32_t fl[288], fd[32];
+        memcpy(fl, hist, sizeof(uint32_t) * 288);
+        memcpy(fd, hist + 288, sizeof(uint32_t) * 32);
+        {   /* at least two distance codes so every decoder accepts the set */
+            int cntd = 0;
+            for (int i = 0; i < 30; i++) cntd += fd[i] != 0;
+            if (cntd < 2 && fd[0] == 0) { fd[0] = 1; cntd++; }
+            if (cntd < 2) fd[1] = 1;
+        }
+        huff_lengths(fl, 286, 15, lens);
+        huff_lengths(fd, 30, 15, lens + 288);
+        canon_codes(lens, 286, codes);
+        canon_codes(lens + 288, 30, codes + 288);
+        hlit = 286; while (hlit > 257 && lens[hlit - 1] == 0) hlit--;
+        hdist = 30; while (hdist > 1 && lens[288 + hdist - 1] == 0) hdist--;
+        uint8_t seq[320];
+        memcpy(seq, lens, (size_t)hlit);
+        memcpy(seq + hlit, lens + 288, (size_t)hdist);
+        ncltok = rle_lengths(seq, hlit + hdist, cltok);
+        uint32_t clf[19];
+        memset(clf, 0, sizeof clf);
+        for (int i = 0; i < ncltok; i++) clf[cltok[i] & 0xFF]++;
+        huff_lengths(clf, 19, 7, cl_lens);
+        canon_codes(cl_lens, 19, cl_codes);
+        hclen = 19; while (hclen > 4 && cl_lens[cl_order[hclen - 1]] == 0) hclen--;
+        /* exact costs in bits */
+        uint64_t data_dyn = 0, data_fix = 0;
+        for (int i = 0; i < 286; i++) {
+            uint32_t f = hist[i];
+            if (!f) continue;
+            int ex = i >= 257 ? len_extra[i - 257] : 0;
+            int fx = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            data_dyn += (uint64_t)f * (uint64_t)(lens[i] + ex);
+            data_fix += (uint64_t)f * (uint64_t)(fx + ex);
+        }
+        for (int i = 0; i < 30; i++) {
+            uint32_t f = hist[288 + i];
+            data_dyn += (uint64_t)f * (uint64_t)(lens[288 + i] + dist_extra[i]);
+            data_fix += (uint64_t)f * (uint64_t)(5 + dist_extra[i]);
+        }
+        uint64_t hdr_dyn = 3 + 5 + 5 + 4 + 3 * (uint64_t)hclen;
+        for (int i = 0; i < ncltok; i++) {
+            int s = cltok[i] & 0xFF;
+            hdr_dyn += cl_lens[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0);
+        }
+        uint64_t cost_dyn = hdr_dyn + data_dyn, cost_fix = 3 + data_fix;
+        uint64_t nchunks = ((uint64_t)n + 65534) / 65535;
+        uint64_t cost_sto = 8 * ((uint64_t)n + 5 * nchunks);
+        uint64_t bestc = cost_dyn; btype = 2;
+        if (cost_fix <= bestc) { bestc = cost_fix; btype = 1; }
+        if (cost_sto <= bestc) { bestc = cost_sto; btype = 0; }
+        if (btype == 1) {
+            int i = 0;
+            for (; i < 144; i++) lens[i] = 8;
+            for (; i < 256; i++) lens[i] = 9;
+            for (; i < 280; i++) lens[i] = 7;
+            for (; i < 288; i++) lens[i] = 8;
+            for (i = 0; i < 32; i++) lens[288 + i] = 5;
+            canon_codes(lens, 288, codes);
+            canon_codes(lens + 288, 30, codes + 288);
+        }
+        use_stored = (btype == 0);
+    }
+    if (dbg && dbg->btype) *dbg->btype = btype;
+    if (dbg && dbg->lens) memcpy(dbg->lens, lens, sizeof lens);
+
+    if (use_stored) {
+        int off = 0;
+        while (off < n) {
+            int len = n - off > 65535 ? 65535 : n - off;
+            int last = final && (off + len == n);
+            putbits(&w, (uint32_t)last, 3); flushbyte(&w);
+            putbits(&w, (uint32_t)len, 16); putbits(&w, (uint32_t)len ^ 0xFFFFu, 16);
+            for (int i = 0; i < len; i++) putbits(&w, data[off + i], 8);
+            off += len;
+        }
+    } else {
+        putbits(&w, (uint32_t)final | ((uint32_t)btype << 1), 3);
+        if (btype == 2) {
+            putbits(&w, (uint32_t)(hlit - 257), 5);
+            putbits(&w, (uint32_t)(hdist - 1), 5);
+            putbits(&w, (uint32_t)(hclen - 4), 4);
+            for (int i = 0; i < hclen; i++) putbits(&w, cl_lens[cl_order[i]], 3);
+            for (int i = 0; i < ncltok; i++) {
+                int s = cltok[i] & 0xFF, ex = cltok[i] >> 8;
+                putbits(&w, cl_codes[s], cl_lens[s]);
+                if (s == 16) putbits(&w, (uint32_t)ex, 2);
+                else if (s == 17) putbits(&w, (uint32_t)ex, 3);
+                else if (s == 18) putbits(&w, (uint32_t)ex, 7);
+            }
+        }
+        for (int s = 0; s < nseg; s++) {
+            const uint32_t *t = tokens + (size_t)s * ZA_SEG;
+            seg_bits[s] = (uint32_t)bitpos(&w);
+            for (uint32_t k = 0; k < seg_ntok[s]; k++) {
+                uint32_t tk = t[k];
+                if (tk & 0x80000000u) {
+                    int len = (int)((tk >> 16) & 0xFF) + 3, dist = (int)(tk & 0x7FFF) + 1;
+                    int lc = len_code(len), dc = dist_code(dist);
+                    putbits(&w, codes[257 + lc], lens[257 + lc]);
+                    putbits(&w, (uint32_t)(len - len_base[lc]), len_extra[lc]);
+                    putbits(&w, codes[288 + dc], lens[288 + dc]);
+                    putbits(&w, (uint32_t)(dist - dist_base[dc]), dist_extra[dc]);
+                } else putbits(&w, codes[tk], lens[tk]);
+            }
+        }
+        seg_bits[nseg] = (uint32_t)bitpos(&w);
+        putbits(&w, codes[256], lens[256]);
+    }
+    if (final) flushbyte(&w);
+    else { putbits(&w, 0, 3); flushbyte(&w); putbits(&w, 0, 16); putbits(&w, 0xFFFF, 16); }
+    if (dbg && dbg->seg_bits) memcpy(dbg->seg_bits, seg_bits, sizeof seg_bits);
+    free(prevdist); free(best); free(tokens);
+    return w.overflow ? ZA_BUF_ERROR : (long)w.pos;
+}
+
+long za_o_deflate_stream(const uint8_t *data, size_t n, int level, int flags, uint8_t *out, size_t cap)
+{
+    size_t off = 0, op = 0;
+    if (n == 0) return za_o_deflate_unit(data, 0, 0, level, flags, out, cap, NULL, NULL);
+    while (off < n) {
+        size_t len = n - off > ZA_MAX_UNIT ? ZA_MAX_UNIT : n - off;
+        int dict = off > ZA_WIN ? ZA_WIN : (int)off;
+        int f = (off + len == n) ? flags : 0;
+        long r = za_o_deflate_unit(data + off, dict, (int)len, level, f, out + op, cap - op, NULL, NULL);
+        if (r < 0) return r;
+        op += (size_t)r; off += len;
+    }
+    return (long)op;
+}
+
+/* ---------------- cpu_baseline helper (bench.py only) ---------------- */
+typedef struct {
+    const uint8_t *data; size_t n, block; int level, tid, nthreads;
+    uint8_t **comp; size_t *comp_len; int phase; int err;
+} bench_arg;
+
+static double now_s(void)
+{
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *bench_worker(void *vp)
+{
+    bench_arg *a = (bench_arg *)vp;
+    size_t nblocks = (a->n + a->block - 1) / a->block;
+    uint8_t *scratch = (uint8_t *)malloc(a->block + 64);
+    for (size_t b = (size_t)a->tid; b < nblocks; b += (size_t)a->nthreads) {
+        size_t off = b * a->block, len = a->n - off > a->block ? a->block : a->n - off;
+        if (a->phase == 0) {
+            size_t cap = len + len / 10 + 512, op = 0, uo = 0;
+            uint8_t *dst = (uint8_t *)malloc(cap);
+            while (uo < len) {     /* reference block -> units, dictionary = previous 32 KiB of input */
+                size_t ul = len - uo > ZA_MAX_UNIT ? ZA_MAX_UNIT : len - uo;
+                size_t abs = off + uo;
+                int dict = abs > ZA_WIN ? ZA_WIN : (int)abs;
+                uint32_t crc;
+                long r = za_o_deflate_unit(a->data + abs, dict, (int)ul, a->level, 0, dst + op, cap - op, &crc, NULL);
+                if (r < 0) { a->err = (int)r; break; }
+                op += (size_t)r; uo += ul;
+            }
+            a->comp[b] = dst; a->comp_len[b] = op;
+        } else {
+            size_t used, got;
+            int dict = off > ZA_WIN ? ZA_WIN : (int)off;
+            int r = za_o_inflate_raw(a->comp[b], a->comp_len[b], scratch, a->block + 64,
+                                     a->data + off - dict, (size_t)dict, &used, &got);
+            /* stream ends on a sync flush, so the decoder runs out of input: BUF_ERROR is expected */
+            if ((r != ZA_BUF_ERROR && r != ZA_STREAM_END) || got != len || memcmp(scratch, a->data + off, len)) a->err = -99;
+        }
+    }
+    free(scratch);
+    return NULL;
+}
+
+int za_o_bench_blocks(const uint8_t *data, size_t n, size_t block, int level, int threads,
+                      double *t_deflate, double *t_inflate, size_t *comp_bytes)
+{
+    size_t nblocks = (n + block - 1) / block;
+    uint8_t **comp = (uint8_t **)calloc(nblocks, sizeof *comp);
+    size_t *clen = (size_t *)calloc(nblocks, sizeof *clen);
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof *th);
+    bench_arg *args = (bench_arg *)calloc((size_t)threads, sizeof *args);
+    int err = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        double t0 = now_s();
+        for (int t = 0; t < threads; t++) {
+            args[t] = (bench_arg){ data, n, block, level, t, threads, comp, clen, phase, 0 };
+            pthread_create(&th[t], NULL, bench_worker, &args[t]);
+        }
+        for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); if (args[t].err) err = args[t].err; }
+        double dt = now_s() - t0;
+        if (phase == 0) *t_deflate = dt; else *t_inflate = dt;
+    }
+    size_t tot = 0;
+    for (size_t b = 0; b < nblocks; b++) { tot += clen[b]; free(comp[b]); }
+    *comp_bytes = tot;
+    free(comp); free(clen); free(th); free(args);
+    return err;
+}
