@@ -1,0 +1,193 @@
+/*
+ * zng_amd.h -- C ABI of the MI355X-native DEFLATE / inflate engine (libzng_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of pycompression/python-zlib-ng: the entry points
+ * below are what a binding of the reference would call instead of the zlib-ng `zng_*` functions it
+ * uses today.  Plain pointers and sizes only; no Python, no torch types.  Every function that
+ * compresses, decompresses or checksums runs hand-written HIP kernels on the GPU -- there is no CPU
+ * fallback, and a missing / unusable GPU is an error (ZNGAMD_E_HIP).
+ *
+ * Reference interface each group replaces (file:line in the reference tree):
+ *   zngamd_deflate_blocks*      ParallelCompress_compress_and_crc      src/zlib_ng/zlib_ngmodule.c:1696-1782
+ *                               (zng_deflateReset :1725, zng_deflateSetDictionary :1735,
+ *                                zng_crc32_z :1741, zng_deflate(Z_SYNC_FLUSH) :1742), batched over the
+ *                               blocks that gzip_ng_threaded.py:299-322 cuts and round-robins
+ *   zngamd_level_ok             level validation of zng_deflateInit2    zlib_ngmodule.c:1645-1658
+ *   zngamd_deflate_stream       zlib_compress_impl body                 zlib_ngmodule.c:199-273
+ *   zngamd_inflate*             zng_inflate call sites                  zlib_ngmodule.c:328, :2539
+ *   zngamd_gzip_scan / _members GzipReader_read_into_buffer             zlib_ngmodule.c:2426-2637
+ *   zngamd_crc32 / _adler32     zlib_crc32 / zlib_adler32               zlib_ngmodule.c:1455-1562
+ *   zngamd_crc32_combine        zlib_crc32_combine                      zlib_ngmodule.c:1585-1596
+ */
+#ifndef ZNG_AMD_H
+#define ZNG_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zngamd_ctx zngamd_ctx;
+
+/* status codes: zlib numbering for the codec, -2xx for the engine */
+#define ZNGAMD_OK              0
+#define ZNGAMD_STREAM_END      1
+#define ZNGAMD_NEED_DICT       2
+#define ZNGAMD_STREAM_ERROR  (-2)
+#define ZNGAMD_DATA_ERROR    (-3)
+#define ZNGAMD_MEM_ERROR     (-4)
+#define ZNGAMD_BUF_ERROR     (-5)
+#define ZNGAMD_E_GZ_MAGIC    (-101)
+#define ZNGAMD_E_GZ_METHOD   (-102)
+#define ZNGAMD_E_GZ_HCRC     (-103)
+#define ZNGAMD_E_GZ_CRC      (-104)
+#define ZNGAMD_E_GZ_LENGTH   (-105)
+#define ZNGAMD_E_GZ_TRUNC    (-106)
+#define ZNGAMD_E_HIP         (-201)   /* HIP runtime error or no usable GPU */
+#define ZNGAMD_E_ARG         (-202)
+#define ZNGAMD_E_OVERFLOW    (-203)   /* a block's compressed output reached its buffer size */
+
+#define ZNGAMD_FLAG_FINAL      1u     /* block ends the deflate stream (BFINAL=1, no sync flush) */
+
+#define ZNGAMD_UNIT_MAX        131072u  /* largest span one kernel unit covers */
+#define ZNGAMD_SLOT_STRIDE     131136u  /* bytes reserved per unit in a device slot buffer */
+#define ZNGAMD_SEG             2048u    /* parse / index segment */
+
+/* ---- context ---- */
+int         zngamd_device_count(void);
+int         zngamd_ctx_create(int device, zngamd_ctx **out);
+void        zngamd_ctx_destroy(zngamd_ctx *ctx);
+const char *zngamd_last_error(zngamd_ctx *ctx);
+const char *zngamd_version(void);
+/* run all work of this context on a caller-owned hipStream_t (pass NULL to go back to the own stream) */
+int         zngamd_set_stream(zngamd_ctx *ctx, void *hip_stream);
+int         zngamd_sync(zngamd_ctx *ctx);
+
+/* device memory helpers for callers that have no allocator of their own */
+int zngamd_dmalloc(zngamd_ctx *ctx, size_t bytes, void **dptr);
+int zngamd_dfree(zngamd_ctx *ctx, void *dptr);
+int zngamd_h2d(zngamd_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int zngamd_d2h(zngamd_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- checksums (GPU) ---- */
+int      zngamd_crc32(zngamd_ctx *ctx, uint32_t crc, const uint8_t *buf, size_t len, uint32_t *out);
+int      zngamd_adler32(zngamd_ctx *ctx, uint32_t adler, const uint8_t *buf, size_t len, uint32_t *out);
+int      zngamd_crc32_dev(zngamd_ctx *ctx, uint32_t crc, const void *dbuf, size_t len, uint32_t *out);
+/* scalar GF(2) arithmetic on three integers (no data pass) */
+uint32_t zngamd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
+/* ---- deflate ---- */
+int zngamd_level_ok(int level);   /* 1 for -1..9, else 0 ("Bad compression level") */
+
+typedef struct {
+    uint64_t off;        /* offset of the block's first byte in `in` */
+    uint32_t len;        /* block length (any size; cut into <=128 KiB units inside) */
+    uint32_t dict_len;   /* bytes of `in` directly before `off` that prime the window (<= 32768) */
+    uint32_t flags;      /* ZNGAMD_FLAG_FINAL */
+    uint32_t reserved;
+} zngamd_block;
+
+/* Compress n_blocks independent blocks of a host buffer.  Block b's raw-deflate bytes go to
+ * out + b*out_cap_per_block, its size to out_len[b], the CRC-32 of its input to crc[b].  Each block
+ * ends on a byte boundary with a sync-flush marker (00 00 FF FF) unless FINAL.  A block whose output
+ * reaches out_cap_per_block gets out_len[b] = 0xFFFFFFFF and the call returns ZNGAMD_E_OVERFLOW. */
+int zngamd_deflate_blocks(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                          const zngamd_block *blocks, uint32_t n_blocks, int level,
+                          uint8_t *out, uint64_t out_cap_per_block,
+                          uint32_t *out_len, uint32_t *crc);
+
+/* Device-resident form.  d_in holds the input; blocks are cut into units as above.
+ * d_slots must hold n_units * ZNGAMD_SLOT_STRIDE bytes, where n_units = zngamd_count_units(...).
+ * Per-unit results stay on the device: d_unit_len[u], d_unit_crc[u]; unit -> block map in h_unit_block
+ * (host, optional).  zngamd_gather_dev then packs the used bytes of the slots contiguously. */
+uint32_t zngamd_count_units(const zngamd_block *blocks, uint32_t n_blocks);
+int zngamd_deflate_blocks_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
+                              const zngamd_block *blocks, uint32_t n_blocks, int level,
+                              void *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc,
+                              uint32_t *h_unit_block);
+/* Packs unit slots back to back at d_dst + dst_base; returns the total in *total_bytes (host).
+ * d_unit_off (device, n_units x u64, may be NULL) receives each unit's byte offset. */
+int zngamd_gather_dev(zngamd_ctx *ctx, const void *d_slots, const uint32_t *d_unit_len, uint32_t n_units,
+                      void *d_dst, uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off,
+                      uint64_t *total_bytes);
+
+/* One whole raw-deflate stream from a host buffer: units chained through the previous 32 KiB of
+ * input, last block FINAL.  Returns the size in *out_len, CRC-32 and Adler-32 of the input. */
+int zngamd_deflate_stream(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, int level,
+                          uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                          uint32_t *crc, uint32_t *adler);
+
+/* ---- inflate ---- */
+/* Raw RFC 1951 stream from a host buffer, optional preset dictionary.  Returns ZNGAMD_STREAM_END when
+ * a final block ended, ZNGAMD_BUF_ERROR when input ran out or out_cap was reached (distinguish with
+ * *out_len == out_cap), ZNGAMD_DATA_ERROR on invalid data.  *in_used = bytes consumed. */
+int zngamd_inflate_raw(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                       const uint8_t *dict, uint32_t dict_len,
+                       uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used,
+                       uint32_t *crc, uint32_t *adler);
+
+/* gzip member table entry produced by the index scan (pass 1) */
+typedef struct {
+    uint64_t in_off;       /* offset of the member's first deflate byte */
+    uint64_t in_len;       /* deflate bytes (0 = unknown: decode sequentially)                     */
+    uint64_t out_off;      /* offset of the member's first output byte                             */
+    uint32_t out_len;      /* ISIZE                                                                 */
+    uint32_t crc;          /* CRC-32 from the trailer                                               */
+    uint32_t index_off;    /* offset (from in_off's buffer start) of the segment bit-index, 0 none  */
+    uint32_t nseg;
+} zngamd_member;
+
+/* Pass 1 on the device: find every member of a multi-member stream written by this engine
+ * (FEXTRA subfield 'Z','A' carrying member size, ISIZE and the segment bit index).  d_members must
+ * hold max_members entries; *n_members / *total_out on the host.  Returns ZNGAMD_E_ARG when the
+ * stream is not fully made of indexed members (caller then uses the sequential reader). */
+int zngamd_gzip_scan_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
+                         zngamd_member *d_members, uint32_t max_members,
+                         uint32_t *n_members, uint64_t *total_out);
+/* Pass 2: decode all members (one wavefront per member, one lane per 2 KiB segment), verify CRC-32
+ * and ISIZE.  d_status[m] receives a ZNGAMD_* code per member. */
+int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
+                                    const zngamd_member *d_members, uint32_t n_members,
+                                    void *d_out, uint64_t out_cap, int32_t *d_status);
+
+/* Host-buffer gzip reader: any multi-member gzip stream (headers with FEXTRA/FNAME/FCOMMENT/FHCRC,
+ * NUL padding between members).  Uses the two-pass path for indexed members and the sequential
+ * decoder otherwise.  *out_len = bytes produced (also on error). */
+int zngamd_gunzip(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                  uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members);
+
+/* Build one indexed gzip member stream (one member per block, FINAL blocks, 'ZA' index) from a host
+ * buffer.  level as above; block_size <= 128 KiB. */
+int zngamd_gzip_members(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, uint32_t block_size,
+                        int level, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+/* Device-resident form of the same (input and output stay in HBM). */
+int zngamd_gzip_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, uint32_t block_size,
+                            int level, void *d_out, uint64_t out_cap, uint64_t *out_len,
+                            uint32_t *n_members);
+
+/* ---- measurement ---- */
+/* With profiling on, every kernel launch is bracketed by HIP events on the context's stream. */
+#define ZNGAMD_K_CHAINS 0
+#define ZNGAMD_K_SEARCH 1
+#define ZNGAMD_K_PARSE  2
+#define ZNGAMD_K_PLAN   3
+#define ZNGAMD_K_PACK   4
+#define ZNGAMD_K_GATHER 5
+#define ZNGAMD_K_SCAN   6
+#define ZNGAMD_K_INFLATE 7
+#define ZNGAMD_K_OTHER  8
+#define ZNGAMD_K_COUNT  9
+int zngamd_profiling(zngamd_ctx *ctx, int on);
+/* accumulated milliseconds and launch counts per kernel class since the last reset */
+int zngamd_kernel_times(zngamd_ctx *ctx, double *ms /*[ZNGAMD_K_COUNT]*/, uint64_t *launches /*[ZNGAMD_K_COUNT]*/, int reset);
+
+/* ---- debugging aid for the parity tests: copy a stage's intermediate of unit `u` of the last
+ * deflate call to the host.  what: 0 prevdist(u16) 1 best(u32) 2 tokens(u32) 3 seg_ntok(u32)
+ * 4 hist(u32) 5 codes(u32) 6 seg_bits(u32) 7 plan(4 x u32) */
+int zngamd_debug_fetch(zngamd_ctx *ctx, int what, uint32_t unit, void *host_dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

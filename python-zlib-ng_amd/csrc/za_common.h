@@ -1,0 +1,121 @@
+// Shared definitions for the MI355X (gfx950) DEFLATE / inflate engine.
+//
+// Product code.  Nothing here includes, links or calls anything under oracle/.
+// The codec ("ZA codec") is specified in DESIGN.md section 3; the kernels implement it with
+// 64-lane wavefronts, LDS-resident hash-chain windows and lane-per-segment parsing/packing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZA_SEG        2048
+#define ZA_SEG_SHIFT  11
+#define ZA_MAX_UNIT   131072
+#define ZA_MAX_SEGS   64
+#define ZA_WIN        32768
+#define ZA_HASH_BITS  15
+#define ZA_MIN_MATCH  4
+#define ZA_MAX_MATCH  258
+#define ZA_TOO_FAR    4096
+
+#define ZA_FLAG_FINAL 1u
+
+// per-unit workspace strides (elements)
+#define ZA_PREV_STRIDE   (ZA_WIN + ZA_MAX_UNIT)   // u16 chain links, index = p + dict_len
+#define ZA_BEST_STRIDE   ZA_MAX_UNIT              // u32 len<<16|dist
+#define ZA_TOK_STRIDE    ZA_MAX_UNIT              // u32 tokens at segment slots
+#define ZA_HIST_STRIDE   320                      // u32: 0..285 lit/len, 288..317 dist
+#define ZA_CODE_STRIDE   320                      // u32: code | len<<16, same layout
+#define ZA_SEGB_STRIDE   (ZA_MAX_SEGS + 1)        // u32 bit offsets
+
+// unit status bits
+#define ZA_ST_OVERFLOW   1u     // compressed output did not fit the slot
+
+struct ZaUnit {
+    uint64_t in_off;     // byte offset of the unit's first byte in the input buffer
+    uint32_t in_len;     // <= ZA_MAX_UNIT
+    uint32_t dict_len;   // <= ZA_WIN bytes readable before in_off
+    uint32_t flags;      // ZA_FLAG_FINAL
+    uint32_t block;      // index of the reference-level block this unit belongs to
+};
+
+// per-unit entropy plan written by the plan kernel, read by the pack kernel
+struct ZaPlan {
+    uint32_t btype;        // 0 stored, 1 fixed, 2 dynamic
+    uint32_t header_bits;  // bits already written to the slot by the plan kernel
+    uint32_t pad0, pad1;
+};
+
+struct ZaLevel { int chain, nice, lazy; };
+
+typedef uint32_t __attribute__((aligned(1))) za_u32u;
+typedef uint64_t __attribute__((aligned(1))) za_u64u;
+
+__device__ __forceinline__ uint32_t za_ld32(const uint8_t *p) { return *(const za_u32u *)p; }
+__device__ __forceinline__ uint64_t za_ld64(const uint8_t *p) { return *(const za_u64u *)p; }
+__device__ __forceinline__ uint32_t za_hash4(uint32_t v) { return (v * 2654435761u) >> (32 - ZA_HASH_BITS); }
+
+__device__ __forceinline__ int za_lane() { return (int)(threadIdx.x & 63); }
+
+// wave-wide inclusive scan (64 lanes) with shuffles
+__device__ __forceinline__ uint32_t za_wave_incl_scan(uint32_t v)
+{
+    int lane = za_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t za_wave_xor_reduce(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// length symbol (0..28) / extra-bit count / extra value from match length 3..258
+__device__ __forceinline__ void za_len_sym(int len, int &code, int &nextra, int &extra)
+{
+    int l = len - 3;
+    if (l < 8) { code = l; nextra = 0; extra = 0; }
+    else if (len == 258) { code = 28; nextra = 0; extra = 0; }
+    else {
+        int nb = 31 - __builtin_clz((unsigned)l);          // floor(log2 l), l >= 8 -> nb >= 3
+        code = 4 * (nb - 1) + ((l >> (nb - 2)) & 3);
+        nextra = nb - 2;
+        extra = l & ((1 << (nb - 2)) - 1);
+    }
+}
+// distance symbol (0..29) from distance 1..32768
+__device__ __forceinline__ void za_dist_sym(int dist, int &code, int &nextra, int &extra)
+{
+    int x = dist - 1;
+    if (x < 2) { code = x; nextra = 0; extra = 0; }
+    else {
+        int nb = 31 - __builtin_clz((unsigned)x);
+        code = 2 * nb + ((x >> (nb - 1)) & 1);
+        nextra = nb - 1;
+        extra = x & ((1 << (nb - 1)) - 1);
+    }
+}
+__device__ __forceinline__ int za_len_extra_bits(int code)   // code 0..28
+{
+    return (code < 8 || code == 28) ? 0 : ((code - 4) >> 2);
+}
+__device__ __forceinline__ int za_dist_extra_bits(int code)  // code 0..29
+{
+    return code < 4 ? 0 : ((code - 2) >> 1);
+}
+
+// GF(2) polynomial product modulo the reflected CRC-32 polynomial
+__host__ __device__ __forceinline__ uint32_t za_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b & 1) ? ((b >> 1) ^ 0xEDB88320u) : (b >> 1);
+    }
+    return p;
+}

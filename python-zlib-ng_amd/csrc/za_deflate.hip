@@ -1,0 +1,683 @@
+// DEFLATE kernels for MI355X (gfx950).  Product code; hand-written HIP, wave64.
+//
+// Replaces, for many independent blocks at once, what the reference does per block in
+// ParallelCompress_compress_and_crc (reference src/zlib_ng/zlib_ngmodule.c:1696-1782):
+// zng_deflateReset + zng_deflateSetDictionary + zng_crc32_z + zng_deflate(Z_SYNC_FLUSH).
+//
+// Pipeline over a batch of units (unit = <=128 KiB of input + <=32 KiB dictionary before it):
+//   k_chains  one wave per unit; u16 head table (64 KiB) in LDS; the 64 positions of a tile are
+//             inserted at once, same-bucket lanes ordered by a ballot bit-slice match-any
+//   k_search  one 1024-thread workgroup per unit; chain links of the sliding window staged in a
+//             128 KiB LDS ring; every position searched in parallel
+//   k_parse   one wave per unit, one lane per 2 KiB segment: greedy/lazy selection, symbol
+//             histogram with LDS atomics, CRC-32 per segment folded with GF(2) products
+//   k_plan    one wave per unit: length-limited canonical Huffman, block-type choice, header bits
+//   k_pack    one wave per unit, one lane per segment: bit lengths -> wave prefix sum -> packing,
+//             boundary words merged with atomic OR
+#include "za_common.h"
+#include "za_crc.h"
+
+// ------------------------------------------------------------------------------------------------
+// k_chains
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                  uint16_t *__restrict__ prev_ws)
+{
+    __shared__ uint16_t head[1 << ZA_HASH_BITS];
+    const ZaUnit u = units[blockIdx.x];
+    const uint8_t *data = in + u.in_off;
+    const int n = (int)u.in_len, dict_len = (int)u.dict_len;
+    uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;
+    const int lane = za_lane();
+    for (int i = lane; i < (1 << ZA_HASH_BITS) / 2; i += 64) ((uint32_t *)head)[i] = 0;
+    __syncthreads();
+    const int total = dict_len + n;
+    const int pmin = ZA_WIN - dict_len;
+    for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        const int p = i - dict_len;
+        const bool valid = (i < total) && (p + ZA_MIN_MATCH <= n);
+        const uint32_t v = valid ? za_ld32(data + p) : 0u;
+        const uint32_t h = za_hash4(v);
+        // lanes of this tile that fall in my bucket (bit-sliced compare over the 15 hash bits)
+        unsigned long long eq = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < ZA_HASH_BITS; b++) {
+            const bool bit = (h >> b) & 1u;
+            const unsigned long long B = __ballot(bit);
+            eq &= bit ? B : ~B;
+        }
+        const unsigned long long lower = eq & ((1ull << lane) - 1ull);
+        const unsigned long long higher = (eq >> lane) >> 1;
+        const uint32_t P = (uint32_t)(ZA_WIN + p);
+        uint32_t d;
+        if (lower) {
+            d = (uint32_t)(lane - (63 - __builtin_clzll(lower)));
+        } else {
+            const uint32_t hv = head[h];
+            d = (P - hv) & 0xFFFFu;
+            if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
+        }
+        if (valid && !higher) head[h] = (uint16_t)(P & 0xFFFFu);
+        if (i < total) prevdist[i] = (uint16_t)(valid ? d : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_search
+// ------------------------------------------------------------------------------------------------
+#define ZA_SEARCH_THREADS 1024
+#define ZA_SEARCH_TILE    4096
+#define ZA_RING           65536
+
+__device__ __forceinline__ int za_match_len(const uint8_t *a, const uint8_t *b, int maxlen, bool wide_ok)
+{
+    int len = 0;
+    if (wide_ok) {
+        while (len < maxlen) {
+            const uint64_t x = za_ld64(a + len) ^ za_ld64(b + len);
+            if (x) { len += (int)(__builtin_ctzll(x) >> 3); break; }
+            len += 8;
+        }
+        return len < maxlen ? len : maxlen;
+    }
+    while (len < maxlen && a[len] == b[len]) len++;
+    return len;
+}
+
+__global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                                 const ZaUnit *__restrict__ units,
+                                                                 const uint16_t *__restrict__ prev_ws,
+                                                                 uint32_t *__restrict__ best_ws, ZaLevel L)
+{
+    __shared__ uint16_t ring[ZA_RING];
+    const ZaUnit u = units[blockIdx.x];
+    const uint8_t *data = in + u.in_off;
+    const int n = (int)u.in_len, dict_len = (int)u.dict_len;
+    const uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;
+    uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
+    const int tid = (int)threadIdx.x;
+    const int total = dict_len + n;
+    // bytes that may be read starting at data[0] without leaving the caller's buffer
+    const long long readable = (long long)(in_total - u.in_off);
+    int loaded = 0;
+    for (int base = 0; base < n; base += ZA_SEARCH_TILE) {
+        int need = dict_len + base + ZA_SEARCH_TILE;
+        if (need > total) need = total;
+        for (int i = loaded + tid; i < need; i += ZA_SEARCH_THREADS) ring[i & (ZA_RING - 1)] = prevdist[i];
+        loaded = need;
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
+            const int p = base + k * ZA_SEARCH_THREADS + tid;
+            if (p >= n) continue;
+            int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
+            if (seg_end > n) seg_end = n;
+            int maxlen = seg_end - p;
+            if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
+            uint32_t result = 0;
+            if (maxlen >= ZA_MIN_MATCH) {
+                const bool wide_ok = (long long)p + ZA_MAX_MATCH + 8 <= readable;
+                const int nice = L.nice < maxlen ? L.nice : maxlen;
+                int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
+                int q = p, depth = L.chain;
+                const uint8_t *me = data + p;
+                while (depth-- > 0) {
+                    const int d = ring[(q + dict_len) & (ZA_RING - 1)];
+                    if (d == 0) break;
+                    q -= d;
+                    const int dist = p - q;
+                    if (dist > ZA_WIN) break;
+                    const uint8_t *cand = data + q;
+                    if (cand[best_len] != me[best_len]) continue;
+                    const int len = za_match_len(cand, me, maxlen, wide_ok);
+                    if (len > best_len) {
+                        best_len = len; best_dist = dist;
+                        if (len >= nice) break;
+                    }
+                }
+                if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
+                    result = ((uint32_t)best_len << 16) | (uint32_t)best_dist;
+            }
+            best[p] = result;
+        }
+        // no second barrier: the next tile's ring stores land >= 57344 entries behind any chain
+        // walk still running (window 32768 + tile 4096 <= ring 65536 - tile 4096)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_parse  (+ histogram + CRC-32)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                 const uint32_t *__restrict__ best_ws, uint32_t *__restrict__ tok_ws,
+                                                 uint32_t *__restrict__ segtok_ws, uint32_t *__restrict__ hist_ws,
+                                                 uint32_t *__restrict__ crc_out,
+                                                 const uint32_t *__restrict__ crc_table,   // [256]
+                                                 const uint32_t *__restrict__ x8k_table,   // [64] x^(8*2048*k)
+                                                 ZaLevel L, int level)
+{
+    __shared__ uint32_t hist[ZA_HIST_STRIDE];
+    __shared__ uint32_t crct[256];
+    const ZaUnit u = units[blockIdx.x];
+    const uint8_t *data = in + u.in_off;
+    const int n = (int)u.in_len;
+    const int lane = za_lane();
+    const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    for (int i = lane; i < ZA_HIST_STRIDE; i += 64) hist[i] = 0;
+    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
+    __syncthreads();
+
+    const int s0 = lane << ZA_SEG_SHIFT;
+    int s1 = s0 + ZA_SEG;
+    if (s1 > n) s1 = n;
+
+    // ---- CRC-32 of the unit (zng_crc32_z at zlib_ngmodule.c:1741)
+    const uint32_t c = za_wave_crc32(data, n, crct, x8k_table);
+    if (lane == 0) crc_out[blockIdx.x] = c;
+
+    // ---- parse
+    uint32_t ntok = 0;
+    if (level > 0 && lane < nseg) {
+        const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
+        uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + s0;
+        int p = s0;
+        while (p < s1) {
+            const uint32_t b = best[p];
+            const int len = (int)(b >> 16);
+            if (len >= ZA_MIN_MATCH) {
+                if (L.lazy && len < L.lazy && p + 1 < s1 && (int)(best[p + 1] >> 16) > len) {
+                    const uint32_t lit = data[p];
+                    tok[ntok++] = lit; atomicAdd(&hist[lit], 1u); p++;
+                    continue;
+                }
+                const int dist = (int)(b & 0xFFFFu);
+                int lc, ln, le, dc, dn, de;
+                za_len_sym(len, lc, ln, le);
+                za_dist_sym(dist, dc, dn, de);
+                tok[ntok++] = 0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1);
+                atomicAdd(&hist[257 + lc], 1u);
+                atomicAdd(&hist[288 + dc], 1u);
+                p += len;
+            } else {
+                const uint32_t lit = data[p];
+                tok[ntok++] = lit; atomicAdd(&hist[lit], 1u); p++;
+            }
+        }
+    }
+    segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] = ntok;
+    __syncthreads();
+    if (lane == 0) hist[256] = 1;
+    __syncthreads();
+    for (int i = lane; i < ZA_HIST_STRIDE; i += 64) hist_ws[(size_t)blockIdx.x * ZA_HIST_STRIDE + i] = hist[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_plan : Huffman code lengths, block type, header bits
+// ------------------------------------------------------------------------------------------------
+struct ZaPlanLds {
+    uint32_t key[288];
+    uint32_t A[288];
+    uint32_t freq[320];
+    uint8_t lens[320];
+    uint16_t codes[320];
+    uint8_t seq[320];
+    uint16_t cltok[320];
+    uint32_t clf[19];
+    uint8_t cl_lens[19];
+    uint16_t cl_codes[19];
+    int m;
+};
+
+// rank-sort the non-zero symbols by (freq, index); all lanes take part.  Result in S.key[0..m).
+__device__ void za_sort_syms(ZaPlanLds &S, const uint32_t *freq, int nsym)
+{
+    const int lane = za_lane();
+    __syncthreads();
+    for (int i = lane; i < 288; i += 64) S.A[i] = (i < nsym && freq[i]) ? ((freq[i] << 9) | (uint32_t)i) : 0u;
+    __syncthreads();
+    int m = 0;
+    for (int i = lane; i < nsym; i += 64) {
+        const uint32_t k = S.A[i];
+        if (!k) continue;
+        int rank = 0;
+        for (int j = 0; j < nsym; j++) { const uint32_t o = S.A[j]; rank += (o != 0u && o < k); }
+        S.key[rank] = k;
+    }
+    for (int j = lane; j < nsym; j += 64) m += (S.A[j] != 0u);
+    for (int d = 32; d >= 1; d >>= 1) m += __shfl_xor(m, d, 64);
+    __syncthreads();
+    if (lane == 0) S.m = m;
+    __syncthreads();
+}
+
+// lane 0 only: Moffat-Katajainen in-place lengths on S.key[0..m) + count-based limiting.
+__device__ void za_lengths_serial(ZaPlanLds &S, int nsym, int limit, uint8_t *lens)
+{
+    const int m = S.m;
+    for (int i = 0; i < nsym; i++) lens[i] = 0;
+    if (m == 0) return;
+    if (m == 1) { lens[S.key[0] & 511u] = 1; return; }
+    uint32_t *A = S.A;
+    for (int i = 0; i < m; i++) A[i] = S.key[i] >> 9;
+    int root, leaf, next, avbl, used, dpth;
+    A[0] += A[1]; root = 0; leaf = 2;
+    for (next = 1; next < m - 1; next++) {
+        if (leaf >= m || A[root] < A[leaf]) { A[next] = A[root]; A[root++] = (uint32_t)next; }
+        else A[next] = A[leaf++];
+        if (leaf >= m || (root < next && A[root] < A[leaf])) { A[next] += A[root]; A[root++] = (uint32_t)next; }
+        else A[next] += A[leaf++];
+    }
+    A[m - 2] = 0;
+    for (next = m - 3; next >= 0; next--) A[next] = A[A[next]] + 1;
+    avbl = 1; used = dpth = 0; root = m - 2; next = m - 1;
+    while (avbl > 0 && dpth < 320) {
+        while (root >= 0 && (int)A[root] == dpth) { used++; root--; }
+        while (avbl > used && next >= 0) { A[next--] = (uint32_t)dpth; avbl--; }
+        if (next < 0) break;
+        avbl = 2 * used; dpth++; used = 0;
+    }
+    int cnt[17];
+    for (int i = 0; i < 17; i++) cnt[i] = 0;
+    bool over = false;
+    for (int i = 0; i < m; i++) {
+        int d = (int)A[i];
+        if (d > limit) { d = limit; over = true; }
+        cnt[d]++;
+    }
+    if (over) {
+        uint32_t total = 0;
+        for (int i = 1; i <= limit; i++) total += (uint32_t)cnt[i] << (limit - i);
+        // every step removes one unit of the Kraft sum; the guard only bounds a corrupted state
+        for (int guard = 0; total != (1u << limit) && guard < (1 << 17); guard++) {
+            cnt[limit]--;
+            for (int i = limit - 1; i > 0; i--)
+                if (cnt[i]) { cnt[i]--; cnt[i + 1] += 2; break; }
+            total--;
+        }
+    }
+    int idx = 0;
+    for (int l = limit; l >= 1; l--)
+        for (int k = 0; k < cnt[l] && idx < m; k++) lens[S.key[idx++] & 511u] = (uint8_t)l;
+}
+
+// lane 0 only: canonical codes, bit-reversed for LSB-first emission
+__device__ void za_canon_serial(const uint8_t *lens, int n, uint16_t *codes)
+{
+    uint32_t bl[16], nc[16];
+    for (int i = 0; i < 16; i++) bl[i] = 0;
+    for (int i = 0; i < n; i++) bl[lens[i]]++;
+    bl[0] = 0;
+    uint32_t code = 0;
+    for (int b = 1; b <= 15; b++) { code = (code + bl[b - 1]) << 1; nc[b] = code; }
+    for (int i = 0; i < n; i++) {
+        const int l = lens[i];
+        uint32_t r = 0;
+        if (l) { const uint32_t c = nc[l]++; r = __brev(c) >> (32 - l); }
+        codes[i] = (uint16_t)r;
+    }
+}
+
+// serial LSB-first bit writer into a zero-initialised, 4-byte aligned slot (plain stores: the plan
+// kernel is the first writer of its slot)
+struct ZaBitW {
+    uint32_t *out; uint32_t cap_words; uint32_t w; uint64_t acc; int nb; bool ovf;
+    __device__ void put(uint32_t v, int n)
+    {
+        acc |= (uint64_t)v << nb; nb += n;
+        if (nb >= 32) {
+            if (w < cap_words) out[w] = (uint32_t)acc; else ovf = true;
+            w++; acc >>= 32; nb -= 32;
+        }
+    }
+    __device__ void finish() { if (nb > 0) { if (w < cap_words) out[w] = (uint32_t)acc; else ovf = true; } }
+    __device__ uint32_t bits() const { return w * 32u + (uint32_t)nb; }
+};
+
+__constant__ uint8_t za_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units, const uint32_t *__restrict__ hist_ws,
+                                                uint32_t *__restrict__ code_ws, ZaPlan *__restrict__ plan_ws,
+                                                uint8_t *__restrict__ out, uint32_t out_stride, int level)
+{
+    __shared__ ZaPlanLds S;
+    const ZaUnit u = units[blockIdx.x];
+    const int n = (int)u.in_len;
+    const int lane = za_lane();
+    const bool final = (u.flags & ZA_FLAG_FINAL) != 0;
+    ZaPlan plan; plan.btype = 0; plan.header_bits = 0; plan.pad0 = plan.pad1 = 0;
+    uint32_t *code_out = code_ws + (size_t)blockIdx.x * ZA_CODE_STRIDE;
+    if (n == 0 || level == 0) {
+        if (lane == 0) plan_ws[blockIdx.x] = plan;
+        return;
+    }
+    const uint32_t *hist = hist_ws + (size_t)blockIdx.x * ZA_HIST_STRIDE;
+    for (int i = lane; i < 320; i += 64) S.freq[i] = hist[i];
+    __syncthreads();
+    if (lane == 0) {   // at least two distance codes
+        int cntd = 0;
+        for (int i = 0; i < 30; i++) cntd += S.freq[288 + i] != 0;
+        if (cntd < 2 && S.freq[288] == 0) { S.freq[288] = 1; cntd++; }
+        if (cntd < 2) S.freq[289] = 1;
+    }
+    __syncthreads();
+    // lit/len tree
+    za_sort_syms(S, S.freq, 286);
+    if (lane == 0) za_lengths_serial(S, 286, 15, S.lens);
+    __syncthreads();
+    if (lane < 2) S.lens[286 + lane] = 0;
+    // distance tree
+    za_sort_syms(S, S.freq + 288, 30);
+    if (lane == 0) { za_lengths_serial(S, 30, 15, S.lens + 288); S.lens[318] = S.lens[319] = 0; }
+    __syncthreads();
+
+    if (lane == 0) {
+        za_canon_serial(S.lens, 286, S.codes);
+        za_canon_serial(S.lens + 288, 30, S.codes + 288);
+        int hlit = 286; while (hlit > 257 && S.lens[hlit - 1] == 0) hlit--;
+        int hdist = 30; while (hdist > 1 && S.lens[288 + hdist - 1] == 0) hdist--;
+        for (int i = 0; i < hlit; i++) S.seq[i] = S.lens[i];
+        for (int i = 0; i < hdist; i++) S.seq[hlit + i] = S.lens[288 + i];
+        // run-length encode the code lengths (tokens: sym | extra<<8)
+        const int nseq = hlit + hdist;
+        int nt = 0, i = 0;
+        while (i < nseq) {
+            const int v = S.seq[i];
+            int run = 1;
+            while (i + run < nseq && S.seq[i + run] == v) run++;
+            i += run;
+            if (v == 0) {
+                while (run >= 3) {
+                    if (run >= 11) { const int r = run > 138 ? 138 : run; S.cltok[nt++] = (uint16_t)(18 | ((r - 11) << 8)); run -= r; }
+                    else { S.cltok[nt++] = (uint16_t)(17 | ((run - 3) << 8)); run = 0; }
+                }
+                while (run-- > 0) S.cltok[nt++] = 0;
+            } else {
+                S.cltok[nt++] = (uint16_t)v; run--;
+                while (run >= 3) { const int r = run > 6 ? 6 : run; S.cltok[nt++] = (uint16_t)(16 | ((r - 3) << 8)); run -= r; }
+                while (run-- > 0) S.cltok[nt++] = (uint16_t)v;
+            }
+        }
+        for (int k = 0; k < 19; k++) S.clf[k] = 0;
+        for (int k = 0; k < nt; k++) S.clf[S.cltok[k] & 0xFF]++;
+        // code-length alphabet: 19 symbols, insertion sort is enough
+        int m = 0;
+        for (int k = 0; k < 19; k++) if (S.clf[k]) {
+            const uint32_t key = (S.clf[k] << 9) | (uint32_t)k;
+            int j = m++;
+            while (j > 0 && S.key[j - 1] > key) { S.key[j] = S.key[j - 1]; j--; }
+            S.key[j] = key;
+        }
+        S.m = m;
+        za_lengths_serial(S, 19, 7, S.cl_lens);
+        za_canon_serial(S.cl_lens, 19, S.cl_codes);
+        int hclen = 19; while (hclen > 4 && S.cl_lens[za_cl_order[hclen - 1]] == 0) hclen--;
+        // exact costs
+        unsigned long long data_dyn = 0, data_fix = 0;
+        for (int s = 0; s < 286; s++) {
+            const uint32_t f = hist[s];
+            if (!f) continue;
+            const int ex = s >= 257 ? za_len_extra_bits(s - 257) : 0;
+            const int fx = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            data_dyn += (unsigned long long)f * (unsigned)(S.lens[s] + ex);
+            data_fix += (unsigned long long)f * (unsigned)(fx + ex);
+        }
+        for (int s = 0; s < 30; s++) {
+            const uint32_t f = hist[288 + s];
+            const int ex = za_dist_extra_bits(s);
+            data_dyn += (unsigned long long)f * (unsigned)(S.lens[288 + s] + ex);
+            data_fix += (unsigned long long)f * (unsigned)(5 + ex);
+        }
+        unsigned long long hdr_dyn = 3 + 5 + 5 + 4 + 3ull * (unsigned)hclen;
+        for (int k = 0; k < nt; k++) {
+            const int s = S.cltok[k] & 0xFF;
+            hdr_dyn += S.cl_lens[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0);
+        }
+        const unsigned long long cost_dyn = hdr_dyn + data_dyn, cost_fix = 3 + data_fix;
+        const unsigned long long nchunks = ((unsigned long long)n + 65534ull) / 65535ull;
+        const unsigned long long cost_sto = 8ull * ((unsigned long long)n + 5ull * nchunks);
+        unsigned long long bestc = cost_dyn; int btype = 2;
+        if (cost_fix <= bestc) { bestc = cost_fix; btype = 1; }
+        if (cost_sto <= bestc) { bestc = cost_sto; btype = 0; }
+        if (btype == 1) {
+            int s = 0;
+            for (; s < 144; s++) S.lens[s] = 8;
+            for (; s < 256; s++) S.lens[s] = 9;
+            for (; s < 280; s++) S.lens[s] = 7;
+            for (; s < 288; s++) S.lens[s] = 8;
+            for (s = 0; s < 32; s++) S.lens[288 + s] = 5;
+            za_canon_serial(S.lens, 288, S.codes);
+            za_canon_serial(S.lens + 288, 30, S.codes + 288);
+        }
+        plan.btype = (uint32_t)btype;
+        if (btype != 0) {
+            ZaBitW w;
+            w.out = (uint32_t *)(out + (size_t)blockIdx.x * out_stride);
+            w.cap_words = out_stride / 4; w.w = 0; w.acc = 0; w.nb = 0; w.ovf = false;
+            w.put((uint32_t)final | ((uint32_t)btype << 1), 3);
+            if (btype == 2) {
+                w.put((uint32_t)(hlit - 257), 5);
+                w.put((uint32_t)(hdist - 1), 5);
+                w.put((uint32_t)(hclen - 4), 4);
+                for (int k = 0; k < hclen; k++) w.put(S.cl_lens[za_cl_order[k]], 3);
+                for (int k = 0; k < nt; k++) {
+                    const int s = S.cltok[k] & 0xFF, ex = S.cltok[k] >> 8;
+                    w.put(S.cl_codes[s], S.cl_lens[s]);
+                    if (s == 16) w.put((uint32_t)ex, 2);
+                    else if (s == 17) w.put((uint32_t)ex, 3);
+                    else if (s == 18) w.put((uint32_t)ex, 7);
+                }
+            }
+            w.finish();
+            plan.header_bits = w.bits();
+        }
+        plan_ws[blockIdx.x] = plan;
+    }
+    __syncthreads();
+    for (int i = lane; i < 320; i += 64) code_out[i] = (uint32_t)S.codes[i] | ((uint32_t)S.lens[i] << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pack
+// ------------------------------------------------------------------------------------------------
+// Per-lane bit packer.  The first word a lane touches (it may share it with the previous lane or
+// with the header) and its trailing partial word are merged with atomic OR; words in between are
+// owned by the lane alone and stored directly.
+struct ZaLaneW {
+    uint32_t *out; uint32_t cap_words; uint32_t w; uint64_t acc; int nb; bool first; bool ovf;
+    __device__ void init(uint32_t *o, uint32_t cap, uint32_t bitpos)
+    {
+        out = o; cap_words = cap; w = bitpos >> 5; nb = (int)(bitpos & 31u); acc = 0; first = true; ovf = false;
+    }
+    __device__ void put(uint32_t v, int n)
+    {
+        acc |= (uint64_t)v << nb; nb += n;
+        if (nb >= 32) {
+            if (w < cap_words) { if (first) atomicOr(&out[w], (uint32_t)acc); else out[w] = (uint32_t)acc; }
+            else ovf = true;
+            first = false; w++; acc >>= 32; nb -= 32;
+        }
+    }
+    __device__ void finish()
+    {
+        if (nb > 0 && (uint32_t)acc != 0u) { if (w < cap_words) atomicOr(&out[w], (uint32_t)acc); else ovf = true; }
+    }
+};
+
+__global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                const uint32_t *__restrict__ tok_ws, const uint32_t *__restrict__ segtok_ws,
+                                                const uint32_t *__restrict__ code_ws, const ZaPlan *__restrict__ plan_ws,
+                                                uint32_t *__restrict__ segbits_ws, uint8_t *__restrict__ out,
+                                                uint32_t out_stride, uint32_t *__restrict__ out_len,
+                                                uint32_t *__restrict__ status)
+{
+    __shared__ uint32_t codes[ZA_CODE_STRIDE];
+    const ZaUnit u = units[blockIdx.x];
+    const uint8_t *data = in + u.in_off;
+    const int n = (int)u.in_len;
+    const int lane = za_lane();
+    const bool final = (u.flags & ZA_FLAG_FINAL) != 0;
+    const ZaPlan plan = plan_ws[blockIdx.x];
+    uint8_t *slot = out + (size_t)blockIdx.x * out_stride;
+    uint32_t *slot32 = (uint32_t *)slot;
+    const uint32_t cap_words = out_stride / 4;
+    uint32_t *segbits = segbits_ws + (size_t)blockIdx.x * ZA_SEGB_STRIDE;
+    const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    bool ovf = false;
+    uint32_t total_bytes = 0;
+
+    if (n == 0) {
+        if (lane == 0) {
+            if (final) { slot[0] = 0x03; slot[1] = 0x00; total_bytes = 2; }
+            else { slot[0] = 0; slot[1] = 0; slot[2] = 0; slot[3] = 0xFF; slot[4] = 0xFF; total_bytes = 5; }
+            out_len[blockIdx.x] = total_bytes; status[blockIdx.x] = 0;
+        }
+        for (int i = lane; i < ZA_SEGB_STRIDE; i += 64) segbits[i] = 0;
+        return;
+    }
+    if (plan.btype == 0) {
+        // stored blocks, 65535 bytes at most each; unit starts byte aligned
+        const uint32_t nchunks = ((uint32_t)n + 65534u) / 65535u;
+        const uint32_t need = (uint32_t)n + 5u * nchunks + (final ? 0u : 5u);
+        if (need > out_stride) ovf = true;
+        else {
+            for (uint32_t c = 0; c < nchunks; c++) {
+                const uint32_t off = c * 65535u;
+                const uint32_t len = (uint32_t)n - off > 65535u ? 65535u : (uint32_t)n - off;
+                uint8_t *dst = slot + off + 5u * c;
+                if (lane == 0) {
+                    dst[0] = (uint8_t)((final && c == nchunks - 1) ? 1 : 0);
+                    dst[1] = (uint8_t)(len & 0xFF); dst[2] = (uint8_t)(len >> 8);
+                    dst[3] = (uint8_t)(~len & 0xFF); dst[4] = (uint8_t)((~len >> 8) & 0xFF);
+                }
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[5 + i] = data[off + i];
+            }
+            total_bytes = (uint32_t)n + 5u * nchunks;
+            if (!final && lane == 0) {
+                uint8_t *t = slot + total_bytes;
+                t[0] = 0; t[1] = 0; t[2] = 0; t[3] = 0xFF; t[4] = 0xFF;
+            }
+            if (!final) total_bytes += 5;
+        }
+        for (int i = lane; i < ZA_SEGB_STRIDE; i += 64) segbits[i] = 0;
+        if (lane == 0) { out_len[blockIdx.x] = ovf ? 0u : total_bytes; status[blockIdx.x] = ovf ? ZA_ST_OVERFLOW : 0u; }
+        return;
+    }
+
+    for (int i = lane; i < ZA_CODE_STRIDE; i += 64) codes[i] = code_ws[(size_t)blockIdx.x * ZA_CODE_STRIDE + i];
+    __syncthreads();
+    const uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + ((size_t)lane << ZA_SEG_SHIFT);
+    const uint32_t ntok = lane < nseg ? segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] : 0u;
+
+    // pass A: bit length of my segment
+    uint32_t bits = 0;
+    for (uint32_t k = 0; k < ntok; k++) {
+        const uint32_t t = tok[k];
+        if (t & 0x80000000u) {
+            int lc, ln, le, dc, dn, de;
+            za_len_sym((int)((t >> 16) & 0xFF) + 3, lc, ln, le);
+            za_dist_sym((int)(t & 0x7FFF) + 1, dc, dn, de);
+            bits += (codes[257 + lc] >> 16) + (uint32_t)ln + (codes[288 + dc] >> 16) + (uint32_t)dn;
+        } else bits += codes[t] >> 16;
+    }
+    const uint32_t incl = za_wave_incl_scan(bits);
+    const uint32_t start = plan.header_bits + incl - bits;
+    const uint32_t end_all = plan.header_bits + __shfl(incl, 63, 64);      // bit offset of EOB
+    if (lane < nseg) segbits[lane] = start;
+    else segbits[lane] = end_all;
+    if (lane == 0) segbits[ZA_MAX_SEGS] = end_all;
+
+    // pass B: emit
+    ZaLaneW w;
+    w.init(slot32, cap_words, start);
+    for (uint32_t k = 0; k < ntok; k++) {
+        const uint32_t t = tok[k];
+        if (t & 0x80000000u) {
+            int lc, ln, le, dc, dn, de;
+            za_len_sym((int)((t >> 16) & 0xFF) + 3, lc, ln, le);
+            za_dist_sym((int)(t & 0x7FFF) + 1, dc, dn, de);
+            const uint32_t cl = codes[257 + lc], cd = codes[288 + dc];
+            // length code + extra fit in 20 bits, distance code + extra in 28
+            w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
+            w.put((cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)), (int)(cd >> 16) + dn);
+        } else {
+            const uint32_t c = codes[t];
+            w.put(c & 0xFFFF, (int)(c >> 16));
+        }
+    }
+    w.finish();
+    ovf = w.ovf;
+    // tail: EOB, then final padding or the sync-flush marker (empty stored block)
+    if (lane == 0) {
+        ZaLaneW t;
+        t.init(slot32, cap_words, end_all);
+        const uint32_t ce = codes[256];
+        t.put(ce & 0xFFFF, (int)(ce >> 16));
+        uint32_t bitpos = end_all + (ce >> 16);
+        if (!final) { t.put(0, 3); bitpos += 3; }
+        const uint32_t padded = (bitpos + 7u) & ~7u;
+        if (padded != bitpos) t.put(0, (int)(padded - bitpos));
+        t.finish();
+        total_bytes = padded >> 3;
+        if (!final) {
+            if (total_bytes + 4 <= out_stride) {
+                // byte stores: the marker may start at any byte; these bytes are zero so far and no
+                // other lane touches them (they lie beyond every token)
+                slot[total_bytes + 2] = 0xFF; slot[total_bytes + 3] = 0xFF;
+            } else t.ovf = true;
+            total_bytes += 4;
+        }
+        if (total_bytes > out_stride) t.ovf = true;
+        ovf = ovf || t.ovf;
+    }
+    const unsigned long long anyovf = __ballot(ovf);
+    if (lane == 0) {
+        out_len[blockIdx.x] = anyovf ? 0u : total_bytes;
+        status[blockIdx.x] = anyovf ? ZA_ST_OVERFLOW : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction: gather the per-unit slots of each reference block / of the whole batch into a
+// contiguous stream at byte offsets computed by a prefix sum (host or device side).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void za_k_gather(const uint8_t *__restrict__ slots, uint32_t out_stride,
+                                                   const uint32_t *__restrict__ out_len,
+                                                   const uint64_t *__restrict__ dst_off, uint8_t *__restrict__ dst)
+{
+    const uint8_t *src = slots + (size_t)blockIdx.x * out_stride;
+    uint8_t *d = dst + dst_off[blockIdx.x];
+    const uint32_t len = out_len[blockIdx.x];
+    // head bytes until the destination is 4-byte aligned, then dwords, then the tail
+    uint32_t headb = (uint32_t)((4u - ((uintptr_t)d & 3u)) & 3u);
+    if (headb > len) headb = len;
+    if (threadIdx.x < headb) d[threadIdx.x] = src[threadIdx.x];
+    const uint32_t nw = (len - headb) >> 2;
+    uint32_t *d32 = (uint32_t *)(d + headb);
+    for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) d32[i] = za_ld32(src + headb + 4u * i);
+    const uint32_t done = headb + 4u * nw;
+    if (threadIdx.x < len - done) d[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+// exclusive prefix sum of unit sizes -> byte offsets (single workgroup; batches are <= a few 10^5)
+__global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict__ out_len, uint32_t n, uint32_t extra,
+                                                     uint64_t base, uint64_t *__restrict__ dst_off,
+                                                     uint64_t *__restrict__ total)
+{
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t b = tid * per, e = (b + per < n) ? b + per : n;
+    unsigned long long s = 0;
+    for (uint32_t i = b; i < e; i++) s += (unsigned long long)out_len[i] + extra;
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = base;
+        for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        *total = run - base;
+    }
+    __syncthreads();
+    unsigned long long run = part[tid];
+    for (uint32_t i = b; i < e; i++) { dst_off[i] = run; run += (unsigned long long)out_len[i] + extra; }
+}

@@ -1,0 +1,559 @@
+// Inflate kernels for MI355X (gfx950).  Product code; hand-written HIP, wave64.
+//
+// Replaces zng_inflate behind zlib_ng.decompress and _GzipReader (reference
+// src/zlib_ng/zlib_ngmodule.c:328 and :2539) and the member loop of GzipReader_read_into_buffer
+// (:2426-2637) for streams of many independent members.
+//
+//   za_k_inflate_serial   any RFC 1951 stream: one wavefront per stream, decode state kept uniform
+//                         across the wave, 32 KiB history ring in LDS, copies done by all 64 lanes
+//   za_k_scan_members     pass 1 of the two-pass scheme: coalesced sweep of the compressed stream
+//                         for this engine's indexed gzip members ('Z','A' FEXTRA subfield)
+//   za_k_inflate_members  pass 2: one wavefront per member, one lane per 2 KiB segment decodes its
+//                         tokens from the indexed bit offset (literals stored directly, matches
+//                         queued), then the wave resolves the queued matches in output order,
+//                         64 at a time, byte-parallel; CRC-32 / ISIZE verified in the same kernel
+//   za_k_assemble_members writes header + index + deflate bytes + trailer of each member
+#include "za_common.h"
+#include "za_crc.h"
+
+#define ZA_LUT_L_BITS 10
+#define ZA_LUT_D_BITS 9
+
+// internal status values (host maps them to ZNGAMD_* codes)
+#define ZA_I_OK          0
+#define ZA_I_END         1
+#define ZA_I_DATA      (-3)
+#define ZA_I_INPUT     (-5)     // ran out of input
+#define ZA_I_OUTFULL   (-6)     // ran out of output space
+#define ZA_I_INDEX     (-7)     // segment index inconsistent with the stream: decode sequentially
+#define ZA_I_CRC       (-104)
+#define ZA_I_LENGTH    (-105)
+
+struct ZaInfTabs {
+    uint16_t lut_l[1 << ZA_LUT_L_BITS];   // (sym<<4)|len, 0 = longer than the LUT or unassigned
+    uint16_t lut_d[1 << ZA_LUT_D_BITS];
+    uint16_t cnt_l[16], cnt_d[16];
+    uint16_t sym_l[288], sym_d[32];
+    uint8_t lens[320];
+    int status;
+};
+
+struct ZaInfResult {
+    int32_t status; uint32_t pad;
+    uint64_t out_len;
+    uint64_t in_bits;      // bits consumed
+};
+
+// bit-serial canonical decode of the low bits of v; returns (sym<<4)|len or 0
+__device__ __forceinline__ uint32_t za_slow_decode(uint32_t v, const uint16_t *cnt, const uint16_t *sym, int maxbits)
+{
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= maxbits; l++) {
+        code |= (int)(v & 1u); v >>= 1;
+        const int c = cnt[l];
+        if (code - c < first) return ((uint32_t)sym[index + (code - first)] << 4) | (uint32_t)l;
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return 0;
+}
+
+// Build count/symbol arrays (lane 0) and the LUT (all lanes) from lens[0..n).  Returns <0 for an
+// over-subscribed set, >0 for an incomplete one, 0 otherwise; *maxlen_out = longest code.
+__device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *lut, int lut_bits,
+                              int *shared_status, int *shared_maxlen)
+{
+    const int lane = za_lane();
+    __syncthreads();
+    if (lane == 0) {
+        uint16_t offs[16];
+        for (int i = 0; i < 16; i++) cnt[i] = 0;
+        for (int i = 0; i < n; i++) cnt[lens[i]]++;
+        int maxlen = 0, left = 1, st = 0;
+        for (int l = 1; l <= 15; l++) if (cnt[l]) maxlen = l;
+        if (cnt[0] != n) {
+            for (int l = 1; l <= 15; l++) { left <<= 1; left -= cnt[l]; if (left < 0) break; }
+            st = left;
+        }
+        cnt[0] = 0;
+        if (st >= 0) {
+            offs[1] = 0;
+            for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]);
+            for (int i = 0; i < n; i++) if (lens[i]) sym[offs[lens[i]]++] = (uint16_t)i;
+        }
+        *shared_status = st; *shared_maxlen = maxlen;
+    }
+    __syncthreads();
+    const int st = *shared_status;
+    if (st >= 0) {
+        for (int e = lane; e < (1 << lut_bits); e += 64) lut[e] = (uint16_t)za_slow_decode((uint32_t)e, cnt, sym, lut_bits);
+    }
+    __syncthreads();
+    return st;
+}
+
+__device__ __forceinline__ uint64_t za_peek(const uint8_t *in, uint64_t bitpos)
+{
+    return za_ld64(in + (bitpos >> 3)) >> (bitpos & 7u);     // >= 57 valid bits; buffer is padded by 8 bytes
+}
+
+__device__ __forceinline__ uint32_t za_decode_sym(uint64_t bits, const uint16_t *lut, int lut_bits,
+                                                  const uint16_t *cnt, const uint16_t *sym)
+{
+    uint32_t e = lut[bits & ((1u << lut_bits) - 1u)];
+    if (!e) e = za_slow_decode((uint32_t)bits, cnt, sym, 15);
+    return e;     // (sym<<4)|len, 0 = invalid code
+}
+
+__device__ __forceinline__ int za_len_base(int code, int &nextra)    // code 0..28
+{
+    if (code < 8) { nextra = 0; return 3 + code; }
+    if (code == 28) { nextra = 0; return 258; }
+    const int nb = (code >> 2) + 1;
+    nextra = nb - 2;
+    return ((4 + (code & 3)) << (nb - 2)) + 3;
+}
+__device__ __forceinline__ int za_dist_base(int code, int &nextra)   // code 0..29
+{
+    if (code < 4) { nextra = 0; return code + 1; }
+    const int nb = code >> 1;
+    nextra = nb - 1;
+    return ((2 + (code & 1)) << (nb - 1)) + 1;
+}
+
+__constant__ uint8_t za_i_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// Parse a fixed or dynamic block header at `bitpos` (uniform across the wave) and build the decode
+// tables.  Returns ZA_I_OK / ZA_I_DATA / ZA_I_INPUT; advances bitpos past the header.
+__device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bitpos, int type, ZaInfTabs &T, int *scratch /*2 ints LDS*/)
+{
+    const int lane = za_lane();
+    if (type == 1) {
+        __syncthreads();
+        for (int i = lane; i < 320; i += 64)
+            T.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : i < 318 ? 5 : 0);
+        za_build_table(T.lens, 288, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1]);
+        za_build_table(T.lens + 288, 30, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1]);
+        return ZA_I_OK;
+    }
+    if (bitpos + 14 > in_bits) return ZA_I_INPUT;
+    uint64_t bits = za_peek(in, bitpos);
+    const int nlen = (int)(bits & 31u) + 257, ndist = (int)((bits >> 5) & 31u) + 1, ncode = (int)((bits >> 10) & 15u) + 4;
+    bitpos += 14;
+    if (nlen > 286 || ndist > 30) return ZA_I_DATA;
+    if (bitpos + 3ull * (unsigned)ncode > in_bits) return ZA_I_INPUT;
+    __syncthreads();
+    if (lane < 19) T.lens[lane] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        uint64_t bp = bitpos;
+        for (int i = 0; i < ncode; i++) { T.lens[za_i_cl_order[i]] = (uint8_t)(za_peek(in, bp) & 7u); bp += 3; }
+    }
+    bitpos += 3ull * (unsigned)ncode;
+    // code-length code: tables go to the distance slots for now (7-bit LUT)
+    int st = za_build_table(T.lens, 19, T.cnt_d, T.sym_d, T.lut_d, 7, &scratch[0], &scratch[1]);
+    if (st != 0) return ZA_I_DATA;                       // must be complete
+    // decode nlen + ndist code lengths (serial, lane 0), result in T.lens[32..] then moved
+    __syncthreads();
+    if (lane == 0) {
+        uint64_t bp = bitpos;
+        int idx = 0, err = ZA_I_OK;
+        uint8_t *L = T.lens + 0;      // reuse from index 0: the 19 code-length lengths are no longer needed
+        uint8_t tmp_prev = 0;
+        while (idx < nlen + ndist) {
+            if (bp > in_bits) { err = ZA_I_INPUT; break; }
+            const uint64_t b = za_peek(in, bp);
+            const uint32_t e = za_decode_sym(b, T.lut_d, 7, T.cnt_d, T.sym_d);
+            if (!e) { err = ZA_I_DATA; break; }
+            const int s = (int)(e >> 4), l = (int)(e & 15u);
+            bp += (unsigned)l;
+            if (bp > in_bits) { err = ZA_I_INPUT; break; }
+            if (s < 16) { L[idx++] = (uint8_t)s; tmp_prev = (uint8_t)s; }
+            else {
+                int rep, val = 0;
+                const uint64_t x = b >> l;
+                if (s == 16) { if (idx == 0) { err = ZA_I_DATA; break; } val = tmp_prev; rep = 3 + (int)(x & 3u); bp += 2; }
+                else if (s == 17) { rep = 3 + (int)(x & 7u); bp += 3; }
+                else { rep = 11 + (int)(x & 127u); bp += 7; }
+                if (bp > in_bits) { err = ZA_I_INPUT; break; }
+                if (idx + rep > nlen + ndist) { err = ZA_I_DATA; break; }
+                while (rep--) L[idx++] = (uint8_t)val;
+                tmp_prev = (uint8_t)val;
+            }
+        }
+        if (err == ZA_I_OK && L[256] == 0) err = ZA_I_DATA;      // missing end-of-block
+        scratch[0] = err;
+        scratch[1] = (int)(bp - bitpos);
+    }
+    __syncthreads();
+    const int err = scratch[0];
+    const int adv = scratch[1];
+    __syncthreads();
+    if (err != ZA_I_OK) return err;
+    bitpos += (unsigned)adv;
+    // distance lengths first (they sit after the literal/length ones), into lens[288..]
+    if (lane < 32) {
+        const uint8_t v = lane < ndist ? T.lens[nlen + lane] : (uint8_t)0;
+        T.lens[288 + lane] = v;
+    }
+    __syncthreads();
+    for (int i = nlen + lane; i < 288; i += 64) T.lens[i] = 0;
+    __syncthreads();
+    int maxl;
+    st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1]);
+    maxl = scratch[1];
+    if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
+    st = za_build_table(T.lens + 288, ndist, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1]);
+    maxl = scratch[1];
+    if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
+    return ZA_I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sequential decoder: one wave per stream
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len,
+                                                          const uint8_t *__restrict__ dict, uint32_t dict_len,
+                                                          uint8_t *__restrict__ out, uint64_t out_cap,
+                                                          ZaInfResult *__restrict__ res)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ uint8_t win[ZA_WIN];
+    __shared__ int scratch[2];
+    const int lane = za_lane();
+    const uint64_t in_bits = in_len * 8ull;
+    uint64_t bitpos = 0, op = 0;
+    int status = ZA_I_OK;
+    for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) win[(ZA_WIN - dict_len + i) & (ZA_WIN - 1)] = dict[i];
+    __syncthreads();
+
+    for (;;) {
+        if (bitpos + 3 > in_bits) { status = ZA_I_INPUT; break; }
+        uint64_t bits = za_peek(in, bitpos);
+        const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
+        bitpos += 3;
+        if (type == 3) { status = ZA_I_DATA; break; }
+        if (type == 0) {
+            bitpos = (bitpos + 7ull) & ~7ull;
+            if (bitpos + 32 > in_bits) { status = ZA_I_INPUT; break; }
+            bits = za_peek(in, bitpos);
+            const uint32_t len = (uint32_t)(bits & 0xFFFFu), nlen = (uint32_t)((bits >> 16) & 0xFFFFu);
+            if ((len ^ 0xFFFFu) != nlen) { status = ZA_I_DATA; break; }
+            bitpos += 32;
+            uint32_t can = len;
+            const uint64_t availb = (in_bits - bitpos) >> 3;
+            bool short_in = false, short_out = false;
+            if ((uint64_t)can > availb) { can = (uint32_t)availb; short_in = true; }
+            if ((uint64_t)can > out_cap - op) { can = (uint32_t)(out_cap - op); short_out = true; short_in = false; }
+            const uint8_t *src = in + (bitpos >> 3);
+            for (uint32_t i = (uint32_t)lane; i < can; i += 64) {
+                const uint8_t b = src[i];
+                win[(op + i) & (ZA_WIN - 1)] = b;
+                out[op + i] = b;
+            }
+            op += can; bitpos += 8ull * can;
+            if (short_out) { status = ZA_I_OUTFULL; break; }
+            if (short_in) { status = ZA_I_INPUT; break; }
+        } else {
+            status = za_read_tables(in, in_bits, bitpos, type, T, scratch);
+            if (status != ZA_I_OK) break;
+            for (;;) {
+                bits = za_peek(in, bitpos);
+                uint32_t e = za_decode_sym(bits, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
+                if (!e) { status = (bitpos + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
+                int sym = (int)(e >> 4);
+                uint32_t used = e & 15u;
+                if (bitpos + used > in_bits) { status = ZA_I_INPUT; break; }
+                if (sym < 256) {
+                    if (op >= out_cap) { status = ZA_I_OUTFULL; break; }
+                    if (lane == 0) { win[op & (ZA_WIN - 1)] = (uint8_t)sym; out[op] = (uint8_t)sym; }
+                    op++; bitpos += used;
+                    continue;
+                }
+                if (sym == 256) { bitpos += used; break; }
+                sym -= 257;
+                if (sym >= 29) { status = ZA_I_DATA; break; }
+                int nx;
+                int len = za_len_base(sym, nx);
+                len += (int)((bits >> used) & ((1u << nx) - 1u));
+                used += (uint32_t)nx;
+                e = za_decode_sym(bits >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
+                if (!e) { status = (bitpos + used + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
+                const int ds = (int)(e >> 4);
+                used += e & 15u;
+                if (ds >= 30) { status = ZA_I_DATA; break; }
+                int dist = za_dist_base(ds, nx);
+                dist += (int)((bits >> used) & ((1u << nx) - 1u));
+                used += (uint32_t)nx;
+                if (bitpos + used > in_bits) { status = ZA_I_INPUT; break; }
+                if ((uint64_t)dist > op + dict_len) { status = ZA_I_DATA; break; }
+                bool short_out = false;
+                if ((uint64_t)len > out_cap - op) { len = (int)(out_cap - op); short_out = true; }
+                for (int base = 0; base < len; base += 64) {
+                    const int i = base + lane;
+                    uint8_t b = 0;
+                    if (i < len) {
+                        const int k = dist < len ? i % dist : i;
+                        b = win[(op - (uint64_t)dist + (uint64_t)k) & (ZA_WIN - 1)];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < len) { win[(op + (uint64_t)i) & (ZA_WIN - 1)] = b; out[op + (uint64_t)i] = b; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                op += (uint64_t)len;
+                if (short_out) { status = ZA_I_OUTFULL; break; }
+                bitpos += used;
+            }
+            if (status != ZA_I_OK) break;
+        }
+        if (last) { status = ZA_I_END; break; }
+    }
+    if (lane == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bitpos; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// indexed gzip members
+// ------------------------------------------------------------------------------------------------
+// Member layout written by za_k_assemble_members (all little endian):
+//   0  1f 8b 08 04 | 4 mtime=0 | 8 xfl | 9 os=ff | 10 XLEN(u16) | 12 'Z' 'A' | 14 SLEN(u16)
+//   16 member_size(u32) | 20 isize(u32) | 24 nseg(u16) | 26 version(u16)=1
+//   28 (ZA_MAX_SEGS+1) x u32 bit offsets from the first deflate byte (entry nseg = offset of EOB)
+//   28+260 = 288 deflate bytes ... | crc32(u32) | isize(u32)
+#define ZA_MEMBER_HDR   288
+#define ZA_MEMBER_XLEN  (ZA_MEMBER_HDR - 12)
+#define ZA_MEMBER_SLEN  (ZA_MEMBER_HDR - 16)
+
+struct ZaMember {          // mirrors zngamd_member
+    uint64_t in_off, in_len, out_off;
+    uint32_t out_len, crc, index_off, nseg;
+};
+
+struct ZaCand { uint64_t off; uint32_t size; uint32_t isize; };
+
+__global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restrict__ in, uint64_t in_len,
+                                                         ZaCand *__restrict__ cands, uint32_t max_cands,
+                                                         uint32_t *__restrict__ n_cands)
+{
+    // every thread owns 16 consecutive byte positions; loads are coalesced 16 B per lane
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t base = t * 16ull;
+    if (base >= in_len) return;
+    uint32_t w[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint64_t o = base + 4ull * k;
+        w[k] = (o + 4 <= in_len) ? *(const uint32_t *)(in + o) : 0u;     // in is 16-byte aligned (hipMalloc)
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int wi = k >> 2, sh = (k & 3) * 8;
+        const uint32_t v = sh ? ((w[wi] >> sh) | (w[wi + 1] << (32 - sh))) : w[wi];
+        if (v != 0x04088b1fu) continue;
+        const uint64_t o = base + (uint64_t)k;
+        if (o + ZA_MEMBER_HDR + 8 > in_len) continue;
+        const uint8_t *h = in + o;
+        if (h[9] != 0xFF || h[10] != (ZA_MEMBER_XLEN & 0xFF) || h[11] != (ZA_MEMBER_XLEN >> 8) || h[12] != 'Z' || h[13] != 'A' ||
+            h[14] != (ZA_MEMBER_SLEN & 0xFF) || h[15] != (ZA_MEMBER_SLEN >> 8) || h[26] != 1 || h[27] != 0) continue;
+        const uint32_t size = za_ld32(h + 16), isize = za_ld32(h + 20);
+        if (size < ZA_MEMBER_HDR + 8 || o + size > in_len) continue;
+        const uint32_t idx = atomicAdd(n_cands, 1u);
+        if (idx < max_cands) { ZaCand c; c.off = o; c.size = size; c.isize = isize; cands[idx] = c; }
+    }
+}
+
+#define ZA_MATCHQ_PER_SEG 688      // >= 2048/3 matches per segment
+
+__global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                           const ZaMember *__restrict__ members,
+                                                           uint8_t *__restrict__ out, uint64_t out_cap,
+                                                           uint2 *__restrict__ matchq,          // [grid][64][ZA_MATCHQ_PER_SEG]
+                                                           const uint32_t *__restrict__ crc_table,
+                                                           const uint32_t *__restrict__ x8k_table,
+                                                           int32_t *__restrict__ status_out)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ int scratch[2];
+    __shared__ uint32_t crct[256];
+    __shared__ uint32_t q_excl[64], q_dst[64], q_dist[64];
+    const int lane = za_lane();
+    const ZaMember m = members[blockIdx.x];
+    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
+    __syncthreads();
+    int status = ZA_I_OK;
+    const uint8_t *src = in + m.in_off;
+    const uint64_t in_bits = m.in_len * 8ull;
+    uint8_t *dst = out + m.out_off;
+    const int n = (int)m.out_len;
+    const int nseg = (int)m.nseg;
+    if (m.in_off + m.in_len + 8 > in_total || m.out_off + m.out_len > out_cap || n > ZA_MAX_UNIT ||
+        nseg != ((n + ZA_SEG - 1) >> ZA_SEG_SHIFT) || m.index_off == 0 || m.index_off > m.in_off || n == 0) {
+        if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX;
+        return;
+    }
+    const uint32_t *index = (const uint32_t *)(src - m.index_off);      // member starts are byte aligned only: unaligned loads
+    uint32_t my_start = za_ld32((const uint8_t *)(index + (lane < nseg ? lane : nseg)));
+    uint32_t my_stop = za_ld32((const uint8_t *)(index + (lane < nseg ? lane + 1 : nseg)));
+    // block header (uniform)
+    uint64_t bitpos = 0;
+    if (in_bits < 3) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+    uint64_t bits = za_peek(src, 0);
+    const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
+    bitpos = 3;
+    if (!last || type == 0 || type == 3) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+    status = za_read_tables(src, in_bits, bitpos, type, T, scratch);
+    if (status != ZA_I_OK) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+    const uint32_t first_start = __shfl(my_start, 0, 64);
+    if ((uint64_t)first_start != bitpos) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+
+    // ---- phase A: every lane decodes its own segment
+    uint2 *myq = matchq + ((size_t)blockIdx.x * 64 + (size_t)lane) * ZA_MATCHQ_PER_SEG;
+    uint32_t nmatch = 0;
+    int lane_err = 0;      // 0 ok, 1 index mismatch, 2 data error
+    if (lane < nseg) {
+        int pos = lane << ZA_SEG_SHIFT;
+        int end = pos + ZA_SEG; if (end > n) end = n;
+        uint64_t bp = my_start;
+        if (bp > in_bits || my_stop > in_bits || my_stop < my_start) lane_err = 1;
+        while (!lane_err && pos < end) {
+            if (bp > in_bits) { lane_err = 1; break; }
+            const uint64_t b = za_peek(src, bp);
+            uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
+            if (!e) { lane_err = 2; break; }
+            int sym = (int)(e >> 4);
+            uint32_t used = e & 15u;
+            if (sym < 256) { dst[pos++] = (uint8_t)sym; bp += used; continue; }
+            if (sym == 256) { lane_err = 1; break; }
+            sym -= 257;
+            if (sym >= 29) { lane_err = 2; break; }
+            int nx;
+            int len = za_len_base(sym, nx);
+            len += (int)((b >> used) & ((1u << nx) - 1u));
+            used += (uint32_t)nx;
+            e = za_decode_sym(b >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
+            if (!e) { lane_err = 2; break; }
+            const int ds = (int)(e >> 4);
+            used += e & 15u;
+            if (ds >= 30) { lane_err = 2; break; }
+            int dist = za_dist_base(ds, nx);
+            dist += (int)((b >> used) & ((1u << nx) - 1u));
+            used += (uint32_t)nx;
+            if (dist > pos) { lane_err = 2; break; }
+            if (pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG) { lane_err = 1; break; }
+            myq[nmatch++] = make_uint2((uint32_t)pos | ((uint32_t)len << 17), (uint32_t)dist);
+            pos += len; bp += used;
+        }
+        if (!lane_err && bp != my_stop) lane_err = 1;
+        if (!lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
+            const uint64_t b = za_peek(src, bp);   // bp == my_stop <= in_bits
+            const uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
+            if (!e || (e >> 4) != 256u) lane_err = 1;
+            else if (((bp + (e & 15u) + 7ull) >> 3) != m.in_len) lane_err = 1;
+        }
+    }
+    const unsigned long long e1 = __ballot(lane_err == 1), e2 = __ballot(lane_err == 2);
+    if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
+    __threadfence_block();       // literals and the match queues are visible to the whole wave
+
+    // ---- phase B: resolve matches in output order, 64 at a time, byte-parallel
+    for (int s = 0; s < nseg; s++) {
+        const uint32_t cnt = __shfl(nmatch, s, 64);
+        const uint2 *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
+        for (uint32_t g = 0; g < cnt; g += 64) {
+            const bool has = g + (uint32_t)lane < cnt;
+            uint2 mm = make_uint2(0, 1);
+            if (has) mm = q[g + lane];
+            const uint32_t mdst = mm.x & 0x1FFFFu, mlen = mm.x >> 17, mdist = mm.y;
+            bool done = !has;
+            unsigned long long pending = __ballot(!done);
+            while (pending) {
+                const int lowest = __builtin_ctzll(pending);
+                const uint32_t frontier = __shfl(mdst, lowest, 64);
+                const uint32_t srcend = mdst - mdist + (mlen < mdist ? mlen : mdist);
+                const bool ready = !done && (srcend <= frontier || lane == lowest);
+                const uint32_t rlen = ready ? mlen : 0u;
+                const uint32_t incl = za_wave_incl_scan(rlen);
+                const uint32_t total = __shfl(incl, 63, 64);
+                __builtin_amdgcn_wave_barrier();
+                q_excl[lane] = incl - rlen; q_dst[lane] = mdst; q_dist[lane] = mdist;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = (uint32_t)lane; j < total; j += 64) {
+                    // largest k with q_excl[k] <= j
+                    int k = 0;
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) if (q_excl[k + step] <= j) k += step;
+                    const uint32_t i = j - q_excl[k], d = q_dist[k], o = q_dst[k];
+                    dst[o + i] = dst[o - d + (i < d ? i : i % d)];
+                }
+                __threadfence_block();
+                done = done || ready;
+                pending = __ballot(!done);
+            }
+        }
+    }
+    // ---- verify
+    // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
+    const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
+    const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
+    if (lane == 0) status_out[blockIdx.x] = (c != want_crc) ? ZA_I_CRC : (want_len != (uint32_t)n) ? ZA_I_LENGTH : ZA_I_OK;
+}
+
+// One workgroup per member: header with the segment index, deflate bytes from the unit slot, trailer.
+__global__ __launch_bounds__(256) void za_k_assemble_members(const uint8_t *__restrict__ slots, uint32_t slot_stride,
+                                                             const uint32_t *__restrict__ unit_len,
+                                                             const uint32_t *__restrict__ unit_crc,
+                                                             const uint32_t *__restrict__ segbits_ws,
+                                                             const ZaUnit *__restrict__ units,
+                                                             const uint64_t *__restrict__ member_off,   // offsets with +296 per member
+                                                             uint8_t *__restrict__ dst, uint8_t xfl)
+{
+    const uint32_t u = blockIdx.x;
+    const uint32_t dlen = unit_len[u];
+    const uint32_t n = units[u].in_len;
+    const uint32_t nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    uint8_t *d = dst + member_off[u];
+    const uint32_t size = ZA_MEMBER_HDR + dlen + 8;
+    const uint32_t *sb = segbits_ws + (size_t)u * ZA_SEGB_STRIDE;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < ZA_MEMBER_HDR; i += blockDim.x) {
+        uint8_t b = 0;
+        switch (i) {
+        case 0: b = 0x1f; break; case 1: b = 0x8b; break; case 2: b = 8; break; case 3: b = 4; break;
+        case 8: b = xfl; break; case 9: b = 0xff; break;
+        case 10: b = ZA_MEMBER_XLEN & 0xFF; break; case 11: b = ZA_MEMBER_XLEN >> 8; break;
+        case 12: b = 'Z'; break; case 13: b = 'A'; break;
+        case 14: b = ZA_MEMBER_SLEN & 0xFF; break; case 15: b = ZA_MEMBER_SLEN >> 8; break;
+        case 24: b = (uint8_t)(nseg & 0xFF); break; case 25: b = (uint8_t)(nseg >> 8); break;
+        case 26: b = 1; break;
+        default:
+            if (i >= 16 && i < 20) b = (uint8_t)(size >> (8 * (i - 16)));
+            else if (i >= 20 && i < 24) b = (uint8_t)(n >> (8 * (i - 20)));
+            else if (i >= 28) {
+                const uint32_t k = (i - 28) >> 2;                       // 0..64
+                const uint32_t v = sb[k < nseg ? k : ZA_MAX_SEGS];      // entries >= nseg hold the EOB offset
+                b = (uint8_t)(v >> (8 * ((i - 28) & 3)));
+            }
+        }
+        d[i] = b;
+    }
+    const uint8_t *src = slots + (size_t)u * slot_stride;
+    uint8_t *p = d + ZA_MEMBER_HDR;
+    for (uint32_t i = tid; i < dlen; i += blockDim.x) p[i] = src[i];
+    if (tid < 8) {
+        const uint32_t v = tid < 4 ? unit_crc[u] : n;
+        p[dlen + tid] = (uint8_t)(v >> (8 * (tid & 3)));
+    }
+}
+
+// byte-wise equality of two device buffers (used by the round-trip checks of bench.py / smoke)
+__global__ __launch_bounds__(256) void za_k_compare(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint64_t n,
+                                                    unsigned long long *__restrict__ mismatches)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16ull;
+    unsigned long long bad = 0;
+    for (uint64_t o = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16ull; o < n; o += stride) {
+        if (o + 16 <= n) {
+            const uint4 x = *(const uint4 *)(a + o), y = *(const uint4 *)(b + o);
+            bad += (x.x != y.x) + (x.y != y.y) + (x.z != y.z) + (x.w != y.w);
+        } else for (uint64_t i = o; i < n; i++) bad += a[i] != b[i];
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}

@@ -1,0 +1,844 @@
+// libzng_amd.so -- host side of the C ABI declared in include/zng_amd.h.  Product code.
+// One translation unit: the kernel files are included so that no relocatable device code is needed.
+//
+// Nothing in this library computes a checksum, a match, a Huffman code or a decoded byte on the
+// CPU: the host code cuts blocks into units, owns device workspaces and streams, launches the
+// kernels and assembles container framing bytes (gzip / zlib headers and trailers).
+#include "za_deflate.hip"
+#include "za_inflate.hip"
+#include "za_checksum.hip"
+#include "../../include/zng_amd.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(zngamd_member) == sizeof(ZaMember), "member layout");
+static_assert(ZNGAMD_SLOT_STRIDE % 4 == 0 && ZNGAMD_SLOT_STRIDE >= ZA_MAX_UNIT + 32, "slot stride");
+static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants");
+
+static const ZaLevel ZA_LEVELS[10] = {
+    {0, 0, 0}, {4, 8, 0}, {8, 16, 0}, {32, 32, 0}, {16, 16, 4}, {32, 32, 16},
+    {128, 128, 16}, {256, 128, 32}, {1024, 258, 128}, {4096, 258, 258}};
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) { want = n; e = hipMalloc((void **)&p, want * sizeof(T)); }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct EvPair { hipEvent_t a, b; int cls; };
+
+struct zngamd_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    std::mutex mu;
+    // constant tables
+    uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
+    // deflate workspaces (per chunk of units)
+    uint32_t chunk_units = 4096;
+    DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
+    // per call
+    DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, status;
+    uint32_t last_units = 0; bool last_single_chunk = false;
+    // staging
+    DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
+    DevBuf<ZaCkPart> ck; DevBuf<uint2> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
+    void *d_small = nullptr;     // 256 B scratch for counters / results
+    // profiling
+    bool prof = false; std::vector<EvPair> evs; std::vector<hipEvent_t> pool;
+    double ms[ZNGAMD_K_COUNT] = {0}; uint64_t launches[ZNGAMD_K_COUNT] = {0};
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return ZNGAMD_E_HIP; } } while (0)
+
+static int fail(zngamd_ctx *c, int code, const char *msg) { c->err = msg; return code; }
+
+static hipEvent_t ev_get(zngamd_ctx *c)
+{
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    zngamd_ctx *c; int cls; hipEvent_t a = nullptr;
+    ProfScope(zngamd_ctx *c_, int cls_) : c(c_), cls(cls_) { if (c->prof) { a = ev_get(c); (void)hipEventRecord(a, c->stream); } }
+    ~ProfScope() { if (c->prof) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream); c->evs.push_back({a, b, cls}); } }
+};
+static void prof_collect(zngamd_ctx *c)
+{
+    for (auto &e : c->evs) {
+        float t = 0; (void)hipEventSynchronize(e.b);
+        if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) { c->ms[e.cls] += t; c->launches[e.cls]++; }
+        c->pool.push_back(e.a); c->pool.push_back(e.b);
+    }
+    c->evs.clear();
+}
+
+extern "C" {
+
+const char *zngamd_version(void) { return "zng_amd 0.1 (gfx950)"; }
+
+int zngamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int zngamd_ctx_create(int device, zngamd_ctx **out)
+{
+    if (!out) return ZNGAMD_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ZNGAMD_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return ZNGAMD_E_HIP;
+    zngamd_ctx *c = new zngamd_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZNGAMD_E_HIP; }
+    c->stream = c->own_stream;
+    if (const char *e = getenv("ZNGAMD_CHUNK_UNITS")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chunk_units = (uint32_t)v; }
+    // tables: CRC-32 byte table and x^(8*2048*k) mod P
+    uint32_t tab[256], x8k[64];
+    for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); tab[i] = v; }
+    {
+        uint32_t xs = 0x80000000u, sq = 0x00800000u;      // x^(8*2048): square x^8 eleven times
+        for (int i = 0; i < 11; i++) sq = za_multmodp(sq, sq);
+        for (int k = 0; k < 64; k++) { x8k[k] = xs; xs = za_multmodp(xs, sq); }
+    }
+    if (hipMalloc((void **)&c->d_crc_table, sizeof tab) != hipSuccess || hipMalloc((void **)&c->d_x8k, sizeof x8k) != hipSuccess ||
+        hipMalloc(&c->d_small, 256) != hipSuccess ||
+        hipMemcpy(c->d_crc_table, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_x8k, x8k, sizeof x8k, hipMemcpyHostToDevice) != hipSuccess) {
+        zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
+    }
+    *out = c;
+    return ZNGAMD_OK;
+}
+
+void zngamd_ctx_destroy(zngamd_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    c->prev.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
+    c->plan.release(); c->units.release(); c->segbits.release(); c->status.release();
+    c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
+    c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
+    if (c->d_crc_table) (void)hipFree(c->d_crc_table);
+    if (c->d_x8k) (void)hipFree(c->d_x8k);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *zngamd_last_error(zngamd_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int zngamd_set_stream(zngamd_ctx *c, void *s)
+{
+    if (!c) return ZNGAMD_E_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return ZNGAMD_OK;
+}
+
+int zngamd_sync(zngamd_ctx *c)
+{
+    if (!c) return ZNGAMD_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZNGAMD_OK;
+}
+
+int zngamd_dmalloc(zngamd_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return ZNGAMD_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(dptr, bytes ? bytes : 1));
+    return ZNGAMD_OK;
+}
+int zngamd_dfree(zngamd_ctx *c, void *dptr) { if (!c) return ZNGAMD_E_ARG; HIPCHK(c, hipFree(dptr)); return ZNGAMD_OK; }
+int zngamd_h2d(zngamd_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return ZNGAMD_E_ARG;
+    if (bytes) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    return ZNGAMD_OK;
+}
+int zngamd_d2h(zngamd_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return ZNGAMD_E_ARG;
+    if (bytes) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    return ZNGAMD_OK;
+}
+
+int zngamd_profiling(zngamd_ctx *c, int on) { if (!c) return ZNGAMD_E_ARG; c->prof = on != 0; return ZNGAMD_OK; }
+int zngamd_kernel_times(zngamd_ctx *c, double *ms, uint64_t *launches, int reset)
+{
+    if (!c) return ZNGAMD_E_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (int i = 0; i < ZNGAMD_K_COUNT; i++) { if (ms) ms[i] = c->ms[i]; if (launches) launches[i] = c->launches[i]; if (reset) { c->ms[i] = 0; c->launches[i] = 0; } }
+    return ZNGAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// checksums
+// ---------------------------------------------------------------------------------------------
+uint32_t zngamd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    uint32_t p = 0x80000000u, sq = 0x00800000u;
+    while (len2) { if (len2 & 1) p = za_multmodp(sq, p); sq = za_multmodp(sq, sq); len2 >>= 1; }
+    return za_multmodp(p, crc1) ^ crc2;
+}
+
+// run the checksum kernel over a device buffer and fold the per-span partials
+static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *crc_io, uint32_t *adler_io)
+{
+    if (n == 0) return ZNGAMD_OK;
+    const uint64_t nspan = (n + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT;
+    if (nspan > 0x7FFFFFFFull) return fail(c, ZNGAMD_E_ARG, "buffer too large");
+    HIPCHK(c, c->ck.ensure(nspan));
+    {
+        ProfScope ps(c, ZNGAMD_K_OTHER);
+        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(64), 0, c->stream, d, n, c->d_crc_table, c->d_x8k, c->ck.p, adler_io ? 1 : 0);
+    }
+    HIPCHK(c, hipGetLastError());
+    std::vector<ZaCkPart> parts(nspan);
+    HIPCHK(c, hipMemcpyAsync(parts.data(), c->ck.p, nspan * sizeof(ZaCkPart), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (crc_io) {
+        // all spans but the last are ZA_MAX_UNIT long: one multiplier serves them
+        uint32_t crc = *crc_io;
+        for (uint64_t i = 0; i < nspan; i++) crc = zngamd_crc32_combine(crc, parts[i].crc, parts[i].len);
+        *crc_io = crc;
+    }
+    if (adler_io) {
+        uint64_t A = *adler_io & 0xFFFF, B = (*adler_io >> 16) & 0xFFFF;
+        for (uint64_t i = 0; i < nspan; i++) {
+            B = (B + (uint64_t)(parts[i].len % 65521u) * A + parts[i].b) % 65521u;
+            A = (A + parts[i].a) % 65521u;
+        }
+        *adler_io = (uint32_t)((B << 16) | A);
+    }
+    return ZNGAMD_OK;
+}
+
+static int stage_in(zngamd_ctx *c, const uint8_t *in, uint64_t n, uint64_t pad_front = 0)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->st_in.ensure(pad_front + n + 64));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->st_in.p + pad_front, in, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->st_in.p + pad_front + n, 0, 64, c->stream));
+    return ZNGAMD_OK;
+}
+
+int zngamd_crc32_dev(zngamd_ctx *c, uint32_t crc, const void *dbuf, size_t len, uint32_t *out)
+{
+    if (!c || !out) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t v = crc;
+    int r = checksum_dev(c, (const uint8_t *)dbuf, len, &v, nullptr);
+    *out = v;
+    return r;
+}
+int zngamd_crc32(zngamd_ctx *c, uint32_t crc, const uint8_t *buf, size_t len, uint32_t *out)
+{
+    if (!c || !out || (!buf && len)) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    int r = stage_in(c, buf, len);
+    if (r) return r;
+    uint32_t v = crc;
+    r = checksum_dev(c, c->st_in.p, len, &v, nullptr);
+    *out = v;
+    return r;
+}
+int zngamd_adler32(zngamd_ctx *c, uint32_t adler, const uint8_t *buf, size_t len, uint32_t *out)
+{
+    if (!c || !out || (!buf && len)) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    int r = stage_in(c, buf, len);
+    if (r) return r;
+    uint32_t v = adler;
+    r = checksum_dev(c, c->st_in.p, len, nullptr, &v);
+    *out = v;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deflate
+// ---------------------------------------------------------------------------------------------
+int zngamd_level_ok(int level) { return level >= -1 && level <= 9; }
+
+static uint32_t units_of(const zngamd_block &b) { return b.len == 0 ? 1u : (uint32_t)(((uint64_t)b.len + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT); }
+
+uint32_t zngamd_count_units(const zngamd_block *blocks, uint32_t n_blocks)
+{
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < n_blocks; i++) t += units_of(blocks[i]);
+    return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blocks, uint64_t in_len, std::vector<ZaUnit> &hu)
+{
+    hu.clear();
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const zngamd_block &B = blocks[b];
+        if (B.dict_len > ZA_WIN || B.dict_len > B.off || B.off + B.len > in_len) return fail(c, ZNGAMD_E_ARG, "block outside the input buffer");
+        const uint32_t nu = units_of(B);
+        for (uint32_t k = 0; k < nu; k++) {
+            ZaUnit u;
+            const uint64_t rel = (uint64_t)k * ZA_MAX_UNIT;
+            u.in_off = B.off + rel;
+            u.in_len = (uint32_t)std::min<uint64_t>(ZA_MAX_UNIT, B.len - rel);
+            u.dict_len = (uint32_t)std::min<uint64_t>(ZA_WIN, (uint64_t)B.dict_len + rel);
+            u.flags = (k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u;
+            u.block = b;
+            hu.push_back(u);
+        }
+    }
+    return ZNGAMD_OK;
+}
+
+// launch the five deflate kernels over all units (in chunks that bound the workspace)
+static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const std::vector<ZaUnit> &hu, int level,
+                             uint8_t *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc)
+{
+    if (level == -1) level = 6;
+    if (level < 0 || level > 9) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    const uint32_t n = (uint32_t)hu.size();
+    if (n == 0) return ZNGAMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t ch = std::min(n, c->chunk_units);
+    HIPCHK(c, c->units.ensure(n)); HIPCHK(c, c->segbits.ensure((size_t)n * ZA_SEGB_STRIDE)); HIPCHK(c, c->status.ensure(n));
+    if (level > 0) {
+        HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
+        HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
+    }
+    HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
+    HIPCHK(c, c->codes.ensure((size_t)ch * ZA_CODE_STRIDE)); HIPCHK(c, c->plan.ensure(ch));
+    HIPCHK(c, hipMemcpyAsync(c->units.p, hu.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_slots, 0, (size_t)n * ZNGAMD_SLOT_STRIDE, c->stream));
+    const ZaLevel L = ZA_LEVELS[level];
+    for (uint32_t c0 = 0; c0 < n; c0 += ch) {
+        const uint32_t m = std::min(ch, n - c0);
+        const ZaUnit *du = c->units.p + c0;
+        if (level > 0) {
+            { ProfScope ps(c, ZNGAMD_K_CHAINS);
+              hipLaunchKernelGGL(za_k_chains, dim3(m), dim3(64), 0, c->stream, d_in, du, c->prev.p); }
+            { ProfScope ps(c, ZNGAMD_K_SEARCH);
+              hipLaunchKernelGGL(za_k_search, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L); }
+        }
+        { ProfScope ps(c, ZNGAMD_K_PARSE);
+          hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, d_in, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
+                             d_unit_crc + c0, c->d_crc_table, c->d_x8k, L, level); }
+        { ProfScope ps(c, ZNGAMD_K_PLAN);
+          hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
+                             d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE, (uint32_t)ZNGAMD_SLOT_STRIDE, level); }
+        { ProfScope ps(c, ZNGAMD_K_PACK);
+          hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok.p, c->segtok.p, c->codes.p, c->plan.p,
+                             c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE,
+                             (uint32_t)ZNGAMD_SLOT_STRIDE, d_unit_len + c0, c->status.p + c0); }
+        HIPCHK(c, hipGetLastError());
+    }
+    c->last_units = n; c->last_single_chunk = (n <= ch);
+    return ZNGAMD_OK;
+}
+
+int zngamd_deflate_blocks_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                              int level, void *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc, uint32_t *h_unit_block)
+{
+    if (!c || (!blocks && n_blocks) || !d_slots || !d_unit_len || !d_unit_crc) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    std::vector<ZaUnit> hu;
+    int r = build_units(c, blocks, n_blocks, in_len, hu);
+    if (r) return r;
+    if (h_unit_block) for (size_t i = 0; i < hu.size(); i++) h_unit_block[i] = hu[i].block;
+    r = deflate_units_dev(c, (const uint8_t *)d_in, in_len, hu, level, (uint8_t *)d_slots, d_unit_len, d_unit_crc);
+    if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZNGAMD_OK;
+}
+
+static int gather_dev(zngamd_ctx *c, const uint8_t *d_slots, const uint32_t *d_unit_len, uint32_t n, uint32_t extra,
+                      uint8_t *d_dst, uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off, uint64_t *total, bool do_copy)
+{
+    if (n == 0) { *total = 0; return ZNGAMD_OK; }
+    uint64_t *offs = d_unit_off;
+    if (!offs) { HIPCHK(c, c->st_off.ensure(n)); offs = c->st_off.p; }
+    uint64_t *d_total = (uint64_t *)c->d_small;
+    { ProfScope ps(c, ZNGAMD_K_GATHER);
+      hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(1024), 0, c->stream, d_unit_len, n, extra, dst_base, offs, d_total); }
+    HIPCHK(c, hipMemcpyAsync(total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dst_base + *total > dst_cap) return fail(c, ZNGAMD_BUF_ERROR, "destination too small");
+    if (do_copy) {
+        ProfScope ps(c, ZNGAMD_K_GATHER);
+        hipLaunchKernelGGL(za_k_gather, dim3(n), dim3(256), 0, c->stream, d_slots, (uint32_t)ZNGAMD_SLOT_STRIDE, d_unit_len, offs, d_dst);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ZNGAMD_OK;
+}
+
+int zngamd_gather_dev(zngamd_ctx *c, const void *d_slots, const uint32_t *d_unit_len, uint32_t n_units, void *d_dst,
+                      uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off, uint64_t *total_bytes)
+{
+    if (!c || !d_slots || !d_unit_len || !d_dst || !total_bytes) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = gather_dev(c, (const uint8_t *)d_slots, d_unit_len, n_units, 0, (uint8_t *)d_dst, dst_base, dst_cap, d_unit_off, total_bytes, true);
+    if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZNGAMD_OK;
+}
+
+// shared by the two host-buffer entry points: input already staged at st_in.p
+static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks, int level,
+                               std::vector<ZaUnit> &hu, std::vector<uint32_t> &ulen, std::vector<uint32_t> &ucrc,
+                               std::vector<uint8_t> &packed)
+{
+    int r = build_units(c, blocks, n_blocks, in_len, hu);
+    if (r) return r;
+    const uint32_t n = (uint32_t)hu.size();
+    HIPCHK(c, c->st_slots.ensure((size_t)n * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(n)); HIPCHK(c, c->st_crc.ensure(n));
+    r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p);
+    if (r) return r;
+    // upper bound of the packed size without a round trip: every unit fits its slot
+    HIPCHK(c, c->st_out.ensure((size_t)n * ZNGAMD_SLOT_STRIDE));
+    uint64_t total = 0;
+    r = gather_dev(c, c->st_slots.p, c->st_len.p, n, 0, c->st_out.p, 0, (uint64_t)n * ZNGAMD_SLOT_STRIDE, nullptr, &total, true);
+    if (r) return r;
+    ulen.resize(n); ucrc.resize(n); packed.resize(total);
+    std::vector<uint32_t> st(n);
+    HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
+    if (total) HIPCHK(c, hipMemcpyAsync(packed.data(), c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_OVERFLOW, "unit overflowed its slot");
+    return ZNGAMD_OK;
+}
+
+int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                          int level, uint8_t *out, uint64_t out_cap_per_block, uint32_t *out_len, uint32_t *crc)
+{
+    if (!c || (!in && in_len) || (!blocks && n_blocks) || !out || !out_len || !crc) return ZNGAMD_E_ARG;
+    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    std::lock_guard<std::mutex> g(c->mu);
+    int r = stage_in(c, in, in_len);
+    if (r) return r;
+    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
+    r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, packed);
+    if (r) return r;
+    int ret = ZNGAMD_OK;
+    size_t pos = 0, u = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        uint64_t tot = 0; uint32_t bc = 0; size_t start = pos;
+        bool first = true;
+        for (; u < hu.size() && hu[u].block == b; u++) {
+            tot += ulen[u]; pos += ulen[u];
+            bc = first ? ucrc[u] : zngamd_crc32_combine(bc, ucrc[u], hu[u].in_len);
+            first = false;
+        }
+        crc[b] = bc;
+        if (tot >= out_cap_per_block) { out_len[b] = 0xFFFFFFFFu; ret = ZNGAMD_E_OVERFLOW; continue; }
+        memcpy(out + (size_t)b * out_cap_per_block, packed.data() + start, tot);
+        out_len[b] = (uint32_t)tot;
+    }
+    if (ret) c->err = "Compressed output exceeds buffer size";
+    return ret;
+}
+
+int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int level, uint8_t *out, uint64_t out_cap,
+                          uint64_t *out_len, uint32_t *crc, uint32_t *adler)
+{
+    if (!c || (!in && in_len) || !out || !out_len) return ZNGAMD_E_ARG;
+    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    if (in_len > 0xFFFFFFFFull) return fail(c, ZNGAMD_E_ARG, "one-shot input limited to 4 GiB - 1");
+    std::lock_guard<std::mutex> g(c->mu);
+    int r = stage_in(c, in, in_len);
+    if (r) return r;
+    zngamd_block B; B.off = 0; B.len = (uint32_t)in_len; B.dict_len = 0; B.flags = ZNGAMD_FLAG_FINAL; B.reserved = 0;
+    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
+    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, packed);
+    if (r) return r;
+    *out_len = packed.size();
+    if (packed.size() > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small");
+    memcpy(out, packed.data(), packed.size());
+    if (crc) { uint32_t v = 0; for (size_t u = 0; u < hu.size(); u++) v = u ? zngamd_crc32_combine(v, ucrc[u], hu[u].in_len) : ucrc[u]; *crc = v; }
+    if (adler) { uint32_t a = 1; r = checksum_dev(c, c->st_in.p, in_len, nullptr, &a); if (r) return r; *adler = a; }
+    return ZNGAMD_OK;
+}
+
+int zngamd_debug_fetch(zngamd_ctx *c, int what, uint32_t unit, void *dst, size_t bytes)
+{
+    if (!c || !dst) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (unit >= c->last_units || !c->last_single_chunk) return fail(c, ZNGAMD_E_ARG, "unit not resident");
+    const void *src = nullptr; size_t lim = 0;
+    switch (what) {
+    case 0: src = c->prev.p + (size_t)unit * ZA_PREV_STRIDE; lim = ZA_PREV_STRIDE * 2ull; break;
+    case 1: src = c->best.p + (size_t)unit * ZA_BEST_STRIDE; lim = ZA_BEST_STRIDE * 4ull; break;
+    case 2: src = c->tok.p + (size_t)unit * ZA_TOK_STRIDE; lim = ZA_TOK_STRIDE * 4ull; break;
+    case 3: src = c->segtok.p + (size_t)unit * ZA_MAX_SEGS; lim = ZA_MAX_SEGS * 4ull; break;
+    case 4: src = c->hist.p + (size_t)unit * ZA_HIST_STRIDE; lim = ZA_HIST_STRIDE * 4ull; break;
+    case 5: src = c->codes.p + (size_t)unit * ZA_CODE_STRIDE; lim = ZA_CODE_STRIDE * 4ull; break;
+    case 6: src = c->segbits.p + (size_t)unit * ZA_SEGB_STRIDE; lim = ZA_SEGB_STRIDE * 4ull; break;
+    case 7: src = c->plan.p + unit; lim = sizeof(ZaPlan); break;
+    default: return fail(c, ZNGAMD_E_ARG, "unknown stage");
+    }
+    if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ZNGAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inflate
+// ---------------------------------------------------------------------------------------------
+static int map_status(int s)
+{
+    switch (s) {
+    case ZA_I_OK: return ZNGAMD_OK;
+    case ZA_I_END: return ZNGAMD_STREAM_END;
+    case ZA_I_DATA: return ZNGAMD_DATA_ERROR;
+    case ZA_I_INPUT: case ZA_I_OUTFULL: return ZNGAMD_BUF_ERROR;
+    case ZA_I_CRC: return ZNGAMD_E_GZ_CRC;
+    case ZA_I_LENGTH: return ZNGAMD_E_GZ_LENGTH;
+    default: return ZNGAMD_DATA_ERROR;
+    }
+}
+
+// sequential decode of one raw stream that already sits (padded) on the device
+static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const uint8_t *d_dict, uint32_t dict_len,
+                              uint8_t *d_out, uint64_t out_cap, ZaInfResult *hres)
+{
+    ZaInfResult *dres = (ZaInfResult *)((uint8_t *)c->d_small + 64);
+    { ProfScope ps(c, ZNGAMD_K_INFLATE);
+      hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, d_in, in_len, d_dict, dict_len, d_out, out_cap, dres); }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hres, dres, sizeof(ZaInfResult), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZNGAMD_OK;
+}
+
+int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len,
+                       uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used, uint32_t *crc, uint32_t *adler)
+{
+    if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (dict_len > ZA_WIN) { dict += dict_len - ZA_WIN; dict_len = ZA_WIN; }
+    // staging layout: [dictionary, padded to 64][stream][64 zero bytes]
+    const uint64_t front = (dict_len + 63u) & ~63ull;
+    int r = stage_in(c, in, in_len, front);
+    if (r) return r;
+    if (dict_len) HIPCHK(c, hipMemcpyAsync(c->st_in.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->st_out.ensure(out_cap + 64));
+    ZaInfResult res;
+    r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res);
+    if (r) return r;
+    *out_len = res.out_len;
+    if (in_used) *in_used = (res.in_bits + 7) >> 3;
+    if (res.out_len) HIPCHK(c, hipMemcpyAsync(out, c->st_out.p, res.out_len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (crc || adler) {
+        uint32_t cv = 0, av = 1;
+        r = checksum_dev(c, c->st_out.p, res.out_len, crc ? &cv : nullptr, adler ? &av : nullptr);
+        if (r) return r;
+        if (crc) *crc = cv;
+        if (adler) *adler = av;
+    }
+    if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
+    return map_status(res.status);
+}
+
+// ---- two-pass reader for indexed members -----------------------------------------------------
+static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out)
+{
+    hm.clear(); *total_out = 0;
+    if (in_len < ZA_MEMBER_HDR + 8) return ZNGAMD_E_ARG;
+    const uint32_t max_c = (uint32_t)std::min<uint64_t>(in_len / (ZA_MEMBER_HDR + 8) + 1, 1u << 26);
+    HIPCHK(c, c->cands.ensure(max_c));
+    uint32_t *d_n = (uint32_t *)((uint8_t *)c->d_small + 128);
+    HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
+    const uint64_t threads = (in_len + 15) / 16;
+    { ProfScope ps(c, ZNGAMD_K_SCAN);
+      hipLaunchKernelGGL(za_k_scan_members, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, d_in, in_len, c->cands.p, max_c, d_n); }
+    HIPCHK(c, hipGetLastError());
+    uint32_t n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n == 0 || n > max_c) return ZNGAMD_E_ARG;
+    std::vector<ZaCand> hc(n);
+    HIPCHK(c, hipMemcpy(hc.data(), c->cands.p, (size_t)n * sizeof(ZaCand), hipMemcpyDeviceToHost));
+    std::sort(hc.begin(), hc.end(), [](const ZaCand &a, const ZaCand &b) { return a.off < b.off; });
+    // keep the chain that starts at offset 0 and tiles the stream exactly (signature hits inside
+    // compressed data are skipped because nothing points at them)
+    uint64_t pos = 0, outp = 0;
+    size_t i = 0;
+    while (pos < in_len) {
+        while (i < hc.size() && hc[i].off < pos) i++;
+        if (i == hc.size() || hc[i].off != pos) return ZNGAMD_E_ARG;
+        ZaMember m;
+        m.in_off = pos + ZA_MEMBER_HDR; m.in_len = hc[i].size - ZA_MEMBER_HDR - 8; m.out_off = outp;
+        m.out_len = hc[i].isize; m.crc = 0; m.index_off = ZA_MEMBER_HDR - 28; m.nseg = (hc[i].isize + ZA_SEG - 1) / ZA_SEG;
+        hm.push_back(m);
+        pos += hc[i].size; outp += hc[i].isize;
+    }
+    if (pos != in_len) return ZNGAMD_E_ARG;
+    *total_out = outp;
+    return ZNGAMD_OK;
+}
+
+int zngamd_gzip_scan_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, zngamd_member *d_members, uint32_t max_members,
+                         uint32_t *n_members, uint64_t *total_out)
+{
+    if (!c || !d_in || !d_members || !n_members || !total_out) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<ZaMember> hm;
+    int r = scan_members_dev(c, (const uint8_t *)d_in, in_len, hm, total_out);
+    prof_collect(c);
+    if (r) return fail(c, r, "stream is not made of indexed members");
+    if (hm.size() > max_members) return fail(c, ZNGAMD_BUF_ERROR, "member table too small");
+    *n_members = (uint32_t)hm.size();
+    HIPCHK(c, hipMemcpy(d_members, hm.data(), hm.size() * sizeof(ZaMember), hipMemcpyHostToDevice));
+    return ZNGAMD_OK;
+}
+
+static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const ZaMember *d_members, uint32_t n,
+                               uint8_t *d_out, uint64_t out_cap, int32_t *d_status)
+{
+    const uint32_t ch = std::min<uint32_t>(n, 8192);
+    HIPCHK(c, c->matchq.ensure((size_t)ch * 64 * ZA_MATCHQ_PER_SEG));
+    for (uint32_t c0 = 0; c0 < n; c0 += ch) {
+        const uint32_t m = std::min(ch, n - c0);
+        ProfScope ps(c, ZNGAMD_K_INFLATE);
+        hipLaunchKernelGGL(za_k_inflate_members, dim3(m), dim3(64), 0, c->stream, d_in, in_len, d_members + c0, d_out, out_cap,
+                           c->matchq.p, c->d_crc_table, c->d_x8k, d_status + c0);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ZNGAMD_OK;
+}
+
+int zngamd_gzip_inflate_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_member *d_members,
+                                    uint32_t n_members, void *d_out, uint64_t out_cap, int32_t *d_status)
+{
+    if (!c || !d_in || !d_members || !d_out || !d_status) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = inflate_members_dev(c, (const uint8_t *)d_in, in_len, (const ZaMember *)d_members, n_members, (uint8_t *)d_out, out_cap, d_status);
+    if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZNGAMD_OK;
+}
+
+// ---- general gzip reader (host buffer) --------------------------------------------------------
+// Restates the member state machine of GzipReader_read_into_buffer (zlib_ngmodule.c:2443-2611):
+// header fields, inflate, CRC / ISIZE check, NUL padding.  Header bytes are parsed on the host (they
+// are framing, not payload); every payload byte is decoded and checksummed on the GPU.
+static int parse_gzip_header(const uint8_t *in, uint64_t in_len, uint64_t pos, uint64_t *data_off, bool *za_indexed, uint32_t *hcrc_len)
+{
+    *za_indexed = false; *hcrc_len = 0;
+    if (in_len - pos < 10) return ZNGAMD_E_GZ_TRUNC;
+    if (!(in[pos] == 0x1f && in[pos + 1] == 0x8b)) return ZNGAMD_E_GZ_MAGIC;
+    if (in[pos + 2] != 8) return ZNGAMD_E_GZ_METHOD;
+    const int flags = in[pos + 3];
+    uint64_t cur = pos + 10;
+    if (flags & 4) {
+        if (cur + 2 >= in_len) return ZNGAMD_E_GZ_TRUNC;
+        const uint64_t fl = in[cur] | (in[cur + 1] << 8);
+        cur += 2;
+        if (cur + fl >= in_len) return ZNGAMD_E_GZ_TRUNC;
+        if (fl == ZA_MEMBER_XLEN && in[cur] == 'Z' && in[cur + 1] == 'A' && flags == 4) *za_indexed = true;
+        cur += fl;
+    }
+    if (flags & 8) {
+        const void *z = memchr(in + cur, 0, in_len - cur);
+        if (!z) return ZNGAMD_E_GZ_TRUNC;
+        cur = (uint64_t)((const uint8_t *)z - in) + 1;
+    }
+    if (flags & 16) {
+        const void *z = memchr(in + cur, 0, in_len - cur);
+        if (!z) return ZNGAMD_E_GZ_TRUNC;
+        cur = (uint64_t)((const uint8_t *)z - in) + 1;
+    }
+    if (flags & 2) {
+        if (cur + 2 >= in_len) return ZNGAMD_E_GZ_TRUNC;
+        *hcrc_len = (uint32_t)(cur - pos);
+        cur += 2;
+    }
+    *data_off = cur;
+    return ZNGAMD_OK;
+}
+
+int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
+{
+    if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    *out_len = 0;
+    if (n_members) *n_members = 0;
+    int r = stage_in(c, in, in_len);
+    if (r) return r;
+    HIPCHK(c, c->st_out.ensure(out_cap + 64));
+    uint64_t pos = 0, op = 0;
+    uint32_t members = 0;
+    int ret = ZNGAMD_OK;
+    // fast path: the whole stream is indexed members -> two-pass scheme
+    {
+        uint64_t doff; bool za; uint32_t hl;
+        if (in_len >= ZA_MEMBER_HDR + 8 && parse_gzip_header(in, in_len, 0, &doff, &za, &hl) == ZNGAMD_OK && za) {
+            std::vector<ZaMember> hm; uint64_t total = 0;
+            if (scan_members_dev(c, c->st_in.p, in_len, hm, &total) == ZNGAMD_OK) {
+                if (total > out_cap) { *out_len = 0; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+                HIPCHK(c, c->members.ensure(hm.size())); HIPCHK(c, c->mstatus.ensure(hm.size()));
+                HIPCHK(c, hipMemcpyAsync(c->members.p, hm.data(), hm.size() * sizeof(ZaMember), hipMemcpyHostToDevice, c->stream));
+                r = inflate_members_dev(c, c->st_in.p, in_len, c->members.p, (uint32_t)hm.size(), c->st_out.p, out_cap, c->mstatus.p);
+                if (r) return r;
+                std::vector<int32_t> st(hm.size());
+                HIPCHK(c, hipMemcpyAsync(st.data(), c->mstatus.p, st.size() * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                prof_collect(c);
+                bool all_ok = true;
+                for (size_t i = 0; i < st.size(); i++) if (st[i] != ZA_I_OK) { all_ok = false; break; }
+                if (all_ok) {
+                    if (total) HIPCHK(c, hipMemcpy(out, c->st_out.p, total, hipMemcpyDeviceToHost));
+                    *out_len = total;
+                    if (n_members) *n_members = (uint32_t)hm.size();
+                    return ZNGAMD_OK;
+                }
+                // anything unexpected (foreign 'ZA' field, stored blocks, corruption): the sequential
+                // reader below decides, member by member
+            }
+        }
+    }
+    for (;;) {
+        if (pos == in_len) break;
+        uint64_t doff = 0; bool za = false; uint32_t hl = 0;
+        r = parse_gzip_header(in, in_len, pos, &doff, &za, &hl);
+        if (r) { ret = r; break; }
+        if (hl) {
+            uint32_t hc = 0;
+            r = checksum_dev(c, c->st_in.p + pos, hl, &hc, nullptr);
+            if (r) return r;
+            const uint32_t want = in[pos + hl] | (in[pos + hl + 1] << 8);
+            if ((hc & 0xFFFFu) != want) { ret = ZNGAMD_E_GZ_HCRC; break; }
+        }
+        ZaInfResult res;
+        r = inflate_serial_dev(c, c->st_in.p + doff, in_len - doff, nullptr, 0, c->st_out.p + op, out_cap - op, &res);
+        if (r) return r;
+        if (res.status != ZA_I_END) {
+            *out_len = op + res.out_len;
+            if (res.status == ZA_I_OUTFULL) ret = ZNGAMD_BUF_ERROR;
+            else if (res.status == ZA_I_INPUT) ret = ZNGAMD_E_GZ_TRUNC;
+            else ret = map_status(res.status);
+            if (ret == ZNGAMD_BUF_ERROR || ret == ZNGAMD_E_GZ_TRUNC) {
+                if (op + res.out_len) HIPCHK(c, hipMemcpy(out, c->st_out.p, op + res.out_len, hipMemcpyDeviceToHost));
+            }
+            c->err = "gzip member did not end"; return ret;
+        }
+        uint32_t crc = 0;
+        r = checksum_dev(c, c->st_out.p + op, res.out_len, &crc, nullptr);
+        if (r) return r;
+        uint64_t cur = doff + ((res.in_bits + 7) >> 3);
+        if (in_len - cur < 8) { ret = ZNGAMD_E_GZ_TRUNC; break; }
+        const uint32_t tc = in[cur] | (in[cur + 1] << 8) | (in[cur + 2] << 16) | ((uint32_t)in[cur + 3] << 24);
+        const uint32_t tl = in[cur + 4] | (in[cur + 5] << 8) | (in[cur + 6] << 16) | ((uint32_t)in[cur + 7] << 24);
+        if (tc != crc) { ret = ZNGAMD_E_GZ_CRC; char b[96]; snprintf(b, sizeof b, "CRC check failed %u != %u", tc, crc); c->err = b; break; }
+        if (tl != (uint32_t)(res.out_len & 0xFFFFFFFFull)) { ret = ZNGAMD_E_GZ_LENGTH; c->err = "Incorrect length of data produced"; break; }
+        cur += 8; op += res.out_len; members++;
+        while (cur < in_len && in[cur] == 0) cur++;
+        pos = cur;
+    }
+    if (op) HIPCHK(c, hipMemcpy(out, c->st_out.p, op, hipMemcpyDeviceToHost));
+    *out_len = op;
+    if (n_members) *n_members = members;
+    return ret;
+}
+
+// ---- indexed member writer ---------------------------------------------------------------------
+static int gzip_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, uint32_t block_size, int level,
+                            uint8_t *d_out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
+{
+    if (block_size == 0 || block_size > ZA_MAX_UNIT) return fail(c, ZNGAMD_E_ARG, "block_size must be 1..131072");
+    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    const uint64_t nb64 = in_len == 0 ? 1 : (in_len + block_size - 1) / block_size;
+    if (nb64 > (1u << 26)) return fail(c, ZNGAMD_E_ARG, "too many members");
+    const uint32_t nb = (uint32_t)nb64;
+    std::vector<ZaUnit> hu(nb);
+    for (uint32_t b = 0; b < nb; b++) {
+        ZaUnit u; u.in_off = (uint64_t)b * block_size; u.in_len = (uint32_t)std::min<uint64_t>(block_size, in_len - u.in_off);
+        u.dict_len = 0; u.flags = ZA_FLAG_FINAL; u.block = b; hu[b] = u;
+    }
+    HIPCHK(c, c->st_slots.ensure((size_t)nb * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(nb)); HIPCHK(c, c->st_crc.ensure(nb));
+    int r = deflate_units_dev(c, d_in, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p);
+    if (r) return r;
+    HIPCHK(c, c->st_off.ensure(nb));
+    uint64_t total = 0;
+    r = gather_dev(c, c->st_slots.p, c->st_len.p, nb, ZA_MEMBER_HDR + 8, d_out, 0, out_cap, c->st_off.p, &total, false);
+    if (r) return r;
+    const int lv = level == -1 ? 6 : level;
+    const uint8_t xfl = lv == 9 ? 2 : lv == 1 ? 4 : 0;
+    { ProfScope ps(c, ZNGAMD_K_GATHER);
+      hipLaunchKernelGGL(za_k_assemble_members, dim3(nb), dim3(256), 0, c->stream, c->st_slots.p, (uint32_t)ZNGAMD_SLOT_STRIDE, c->st_len.p,
+                         c->st_crc.p, c->segbits.p, c->units.p, c->st_off.p, d_out, xfl); }
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint32_t> st(nb);
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, nb * 4ull, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    for (uint32_t i = 0; i < nb; i++) if (st[i]) return fail(c, ZNGAMD_E_OVERFLOW, "unit overflowed its slot");
+    *out_len = total;
+    if (n_members) *n_members = nb;
+    return ZNGAMD_OK;
+}
+
+int zngamd_gzip_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, uint32_t block_size, int level, void *d_out,
+                            uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
+{
+    if (!c || (!d_in && in_len) || !d_out || !out_len) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return gzip_members_dev(c, (const uint8_t *)d_in, in_len, block_size, level, (uint8_t *)d_out, out_cap, out_len, n_members);
+}
+
+int zngamd_gzip_members(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint32_t block_size, int level, uint8_t *out,
+                        uint64_t out_cap, uint64_t *out_len)
+{
+    if (!c || (!in && in_len) || !out || !out_len) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    int r = stage_in(c, in, in_len);
+    if (r) return r;
+    const uint64_t nb = in_len == 0 ? 1 : (in_len + (block_size ? block_size : 1) - 1) / (block_size ? block_size : 1);
+    const uint64_t bound = in_len + nb * (ZA_MEMBER_HDR + 8 + 64);
+    HIPCHK(c, c->st_aux.ensure(bound));
+    uint64_t total = 0;
+    r = gzip_members_dev(c, c->st_in.p, in_len, block_size, level, c->st_aux.p, bound, &total, nullptr);
+    if (r) return r;
+    *out_len = total;
+    if (total > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small");
+    if (total) HIPCHK(c, hipMemcpy(out, c->st_aux.p, total, hipMemcpyDeviceToHost));
+    return ZNGAMD_OK;
+}
+
+}  // extern "C"

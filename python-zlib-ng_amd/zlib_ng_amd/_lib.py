@@ -1,0 +1,279 @@
+"""ctypes binding of libzng_amd.so (C ABI declared in include/zng_amd.h).
+
+There is no fallback: if the library is missing, or no MI355X-class GPU is usable, importing
+works but the first call that needs the engine raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzng_amd.so")
+
+OK, STREAM_END, NEED_DICT = 0, 1, 2
+STREAM_ERROR, DATA_ERROR, MEM_ERROR, BUF_ERROR = -2, -3, -4, -5
+E_GZ_MAGIC, E_GZ_METHOD, E_GZ_HCRC, E_GZ_CRC, E_GZ_LENGTH, E_GZ_TRUNC = -101, -102, -103, -104, -105, -106
+E_HIP, E_ARG, E_OVERFLOW = -201, -202, -203
+
+FLAG_FINAL = 1
+UNIT_MAX = 131072
+SLOT_STRIDE = 131136
+SEG = 2048
+K_NAMES = ["chains", "search", "parse", "plan", "pack", "gather", "scan", "inflate", "other"]
+
+# every symbol include/zng_amd.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "zngamd_device_count", "zngamd_ctx_create", "zngamd_ctx_destroy", "zngamd_last_error", "zngamd_version",
+    "zngamd_set_stream", "zngamd_sync", "zngamd_dmalloc", "zngamd_dfree", "zngamd_h2d", "zngamd_d2h",
+    "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
+    "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
+    "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
+    "zngamd_gunzip", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
+    "zngamd_kernel_times", "zngamd_debug_fetch",
+]
+
+
+class Block(C.Structure):
+    _fields_ = [("off", C.c_uint64), ("len", C.c_uint32), ("dict_len", C.c_uint32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Member(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint64), ("out_off", C.c_uint64),
+                ("out_len", C.c_uint32), ("crc", C.c_uint32), ("index_off", C.c_uint32), ("nseg", C.c_uint32)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python python-zlib-ng_amd/build.py` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp, u8p, u32p, u64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+        L.zngamd_device_count.restype = C.c_int
+        L.zngamd_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.zngamd_ctx_destroy.argtypes = [vp]
+        L.zngamd_ctx_destroy.restype = None
+        L.zngamd_last_error.argtypes = [vp]
+        L.zngamd_last_error.restype = C.c_char_p
+        L.zngamd_version.restype = C.c_char_p
+        L.zngamd_set_stream.argtypes = [vp, vp]
+        L.zngamd_sync.argtypes = [vp]
+        L.zngamd_dmalloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.zngamd_dfree.argtypes = [vp, vp]
+        L.zngamd_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.zngamd_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.zngamd_crc32.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.zngamd_adler32.argtypes = [vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.zngamd_crc32_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.zngamd_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.zngamd_crc32_combine.restype = C.c_uint32
+        L.zngamd_level_ok.argtypes = [C.c_int]
+        L.zngamd_deflate_blocks.argtypes = [vp, u8p, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
+                                            u8p, C.c_uint64, u32p, u32p]
+        L.zngamd_count_units.argtypes = [C.POINTER(Block), C.c_uint32]
+        L.zngamd_count_units.restype = C.c_uint32
+        L.zngamd_deflate_blocks_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
+                                                vp, vp, vp, u32p]
+        L.zngamd_gather_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint64, vp,
+                                        C.POINTER(C.c_uint64)]
+        L.zngamd_deflate_stream.argtypes = [vp, u8p, C.c_uint64, C.c_int, u8p, C.c_uint64,
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.zngamd_inflate_raw.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint32, u8p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.zngamd_gzip_scan_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint64)]
+        L.zngamd_gzip_inflate_members_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp]
+        L.zngamd_gunzip.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint32)]
+        L.zngamd_gzip_members.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, C.c_int, u8p, C.c_uint64,
+                                          C.POINTER(C.c_uint64)]
+        L.zngamd_gzip_members_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, C.c_uint64,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        L.zngamd_profiling.argtypes = [vp, C.c_int]
+        L.zngamd_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
+        _lib = L
+        return L
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zng_amd error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def _addr(buf):
+    """Address + keep-alive object of a bytes-like without copying when possible."""
+    if isinstance(buf, bytes):
+        return C.cast(C.c_char_p(buf), C.c_void_p), buf
+    mv = memoryview(buf)
+    if mv.readonly or not mv.contiguous:
+        b = mv.tobytes()
+        return C.cast(C.c_char_p(b), C.c_void_p), b
+    arr = (C.c_char * mv.nbytes).from_buffer(mv)
+    return C.cast(arr, C.c_void_p), arr
+
+
+class Context:
+    """One engine context = one GPU + one HIP stream + grow-only device workspaces."""
+
+    def __init__(self, device=None):
+        L = load()
+        if device is None:
+            device = int(os.environ.get("ZNGAMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = L.zngamd_device_count()
+            if n > 0:
+                device %= n
+        h = C.c_void_p()
+        r = L.zngamd_ctx_create(device, C.byref(h))
+        if r != OK:
+            raise RuntimeError(
+                f"zng_amd: no usable GPU (zngamd_ctx_create({device}) -> {r}); this engine has no CPU path")
+        self.L, self.h, self.device = L, h, device
+
+    def close(self):
+        if self.h:
+            self.L.zngamd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def err(self):
+        return self.L.zngamd_last_error(self.h).decode("utf-8", "replace")
+
+    def _chk(self, r, ok=(OK,)):
+        if r not in ok:
+            raise EngineError(r, self.err())
+        return r
+
+    # ---- checksums
+    def crc32(self, data, value=0):
+        p, keep = _addr(data)
+        out = C.c_uint32(0)
+        self._chk(self.L.zngamd_crc32(self.h, value & 0xFFFFFFFF, p, memoryview(data).nbytes, C.byref(out)))
+        return out.value
+
+    def adler32(self, data, value=1):
+        p, keep = _addr(data)
+        out = C.c_uint32(0)
+        self._chk(self.L.zngamd_adler32(self.h, value & 0xFFFFFFFF, p, memoryview(data).nbytes, C.byref(out)))
+        return out.value
+
+    def crc32_combine(self, crc1, crc2, len2):
+        return self.L.zngamd_crc32_combine(crc1 & 0xFFFFFFFF, crc2 & 0xFFFFFFFF, len2)
+
+    # ---- deflate
+    def deflate_blocks(self, buf, blocks, level, out_cap):
+        """blocks: list of (off, len, dict_len, flags).  -> (list of bytes|None, list of crc, overflowed)"""
+        n = len(blocks)
+        arr = (Block * max(n, 1))()
+        for i, (off, ln, dl, fl) in enumerate(blocks):
+            arr[i] = Block(off, ln, dl, fl, 0)
+        p, keep = _addr(buf)
+        out = C.create_string_buffer(max(n, 1) * out_cap)
+        lens = (C.c_uint32 * max(n, 1))()
+        crcs = (C.c_uint32 * max(n, 1))()
+        r = self.L.zngamd_deflate_blocks(self.h, p, memoryview(buf).nbytes, arr, n, level,
+                                         C.cast(out, C.c_void_p), out_cap, C.cast(lens, C.c_void_p),
+                                         C.cast(crcs, C.c_void_p))
+        self._chk(r, (OK, E_OVERFLOW))
+        res = []
+        for i in range(n):
+            if lens[i] == 0xFFFFFFFF:
+                res.append(None)
+            else:
+                res.append(out.raw[i * out_cap:i * out_cap + lens[i]])
+        return res, list(crcs[:n]), r == E_OVERFLOW
+
+    def deflate_stream(self, data, level):
+        """-> (raw deflate bytes, crc32, adler32)"""
+        p, keep = _addr(data)
+        n = memoryview(data).nbytes
+        cap = n + (n // UNIT_MAX + 1) * 64 + 64
+        out = C.create_string_buffer(cap)
+        ol = C.c_uint64(0)
+        crc, ad = C.c_uint32(0), C.c_uint32(1)
+        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, C.cast(out, C.c_void_p), cap,
+                                               C.byref(ol), C.byref(crc), C.byref(ad)))
+        return out.raw[:ol.value], crc.value, ad.value
+
+    def debug_fetch(self, what, unit, nbytes):
+        b = C.create_string_buffer(nbytes)
+        self._chk(self.L.zngamd_debug_fetch(self.h, what, unit, C.cast(b, C.c_void_p), nbytes))
+        return b.raw
+
+    # ---- inflate
+    def inflate_raw(self, data, out_cap, zdict=b""):
+        """-> (code, out bytes, in_used, crc32, adler32)"""
+        p, keep = _addr(data)
+        dp, dkeep = _addr(zdict) if len(zdict) else (None, None)
+        out = C.create_string_buffer(max(out_cap, 1))
+        ol, used = C.c_uint64(0), C.c_uint64(0)
+        crc, ad = C.c_uint32(0), C.c_uint32(1)
+        r = self.L.zngamd_inflate_raw(self.h, p, memoryview(data).nbytes, dp, len(zdict),
+                                      C.cast(out, C.c_void_p), out_cap, C.byref(ol), C.byref(used),
+                                      C.byref(crc), C.byref(ad))
+        if r in (E_HIP, E_ARG):
+            raise EngineError(r, self.err())
+        return r, out.raw[:ol.value], used.value, crc.value, ad.value
+
+    def gunzip(self, data, out_cap):
+        """-> (code, out bytes, n_members)"""
+        p, keep = _addr(data)
+        out = C.create_string_buffer(max(out_cap, 1))
+        ol, nm = C.c_uint64(0), C.c_uint32(0)
+        r = self.L.zngamd_gunzip(self.h, p, memoryview(data).nbytes, C.cast(out, C.c_void_p), out_cap,
+                                 C.byref(ol), C.byref(nm))
+        if r in (E_HIP, E_ARG):
+            raise EngineError(r, self.err())
+        return r, out.raw[:ol.value], nm.value
+
+    def gzip_members(self, data, block_size, level):
+        p, keep = _addr(data)
+        n = memoryview(data).nbytes
+        nb = max(1, (n + block_size - 1) // max(block_size, 1))
+        cap = n + nb * 400 + 64
+        out = C.create_string_buffer(cap)
+        ol = C.c_uint64(0)
+        self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, C.cast(out, C.c_void_p), cap,
+                                             C.byref(ol)))
+        return out.raw[:ol.value]
+
+    # ---- measurement
+    def profiling(self, on):
+        self._chk(self.L.zngamd_profiling(self.h, 1 if on else 0))
+
+    def kernel_times(self, reset=True):
+        ms = (C.c_double * len(K_NAMES))()
+        ln = (C.c_uint64 * len(K_NAMES))()
+        self._chk(self.L.zngamd_kernel_times(self.h, ms, ln, 1 if reset else 0))
+        return {k: (ms[i], ln[i]) for i, k in enumerate(K_NAMES)}
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    """Process-wide context on the GPU chosen by ZNGAMD_DEVICE / LOCAL_RANK (default 0)."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Context()
+        return _default
