@@ -27,7 +27,7 @@ uint32_t za_o_crc32(uint32_t crc, const uint8_t *buf, size_t len)
 
 uint32_t za_o_adler32(uint32_t adler, const uint8_t *buf, size_t len)
 {
-    uint32_t a = adler & 0xFFFF, b = (adler >> 16) & 0xFFFF;
+    uint32_t a = (adler & 0xFFFF) % 65521u, b = ((adler >> 16) & 0xFFFF) % 65521u;
     while (len > 0) {
         size_t k = len < 5552 ? len : 5552;   /* largest n with 255n(n+1)/2 + (n+1)(65520) < 2^32 */
         len -= k;

@@ -275,7 +275,8 @@ int zngamd_adler32(zngamd_ctx *c, uint32_t adler, const uint8_t *buf, size_t len
     std::lock_guard<std::mutex> g(c->mu);
     int r = stage_in(c, buf, len);
     if (r) return r;
-    uint32_t v = adler;
+    // the seed halves are reduced even when there is no data (zlib semantics the reference inherits)
+    uint32_t v = ((((adler >> 16) & 0xFFFFu) % 65521u) << 16) | ((adler & 0xFFFFu) % 65521u);
     r = checksum_dev(c, c->st_in.p, len, nullptr, &v);
     *out = v;
     return r;
