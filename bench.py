@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- MB/s compress+decompress, 128 KiB blocks, level 6 (BASELINE.json metric).
+
+One "step" = one pass of the hot path over this rank's shard of synthetic text already resident in HBM:
+  (1) compress: every 128 KiB block, primed with the previous 32 KiB of input as dictionary
+      (reference semantics: gzip_ng_threaded.py:299-322 + zlib_ngmodule.c:1696-1782), through the five
+      deflate kernels, gathered into one contiguous raw-deflate slice; with N > 1 ranks the slices are
+      exchanged with an RCCL all-gather and re-assembled into the member stream on every rank;
+  (2) decompress: two-pass inflate (member scan, then one wavefront per member) of a pre-built stream
+      of independent indexed gzip members of the same text (BASELINE.json configs[2]).
+value = uncompressed bytes of all ranks / (max over ranks of the step time): the rate at which data goes
+through compress and then decompress.  Inputs are in HBM when the timed region starts.
+
+    python bench.py                      # 1 GPU, 4 GiB shard
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
+
+BLOCK = 131072
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size-mib", type=int, default=4096, help="uncompressed MiB per GPU (weak scaling)")
+    ap.add_argument("--unique-mib", type=int, default=64, help="MiB of distinct text, tiled to --size-mib")
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=0, help="0 = sized for ~10-30 s")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from zlib_ng_amd import _lib, corpus, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch through torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the engine has no CPU path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = _lib.Context(device=local)
+    L, h = ctx.L, ctx.h
+
+    # ---- synthetic shard, resident in HBM --------------------------------------------------------
+    size = args.size_mib << 20
+    uniq = min(args.unique_mib << 20, size)
+    uniq -= uniq % BLOCK
+    host = corpus.text(uniq, seed=1 + rank)
+    base = torch.from_numpy(host).to(dev)
+    reps = (size + uniq - 1) // uniq
+    d_in = torch.empty(reps * uniq + 64, dtype=torch.uint8, device=dev)
+    d_in[:reps * uniq].view(reps, uniq)[:] = base
+    d_in[reps * uniq:] = 0
+    nblocks = size // BLOCK
+    size = nblocks * BLOCK
+    torch.cuda.synchronize()
+
+    blocks = (_lib.Block * nblocks)()
+    for b in range(nblocks):
+        blocks[b] = _lib.Block(b * BLOCK, BLOCK, 32768 if b else 0, 0, 0)
+    n_units = L.zngamd_count_units(blocks, nblocks)
+    assert n_units == nblocks
+    d_slots = torch.empty(n_units * _lib.SLOT_STRIDE, dtype=torch.uint8, device=dev)
+    d_ulen = torch.empty(n_units, dtype=torch.int32, device=dev)
+    d_ucrc = torch.empty(n_units, dtype=torch.int32, device=dev)
+    d_comp = torch.empty(size // 2 + (64 << 20), dtype=torch.uint8, device=dev)   # text compresses ~3x
+    d_out = torch.empty(size + 64, dtype=torch.uint8, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+
+    def chk(r, what):
+        if r != 0:
+            raise RuntimeError(f"{what} failed: {r} {ctx.err()}")
+
+    # pre-built multi-member stream for the inflate leg (outside the timed region)
+    d_members_stream = torch.empty(size // 2 + nblocks * 400 + (64 << 20), dtype=torch.uint8, device=dev)
+    ms_len, ms_n = C.c_uint64(0), C.c_uint32(0)
+    chk(L.zngamd_gzip_members_dev(h, ptr(d_in), size, BLOCK, args.level, ptr(d_members_stream),
+                                  d_members_stream.numel() - 64, C.byref(ms_len), C.byref(ms_n)), "gzip_members_dev")
+    d_members_stream[ms_len.value:ms_len.value + 64] = 0
+    d_mtab = torch.empty(nblocks * C.sizeof(_lib.Member), dtype=torch.uint8, device=dev)
+    d_mstat = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    comp_total = C.c_uint64(0)
+    gathered = {}
+
+    def step():
+        # (1) compress + gather (+ all-gather of the slices)
+        chk(L.zngamd_deflate_blocks_dev(h, ptr(d_in), size, blocks, nblocks, args.level, ptr(d_slots), ptr(d_ulen),
+                                        ptr(d_ucrc), None), "deflate_blocks_dev")
+        chk(L.zngamd_gather_dev(h, ptr(d_slots), ptr(d_ulen), n_units, ptr(d_comp), 0, d_comp.numel(), None,
+                                C.byref(comp_total)), "gather_dev")
+        if world > 1:
+            stream, total, _ = shard.allgather_stream(d_comp, comp_total.value, scratch=gathered)
+            gathered["total"] = total
+            torch.cuda.synchronize()
+        # (2) two-pass inflate of the pre-built member stream
+        nm, tot = C.c_uint32(0), C.c_uint64(0)
+        chk(L.zngamd_gzip_scan_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nblocks, C.byref(nm),
+                                   C.byref(tot)), "gzip_scan_dev")
+        chk(L.zngamd_gzip_inflate_members_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nm.value,
+                                              ptr(d_out), size, ptr(d_mstat)), "gzip_inflate_members_dev")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profiling(True)
+    ctx.kernel_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = ctx.kernel_times(reset=True)
+    ctx.profiling(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- correctness of what was timed -------------------------------------------------------------
+    assert int((d_mstat != 0).sum().item()) == 0, "inflate reported member errors"
+    assert torch.equal(d_out[:size], d_in[:size]), "inflate output differs from the input"
+    nchk = min(nblocks, 256)                      # compressed stream: a prefix through the system zlib
+    ul = d_ulen[:nchk].cpu().numpy().astype(np.int64)
+    pref = bytes(d_comp[:int(ul.sum())].cpu().numpy())
+    dec = zlib.decompressobj(-15).decompress(pref)
+    assert dec == bytes(host[:nchk * BLOCK] if nchk * BLOCK <= uniq else d_in[:nchk * BLOCK].cpu().numpy()), \
+        "compressed stream does not inflate to the input"
+    comp_bytes = int(d_ulen.to(torch.int64).sum().item())
+
+    # ---- per-leg numbers -----------------------------------------------------------------------------
+    steps = args.steps
+    deflate_ms = sum(kt[k][0] for k in ("chains", "search", "parse", "plan", "pack", "gather")) / steps
+    inflate_ms = (kt["scan"][0] + kt["inflate"][0]) / steps
+    dom = max(("chains", "search", "parse", "plan", "pack", "inflate"), key=lambda k: kt[k][0])
+    launches = max(1, kt[dom][1])
+    avg_ms = kt[dom][0] / launches
+    # algorithmic bytes per launch of the dominant kernel: deflate N_in + C_out, inflate C_in + N_out
+    per_step_bytes = size + (ms_len.value if dom == "inflate" else comp_bytes)
+    launches_per_step = launches / steps
+    alg_bytes = per_step_bytes / launches_per_step
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roofline["traffic"] = json.load(open(pmc)).get(roofline["kernel"])
+        except Exception:
+            pass
+
+    out = {
+        "metric": "MB/s compress+decompress, 128 KiB blocks level 6",
+        "value": round(world * size / dt * steps / 1e6, 1), "unit": "MB/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{args.size_mib} MiB/GPU seeded Zipf-word text ({uniq >> 20} MiB distinct, tiled), "
+                               f"128 KiB blocks, level {args.level}: dict-chained deflate + gather"
+                               f"{' + RCCL all-gather' if world > 1 else ''}, then two-pass inflate of "
+                               f"{nblocks} independent gzip members",
+                   "block": BLOCK, "level": args.level, "bytes_per_gpu": size},
+        "compress_MBps": round(world * size / (deflate_ms * 1e-3) / 1e6, 1),
+        "decompress_MBps": round(world * size / (inflate_ms * 1e-3) / 1e6, 1),
+        "ratio": round(size / comp_bytes, 4),
+        "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kt.items() if v[1]},
+        "roofline": roofline,
+        "roofline_inflate": {"bound": "hbm", "kernel": "za_k_inflate_members",
+                             "achieved": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6, 2),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
+    }
+
+    # ---- CPU baseline on this box's host cores (rank 0, N = 1 only) ------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        cores = len(os.sched_getaffinity(0))
+        sample = args.cpu_sample_mib << 20 if args.cpu_sample_mib else min(uniq, (4 << 20) * cores)
+        sample -= sample % BLOCK
+        arr = np.ascontiguousarray(host[:sample])
+        td, ti, cb = O.bench_blocks(arr, BLOCK, args.level, cores)
+        out["cpu_baseline"] = {"value": round(sample / (td + ti) / 1e6, 1), "unit": "MB/s", "cores": cores,
+                               "kind": "port",
+                               "sample": f"first {sample >> 20} MiB of the same text, 128 KiB blocks + 32 KiB dictionary, "
+                                         f"level {args.level}, oracle C codec on {cores} threads",
+                               "compress_MBps": round(sample / td / 1e6, 1),
+                               "decompress_MBps": round(sample / ti / 1e6, 1), "ratio": round(sample / cb, 4)}
+        # context: the system zlib (1.2.x) on the same sample, same protocol, thread pool releases the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        mv = memoryview(arr)
+
+        def zc(b):
+            co = zlib.compressobj(args.level, zlib.DEFLATED, -15, 8, 0, bytes(mv[max(0, b * BLOCK - 32768):b * BLOCK])) \
+                if b else zlib.compressobj(args.level, zlib.DEFLATED, -15)
+            return co.compress(mv[b * BLOCK:(b + 1) * BLOCK]) + co.flush(zlib.Z_SYNC_FLUSH)
+
+        def zd(bc):
+            b, c = bc
+            do = zlib.decompressobj(-15, zdict=bytes(mv[max(0, b * BLOCK - 32768):b * BLOCK])) if b else zlib.decompressobj(-15)
+            return len(do.decompress(c))
+        nb = sample // BLOCK
+        with ThreadPoolExecutor(cores) as ex:
+            t = time.perf_counter(); comp = list(ex.map(zc, range(nb))); tzc = time.perf_counter() - t
+            t = time.perf_counter(); n_out = sum(ex.map(zd, enumerate(comp))); tzd = time.perf_counter() - t
+        assert n_out == sample
+        out["cpu_zlib"] = {"value": round(sample / (tzc + tzd) / 1e6, 1), "unit": "MB/s", "cores": cores,
+                           "library": "zlib " + zlib.ZLIB_RUNTIME_VERSION,
+                           "compress_MBps": round(sample / tzc / 1e6, 1), "decompress_MBps": round(sample / tzd / 1e6, 1),
+                           "ratio": round(sample / sum(map(len, comp)), 4)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,8 +113,9 @@ int zngamd_gather_dev(zngamd_ctx *ctx, const void *d_slots, const uint32_t *d_un
                       uint64_t *total_bytes);
 
 /* One whole raw-deflate stream from a host buffer: units chained through the previous 32 KiB of
- * input, last block FINAL.  Returns the size in *out_len, CRC-32 and Adler-32 of the input. */
-int zngamd_deflate_stream(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, int level,
+ * input, last block FINAL.  window_bits 9..15 bounds match distances to 2^window_bits (the window a
+ * decoder opened with that wbits keeps).  Returns the size in *out_len, CRC-32 and Adler-32 of the input. */
+int zngamd_deflate_stream(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, int level, int window_bits,
                           uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                           uint32_t *crc, uint32_t *adler);
 

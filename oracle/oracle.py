@@ -124,11 +124,13 @@ def deflate_unit(data, zdict=b"", level=6, flags=0, debug=False, cap=None):
     return res, crc.value
 
 
-def deflate_stream(data, level=6, flags=FLAG_FINAL):
+def deflate_stream(data, level=6, flags=FLAG_FINAL, window_bits=15):
     data = bytes(data)
+    lib().za_o_set_max_dist(1 << window_bits)
     cap = len(data) + len(data) // 8 + 1024
     out = np.zeros(cap, dtype=np.uint8)
     r = lib().za_o_deflate_stream(data, len(data), level, flags, out.ctypes.data, cap)
+    lib().za_o_set_max_dist(WIN)
     if r < 0:
         raise RuntimeError(f"oracle deflate_stream failed: {r}")
     return out[:r].tobytes()

@@ -25,11 +25,17 @@
 #include <time.h>
 
 typedef struct { int chain, nice, lazy; } za_level;
-/* (max_chain, nice_length, max_lazy) per level -- the classic zlib configuration table values */
+/* (max_chain, nice_length, max_lazy) per level.  Calibrated for this codec (every position is
+ * searched and a whole 128 KiB unit shares one Huffman block), so that the ratio at each level is at
+ * least that of zlib 1.2.11 at the same level on the text / FASTQ / mixed corpora. */
 static const za_level LEVELS[10] = {
-    {0, 0, 0}, {4, 8, 0}, {8, 16, 0}, {32, 32, 0}, {16, 16, 4}, {32, 32, 16},
-    {128, 128, 16}, {256, 128, 32}, {1024, 258, 128}, {4096, 258, 258}
+    {0, 0, 0}, {4, 8, 0}, {6, 16, 0}, {8, 16, 0}, {8, 32, 8}, {12, 32, 16},
+    {16, 32, 16}, {32, 64, 16}, {64, 128, 32}, {512, 258, 128}
 };
+
+/* test-only override of the level table (parameter studies); chain <= 0 switches it off */
+static za_level g_override = {0, 0, 0};
+void za_o_override_level(int chain, int nice, int lazy) { g_override.chain = chain; g_override.nice = nice; g_override.lazy = lazy; }
 
 static inline uint32_t ld32(const uint8_t *p)
 {
@@ -56,7 +62,7 @@ static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *pr
 
 /* ---------------- stage 2 ---------------- */
 static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const uint16_t *prevdist,
-                              int p, const za_level *L)
+                              int p, const za_level *L, int max_dist)
 {
     int seg_end = (p / ZA_SEG + 1) * ZA_SEG;
     if (seg_end > n) seg_end = n;
@@ -71,7 +77,7 @@ static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const ui
         if (d == 0) break;
         q -= d;
         int dist = p - q;
-        if (dist > ZA_WIN) break;
+        if (dist > max_dist) break;
         if (data[q + best_len] != data[p + best_len]) continue;
         int len = 0;
         while (len < maxlen && data[q + len] == data[p + len]) len++;
@@ -225,13 +231,18 @@ static int rle_lengths(const uint8_t *seq, int n, uint16_t *tok)
     return nt;
 }
 
+/* window limit for the next calls (zlib-container / raw streams with wbits < 15): distances above it
+ * are never emitted.  32768 = full window. */
+static __thread int g_max_dist = ZA_WIN;
+void za_o_set_max_dist(int max_dist) { g_max_dist = (max_dist < 1 || max_dist > ZA_WIN) ? ZA_WIN : max_dist; }
+
 long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int flags,
                        uint8_t *out, size_t cap, uint32_t *crc, za_o_debug *dbg)
 {
     if (level == -1) level = 6;
     if (level < 0 || level > 9 || n < 0 || n > ZA_MAX_UNIT || dict_len < 0 || dict_len > ZA_WIN)
         return ZA_STREAM_ERROR;
-    const za_level *L = &LEVELS[level];
+    const za_level *L = (g_override.chain > 0 && level > 0) ? &g_override : &LEVELS[level];
     int final = (flags & ZA_FLAG_FINAL) != 0;
     bitwr w = { out, cap, 0, 0, 0, 0 };
     if (crc) *crc = za_o_crc32(0, data, (size_t)n);
@@ -266,7 +277,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         tokens = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
         if (!prevdist || !best || !tokens) { free(prevdist); free(best); free(tokens); return ZA_MEM_ERROR; }
         stage1_chains(data, dict_len, n, prevdist);
-        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, p, L);
+        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, p, L, g_max_dist);
         /* stage 3: parse every segment on its own */
         for (int s = 0; s < nseg; s++) {
             int p = s * ZA_SEG, end = p + ZA_SEG;

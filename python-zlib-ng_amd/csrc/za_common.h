@@ -45,7 +45,7 @@ struct ZaPlan {
     uint32_t pad0, pad1;
 };
 
-struct ZaLevel { int chain, nice, lazy; };
+struct ZaLevel { int chain, nice, lazy, max_dist; };
 
 typedef uint32_t __attribute__((aligned(1))) za_u32u;
 typedef uint64_t __attribute__((aligned(1))) za_u64u;

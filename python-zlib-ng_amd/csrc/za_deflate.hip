@@ -127,7 +127,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     if (d == 0) break;
                     q -= d;
                     const int dist = p - q;
-                    if (dist > ZA_WIN) break;
+                    if (dist > L.max_dist) break;
                     const uint8_t *cand = data + q;
                     if (cand[best_len] != me[best_len]) continue;
                     const int len = za_match_len(cand, me, maxlen, wide_ok);

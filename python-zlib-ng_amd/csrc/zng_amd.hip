@@ -21,9 +21,11 @@ static_assert(sizeof(zngamd_member) == sizeof(ZaMember), "member layout");
 static_assert(ZNGAMD_SLOT_STRIDE % 4 == 0 && ZNGAMD_SLOT_STRIDE >= ZA_MAX_UNIT + 32, "slot stride");
 static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants");
 
+// (max_chain, nice_length, max_lazy) per level -- DESIGN.md 3.6: calibrated so that the ratio at each
+// level is >= zlib 1.2.11's at the same level on the text / FASTQ / mixed corpora
 static const ZaLevel ZA_LEVELS[10] = {
-    {0, 0, 0}, {4, 8, 0}, {8, 16, 0}, {32, 32, 0}, {16, 16, 4}, {32, 32, 16},
-    {128, 128, 16}, {256, 128, 32}, {1024, 258, 128}, {4096, 258, 258}};
+    {0, 0, 0, ZA_WIN}, {4, 8, 0, ZA_WIN}, {6, 16, 0, ZA_WIN}, {8, 16, 0, ZA_WIN}, {8, 32, 8, ZA_WIN}, {12, 32, 16, ZA_WIN},
+    {16, 32, 16, ZA_WIN}, {32, 64, 16, ZA_WIN}, {64, 128, 32, ZA_WIN}, {512, 258, 128, ZA_WIN}};
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;
@@ -319,7 +321,7 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
 
 // launch the five deflate kernels over all units (in chunks that bound the workspace)
 static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const std::vector<ZaUnit> &hu, int level,
-                             uint8_t *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc)
+                             uint8_t *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc, int max_dist = ZA_WIN)
 {
     if (level == -1) level = 6;
     if (level < 0 || level > 9) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
@@ -336,7 +338,8 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     HIPCHK(c, c->codes.ensure((size_t)ch * ZA_CODE_STRIDE)); HIPCHK(c, c->plan.ensure(ch));
     HIPCHK(c, hipMemcpyAsync(c->units.p, hu.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(d_slots, 0, (size_t)n * ZNGAMD_SLOT_STRIDE, c->stream));
-    const ZaLevel L = ZA_LEVELS[level];
+    ZaLevel L = ZA_LEVELS[level];
+    L.max_dist = (max_dist < 1 || max_dist > ZA_WIN) ? ZA_WIN : max_dist;
     for (uint32_t c0 = 0; c0 < n; c0 += ch) {
         const uint32_t m = std::min(ch, n - c0);
         const ZaUnit *du = c->units.p + c0;
@@ -414,13 +417,13 @@ int zngamd_gather_dev(zngamd_ctx *c, const void *d_slots, const uint32_t *d_unit
 // shared by the two host-buffer entry points: input already staged at st_in.p
 static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks, int level,
                                std::vector<ZaUnit> &hu, std::vector<uint32_t> &ulen, std::vector<uint32_t> &ucrc,
-                               std::vector<uint8_t> &packed)
+                               std::vector<uint8_t> &packed, int max_dist = ZA_WIN)
 {
     int r = build_units(c, blocks, n_blocks, in_len, hu);
     if (r) return r;
     const uint32_t n = (uint32_t)hu.size();
     HIPCHK(c, c->st_slots.ensure((size_t)n * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(n)); HIPCHK(c, c->st_crc.ensure(n));
-    r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p);
+    r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p, max_dist);
     if (r) return r;
     // upper bound of the packed size without a round trip: every unit fits its slot
     HIPCHK(c, c->st_out.ensure((size_t)n * ZNGAMD_SLOT_STRIDE));
@@ -469,8 +472,8 @@ int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, con
     return ret;
 }
 
-int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int level, uint8_t *out, uint64_t out_cap,
-                          uint64_t *out_len, uint32_t *crc, uint32_t *adler)
+int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int level, int window_bits, uint8_t *out,
+                          uint64_t out_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler)
 {
     if (!c || (!in && in_len) || !out || !out_len) return ZNGAMD_E_ARG;
     if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
@@ -480,7 +483,8 @@ int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int
     if (r) return r;
     zngamd_block B; B.off = 0; B.len = (uint32_t)in_len; B.dict_len = 0; B.flags = ZNGAMD_FLAG_FINAL; B.reserved = 0;
     std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
-    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, packed);
+    if (window_bits < 9 || window_bits > 15) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, packed, 1 << window_bits);
     if (r) return r;
     *out_len = packed.size();
     if (packed.size() > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small");

@@ -86,7 +86,7 @@ def load():
                                                 vp, vp, vp, u32p]
         L.zngamd_gather_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint64, vp,
                                         C.POINTER(C.c_uint64)]
-        L.zngamd_deflate_stream.argtypes = [vp, u8p, C.c_uint64, C.c_int, u8p, C.c_uint64,
+        L.zngamd_deflate_stream.argtypes = [vp, u8p, C.c_uint64, C.c_int, C.c_int, u8p, C.c_uint64,
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.zngamd_inflate_raw.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint32, u8p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -201,7 +201,7 @@ class Context:
                 res.append(out.raw[i * out_cap:i * out_cap + lens[i]])
         return res, list(crcs[:n]), r == E_OVERFLOW
 
-    def deflate_stream(self, data, level):
+    def deflate_stream(self, data, level, window_bits=15):
         """-> (raw deflate bytes, crc32, adler32)"""
         p, keep = _addr(data)
         n = memoryview(data).nbytes
@@ -209,7 +209,7 @@ class Context:
         out = C.create_string_buffer(cap)
         ol = C.c_uint64(0)
         crc, ad = C.c_uint32(0), C.c_uint32(1)
-        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, C.cast(out, C.c_void_p), cap,
+        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, window_bits, C.cast(out, C.c_void_p), cap,
                                                C.byref(ol), C.byref(crc), C.byref(ad)))
         return out.raw[:ol.value], crc.value, ad.value
 

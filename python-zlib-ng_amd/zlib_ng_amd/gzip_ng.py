@@ -1,0 +1,100 @@
+"""gzip_ng -- drop-in face of the reference's `zlib_ng.gzip_ng` (reference src/zlib_ng/gzip_ng.py:33-205)
+on the MI355X engine: `open`, `GzipNGFile` / `GzipFile`, one-shot `compress` / `decompress`,
+`BadGzipFile`, `READ_BUFFER_SIZE`.
+
+The single-stream file object keeps CPython's gzip.GzipFile for header / trailer / buffering logic and
+swaps in this package's compressor object and C-ABI backed reader, as the reference does
+(gzip_ng.py:140-149).  Compression inside one GzipNGFile is one LZ77 window over the whole file (sequential
+by construction); the data-parallel writer is gzip_ng_threaded.
+"""
+import gzip
+import io
+import struct
+import time
+
+from . import zlib_ng
+from .zlib_ng import _GzipReader
+
+__all__ = ["GzipFile", "open", "compress", "decompress", "BadGzipFile", "READ_BUFFER_SIZE"]
+
+_COMPRESS_LEVEL_FAST = zlib_ng.Z_BEST_SPEED
+_COMPRESS_LEVEL_TRADEOFF = zlib_ng.Z_DEFAULT_COMPRESSION
+_COMPRESS_LEVEL_BEST = zlib_ng.Z_BEST_COMPRESSION
+
+#: bytes requested from the underlying file per refill when decompressing (gzip_ng.py:42)
+READ_BUFFER_SIZE = 512 * 1024
+
+FTEXT, FHCRC, FEXTRA, FNAME, FCOMMENT = 1, 2, 4, 8, 16
+READ, WRITE = gzip.READ, gzip.WRITE
+BadGzipFile = gzip.BadGzipFile
+
+
+def _is_pathlike(obj):
+    return isinstance(obj, (str, bytes)) or hasattr(obj, "__fspath__")
+
+
+def open(filename, mode="rb", compresslevel=_COMPRESS_LEVEL_TRADEOFF, encoding=None, errors=None, newline=None):
+    """gzip.open look-alike (gzip_ng.py:51-95): binary modes give a GzipNGFile, text modes wrap it in a
+    TextIOWrapper."""
+    text = "t" in mode
+    if text and "b" in mode:
+        raise ValueError("Invalid mode: %r" % (mode,))
+    if not text:
+        for name, val in (("encoding", encoding), ("errors", errors), ("newline", newline)):
+            if val is not None:
+                raise ValueError(f"Argument '{name}' not supported in binary mode")
+    raw_mode = mode.replace("t", "")
+    if _is_pathlike(filename):
+        fobj = GzipNGFile(filename, raw_mode, compresslevel)
+    elif hasattr(filename, "read") or hasattr(filename, "write"):
+        fobj = GzipNGFile(None, raw_mode, compresslevel, filename)
+    else:
+        raise TypeError("filename must be a str or bytes object, or a file")
+    return io.TextIOWrapper(fobj, encoding, errors, newline) if text else fobj
+
+
+class GzipNGFile(gzip.GzipFile):
+    """gzip.GzipFile whose deflate / inflate / CRC work runs on the GPU engine (gzip_ng.py:98-176)."""
+
+    def __init__(self, filename=None, mode=None, compresslevel=_COMPRESS_LEVEL_BEST, fileobj=None, mtime=None):
+        super().__init__(filename, mode, compresslevel, fileobj, mtime)
+        if self.mode == WRITE:
+            self.compress = zlib_ng.compressobj(compresslevel, zlib_ng.DEFLATED, -zlib_ng.MAX_WBITS,
+                                                zlib_ng.DEF_MEM_LEVEL, 0)
+        elif self.mode == READ:
+            self._buffer = io.BufferedReader(_GzipReader(self.fileobj, READ_BUFFER_SIZE))
+
+    def __repr__(self):
+        return "<gzip_ng " + repr(self.fileobj)[1:-1] + " " + hex(id(self)) + ">"
+
+    def write(self, data):
+        self._check_not_closed()
+        if self.mode != WRITE:
+            import errno
+            raise OSError(errno.EBADF, "write() on read-only GzipNGFile object")
+        if self.fileobj is None:
+            raise ValueError("write() on closed GzipNGFile object")
+        view = data if isinstance(data, bytes) else memoryview(data)
+        nbytes = len(data) if isinstance(data, bytes) else view.nbytes
+        if nbytes:
+            self.fileobj.write(self.compress.compress(view))
+            self.size += nbytes
+            self.crc = zlib_ng.crc32(view, self.crc)
+            self.offset += nbytes
+        return nbytes
+
+
+GzipFile = GzipNGFile
+_GzipNGReader = _GzipReader
+
+
+def compress(data, compresslevel=_COMPRESS_LEVEL_BEST, *, mtime=None):
+    """One-shot gzip member (gzip_ng.py:184-197): engine output with wbits=31, then mtime and OS=255 patched in."""
+    member = zlib_ng.compress(data, level=compresslevel, wbits=31)
+    stamp = int(time.time() if mtime is None else mtime)
+    return struct.pack("<4sLBB", member[:4], stamp, member[8], 255) + member[10:]
+
+
+def decompress(data):
+    """One-shot gunzip of any number of members (gzip_ng.py:200-205)."""
+    return _GzipReader(data).readall()

@@ -1,0 +1,308 @@
+"""gzip_ng_threaded -- drop-in face of the reference's block-parallel gzip reader / writer
+(reference src/zlib_ng/gzip_ng_threaded.py:22-437), with the blocks compressed on the GPU.
+
+Reference design: N worker threads each own a `_ParallelCompress`; `write()` cuts the stream into blocks
+of at most `block_size`, primes block i with the last 32 KiB of block i-1 and deals blocks round-robin to
+the workers; a writer thread drains results in order and folds CRCs with crc32_combine.
+
+Here the data-parallel axis is the GPU, not threads: `threads` is the number of blocks kept in flight.
+`write()` cuts and primes blocks exactly as the reference does and puts them on `threads` bounded
+queues in round-robin order; ONE worker thread drains whatever is queued (in the same order), submits
+those blocks to the engine as a single batch (`_ParallelCompress.compress_and_crc_batch`), and writes
+the results in order.  The byte stream has the reference's framing: 10-byte header (with its OS/XFL
+byte order), sync-flushed raw-deflate blocks, `03 00`, CRC32, ISIZE; `flush()` ends the member and
+starts a new one; `close()` after the buffered writer's implicit flush leaves a trailing empty member.
+"""
+import builtins
+import io
+import multiprocessing
+import os
+import queue
+import struct
+import threading
+
+from . import gzip_ng, zlib_ng
+
+DEFLATE_WINDOW_SIZE = 2 ** 15
+
+
+def open(filename, mode="rb", compresslevel=gzip_ng._COMPRESS_LEVEL_TRADEOFF, encoding=None, errors=None,
+         newline=None, *, threads=1, block_size=1024 * 1024):
+    """Like gzip.open for streamed reading / writing (no seeking).  threads == 0 defers to gzip_ng.open,
+    threads < 0 uses the CPU count (gzip_ng_threaded.py:22-75)."""
+    if threads == 0:
+        return gzip_ng.open(filename, mode, compresslevel, encoding, errors, newline)
+    if threads < 0:
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except Exception:
+            try:
+                threads = multiprocessing.cpu_count()
+            except Exception:
+                threads = 1
+    if "r" in mode:
+        stream = io.BufferedReader(_ThreadedGzipReader(filename, block_size=block_size))
+    else:
+        stream = FlushableBufferedWriter(
+            _ThreadedGzipWriter(filename, mode.replace("t", "b"), block_size=block_size, level=compresslevel,
+                                threads=threads),
+            buffer_size=block_size)
+    return io.TextIOWrapper(stream, encoding, errors, newline) if "t" in mode else stream
+
+
+def open_as_binary_stream(filename, open_mode):
+    if isinstance(filename, (str, bytes)) or hasattr(filename, "__fspath__"):
+        return builtins.open(filename, open_mode), True
+    if hasattr(filename, "read") or hasattr(filename, "write"):
+        return filename, False
+    raise TypeError("filename must be a str or bytes object, or a file")
+
+
+class _ThreadedGzipReader(io.RawIOBase):
+    """Background thread pulls `block_size` chunks out of a `_GzipReader` into a bounded queue
+    (gzip_ng_threaded.py:90-167)."""
+
+    def __init__(self, filename, queue_size=2, block_size=1024 * 1024):
+        self.raw, self.closefd = open_as_binary_stream(filename, "rb")
+        self.fileobj = zlib_ng._GzipReader(self.raw, buffersize=8 * block_size)
+        self.pos = 0
+        self.read_file = False
+        self.queue = queue.Queue(queue_size)
+        self.eof = False
+        self.exception = None
+        self.buffer = io.BytesIO()
+        self.block_size = block_size
+        self._closed = False
+        self.running = True
+        self._calling_thread = threading.current_thread()
+        self.worker = threading.Thread(target=self._decompress)
+        self.worker.start()
+
+    def _check_closed(self, msg=None):
+        if self._closed:
+            raise ValueError("I/O operation on closed file")
+
+    def _alive(self):
+        return self.running and self._calling_thread.is_alive()
+
+    def _decompress(self):
+        while self._alive():
+            try:
+                chunk = self.fileobj.read(self.block_size)
+            except Exception as exc:
+                self.exception = exc
+                return
+            if not chunk:
+                return
+            while self._alive():
+                try:
+                    self.queue.put(chunk, timeout=0.05)
+                    break
+                except queue.Full:
+                    continue
+
+    def readinto(self, b):
+        self._check_closed()
+        got = self.buffer.readinto(b)
+        while got == 0:
+            try:
+                chunk = self.queue.get(timeout=0.01)
+            except queue.Empty:
+                if self.worker.is_alive():
+                    continue
+                if not self.queue.empty():
+                    continue
+                if self.exception:
+                    raise self.exception
+                return 0
+            self.buffer = io.BytesIO(chunk)
+            got = self.buffer.readinto(b)
+        self.pos += got
+        return got
+
+    def readable(self):
+        return True
+
+    def tell(self):
+        self._check_closed()
+        return self.pos
+
+    def close(self):
+        if self._closed:
+            return
+        self.running = False
+        self.worker.join()
+        self.fileobj.close()
+        if self.closefd:
+            self.raw.close()
+        self._closed = True
+
+    @property
+    def closed(self):
+        return self._closed
+
+
+class FlushableBufferedWriter(io.BufferedWriter):
+    def flush(self):
+        super().flush()
+        self.raw.flush()
+
+
+class _ThreadedGzipWriter(io.RawIOBase):
+    """Block-parallel gzip writer; see the module docstring for how the reference's thread fan-out maps
+    onto one engine batch per drain."""
+
+    def __init__(self, filename, mode="wb", level=zlib_ng.Z_DEFAULT_COMPRESSION, threads=1, queue_size=1,
+                 block_size=1024 * 1024):
+        self._closed = True           # so that __del__/__exit__ are harmless if __init__ fails
+        if "t" in mode or "r" in mode:
+            raise ValueError("Only binary writing is supported")
+        if "b" not in mode:
+            mode += "b"
+        if threads < 1:
+            raise ValueError(f"threads should be at least 1, got {threads}")
+        self.lock = threading.Lock()
+        self._calling_thread = threading.current_thread()
+        self.exception = None
+        self.level = level
+        self.previous_block = b""
+        self.block_size = block_size
+        # incompressible data grows a little; 10 % head-room as in gzip_ng_threaded.py:229-231
+        self.compressors = [zlib_ng._ParallelCompress(buffersize=block_size + max(block_size // 10, 500), level=level)]
+        self.threads = threads
+        self.input_queues = [queue.Queue(queue_size) for _ in range(threads)]
+        self.output_queues = []
+        self.compression_workers = []
+        self.output_worker = threading.Thread(target=self._compress_and_write)
+        self.index = 0
+        self._drain_index = 0
+        self._crc = 0
+        self._size = 0
+        self.running = False
+        self.raw, self.closefd = open_as_binary_stream(filename, mode)
+        self._closed = False
+        self._write_gzip_header()
+        self.start()
+
+    def _check_closed(self, msg=None):
+        if self._closed:
+            raise ValueError("I/O operation on closed file")
+
+    def _write_gzip_header(self):
+        # gzip_ng_threaded.py:269-284: note the order of the last two bytes (OS, then XFL)
+        xfl = 2 if self.level == zlib_ng.Z_BEST_COMPRESSION else 4 if self.level == zlib_ng.Z_BEST_SPEED else 0
+        self.raw.write(struct.pack("BBBBIBB", 0x1f, 0x8b, 8, 0, 0, 0xff, xfl))
+
+    def start(self):
+        self.running = True
+        self.output_worker.start()
+
+    def stop(self):
+        """Stop without caring for queued work."""
+        self.running = False
+        self.output_worker.join()
+
+    def write(self, b):
+        self._check_closed()
+        with self.lock:
+            if self.exception:
+                raise self.exception
+        nbytes = b.nbytes if isinstance(b, memoryview) else len(b)
+        if nbytes > self.block_size:
+            view = memoryview(b)
+            done = 0
+            for lo in range(0, nbytes, self.block_size):
+                done += self.write(view[lo:lo + self.block_size])
+            return done
+        data = bytes(b)
+        zdict = memoryview(self.previous_block)[-DEFLATE_WINDOW_SIZE:]
+        self.previous_block = data
+        slot = self.index % self.threads
+        self.index += 1
+        self.input_queues[slot].put((data, zdict))
+        return len(data)
+
+    def _end_gzip_stream(self):
+        self._check_closed()
+        for q in self.input_queues:
+            q.join()
+        # empty final block, then CRC32 and ISIZE (gzip_ng_threaded.py:332-338)
+        self.raw.write(b"\x03\x00" + struct.pack("<II", self._crc, self._size & 0xFFFFFFFF))
+        self._crc = 0
+        self._size = 0
+        self.raw.flush()
+
+    def flush(self):
+        self._end_gzip_stream()
+        self._write_gzip_header()
+
+    def close(self):
+        if self._closed:
+            return
+        self._end_gzip_stream()
+        self.stop()
+        if self.exception:
+            self.raw.close()
+            self._closed = True
+            raise self.exception
+        if self.closefd:
+            self.raw.close()
+        self._closed = True
+
+    @property
+    def closed(self):
+        return self._closed
+
+    def _alive(self):
+        return self.running and self._calling_thread.is_alive()
+
+    def _compress_and_write(self):
+        compressor = self.compressors[0]
+        nq = self.threads
+        while True:
+            # take blocks in the order write() dealt them; block only for the first one
+            batch, origins = [], []
+            q = self.input_queues[self._drain_index % nq]
+            try:
+                batch.append(q.get(timeout=0.05))
+            except queue.Empty:
+                if not self._alive():
+                    return
+                continue
+            origins.append(q)
+            self._drain_index += 1
+            while len(batch) < nq:
+                q = self.input_queues[self._drain_index % nq]
+                try:
+                    batch.append(q.get_nowait())
+                except queue.Empty:
+                    break
+                origins.append(q)
+                self._drain_index += 1
+            try:
+                results = compressor.compress_and_crc_batch(batch)
+            except Exception as exc:
+                for q in origins:
+                    q.task_done()
+                self._set_error_and_empty_queue(exc)
+                return
+            for (data, _), (compressed, crc), q in zip(batch, results, origins):
+                self._crc = zlib_ng.crc32_combine(self._crc, crc, len(data))
+                self._size += len(data)
+                self.raw.write(compressed)
+                q.task_done()
+
+    def _set_error_and_empty_queue(self, error, q=None):
+        with self.lock:
+            self.exception = error
+            self.running = False
+            for q in self.input_queues:
+                while True:
+                    try:
+                        q.get(timeout=0.05)
+                        q.task_done()
+                    except queue.Empty:
+                        break
+
+    def writable(self):
+        return True

@@ -1,0 +1,66 @@
+"""Block sharding across ranks and re-assembly of the compressed stream (multi-GPU leg).
+
+The reference's only parallel strategy is round-robin blocks over threads with an in-order writer
+(gzip_ng_threaded.py:316-321, :382-398).  Here every rank owns a contiguous range of blocks, compresses
+it on its own GPU and the variable-size slices are exchanged with one all-gather (RCCL over xGMI with
+backend "nccl"; the same code runs on "gloo" for CPU tests).  Only torch.distributed plumbing and
+integer arithmetic live here; no payload byte is computed on the host.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def shard_range(n_blocks, rank, world):
+    """Contiguous block range [lo, hi) of `rank` (replaces `index % threads`, gzip_ng_threaded.py:320)."""
+    lo = (n_blocks * rank) // world
+    hi = (n_blocks * (rank + 1)) // world
+    return lo, hi
+
+
+def allgather_stream(local, local_len, group=None, scratch=None):
+    """All ranks contribute local[:local_len] (uint8, 1-D); every rank gets the slices concatenated in
+    rank order.  Returns (stream tensor, total length, per-rank sizes).  `scratch` caches buffers."""
+    world = dist.get_world_size(group)
+    dev = local.device
+    mine = torch.tensor([int(local_len)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    hs = [int(s.item()) for s in sizes]
+    mx = max(max(hs), 1)
+    if local.numel() < mx:
+        raise ValueError("local buffer shorter than the largest slice")
+    scratch = scratch if scratch is not None else {}
+    need = world * mx
+    if scratch.get("cap", 0) < need:
+        scratch["buf"] = torch.empty(need + need // 8, dtype=torch.uint8, device=dev)
+        scratch["cap"] = scratch["buf"].numel()
+    if scratch.get("scap", 0) < sum(hs):
+        scratch["stream"] = torch.empty(sum(hs) + sum(hs) // 8 + 64, dtype=torch.uint8, device=dev)
+        scratch["scap"] = scratch["stream"].numel()
+    parts = [scratch["buf"][r * mx:(r + 1) * mx] for r in range(world)]
+    dist.all_gather(parts, local[:mx].contiguous(), group=group)
+    off = 0
+    for r, s in enumerate(hs):          # rank order == block order: ranges are contiguous
+        scratch["stream"][off:off + s] = parts[r][:s]
+        off += s
+    return scratch["stream"], off, hs
+
+
+def combine_crcs(crcs_and_lens):
+    """Fold (crc32, uncompressed_len) pairs in order, as _write does (gzip_ng_threaded.py:394)."""
+    L = _lib.load()
+    crc = 0
+    for c, n in crcs_and_lens:
+        crc = L.zngamd_crc32_combine(crc, c & 0xFFFFFFFF, n)
+    return crc
+
+
+def gzip_frame(body_len_total, crc, size, level):
+    """Header / trailer bytes of the reference's threaded writer (gzip_ng_threaded.py:269-284, :324-338)."""
+    import struct
+    xfl = 2 if level == 9 else 4 if level == 1 else 0
+    header = struct.pack("BBBBIBB", 0x1f, 0x8b, 8, 0, 0, 0xff, xfl)
+    trailer = b"\x03\x00" + struct.pack("<II", crc & 0xFFFFFFFF, size & 0xFFFFFFFF)
+    return header, trailer

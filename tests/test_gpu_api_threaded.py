@@ -1,0 +1,213 @@
+"""gzip_ng_threaded on the GPU engine.  Cases follow the reference's tests/test_gzip_ng_threaded.py
+(read == stdlib, threads in {1,3,-1} with 8 KiB blocks, incompressible data, injected oversized block,
+bad level, threads=0, append, caller's stream stays open, flush makes a complete file each time)."""
+import gzip
+import io
+import itertools
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TEST_FILE = os.path.join(GOLDEN, "test.fastq.gz")
+
+
+@pytest.fixture(scope="module")
+def T():
+    from zlib_ng_amd import gzip_ng_threaded
+    return gzip_ng_threaded
+
+
+@pytest.fixture(scope="module")
+def Z():
+    from zlib_ng_amd import zlib_ng
+    return zlib_ng
+
+
+def test_threaded_read(T):
+    with T.open(TEST_FILE, "rb") as f:
+        thread_data = f.read()
+    with gzip.open(TEST_FILE, "rb") as f:
+        assert thread_data == f.read()
+
+
+@pytest.mark.parametrize(["mode", "threads"], itertools.product(["wb", "wt"], [1, 3, -1]))
+def test_threaded_write(T, mode, threads):
+    with tempfile.NamedTemporaryFile("wb", delete=False) as tmp:
+        with T.open(tmp, mode, threads=threads, block_size=8 * 1024) as out_file:
+            with gzip.open(TEST_FILE, "rb" if "b" in mode else "rt") as in_file:
+                while True:
+                    block = in_file.read(128 * 1024)
+                    if not block:
+                        break
+                    out_file.write(block)
+    with gzip.open(TEST_FILE, "rt") as a, gzip.open(tmp.name, "rt") as b:
+        assert a.read() == b.read()
+    os.unlink(tmp.name)
+
+
+def test_threaded_write_framing_matches_reference_layout(T, fastq):
+    """header 1f8b0800 00000000 ff xfl | blocks | 03 00 | crc isize | trailing empty member;
+    byte-identical for 1 and 3 threads."""
+    import struct
+    import zlib
+    data = fastq[:512 * 1024]
+    outs = []
+    for threads in (1, 3):
+        bio = io.BytesIO()
+        with T.open(bio, "wb", compresslevel=6, threads=threads, block_size=128 * 1024) as f:
+            f.write(data)
+        outs.append(bio.getvalue())
+    assert outs[0] == outs[1]
+    blob = outs[0]
+    assert blob[:10] == bytes.fromhex("1f8b0800" "00000000" "ff00")
+    empty = bytes.fromhex("1f8b0800" "00000000" "ff00" "0300" "00000000" "00000000")
+    assert blob.endswith(empty)
+    first = blob[:-len(empty)]
+    assert first[-10:-8] == b"\x03\x00"
+    assert struct.unpack("<II", first[-8:]) == (zlib.crc32(data), len(data))
+    assert gzip.decompress(blob) == data
+
+
+def test_threaded_open_no_threads(T):
+    with tempfile.TemporaryFile("rb") as tmp:
+        klass = T.open(tmp, "rb", threads=0)
+        assert isinstance(klass, gzip.GzipFile)
+
+
+def test_threaded_open_not_a_file_or_pathlike(T):
+    with pytest.raises(TypeError) as error:
+        T.open((1, 2, 3))
+    error.match("str")
+    error.match("bytes")
+    error.match("file")
+
+
+@pytest.mark.timeout(30)
+def test_threaded_read_error(T):
+    data = open(TEST_FILE, "rb").read()
+    with T.open(io.BytesIO(data[:-8]), "rb") as tr_f:
+        with pytest.raises(EOFError):
+            tr_f.read()
+
+
+@pytest.mark.timeout(30)
+@pytest.mark.parametrize("threads", [1, 3])
+def test_threaded_write_oversized_block_no_error(T, threads):
+    data = os.urandom(1024 * 63)
+    with tempfile.NamedTemporaryFile(mode="wb", delete=False) as tmp:
+        with T.open(tmp, "wb", compresslevel=3, threads=threads, block_size=8 * 1024) as writer:
+            writer.write(data)
+    with gzip.open(tmp.name, "rb") as gzipped:
+        assert data == gzipped.read()
+    os.unlink(tmp.name)
+
+
+@pytest.mark.timeout(30)
+@pytest.mark.parametrize("threads", [1, 3])
+def test_threaded_write_error(T, threads):
+    f = T._ThreadedGzipWriter(io.BytesIO(), level=3, threads=threads, block_size=8 * 1024)
+    f.input_queues[0].put((os.urandom(1024 * 64), b""))
+    with pytest.raises(OverflowError) as error:
+        f.close()
+    error.match("Compressed output exceeds buffer size")
+
+
+def test_close_reader_and_writer(T):
+    f = T._ThreadedGzipReader(io.BytesIO(open(TEST_FILE, "rb").read()), "rb")
+    f.close()
+    assert f.closed
+    f.close()
+    for threads in (1, 3):
+        w = T._ThreadedGzipWriter(io.BytesIO(), threads=threads)
+        w.close()
+        assert w.closed
+        w.close()
+        with pytest.raises(ValueError) as error:
+            w.write(b"abc")
+        error.match("closed")
+
+
+def test_readable_writable(T):
+    with T.open(TEST_FILE, "rb") as f:
+        assert not f.writable()
+    with T.open(io.BytesIO(), "wb") as f:
+        assert not f.readable()
+
+
+def test_writer_wrong_level(T, Z):
+    with tempfile.NamedTemporaryFile("wb") as tmp:
+        with pytest.raises(Z.error) as error:
+            T.open(tmp.name, mode="wb", compresslevel=42)
+        error.match("Bad compression level")
+
+
+def test_writer_too_low_threads(T):
+    with pytest.raises(ValueError) as error:
+        T._ThreadedGzipWriter(io.BytesIO(), threads=0)
+    error.match("threads")
+    error.match("at least 1")
+
+
+def test_reader_read_after_close(T):
+    with open(TEST_FILE, "rb") as test_f:
+        f = T._ThreadedGzipReader(test_f)
+        f.close()
+        with pytest.raises(ValueError) as error:
+            f.read(1024)
+        error.match("closed")
+
+
+def test_append_binary_and_text(T, tmp_path):
+    p = tmp_path / "test.txt.gz"
+    with T.open(p, "wb") as f:
+        f.write(b"AB")
+    with T.open(p, mode="ab") as f:
+        f.write(b"CD")
+    assert gzip.open(p, "rb").read() == b"ABCD"
+    q = tmp_path / "t2.txt.gz"
+    with T.open(q, "wt") as f:
+        f.write("AB")
+    with T.open(q, mode="at") as f:
+        f.write("CD")
+    assert gzip.open(q, "rt").read() == "ABCD"
+
+
+def test_streams_not_closed(T):
+    s = io.BytesIO(gzip.compress(b"thisisatest"))
+    with T.open(s, "rb") as f:
+        assert f.read() == b"thisisatest"
+    assert not s.closed
+    s = io.BytesIO()
+    with T.open(s, "wb") as f:
+        f.write(b"thisisatest")
+    assert not s.closed
+    assert gzip.decompress(s.getvalue()) == b"thisisatest"
+
+
+@pytest.mark.parametrize("threads", [1, 2])
+def test_flush(T, tmp_path, threads):
+    p = tmp_path / "output.gz"
+    with T.open(p, "wb", threads=threads) as f:
+        f.write(b"1")
+        f.flush()
+        assert gzip.decompress(p.read_bytes()) == b"1"
+        f.write(b"2")
+        f.flush()
+        assert gzip.decompress(p.read_bytes()) == b"12"
+        f.write(b"3")
+        f.flush()
+        assert gzip.decompress(p.read_bytes()) == b"123"
+    assert gzip.decompress(p.read_bytes()) == b"123"
+
+
+def test_large_blocks_default_size(T, fastq):
+    """Default block_size is 1 MiB (gzip_ng_threaded.py:23-24): blocks are cut into 128 KiB units inside."""
+    bio = io.BytesIO()
+    with T.open(bio, "wb", threads=4) as f:
+        f.write(fastq)
+    assert gzip.decompress(bio.getvalue()) == fastq

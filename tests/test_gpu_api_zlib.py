@@ -1,0 +1,173 @@
+"""zlib_ng / gzip_ng one-shot API on the GPU engine against CPython's zlib / gzip, after the reference's
+tests/test_compat.py (cross-decode both directions over levels x wbits x sizes, checksums over seeds) and
+the known-answer tests of tests/test_zlib_compliance.py / test_gzip_ng.py."""
+import gzip
+import io
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [0, 1, 2, 5, 100, 1023, 4096, 65536, 131072, 131073, 500001]
+SEEDS = [int(s) for s in open(os.path.join(GOLDEN, "seeds.txt")).read().split()][:12] + \
+        [-(2 ** 64 + 5), -3, -1, 0, 1, 2 ** 64 + 5]
+
+
+@pytest.fixture(scope="module")
+def Z():
+    from zlib_ng_amd import zlib_ng
+    return zlib_ng
+
+
+@pytest.fixture(scope="module")
+def G():
+    from zlib_ng_amd import gzip_ng
+    return gzip_ng
+
+
+def test_checksum_kats(Z):
+    # reference tests/test_zlib_compliance.py:94-120
+    assert Z.crc32(b"penguin", 0) == 0x0e5c1a120 & 0xFFFFFFFF
+    assert Z.crc32(b"penguin", 1) == 0x43b6aa94
+    assert Z.adler32(b"penguin", 0) == 0x0bcf02f6
+    assert Z.adler32(b"penguin", 1) == 0x0bd602f7
+    assert Z.crc32(b"penguin") == Z.crc32(b"penguin", 0)
+    assert Z.adler32(b"penguin") == Z.adler32(b"penguin", 1)
+    assert Z.crc32(b"abcdefghijklmnop") == 2486878355
+    assert Z.crc32(b"spam") == 1138425661
+    assert Z.adler32(b"spam") == 72286642
+    foo = b"abcdefghijklmnop"
+    assert Z.adler32(foo + foo) == 3573550353
+    assert Z.crc32(b"") == 0 and Z.adler32(b"") == 1
+    assert Z.crc32_combine(Z.crc32(b"abc"), Z.crc32(b"defg"), 4) == Z.crc32(b"abcdefg")
+
+
+def test_checksums_vs_stdlib_over_seeds(Z, fastq):
+    for n in (0, 8, 64, 4096, 2 ** 17, 2 ** 19):
+        for seed in SEEDS:
+            assert Z.crc32(fastq[:n], seed) == zlib.crc32(fastq[:n], seed)
+            assert Z.adler32(fastq[:n], seed) == zlib.adler32(fastq[:n], seed)
+
+
+@pytest.mark.parametrize("level", [-1, 0, 1, 3, 6, 9])
+def test_compress_decodes_with_stdlib(Z, fastq, level):
+    for wbits in (9, 12, 15, -9, -15, 25, 31):
+        for n in SIZES:
+            c = Z.compress(fastq[:n], level, wbits)
+            assert zlib.decompress(c, wbits) == fastq[:n], (level, wbits, n)
+
+
+def test_stdlib_compressed_decodes(Z, fastq):
+    for level in (0, 1, 6, 9):
+        for wbits in (9, 15, -12, -15, 25, 31):
+            for mem in (1, 8, 9):
+                for strategy in (0, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                    for n in (0, 1, 1000, 200000):
+                        co = zlib.compressobj(level, zlib.DEFLATED, wbits, mem, strategy)
+                        c = co.compress(fastq[:n]) + co.flush()
+                        assert Z.decompress(c, wbits) == fastq[:n]
+    z = zlib.compress(fastq[:5000])
+    g = gzip.compress(fastq[:5000])
+    assert Z.decompress(z, 47) == Z.decompress(g, 47) == fastq[:5000]      # auto-detect
+    assert Z.decompress(z + b"trailing garbage") == fastq[:5000]
+
+
+def test_kats_and_errors(Z):
+    assert Z.decompress(b'x\x9cK\xcb\xcf\x07\x00\x02\x82\x01E') == b"foo"       # test_zlib_compliance.py:612-614
+    assert Z.decompress(b"x\x9cKLJ\x06\x00\x02M\x01\x27") == b"abc"            # :497 (+ the missing Adler byte)
+    with pytest.raises(Z.error):
+        Z.decompress(b"x\x9cKLJ\x06\x00\x02M\x01")
+    assert Z.compress(b"", wbits=-15) == b"\x03\x00"                             # gzip_ng_threaded.py:333 terminator
+    with pytest.raises(Z.error) as e:
+        Z.decompress(zlib.compress(b"a" * 1000)[:-4])
+    e.match("Error -5 while decompressing data: incomplete or truncated stream")  # :249-255
+    with pytest.raises(Z.error) as e:
+        Z.decompress(b"this is not zlib data")
+    e.match("Error -3 while decompressing data")
+    with pytest.raises(Z.error) as e:
+        Z.compress(b"abc", 42)
+    e.match("Bad compression level")
+    with pytest.raises(Z.error) as e:
+        Z.decompress(zlib.compress(b"x" * 100, wbits=15), 9)
+    e.match("invalid window size")                                                # :868
+    with pytest.raises(TypeError):
+        Z.compress("a string")
+    with pytest.raises(ValueError):
+        Z.decompress(b"", 15, -1)
+
+
+def test_parallel_compress_surface(Z, fastq):
+    with pytest.raises(Z.error) as e:
+        Z._ParallelCompress(1000, 42)
+    e.match("Bad compression level")
+    pc = Z._ParallelCompress(131072 + 13107, 6)
+    with pytest.raises(TypeError):
+        pc.compress_and_crc(b"only one")
+    blk, zd = fastq[200000:300000], fastq[200000 - 32768:200000]
+    out, crc = pc.compress_and_crc(blk, zd)
+    assert out.endswith(b"\x00\x00\xff\xff") and crc == zlib.crc32(blk)
+    assert zlib.decompressobj(-15, zdict=zd).decompress(out) == blk
+    d = zlib.decompressobj(-15, zdict=zd)
+    assert d.decompress(out + b"\x03\x00") == blk and d.eof
+    small = Z._ParallelCompress(8192 + 819, 3)
+    with pytest.raises(OverflowError) as e:
+        small.compress_and_crc(os.urandom(65536), b"")
+    e.match("Compressed output exceeds buffer size")
+
+
+def test_gzip_ng_one_shot_and_files(G, Z, fastq, tmp_path):
+    data = fastq[:300000]
+    c = G.compress(data, 6, mtime=1)
+    assert c[4:8] == b"\x01\x00\x00\x00" and c[9] == 255
+    assert gzip.decompress(c) == data and G.decompress(c) == data
+    assert G.decompress(gzip.compress(data, 1)) == data
+    assert G.decompress(gzip.compress(data) + gzip.compress(data[:100]) + bytes(50)) == data + data[:100]
+    for name in ("test.fastq.gz", "concatenated.fastq.gz", "test.fastq.bgzip.gz"):
+        raw = open(os.path.join(GOLDEN, name), "rb").read()
+        assert G.decompress(raw) == gzip.decompress(raw)
+    # FEXTRA known answer, tests/test_gzip_compliance.py:622-628
+    gz_extra = (b'\x1f\x8b\x08\x04\xb2\x17cQ\x02\xff\x09\x00XX\x05\x00Extra\x0bI-.\x01\x002\xd1Mx\x04\x00\x00\x00')
+    assert G.decompress(gz_extra) == b"Test"
+    # file objects
+    p = tmp_path / "f.gz"
+    with G.open(p, "wb", compresslevel=6) as f:
+        for i in range(0, len(data), 70000):
+            f.write(data[i:i + 70000])
+    assert gzip.open(p).read() == data
+    with G.open(p, "rb") as f:
+        assert f.read() == data
+    with G.open(p, "rb") as f:
+        f.seek(1000)
+        assert f.read(50) == data[1000:1050]
+    with G.open(p, "rt") as f:
+        assert f.readline() == data.split(b"\n")[0].decode() + "\n"
+
+
+def test_gzip_reader_errors(G, Z, fastq):
+    raw = gzip.compress(fastq[:30000], mtime=0)
+    with pytest.raises(G.BadGzipFile) as e:
+        G.decompress(raw[:-8] + bytes([raw[-8] ^ 1]) + raw[-7:])
+    e.match("CRC check failed")
+    with pytest.raises(G.BadGzipFile) as e:
+        G.decompress(raw[:-4] + bytes([raw[-4] ^ 1]) + raw[-3:])
+    e.match("Incorrect length of data produced")
+    with pytest.raises(G.BadGzipFile) as e:
+        G.decompress(b"\x1f\x8c" + raw[2:])
+    e.match("Not a gzipped file")
+    with pytest.raises(G.BadGzipFile) as e:
+        G.decompress(raw[:2] + b"\x07" + raw[3:])
+    e.match("Unknown compression method")
+    with pytest.raises(EOFError) as e:
+        G.decompress(raw[:-3])
+    e.match("Compressed file ended before the end-of-stream marker was reached")
+    with pytest.raises(G.BadGzipFile):
+        G.decompress(raw + b"garbage!")
+    r = Z._GzipReader(raw + b"garbage!")
+    assert r.read(30000) == fastq[:30000]          # good member is served, the error comes after it
+    with pytest.raises(G.BadGzipFile):
+        r.read(10)
