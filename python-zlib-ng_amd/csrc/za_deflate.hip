@@ -20,69 +20,110 @@
 // ------------------------------------------------------------------------------------------------
 // k_chains
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
-                                                  uint16_t *__restrict__ prev_ws)
+// One 512-thread workgroup per unit.  The 15-bit bucket space is split into 8 classes by the top 3 hash
+// bits; wave w owns class w and a private 4096-entry u16 head table (8 x 8 KiB of LDS).  Every wave
+// sweeps all positions 64 at a time, keeps the ones of its class, compacts them (ballot + mbcnt) into a
+// small LDS ring in position order, and whenever 64 are pending inserts them as one dense tile:
+// same-bucket lanes are ordered by a 12-ballot bit-slice match-any, so the result is exactly the
+// sequential insertion order -- with no barrier between waves, since no two waves share a bucket.
+#define ZA_CH_WAVES 8
+#define ZA_CH_SUB   (ZA_HASH_BITS - 3)        // bits of the per-wave table index
+
+__device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, uint32_t rd, int m, int pmin,
+                                                uint16_t *__restrict__ prevdist, int dict_len)
 {
-    __shared__ uint16_t head[1 << ZA_HASH_BITS];
+    const int lane = za_lane();
+    const bool valid = lane < m;
+    const uint32_t e = stage[(rd + (uint32_t)lane) & 127u];
+    const uint32_t P = e & 0x3FFFFu, h = (e >> 18) & ((1u << ZA_CH_SUB) - 1u);
+    unsigned long long eq = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < ZA_CH_SUB; b++) {
+        const bool bit = (h >> b) & 1u;
+        const unsigned long long B = __ballot(bit);
+        eq &= bit ? B : ~B;
+    }
+    const unsigned long long lower = eq & ((1ull << lane) - 1ull);
+    const unsigned long long higher = (eq >> lane) >> 1;
+    const int j = lower ? 63 - __builtin_clzll(lower) : lane;
+    const uint32_t Pj = __shfl(P, j, 64);
+    uint32_t d;
+    if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
+    else {
+        const uint32_t hv = head[h];
+        d = (P - hv) & 0xFFFFu;
+        if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
+    }
+    if (valid && !higher) head[h] = (uint16_t)(P & 0xFFFFu);
+    if (valid) prevdist[(int)P - ZA_WIN + dict_len] = (uint16_t)d;
+}
+
+__global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                                uint16_t *__restrict__ prev_ws)
+{
+    __shared__ uint16_t head_all[ZA_CH_WAVES][1 << ZA_CH_SUB];
+    __shared__ uint32_t stage_all[ZA_CH_WAVES][128];
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
     uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;
     const int lane = za_lane();
-    for (int i = lane; i < (1 << ZA_HASH_BITS) / 2; i += 64) ((uint32_t *)head)[i] = 0;
-    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint16_t *head = head_all[wave];
+    uint32_t *stage = stage_all[wave];
+    for (int i = lane; i < (1 << ZA_CH_SUB) / 2; i += 64) ((uint32_t *)head)[i] = 0;
+    __builtin_amdgcn_wave_barrier();
     const int total = dict_len + n;
     const int pmin = ZA_WIN - dict_len;
+    uint32_t rd = 0, wr = 0;
+    // software pipeline: the next tile's bytes are in flight while this one is classified
+    int i0 = lane, p0 = i0 - dict_len;
+    bool valid0 = (i0 < total) && (p0 + ZA_MIN_MATCH <= n);
+    uint32_t v0 = valid0 ? za_ld32(data + p0) : 0u;
     for (int base = 0; base < total; base += 64) {
-        const int i = base + lane;
-        const int p = i - dict_len;
-        const bool valid = (i < total) && (p + ZA_MIN_MATCH <= n);
-        const uint32_t v = valid ? za_ld32(data + p) : 0u;
-        const uint32_t h = za_hash4(v);
-        // lanes of this tile that fall in my bucket (bit-sliced compare over the 15 hash bits)
-        unsigned long long eq = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < ZA_HASH_BITS; b++) {
-            const bool bit = (h >> b) & 1u;
-            const unsigned long long B = __ballot(bit);
-            eq &= bit ? B : ~B;
+        const int i1 = base + 64 + lane, p1 = i1 - dict_len;
+        const bool valid1 = (i1 < total) && (p1 + ZA_MIN_MATCH <= n);
+        const uint32_t v1 = valid1 ? za_ld32(data + p1) : 0u;
+        const uint32_t h = za_hash4(v0);
+        const bool mine = valid0 && (h >> ZA_CH_SUB) == wave;
+        const unsigned long long mask = __ballot(mine);
+        if (mine) {
+            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            stage[(wr + rank) & 127u] = (uint32_t)(ZA_WIN + p0) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
         }
-        const unsigned long long lower = eq & ((1ull << lane) - 1ull);
-        const unsigned long long higher = (eq >> lane) >> 1;
-        const uint32_t P = (uint32_t)(ZA_WIN + p);
-        uint32_t d;
-        if (lower) {
-            d = (uint32_t)(lane - (63 - __builtin_clzll(lower)));
-        } else {
-            const uint32_t hv = head[h];
-            d = (P - hv) & 0xFFFFu;
-            if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
+        wr += (uint32_t)__builtin_popcountll(mask);
+        __builtin_amdgcn_wave_barrier();
+        if (wr - rd >= 64u) {
+            za_chains_dense(head, stage, rd, 64, pmin, prevdist, dict_len);
+            rd += 64u;
         }
-        if (valid && !higher) head[h] = (uint16_t)(P & 0xFFFFu);
-        if (i < total) prevdist[i] = (uint16_t)(valid ? d : 0u);
+        p0 = p1; valid0 = valid1; v0 = v1;
+    }
+    if (wr != rd) za_chains_dense(head, stage, rd, (int)(wr - rd), pmin, prevdist, dict_len);
+    // positions with fewer than 4 bytes left are never inserted: their link is 0
+    if (wave == 0 && lane < ZA_MIN_MATCH - 1) {
+        const int p = n - 1 - lane;
+        if (p >= -dict_len) prevdist[p + dict_len] = 0;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_search
 // ------------------------------------------------------------------------------------------------
+// One 1024-thread workgroup per unit.  The sliding window lives in LDS: the chain links of the last
+// 40960 positions (u16 ring) and the input bytes of the last 65536 positions (byte ring), both indexed
+// by the absolute position P = 32768 + p.  A tile of 4096 positions is staged per barrier; every
+// position of the tile is then searched in parallel with LDS traffic only.
 #define ZA_SEARCH_THREADS 1024
 #define ZA_SEARCH_TILE    4096
-#define ZA_RING           65536
+#define ZA_RING           40960            // chain-link ring: window 32768 + two tiles
+#define ZA_BYTES          65536            // byte ring (power of two)
+#define ZA_LOOKAHEAD      272              // bytes staged beyond the tile: max match 258 + wide compares
 
-__device__ __forceinline__ int za_match_len(const uint8_t *a, const uint8_t *b, int maxlen, bool wide_ok)
+__device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t addr)
 {
-    int len = 0;
-    if (wide_ok) {
-        while (len < maxlen) {
-            const uint64_t x = za_ld64(a + len) ^ za_ld64(b + len);
-            if (x) { len += (int)(__builtin_ctzll(x) >> 3); break; }
-            len += 8;
-        }
-        return len < maxlen ? len : maxlen;
-    }
-    while (len < maxlen && a[len] == b[len]) len++;
-    return len;
+    const uint32_t idx = addr & (ZA_BYTES - 1), w = idx >> 2;
+    return __builtin_amdgcn_alignbyte(win32[w + 1], win32[w], idx & 3u);     // win32 has 4 mirrored pad dwords
 }
 
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
@@ -91,21 +132,42 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                                                                  uint32_t *__restrict__ best_ws, ZaLevel L)
 {
     __shared__ uint16_t ring[ZA_RING];
+    __shared__ uint32_t win32[ZA_BYTES / 4 + 4];
+    uint8_t *win8 = (uint8_t *)win32;
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
-    const uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;
+    const uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;     // index p + dict_len
     uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     const int tid = (int)threadIdx.x;
-    const int total = dict_len + n;
     // bytes that may be read starting at data[0] without leaving the caller's buffer
     const long long readable = (long long)(in_total - u.in_off);
-    int loaded = 0;
+    int links_loaded = -dict_len;        // positions p < links_loaded have their chain link in the ring
+    int bytes_loaded = -dict_len;        // positions p < bytes_loaded have their byte in the byte ring
+    bytes_loaded &= ~3;                  // staged in aligned dwords (P is a multiple of 4 when p is)
     for (int base = 0; base < n; base += ZA_SEARCH_TILE) {
-        int need = dict_len + base + ZA_SEARCH_TILE;
-        if (need > total) need = total;
-        for (int i = loaded + tid; i < need; i += ZA_SEARCH_THREADS) ring[i & (ZA_RING - 1)] = prevdist[i];
-        loaded = need;
+        // ---- stage chain links up to the tile end, bytes up to tile end + lookahead
+        int need_links = base + ZA_SEARCH_TILE;
+        if (need_links > n) need_links = n;
+        for (int p = links_loaded + tid; p < need_links; p += ZA_SEARCH_THREADS)
+            ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = prevdist[p + dict_len];
+        links_loaded = need_links;
+        int need_bytes = base + ZA_SEARCH_TILE + ZA_LOOKAHEAD;
+        if (need_bytes > n) need_bytes = n;
+        need_bytes = (need_bytes + 3) & ~3;
+        for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) {
+            uint32_t v;
+            if (p >= -dict_len && (long long)p + 4 <= readable) v = za_ld32(data + p);
+            else {      // edges: before the dictionary start or past the caller's buffer
+                v = 0;
+                for (int k = 0; k < 4; k++)
+                    if (p + k >= -dict_len && (long long)(p + k) < readable) v |= (uint32_t)data[p + k] << (8 * k);
+            }
+            const uint32_t w = ((uint32_t)(ZA_WIN + p) & (ZA_BYTES - 1)) >> 2;
+            win32[w] = v;
+            if (w < 4) win32[w + ZA_BYTES / 4] = v;
+        }
+        bytes_loaded = need_bytes;
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
@@ -117,23 +179,37 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
             uint32_t result = 0;
             if (maxlen >= ZA_MIN_MATCH) {
-                const bool wide_ok = (long long)p + ZA_MAX_MATCH + 8 <= readable;
+                const uint32_t P = (uint32_t)(ZA_WIN + p);
                 const int nice = L.nice < maxlen ? L.nice : maxlen;
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
-                int q = p, depth = L.chain;
-                const uint8_t *me = data + p;
+                uint32_t me_bl = win8[(P + 3u) & (ZA_BYTES - 1)];          // my byte at offset best_len
+                const uint32_t me0 = za_lds_ld32(win32, P);
+                uint32_t q = P;
+                int depth = L.chain;
                 while (depth-- > 0) {
-                    const int d = ring[(q + dict_len) & (ZA_RING - 1)];
+                    const uint32_t d = ring[q % ZA_RING];
                     if (d == 0) break;
                     q -= d;
-                    const int dist = p - q;
+                    const int dist = (int)(P - q);
                     if (dist > L.max_dist) break;
-                    const uint8_t *cand = data + q;
-                    if (cand[best_len] != me[best_len]) continue;
-                    const int len = za_match_len(cand, me, maxlen, wide_ok);
+                    if (win8[(q + (uint32_t)best_len) & (ZA_BYTES - 1)] != me_bl) continue;
+                    // full compare, 4 bytes per step
+                    int len = 0;
+                    uint32_t x = za_lds_ld32(win32, q) ^ me0;
+                    if (x == 0) {
+                        len = 4;
+                        while (len < maxlen) {
+                            x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
+                            if (x) break;
+                            len += 4;
+                        }
+                    }
+                    if (x) len += (int)(__builtin_ctz(x) >> 3);
+                    if (len > maxlen) len = maxlen;
                     if (len > best_len) {
                         best_len = len; best_dist = dist;
                         if (len >= nice) break;
+                        me_bl = win8[(P + (uint32_t)len) & (ZA_BYTES - 1)];
                     }
                 }
                 if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
@@ -141,15 +217,27 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             }
             best[p] = result;
         }
-        // no second barrier: the next tile's ring stores land >= 57344 entries behind any chain
-        // walk still running (window 32768 + tile 4096 <= ring 65536 - tile 4096)
+        // one barrier per tile is enough for the rings: the next tile's stores land at least
+        // 65536-4096-272-32768 byte slots / 40960-4096-32768 link slots behind any walk still running,
+        // and nobody reads positions that are not staged yet.  The barrier below orders the NEXT
+        // staging pass after this tile's reads of slots that it will overwrite only if the margin
+        // were smaller than one tile; with the sizes above it is not needed.
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_parse  (+ histogram + CRC-32)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+// One wave per unit, one lane per 2 KiB segment.  Each lane walks its own stream of `best` entries and
+// input bytes; a dependent global load per token would cost microseconds, so both streams are staged
+// through LDS in chunks of 32 positions per lane (rows with an odd dword stride: conflict free), with
+// the next chunk's global loads in flight while the current one is parsed.
+#define ZA_PCH 32
+#define ZA_PROW (ZA_PCH + 1)          // best entries per row: chunk + one look-ahead (lazy rule)
+#define ZA_DROW (ZA_PCH / 4 + 1)      // data dwords per row (+1 keeps the stride odd)
+
+__global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                 const ZaUnit *__restrict__ units,
                                                  const uint32_t *__restrict__ best_ws, uint32_t *__restrict__ tok_ws,
                                                  uint32_t *__restrict__ segtok_ws, uint32_t *__restrict__ hist_ws,
                                                  uint32_t *__restrict__ crc_out,
@@ -159,8 +247,11 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
 {
     __shared__ uint32_t hist[ZA_HIST_STRIDE];
     __shared__ uint32_t crct[256];
+    __shared__ uint32_t rowb[64 * ZA_PROW];
+    __shared__ uint32_t rowd[64 * ZA_DROW];
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
+    const long long readable = (long long)(in_total - u.in_off);
     const int n = (int)u.in_len;
     const int lane = za_lane();
     const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
@@ -171,40 +262,99 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     const int s0 = lane << ZA_SEG_SHIFT;
     int s1 = s0 + ZA_SEG;
     if (s1 > n) s1 = n;
+    const bool active = lane < nseg;
+    const bool do_parse = level > 0;
+    const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
+    uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + s0;
+    uint32_t *myb = rowb + lane * ZA_PROW;
+    uint32_t *myd = rowd + lane * ZA_DROW;
 
-    // ---- CRC-32 of the unit (zng_crc32_z at zlib_ngmodule.c:1741)
-    const uint32_t c = za_wave_crc32(data, n, crct, x8k_table);
-    if (lane == 0) crc_out[blockIdx.x] = c;
+    uint4 pb[ZA_PCH / 4];          // prefetched best entries of the next chunk
+    uint32_t pla = 0;              // its look-ahead entry
+    uint32_t pd[ZA_PCH / 4];       // prefetched data dwords
+    auto prefetch = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < ZA_PCH / 4; j++) {
+            pb[j] = make_uint4(0, 0, 0, 0);
+            pd[j] = 0;
+        }
+        pla = 0;
+        if (active && cb < s1) {
+            if (do_parse) {
+#pragma unroll
+                for (int j = 0; j < ZA_PCH / 4; j++) pb[j] = *(const uint4 *)(best + cb + 4 * j);   // workspace rows are 16 B aligned
+                if (cb + ZA_PCH < n) pla = best[cb + ZA_PCH];
+            }
+#pragma unroll
+            for (int j = 0; j < ZA_PCH / 4; j++) {
+                const int o = cb + 4 * j;
+                if ((long long)o + 4 <= readable) pd[j] = za_ld32(data + o);
+                else for (int k = 0; k < 4; k++) if ((long long)(o + k) < readable) pd[j] |= (uint32_t)data[o + k] << (8 * k);
+            }
+        }
+    };
 
-    // ---- parse
     uint32_t ntok = 0;
-    if (level > 0 && lane < nseg) {
-        const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
-        uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + s0;
-        int p = s0;
-        while (p < s1) {
-            const uint32_t b = best[p];
-            const int len = (int)(b >> 16);
-            if (len >= ZA_MIN_MATCH) {
-                if (L.lazy && len < L.lazy && p + 1 < s1 && (int)(best[p + 1] >> 16) > len) {
-                    const uint32_t lit = data[p];
-                    tok[ntok++] = lit; atomicAdd(&hist[lit], 1u); p++;
-                    continue;
+    uint32_t crc_r = 0xFFFFFFFFu;
+    int p = s0;
+    prefetch(s0);
+#pragma unroll 1
+    for (int c = 0; c < ZA_SEG / ZA_PCH; c++) {
+        const int cb = s0 + c * ZA_PCH;
+        // wave-uniform early exit: every active lane is past its segment end
+        if (__ballot(active && cb < s1) == 0ull) break;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < ZA_PCH / 4; j++) {
+            myb[4 * j + 0] = pb[j].x; myb[4 * j + 1] = pb[j].y; myb[4 * j + 2] = pb[j].z; myb[4 * j + 3] = pb[j].w;
+            myd[j] = pd[j];
+        }
+        myb[ZA_PCH] = pla;
+        __builtin_amdgcn_wave_barrier();
+        prefetch(cb + ZA_PCH);
+        int ce = cb + ZA_PCH;
+        if (ce > s1) ce = s1;
+        if (active) {
+            // CRC-32 over this chunk's bytes (zng_crc32_z at zlib_ngmodule.c:1741)
+            const uint8_t *bytes = (const uint8_t *)myd;
+            for (int k = cb; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb]) & 0xFF] ^ (crc_r >> 8);
+            if (do_parse) {
+                while (p < ce) {
+                    const uint32_t b = myb[p - cb];
+                    const int len = (int)(b >> 16);
+                    if (len >= ZA_MIN_MATCH &&
+                        !(L.lazy && len < L.lazy && p + 1 < s1 && (int)(myb[p + 1 - cb] >> 16) > len)) {
+                        const int dist = (int)(b & 0xFFFFu);
+                        int lc, ln, le, dc, dn, de;
+                        za_len_sym(len, lc, ln, le);
+                        za_dist_sym(dist, dc, dn, de);
+                        tok[ntok++] = 0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1);
+                        atomicAdd(&hist[257 + lc], 1u);
+                        atomicAdd(&hist[288 + dc], 1u);
+                        p += len;
+                    } else {
+                        const uint32_t lit = bytes[p - cb];
+                        tok[ntok++] = lit;
+                        atomicAdd(&hist[lit], 1u);
+                        p++;
+                    }
                 }
-                const int dist = (int)(b & 0xFFFFu);
-                int lc, ln, le, dc, dn, de;
-                za_len_sym(len, lc, ln, le);
-                za_dist_sym(dist, dc, dn, de);
-                tok[ntok++] = 0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1);
-                atomicAdd(&hist[257 + lc], 1u);
-                atomicAdd(&hist[288 + dc], 1u);
-                p += len;
-            } else {
-                const uint32_t lit = data[p];
-                tok[ntok++] = lit; atomicAdd(&hist[lit], 1u); p++;
             }
         }
     }
+    // ---- fold the per-segment CRCs: crc(A||B) = crc(A) * x^(8|B|) ^ crc(B)
+    uint32_t cseg = 0;
+    if (active) {
+        cseg = crc_r ^ 0xFFFFFFFFu;
+        if (lane < nseg - 1) {
+            const int tail = n - ((nseg - 1) << ZA_SEG_SHIFT);
+            uint32_t xt = 0x80000000u, sq = 0x00800000u;
+            for (int m = tail; m; m >>= 1) { if (m & 1) xt = za_multmodp(sq, xt); sq = za_multmodp(sq, sq); }
+            cseg = za_multmodp(za_multmodp(x8k_table[nseg - 2 - lane], xt), cseg);
+        }
+    }
+    cseg = za_wave_xor_reduce(cseg);
+    if (lane == 0) crc_out[blockIdx.x] = cseg;
     segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] = ntok;
     __syncthreads();
     if (lane == 0) hist[256] = 1;
@@ -483,6 +633,8 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
 // Per-lane bit packer.  The first word a lane touches (it may share it with the previous lane or
 // with the header) and its trailing partial word are merged with atomic OR; words in between are
 // owned by the lane alone and stored directly.
+#define ZA_TCH 32      // tokens staged per lane and chunk in k_pack
+
 struct ZaLaneW {
     uint32_t *out; uint32_t cap_words; uint32_t w; uint64_t acc; int nb; bool first; bool ovf;
     __device__ void init(uint32_t *o, uint32_t cap, uint32_t bitpos)
@@ -512,6 +664,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
                                                 uint32_t *__restrict__ status)
 {
     __shared__ uint32_t codes[ZA_CODE_STRIDE];
+    __shared__ uint32_t rowt[64 * (ZA_TCH + 1)];
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len;
@@ -568,18 +721,45 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     __syncthreads();
     const uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + ((size_t)lane << ZA_SEG_SHIFT);
     const uint32_t ntok = lane < nseg ? segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] : 0u;
+    uint32_t maxtok = ntok;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(maxtok, d, 64); maxtok = o > maxtok ? o : maxtok; }
+    uint32_t *myt = rowt + lane * (ZA_TCH + 1);
+
+    // Walk my tokens in chunks of ZA_TCH staged through LDS (next chunk's loads in flight meanwhile).
+    auto for_each_token = [&](auto &&fn) {
+        uint4 pt[ZA_TCH / 4];
+        auto prefetch = [&](uint32_t k0) {
+            if (k0 < ntok) {
+#pragma unroll
+                for (int j = 0; j < ZA_TCH / 4; j++) pt[j] = *(const uint4 *)(tok + k0 + 4 * j);
+            }
+        };
+        prefetch(0);
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < maxtok; k0 += ZA_TCH) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < ZA_TCH / 4; j++) {
+                myt[4 * j + 0] = pt[j].x; myt[4 * j + 1] = pt[j].y; myt[4 * j + 2] = pt[j].z; myt[4 * j + 3] = pt[j].w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            prefetch(k0 + ZA_TCH);
+            uint32_t ke = k0 + ZA_TCH;
+            if (ke > ntok) ke = ntok;
+            for (uint32_t k = k0; k < ke; k++) fn(myt[k - k0]);
+        }
+    };
 
     // pass A: bit length of my segment
     uint32_t bits = 0;
-    for (uint32_t k = 0; k < ntok; k++) {
-        const uint32_t t = tok[k];
+    for_each_token([&](uint32_t t) {
         if (t & 0x80000000u) {
             int lc, ln, le, dc, dn, de;
             za_len_sym((int)((t >> 16) & 0xFF) + 3, lc, ln, le);
             za_dist_sym((int)(t & 0x7FFF) + 1, dc, dn, de);
             bits += (codes[257 + lc] >> 16) + (uint32_t)ln + (codes[288 + dc] >> 16) + (uint32_t)dn;
         } else bits += codes[t] >> 16;
-    }
+    });
     const uint32_t incl = za_wave_incl_scan(bits);
     const uint32_t start = plan.header_bits + incl - bits;
     const uint32_t end_all = plan.header_bits + __shfl(incl, 63, 64);      // bit offset of EOB
@@ -590,8 +770,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     // pass B: emit
     ZaLaneW w;
     w.init(slot32, cap_words, start);
-    for (uint32_t k = 0; k < ntok; k++) {
-        const uint32_t t = tok[k];
+    for_each_token([&](uint32_t t) {
         if (t & 0x80000000u) {
             int lc, ln, le, dc, dn, de;
             za_len_sym((int)((t >> 16) & 0xFF) + 3, lc, ln, le);
@@ -604,7 +783,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             const uint32_t c = codes[t];
             w.put(c & 0xFFFF, (int)(c >> 16));
         }
-    }
+    });
     w.finish();
     ovf = w.ovf;
     // tail: EOB, then final padding or the sync-flush marker (empty stored block)
