@@ -33,6 +33,10 @@ static const za_level LEVELS[10] = {
     {16, 32, 16}, {32, 64, 16}, {64, 128, 32}, {512, 258, 128}
 };
 
+/* test-only: forced token-boundary granularity (default ZA_SEG) */
+static int g_cut = ZA_SEG;
+void za_o_set_cut(int cut) { g_cut = cut; }
+
 /* test-only override of the level table (parameter studies); chain <= 0 switches it off */
 static za_level g_override = {0, 0, 0};
 void za_o_override_level(int chain, int nice, int lazy) { g_override.chain = chain; g_override.nice = nice; g_override.lazy = lazy; }
@@ -64,7 +68,7 @@ static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *pr
 static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const uint16_t *prevdist,
                               int p, const za_level *L, int max_dist)
 {
-    int seg_end = (p / ZA_SEG + 1) * ZA_SEG;
+    int seg_end = (p / g_cut + 1) * g_cut;          /* g_cut == ZA_SEG except in parameter studies */
     if (seg_end > n) seg_end = n;
     int maxlen = seg_end - p;
     if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;

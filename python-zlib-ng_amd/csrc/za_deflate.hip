@@ -76,28 +76,44 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     const int total = dict_len + n;
     const int pmin = ZA_WIN - dict_len;
     uint32_t rd = 0, wr = 0;
-    // software pipeline: the next tile's bytes are in flight while this one is classified
-    int i0 = lane, p0 = i0 - dict_len;
-    bool valid0 = (i0 < total) && (p0 + ZA_MIN_MATCH <= n);
-    uint32_t v0 = valid0 ? za_ld32(data + p0) : 0u;
-    for (int base = 0; base < total; base += 64) {
-        const int i1 = base + 64 + lane, p1 = i1 - dict_len;
-        const bool valid1 = (i1 < total) && (p1 + ZA_MIN_MATCH <= n);
-        const uint32_t v1 = valid1 ? za_ld32(data + p1) : 0u;
-        const uint32_t h = za_hash4(v0);
-        const bool mine = valid0 && (h >> ZA_CH_SUB) == wave;
-        const unsigned long long mask = __ballot(mine);
-        if (mine) {
-            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            stage[(wr + rank) & 127u] = (uint32_t)(ZA_WIN + p0) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+    // software pipeline: a group of 4 tiles (256 positions) is in flight while the previous group is
+    // classified -- one tile of look-ahead left the wave waiting on every load
+    uint32_t va[4], vb[4];
+    auto load_group = [&](int gbase, uint32_t (&v)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int i = gbase + 64 * t + lane, p = i - dict_len;
+            v[t] = ((i < total) && (p + ZA_MIN_MATCH <= n)) ? za_ld32(data + p) : 0u;
         }
-        wr += (uint32_t)__builtin_popcountll(mask);
-        __builtin_amdgcn_wave_barrier();
-        if (wr - rd >= 64u) {
-            za_chains_dense(head, stage, rd, 64, pmin, prevdist, dict_len);
-            rd += 64u;
+    };
+    auto do_group = [&](int gbase, const uint32_t (&v)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int i = gbase + 64 * t + lane, p = i - dict_len;
+            const bool valid = (i < total) && (p + ZA_MIN_MATCH <= n);
+            const uint32_t h = za_hash4(v[t]);
+            const bool mine = valid && (h >> ZA_CH_SUB) == wave;
+            const unsigned long long mask = __ballot(mine);
+            if (mine) {
+                const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                stage[(wr + rank) & 127u] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+            }
+            wr += (uint32_t)__builtin_popcountll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (wr - rd >= 64u) {
+                za_chains_dense(head, stage, rd, 64, pmin, prevdist, dict_len);
+                rd += 64u;
+            }
         }
-        p0 = p1; valid0 = valid1; v0 = v1;
+    };
+    load_group(0, va);
+    for (int gbase = 0; gbase < total; gbase += 512) {
+        load_group(gbase + 256, vb);
+        do_group(gbase, va);
+        if (gbase + 256 < total) {
+            load_group(gbase + 512, va);
+            do_group(gbase + 256, vb);
+        }
     }
     if (wr != rd) za_chains_dense(head, stage, rd, (int)(wr - rd), pmin, prevdist, dict_len);
     // positions with fewer than 4 bytes left are never inserted: their link is 0
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                                                                  uint32_t *__restrict__ best_ws, ZaLevel L)
 {
     __shared__ uint16_t ring[ZA_RING];
-    __shared__ uint32_t win32[ZA_BYTES / 4 + 4];
+    __shared__ uint32_t win32[ZA_BYTES / 4 + 8];
     uint8_t *win8 = (uint8_t *)win32;
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             }
             const uint32_t w = ((uint32_t)(ZA_WIN + p) & (ZA_BYTES - 1)) >> 2;
             win32[w] = v;
-            if (w < 4) win32[w + ZA_BYTES / 4] = v;
+            if (w < 8) win32[w + ZA_BYTES / 4] = v;
         }
         bytes_loaded = need_bytes;
         __syncthreads();
@@ -182,35 +198,46 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 const uint32_t P = (uint32_t)(ZA_WIN + p);
                 const int nice = L.nice < maxlen ? L.nice : maxlen;
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
-                uint32_t me_bl = win8[(P + 3u) & (ZA_BYTES - 1)];          // my byte at offset best_len
-                const uint32_t me0 = za_lds_ld32(win32, P);
+                // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
+                // against them without branches (this also plays the role of zlib's quick-reject byte)
+                const uint32_t me0 = za_lds_ld32(win32, P), me1 = za_lds_ld32(win32, P + 4u),
+                               me2 = za_lds_ld32(win32, P + 8u), me3 = za_lds_ld32(win32, P + 12u);
                 uint32_t q = P;
+                int qs = (int)(P % ZA_RING);                                 // ring slot of q, kept incrementally
+                uint32_t d = ring[qs];
                 int depth = L.chain;
                 while (depth-- > 0) {
-                    const uint32_t d = ring[q % ZA_RING];
                     if (d == 0) break;
                     q -= d;
+                    qs -= (int)d;
+                    qs += qs < 0 ? ZA_RING : 0;
                     const int dist = (int)(P - q);
                     if (dist > L.max_dist) break;
-                    if (win8[(q + (uint32_t)best_len) & (ZA_BYTES - 1)] != me_bl) continue;
-                    // full compare, 4 bytes per step
-                    int len = 0;
-                    uint32_t x = za_lds_ld32(win32, q) ^ me0;
-                    if (x == 0) {
-                        len = 4;
+                    // one LDS round trip per chain step: next link + 5 aligned dwords of the candidate
+                    d = ring[qs];
+                    const uint32_t idx = q & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
+                    const uint32_t c0 = win32[w], c1 = win32[w + 1], c2 = win32[w + 2], c3 = win32[w + 3], c4 = win32[w + 4];
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0;
+                    const uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2;
+                    const uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
+                    int len = x0 ? (int)(__builtin_ctz(x0) >> 3)
+                            : x1 ? 4 + (int)(__builtin_ctz(x1) >> 3)
+                            : x2 ? 8 + (int)(__builtin_ctz(x2) >> 3)
+                            : x3 ? 12 + (int)(__builtin_ctz(x3) >> 3) : 16;
+                    if (len == 16 && maxlen > 16 && best_len < maxlen) {
+                        // rare: at least 16 equal bytes -- finish the compare the long way
                         while (len < maxlen) {
-                            x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
-                            if (x) break;
+                            const uint32_t x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
+                            if (x) { len += (int)(__builtin_ctz(x) >> 3); break; }
                             len += 4;
                         }
                     }
-                    if (x) len += (int)(__builtin_ctz(x) >> 3);
-                    if (len > maxlen) len = maxlen;
-                    if (len > best_len) {
-                        best_len = len; best_dist = dist;
-                        if (len >= nice) break;
-                        me_bl = win8[(P + (uint32_t)len) & (ZA_BYTES - 1)];
-                    }
+                    len = len < maxlen ? len : maxlen;
+                    const bool better = len > best_len;
+                    best_len = better ? len : best_len;
+                    best_dist = better ? dist : best_dist;
+                    if (best_len >= nice) break;
                 }
                 if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
                     result = ((uint32_t)best_len << 16) | (uint32_t)best_dist;
