@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
 }
 
 #define ZA_MATCHQ_PER_SEG 688      // >= 2048/3 matches per segment
+#define ZA_IROW 19                 // dwords per lane row of staged input: 72 bytes + 1 (odd stride)
 
 __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__restrict__ in, uint64_t in_total,
                                                            const ZaMember *__restrict__ members,
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
     __shared__ uint32_t q_excl[64], q_dst[64], q_dist[64];
+    __shared__ uint32_t rows[64 * ZA_IROW];
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
@@ -404,46 +406,82 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
     const uint32_t first_start = __shfl(my_start, 0, 64);
     if ((uint64_t)first_start != bitpos) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
 
-    // ---- phase A: every lane decodes its own segment
+    // ---- phase A: every lane decodes its own segment.
+    // A dependent 8-byte global load per token would cost microseconds, so each lane's compressed bytes
+    // are staged through an LDS row: round r holds bytes [56 r, 56 r + 72) counted from the lane's first
+    // byte; a lane decodes while its read position is inside the first 56 bytes of the row, and the next
+    // row is already in flight in registers meanwhile.
     uint2 *myq = matchq + ((size_t)blockIdx.x * 64 + (size_t)lane) * ZA_MATCHQ_PER_SEG;
     uint32_t nmatch = 0;
     int lane_err = 0;      // 0 ok, 1 index mismatch, 2 data error
-    if (lane < nseg) {
+    {
+        uint32_t *myrow = rows + lane * ZA_IROW;
+        const bool act = lane < nseg;
         int pos = lane << ZA_SEG_SHIFT;
         int end = pos + ZA_SEG; if (end > n) end = n;
         uint64_t bp = my_start;
-        if (bp > in_bits || my_stop > in_bits || my_stop < my_start) lane_err = 1;
-        while (!lane_err && pos < end) {
-            if (bp > in_bits) { lane_err = 1; break; }
-            const uint64_t b = za_peek(src, bp);
-            uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
-            if (!e) { lane_err = 2; break; }
-            int sym = (int)(e >> 4);
-            uint32_t used = e & 15u;
-            if (sym < 256) { dst[pos++] = (uint8_t)sym; bp += used; continue; }
-            if (sym == 256) { lane_err = 1; break; }
-            sym -= 257;
-            if (sym >= 29) { lane_err = 2; break; }
-            int nx;
-            int len = za_len_base(sym, nx);
-            len += (int)((b >> used) & ((1u << nx) - 1u));
-            used += (uint32_t)nx;
-            e = za_decode_sym(b >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
-            if (!e) { lane_err = 2; break; }
-            const int ds = (int)(e >> 4);
-            used += e & 15u;
-            if (ds >= 30) { lane_err = 2; break; }
-            int dist = za_dist_base(ds, nx);
-            dist += (int)((b >> used) & ((1u << nx) - 1u));
-            used += (uint32_t)nx;
-            if (dist > pos) { lane_err = 2; break; }
-            if (pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG) { lane_err = 1; break; }
-            myq[nmatch++] = make_uint2((uint32_t)pos | ((uint32_t)len << 17), (uint32_t)dist);
-            pos += len; bp += used;
+        if (act && (bp > in_bits || my_stop > in_bits || my_stop < my_start)) lane_err = 1;
+        const uint64_t byte0 = my_start >> 3;                       // lane origin inside src
+        const uint64_t readable = in_total - m.in_off;              // bytes that may be read from src
+        bool done = !act || lane_err != 0 || pos >= end;
+        uint32_t pre[ZA_IROW - 1];
+        auto prefetch = [&](uint32_t r) {
+#pragma unroll
+            for (int j = 0; j < ZA_IROW - 1; j++) {
+                const uint64_t o = byte0 + 56ull * r + 4ull * (unsigned)j;
+                pre[j] = (!done && o + 4 <= readable) ? za_ld32(src + o) : 0u;
+            }
+        };
+        prefetch(0);
+#pragma unroll 1
+        for (uint32_t r = 0;; r++) {
+            if (__ballot(!done) == 0ull) break;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < ZA_IROW - 1; j++) myrow[j] = pre[j];
+            __builtin_amdgcn_wave_barrier();
+            prefetch(r + 1);
+            const uint64_t row_bit0 = (byte0 + 56ull * r) * 8ull;
+            const uint64_t row_lim = row_bit0 + 56ull * 8ull;       // decode while bp < row_lim
+            while (!done && bp < row_lim) {
+                if (bp > in_bits) { lane_err = 1; break; }
+                const uint32_t rel = (uint32_t)(bp - row_bit0);     // < 448
+                const uint32_t w = rel >> 5, sh = rel & 31u;
+                // 64 bits starting at bit `rel` of the row (3 dwords)
+                const uint32_t d0 = myrow[w], d1 = myrow[w + 1], d2 = myrow[w + 2];
+                const uint64_t lo = ((uint64_t)d1 << 32) | d0;
+                const uint64_t b = sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
+                uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
+                if (!e) { lane_err = 2; break; }
+                int sym = (int)(e >> 4);
+                uint32_t used = e & 15u;
+                if (sym < 256) { dst[pos++] = (uint8_t)sym; bp += used; if (pos >= end) done = true; continue; }
+                if (sym == 256) { lane_err = 1; break; }
+                sym -= 257;
+                if (sym >= 29) { lane_err = 2; break; }
+                int nx;
+                int len = za_len_base(sym, nx);
+                len += (int)((b >> used) & ((1u << nx) - 1u));
+                used += (uint32_t)nx;
+                e = za_decode_sym(b >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
+                if (!e) { lane_err = 2; break; }
+                const int ds = (int)(e >> 4);
+                used += e & 15u;
+                if (ds >= 30) { lane_err = 2; break; }
+                int dist = za_dist_base(ds, nx);
+                dist += (int)((b >> used) & ((1u << nx) - 1u));
+                used += (uint32_t)nx;
+                if (dist > pos) { lane_err = 2; break; }
+                if (pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG) { lane_err = 1; break; }
+                myq[nmatch++] = make_uint2((uint32_t)pos | ((uint32_t)len << 17), (uint32_t)dist);
+                pos += len; bp += used;
+                if (pos >= end) done = true;
+            }
+            if (lane_err) done = true;
         }
-        if (!lane_err && bp != my_stop) lane_err = 1;
-        if (!lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
-            const uint64_t b = za_peek(src, bp);   // bp == my_stop <= in_bits
+        if (act && !lane_err && bp != my_stop) lane_err = 1;
+        if (act && !lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
+            const uint64_t b = za_peek(src, bp);         // bp == my_stop <= in_bits
             const uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
             if (!e || (e >> 4) != 256u) lane_err = 1;
             else if (((bp + (e & 15u) + 7ull) >> 3) != m.in_len) lane_err = 1;
@@ -475,13 +513,24 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
                 __builtin_amdgcn_wave_barrier();
                 q_excl[lane] = incl - rlen; q_dst[lane] = mdst; q_dist[lane] = mdist;
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t j = (uint32_t)lane; j < total; j += 64) {
-                    // largest k with q_excl[k] <= j
-                    int k = 0;
+                // 4 bytes per lane and pass: four independent searches, loads, then stores
+                for (uint32_t j0 = (uint32_t)lane; j0 < total; j0 += 256) {
+                    uint32_t so[4], sd[4];
+                    uint8_t v[4];
 #pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) if (q_excl[k + step] <= j) k += step;
-                    const uint32_t i = j - q_excl[k], d = q_dist[k], o = q_dst[k];
-                    dst[o + i] = dst[o - d + (i < d ? i : i % d)];
+                    for (int t = 0; t < 4; t++) {
+                        const uint32_t j = j0 + 64u * (unsigned)t;
+                        int k = 0;                     // largest k with q_excl[k] <= j
+#pragma unroll
+                        for (int step = 32; step >= 1; step >>= 1) if (q_excl[k + step] <= j) k += step;
+                        const uint32_t i = j - q_excl[k], d = q_dist[k], o = q_dst[k];
+                        so[t] = o - d + (i < d ? i : i % d);
+                        sd[t] = o + i;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[t] = (j0 + 64u * (unsigned)t < total) ? dst[so[t]] : (uint8_t)0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) if (j0 + 64u * (unsigned)t < total) dst[sd[t]] = v[t];
                 }
                 __threadfence_block();
                 done = done || ready;
@@ -489,7 +538,6 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
             }
         }
     }
-    // ---- verify
     // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
     const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
     const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
