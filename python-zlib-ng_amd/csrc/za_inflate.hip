@@ -374,7 +374,6 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
-    __shared__ uint32_t q_excl[64], q_dst[64], q_dist[64];
     __shared__ uint32_t rows[64 * ZA_IROW];
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
@@ -491,7 +490,12 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
     if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
     __threadfence_block();       // literals and the match queues are visible to the whole wave
 
-    // ---- phase B: resolve matches in output order, 64 at a time, byte-parallel
+    // ---- phase B: resolve matches in output order, 64 at a time.  A match is ready when its source lies
+    // below the first unresolved match of the group (the lowest pending one always is).  Each ready lane
+    // copies its own match: 16 bytes per batch as four unaligned dword loads followed by the stores (the
+    // loads of a batch are independent, so they overlap); a self-overlapping match (dist < len) reads its
+    // period byte-wise, which lies entirely below its destination.
+    const uint64_t out_room = out_cap - m.out_off;     // bytes of dst that may be touched
     for (int s = 0; s < nseg; s++) {
         const uint32_t cnt = __shfl(nmatch, s, 64);
         const uint2 *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
@@ -507,30 +511,38 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
                 const uint32_t frontier = __shfl(mdst, lowest, 64);
                 const uint32_t srcend = mdst - mdist + (mlen < mdist ? mlen : mdist);
                 const bool ready = !done && (srcend <= frontier || lane == lowest);
-                const uint32_t rlen = ready ? mlen : 0u;
-                const uint32_t incl = za_wave_incl_scan(rlen);
-                const uint32_t total = __shfl(incl, 63, 64);
-                __builtin_amdgcn_wave_barrier();
-                q_excl[lane] = incl - rlen; q_dst[lane] = mdst; q_dist[lane] = mdist;
-                __builtin_amdgcn_wave_barrier();
-                // 4 bytes per lane and pass: four independent searches, loads, then stores
-                for (uint32_t j0 = (uint32_t)lane; j0 < total; j0 += 256) {
-                    uint32_t so[4], sd[4];
-                    uint8_t v[4];
+                if (ready) {
+                    uint8_t *o = dst + mdst;
+                    const uint8_t *sp = o - mdist;
+                    if (mdist >= mlen && (uint64_t)mdst + mlen + 4 <= out_room) {
+                        for (uint32_t i = 0; i < mlen; i += 16) {
+                            const uint32_t rem = mlen - i;
+                            uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                            v0 = za_ld32(sp + i);
+                            if (rem > 4) v1 = za_ld32(sp + i + 4);
+                            if (rem > 8) v2 = za_ld32(sp + i + 8);
+                            if (rem > 12) v3 = za_ld32(sp + i + 12);
+                            const uint32_t vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const uint32_t j = j0 + 64u * (unsigned)t;
-                        int k = 0;                     // largest k with q_excl[k] <= j
+                            for (int k = 0; k < 4; k++) {
+                                const int left = (int)rem - 4 * k;
+                                if (left >= 4) *(za_u32u *)(o + i + 4 * k) = vv[k];
+                                else if (left > 0) {
+                                    o[i + 4 * k] = (uint8_t)vv[k];
+                                    if (left > 1) o[i + 4 * k + 1] = (uint8_t)(vv[k] >> 8);
+                                    if (left > 2) o[i + 4 * k + 2] = (uint8_t)(vv[k] >> 16);
+                                }
+                            }
+                        }
+                    } else {
+                        for (uint32_t i = 0; i < mlen; i += 4) {
+                            uint8_t b[4];
 #pragma unroll
-                        for (int step = 32; step >= 1; step >>= 1) if (q_excl[k + step] <= j) k += step;
-                        const uint32_t i = j - q_excl[k], d = q_dist[k], o = q_dst[k];
-                        so[t] = o - d + (i < d ? i : i % d);
-                        sd[t] = o + i;
+                            for (int k = 0; k < 4; k++) b[k] = (i + k < mlen) ? sp[(i + k) % mdist] : (uint8_t)0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) if (i + k < mlen) o[i + k] = b[k];
+                        }
                     }
-#pragma unroll
-                    for (int t = 0; t < 4; t++) v[t] = (j0 + 64u * (unsigned)t < total) ? dst[so[t]] : (uint8_t)0;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) if (j0 + 64u * (unsigned)t < total) dst[sd[t]] = v[t];
                 }
                 __threadfence_block();
                 done = done || ready;
