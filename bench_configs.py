@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""bench_configs.py -- the other BASELINE.json configurations (bench.py is the headline metric).
+
+  config 0  zlib_ng.compress / decompress level 6 on a 1 MiB os.urandom buffer (API plumbing, PCIe included)
+  config 1  single-GPU deflate level 1 (and 6) on 1 GiB synthetic text, 128 KiB blocks (device resident)
+  config 2  single-GPU inflate of a 4 GiB multi-member stream: the inflate leg of bench.py
+  config 4  level 9 on a Silesia-like mixed corpus: ratio + MB/s next to the system zlib at level 9
+Prints one JSON line per configuration.  Needs a GPU.
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
+
+BLOCK = 131072
+
+
+def deflate_dev(ctx, _lib, torch, d_in, size, level, chained=True, steps=2):
+    L, h = ctx.L, ctx.h
+    nb = size // BLOCK
+    blocks = (_lib.Block * nb)()
+    for b in range(nb):
+        blocks[b] = _lib.Block(b * BLOCK, BLOCK, 32768 if (b and chained) else 0, 0, 0)
+    slots = torch.empty(nb * _lib.SLOT_STRIDE, dtype=torch.uint8, device="cuda")
+    ul = torch.empty(nb, dtype=torch.int32, device="cuda")
+    uc = torch.empty(nb, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    best = None
+    for _ in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = L.zngamd_deflate_blocks_dev(h, p(d_in), size, blocks, nb, level, p(slots), p(ul), p(uc), None)
+        dt = time.perf_counter() - t0
+        assert r == 0, ctx.err()
+        best = dt if best is None else min(best, dt)
+    comp = int(ul.to(torch.int64).sum().item())
+    return best, comp, slots, ul
+
+
+def main():
+    import torch
+    from zlib_ng_amd import _lib, corpus, zlib_ng
+    ctx = _lib.default_context()
+    out = []
+
+    # ---- config 0: API plumbing on incompressible data (host buffers, PCIe in the loop)
+    buf = os.urandom(1 << 20)
+    zlib_ng.compress(buf[:1000], 6)                # first call creates the context / workspaces
+    t0 = time.perf_counter(); c = zlib_ng.compress(buf, 6); t1 = time.perf_counter()
+    d = zlib_ng.decompress(c); t2 = time.perf_counter()
+    assert d == buf and zlib.decompress(c) == buf
+    out.append({"config": 0, "workload": "zlib_ng.compress/decompress level 6, 1 MiB os.urandom, host API",
+                "compressed_bytes": len(c), "compress_ms": round((t1 - t0) * 1e3, 2), "decompress_ms": round((t2 - t1) * 1e3, 2)})
+
+    # ---- config 1: level 1 (and 6 for comparison), 1 GiB text
+    size = 1 << 30
+    host = corpus.text(64 << 20, seed=1)
+    d_in = torch.cat([torch.from_numpy(host).cuda().repeat(size // host.size), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    for level in (1, 6):
+        dt, comp, slots, ul = deflate_dev(ctx, _lib, torch, d_in, size, level)
+        parts = []
+        for b in range(64):                        # first 64 blocks through the system zlib
+            n = int(ul[b].item())
+            parts.append(bytes(slots[b * _lib.SLOT_STRIDE:b * _lib.SLOT_STRIDE + n].cpu().numpy()))
+        assert zlib.decompressobj(-15).decompress(b"".join(parts)) == host[:64 * BLOCK].tobytes()
+        out.append({"config": 1 if level == 1 else "1b",
+                    "workload": f"deflate level {level}, 1 GiB Zipf text, 128 KiB dict-chained blocks, device resident",
+                    "MBps": round(size / dt / 1e6, 1), "ratio": round(size / comp, 4),
+                    "zlib_ratio_same_level": round((4 << 20) / len(zlib.compress(host[:4 << 20].tobytes(), level)), 4)})
+        del slots, ul
+    del d_in
+
+    # ---- config 4: level 9 on the mixed corpus
+    mixed = corpus.mixed(200 << 20, seed=5)
+    size = (mixed.size // BLOCK) * BLOCK
+    d_in = torch.cat([torch.from_numpy(mixed[:size]).cuda(), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    dt, comp, slots, ul = deflate_dev(ctx, _lib, torch, d_in, size, 9, steps=1)
+    import numpy as np
+    # 16 x 1 MiB taken evenly across the corpus (every data class is represented)
+    sample = np.concatenate([mixed[o:o + (1 << 20)] for o in range(0, size - (1 << 20), size // 16)][:16]).tobytes()
+    t0 = time.perf_counter(); zc = zlib.compress(sample, 9); tz = time.perf_counter() - t0
+    out.append({"config": 4, "workload": f"deflate level 9, {size >> 20} MiB Silesia-like mix, 128 KiB dict-chained blocks, device resident",
+                "MBps": round(size / dt / 1e6, 1), "ratio": round(size / comp, 4),
+                "zlib9_ratio_16x1MiB_strided_sample": round(len(sample) / len(zc), 4), "zlib9_MBps_1core": round(len(sample) / tz / 1e6, 1)})
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()

@@ -217,14 +217,21 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     d = ring[qs];
                     const uint32_t idx = q & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
                     const uint32_t c0 = win32[w], c1 = win32[w + 1], c2 = win32[w + 2], c3 = win32[w + 3], c4 = win32[w + 4];
-                    const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0;
-                    const uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
-                    const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2;
-                    const uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
-                    int len = x0 ? (int)(__builtin_ctz(x0) >> 3)
-                            : x1 ? 4 + (int)(__builtin_ctz(x1) >> 3)
-                            : x2 ? 8 + (int)(__builtin_ctz(x2) >> 3)
-                            : x3 ? 12 + (int)(__builtin_ctz(x3) >> 3) : 16;
+                    uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0;
+                    uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
+                    uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2;
+                    uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
+                    // keep all four compares unconditional: hipcc otherwise sinks the loads into nested
+                    // branches, one LDS round trip per level
+                    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+                    uint32_t n0 = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4u;
+                    uint32_t n1 = x1 ? (uint32_t)__builtin_ctz(x1) >> 3 : 4u;
+                    uint32_t n2 = x2 ? (uint32_t)__builtin_ctz(x2) >> 3 : 4u;
+                    uint32_t n3 = x3 ? (uint32_t)__builtin_ctz(x3) >> 3 : 4u;
+                    asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3));
+                    const uint32_t hi = n2 < 4u ? 8u + n2 : 12u + n3;
+                    const uint32_t lo = n0 < 4u ? n0 : 4u + n1;
+                    int len = (int)((n0 < 4u || n1 < 4u) ? lo : hi);
                     if (len == 16 && maxlen > 16 && best_len < maxlen) {
                         // rare: at least 16 equal bytes -- finish the compare the long way
                         while (len < maxlen) {
