@@ -26,35 +26,47 @@
 // small LDS ring in position order, and whenever 64 are pending inserts them as one dense tile:
 // same-bucket lanes are ordered by a 12-ballot bit-slice match-any, so the result is exactly the
 // sequential insertion order -- with no barrier between waves, since no two waves share a bucket.
-#define ZA_CH_WAVES 8
-#define ZA_CH_SUB   (ZA_HASH_BITS - 3)        // bits of the per-wave table index
+#define ZA_CH_WAVES 4
+#define ZA_CH_STAGE 512u                      // pending-entry ring per wave: 63 left over + 256 of one group
+#define ZA_CH_SUB   (ZA_HASH_BITS - 2)        // bits of the per-wave table index
 
 __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, uint32_t rd, int m, int pmin,
                                                 uint16_t *__restrict__ prevdist, int dict_len)
 {
     const int lane = za_lane();
     const bool valid = lane < m;
-    const uint32_t e = stage[(rd + (uint32_t)lane) & 127u];
+    const uint32_t e = stage[(rd + (uint32_t)lane) & (ZA_CH_STAGE - 1u)];
     const uint32_t P = e & 0x3FFFFu, h = (e >> 18) & ((1u << ZA_CH_SUB) - 1u);
-    unsigned long long eq = __ballot(valid);
+    const uint16_t P16 = (uint16_t)(P & 0xFFFFu);
+    // link through the table state left by the earlier tiles
+    const uint32_t hv = head[h];
+    uint32_t d = (P - hv) & 0xFFFFu;
+    if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
+    // Fast path: every valid lane stores its position and reads the bucket back.  If all of them read
+    // their own value no two lanes share a bucket, the links above are final and so is the table.
+    // (volatile: the read-back must come from LDS, where another lane's store may have landed, not from
+    // this lane's own store forwarded by the compiler)
+    volatile uint16_t *vhead = head;
+    if (valid) vhead[h] = P16;
+    __builtin_amdgcn_wave_barrier();
+    const bool clash = valid && vhead[h] != P16;
+    if (__ballot(clash) != 0ull) {
+        // Some bucket is hit twice in this tile: order the lanes exactly (15/13/12-ballot bit-slice
+        // match-any), link later lanes to the nearest earlier one and leave the last position in the table.
+        unsigned long long eq = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < ZA_CH_SUB; b++) {
-        const bool bit = (h >> b) & 1u;
-        const unsigned long long B = __ballot(bit);
-        eq &= bit ? B : ~B;
+        for (int b = 0; b < ZA_CH_SUB; b++) {
+            const bool bit = (h >> b) & 1u;
+            const unsigned long long B = __ballot(bit);
+            eq &= bit ? B : ~B;
+        }
+        const unsigned long long lower = eq & ((1ull << lane) - 1ull);
+        const unsigned long long higher = (eq >> lane) >> 1;
+        const int j = lower ? 63 - __builtin_clzll(lower) : lane;
+        const uint32_t Pj = __shfl(P, j, 64);
+        if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
+        if (valid && !higher) head[h] = P16;
     }
-    const unsigned long long lower = eq & ((1ull << lane) - 1ull);
-    const unsigned long long higher = (eq >> lane) >> 1;
-    const int j = lower ? 63 - __builtin_clzll(lower) : lane;
-    const uint32_t Pj = __shfl(P, j, 64);
-    uint32_t d;
-    if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
-    else {
-        const uint32_t hv = head[h];
-        d = (P - hv) & 0xFFFFu;
-        if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
-    }
-    if (valid && !higher) head[h] = (uint16_t)(P & 0xFFFFu);
     if (valid) prevdist[(int)P - ZA_WIN + dict_len] = (uint16_t)d;
 }
 
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
                                                                 uint16_t *__restrict__ prev_ws)
 {
     __shared__ uint16_t head_all[ZA_CH_WAVES][1 << ZA_CH_SUB];
-    __shared__ uint32_t stage_all[ZA_CH_WAVES][128];
+    __shared__ uint32_t stage_all[ZA_CH_WAVES][ZA_CH_STAGE];
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
@@ -87,6 +99,7 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
         }
     };
     auto do_group = [&](int gbase, const uint32_t (&v)[4]) {
+        // classify the four tiles back to back (independent work), then drain the ring
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int i = gbase + 64 * t + lane, p = i - dict_len;
@@ -96,24 +109,31 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
             const unsigned long long mask = __ballot(mine);
             if (mine) {
                 const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                stage[(wr + rank) & 127u] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+                stage[(wr + rank) & (ZA_CH_STAGE - 1u)] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
             }
             wr += (uint32_t)__builtin_popcountll(mask);
-            __builtin_amdgcn_wave_barrier();
-            if (wr - rd >= 64u) {
-                za_chains_dense(head, stage, rd, 64, pmin, prevdist, dict_len);
-                rd += 64u;
-            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (wr - rd >= 64u) {
+            za_chains_dense(head, stage, rd, 64, pmin, prevdist, dict_len);
+            rd += 64u;
         }
     };
-    load_group(0, va);
-    for (int gbase = 0; gbase < total; gbase += 512) {
-        load_group(gbase + 256, vb);
+    // three groups (768 positions) of loads stay in flight ahead of the one being classified
+    uint32_t vc[4], vd[4];
+    load_group(0, va); load_group(256, vb); load_group(512, vc);
+    for (int gbase = 0; gbase < total; gbase += 1024) {
+        load_group(gbase + 768, vd);
         do_group(gbase, va);
-        if (gbase + 256 < total) {
-            load_group(gbase + 512, va);
-            do_group(gbase + 256, vb);
-        }
+        if (gbase + 256 >= total) break;
+        load_group(gbase + 1024, va);
+        do_group(gbase + 256, vb);
+        if (gbase + 512 >= total) break;
+        load_group(gbase + 1280, vb);
+        do_group(gbase + 512, vc);
+        if (gbase + 768 >= total) break;
+        load_group(gbase + 1536, vc);
+        do_group(gbase + 768, vd);
     }
     if (wr != rd) za_chains_dense(head, stage, rd, (int)(wr - rd), pmin, prevdist, dict_len);
     // positions with fewer than 4 bytes left are never inserted: their link is 0
