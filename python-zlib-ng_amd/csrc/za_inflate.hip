@@ -211,14 +211,13 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 // ------------------------------------------------------------------------------------------------
 // sequential decoder: one wave per stream
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len,
-                                                          const uint8_t *__restrict__ dict, uint32_t dict_len,
-                                                          uint8_t *__restrict__ out, uint64_t out_cap,
-                                                          ZaInfResult *__restrict__ res)
+// Wave-uniform sequential RFC 1951 decode of one stream (all 64 lanes call with identical arguments).
+// T / win / scratch are the caller's LDS; returns a ZA_I_* status, bits consumed and bytes produced.
+__device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
+                                      const uint8_t *__restrict__ dict, uint32_t dict_len,
+                                      uint8_t *__restrict__ out, uint64_t out_cap,
+                                      ZaInfTabs &T, uint8_t *win, int *scratch, uint64_t &bits_used, uint64_t &out_len)
 {
-    __shared__ ZaInfTabs T;
-    __shared__ uint8_t win[ZA_WIN];
-    __shared__ int scratch[2];
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
     uint64_t bitpos = 0, op = 0;
@@ -307,7 +306,22 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
         }
         if (last) { status = ZA_I_END; break; }
     }
-    if (lane == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bitpos; }
+    bits_used = bitpos; out_len = op;
+    return status;
+}
+
+
+__global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len,
+                                                          const uint8_t *__restrict__ dict, uint32_t dict_len,
+                                                          uint8_t *__restrict__ out, uint64_t out_cap,
+                                                          ZaInfResult *__restrict__ res)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ uint8_t win[ZA_WIN];
+    __shared__ int scratch[2];
+    uint64_t bits = 0, op = 0;
+    const int status = za_inflate_serial_core(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, bits, op);
+    if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -554,6 +568,54 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
     const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
     const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
     if (lane == 0) status_out[blockIdx.x] = (c != want_crc) ? ZA_I_CRC : (want_len != (uint32_t)n) ? ZA_I_LENGTH : ZA_I_OK;
+}
+
+// Members whose extent is known up front without this engine's index (BGZF: 'B','C' subfield with the
+// block size; reference fixture tests/data/test.fastq.bgzip.gz): one wavefront per member runs the
+// sequential decoder, then checks CRC-32 and ISIZE against the trailer (zlib_ngmodule.c:2577-2599).
+__global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                                  const ZaMember *__restrict__ members,
+                                                                  uint8_t *__restrict__ out, uint64_t out_cap,
+                                                                  const uint32_t *__restrict__ crc_table,
+                                                                  const uint32_t *__restrict__ x8k_table,
+                                                                  int32_t *__restrict__ status_out)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ uint8_t win[ZA_WIN];
+    __shared__ int scratch[2];
+    __shared__ uint32_t crct[256];
+    const int lane = za_lane();
+    const ZaMember m = members[blockIdx.x];
+    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
+    __syncthreads();
+    if (m.in_off + m.in_len + 8 > in_total || m.out_off + m.out_len > out_cap) {
+        if (lane == 0) status_out[blockIdx.x] = ZA_I_DATA;
+        return;
+    }
+    const uint8_t *src = in + m.in_off;
+    uint8_t *dst = out + m.out_off;
+    uint64_t bits = 0, op = 0;
+    int status = za_inflate_serial_core(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, bits, op);
+    if (status == ZA_I_END) {
+        status = ZA_I_OK;
+        if (((bits + 7) >> 3) != m.in_len) status = ZA_I_DATA;          // the member must end where its size says
+        else if (op != m.out_len) status = ZA_I_LENGTH;
+        else {
+            __threadfence_block();
+            uint32_t crc = 0;
+            for (uint64_t o = 0; o < op; o += ZA_MAX_UNIT) {
+                const int len = (int)((op - o) > ZA_MAX_UNIT ? ZA_MAX_UNIT : (op - o));
+                const uint32_t c = za_wave_crc32(dst + o, len, crct, x8k_table);
+                uint32_t xp = 0x80000000u, sq = 0x00800000u;            // crc = crc * x^(8 len) ^ c
+                for (int k = len; k; k >>= 1) { if (k & 1) xp = za_multmodp(sq, xp); sq = za_multmodp(sq, sq); }
+                crc = za_multmodp(xp, crc) ^ c;
+            }
+            const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
+            if (crc != want_crc) status = ZA_I_CRC;
+            else if (want_len != (uint32_t)op) status = ZA_I_LENGTH;
+        }
+    } else if (status == ZA_I_OUTFULL) status = ZA_I_LENGTH;
+    if (lane == 0) status_out[blockIdx.x] = status;
 }
 
 // One workgroup per member: header with the segment index, deflate bytes from the unit slot, trailer.

@@ -697,6 +697,41 @@ static int parse_gzip_header(const uint8_t *in, uint64_t in_len, uint64_t pos, u
     return ZNGAMD_OK;
 }
 
+// BGZF hop: every member must be `1f 8b 08 04`, carry a 'B','C' subfield of length 2 (block size - 1) and
+// tile the buffer exactly; anything else makes the caller use the general reader.
+static bool hop_bgzf(const uint8_t *in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out)
+{
+    auto le16 = [&](uint64_t o) { return (uint32_t)in[o] | ((uint32_t)in[o + 1] << 8); };
+    auto le32 = [&](uint64_t o) { return (uint32_t)in[o] | ((uint32_t)in[o + 1] << 8) | ((uint32_t)in[o + 2] << 16) | ((uint32_t)in[o + 3] << 24); };
+    uint64_t pos = 0, outp = 0;
+    hm.clear();
+    while (pos < in_len) {
+        if (in_len - pos < 12 + 6 + 8) return false;
+        if (in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8 || in[pos + 3] != 4) return false;
+        const uint64_t xlen = le16(pos + 10);
+        uint64_t cur = pos + 12;
+        const uint64_t end = cur + xlen;
+        if (end + 8 > in_len) return false;
+        long bsize = -1;
+        while (cur + 4 <= end) {
+            const uint32_t sl = le16(cur + 2);
+            if (cur + 4 + sl > end) return false;
+            if (in[cur] == 'B' && in[cur + 1] == 'C' && sl == 2) bsize = (long)le16(cur + 4);
+            cur += 4 + sl;
+        }
+        if (bsize < 0) return false;
+        const uint64_t msize = (uint64_t)bsize + 1;
+        if (msize < (end - pos) + 8 || pos + msize > in_len) return false;
+        ZaMember m;
+        m.in_off = end; m.in_len = msize - (end - pos) - 8; m.out_off = outp;
+        m.out_len = le32(pos + msize - 4); m.crc = le32(pos + msize - 8); m.index_off = 0; m.nseg = 0;
+        hm.push_back(m);
+        pos += msize; outp += m.out_len;
+    }
+    *total_out = outp;
+    return pos == in_len;
+}
+
 int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
 {
     if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
@@ -715,7 +750,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
         if (in_len >= ZA_MEMBER_HDR + 8 && parse_gzip_header(in, in_len, 0, &doff, &za, &hl) == ZNGAMD_OK && za) {
             std::vector<ZaMember> hm; uint64_t total = 0;
             if (scan_members_dev(c, c->st_in.p, in_len, hm, &total) == ZNGAMD_OK) {
-                if (total > out_cap) { *out_len = 0; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+                if (total > out_cap) { *out_len = total; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
                 HIPCHK(c, c->members.ensure(hm.size())); HIPCHK(c, c->mstatus.ensure(hm.size()));
                 HIPCHK(c, hipMemcpyAsync(c->members.p, hm.data(), hm.size() * sizeof(ZaMember), hipMemcpyHostToDevice, c->stream));
                 r = inflate_members_dev(c, c->st_in.p, in_len, c->members.p, (uint32_t)hm.size(), c->st_out.p, out_cap, c->mstatus.p);
@@ -735,6 +770,38 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
                 // anything unexpected (foreign 'ZA' field, stored blocks, corruption): the sequential
                 // reader below decides, member by member
             }
+        }
+    }
+    // second fast path: BGZF-style members ('B','C' subfield = block size - 1).  The member table comes from a
+    // header hop over the host copy; all members are then decoded in one launch, one wavefront each.
+    {
+        std::vector<ZaMember> hm; uint64_t total = 0;
+        if (hop_bgzf(in, in_len, hm, &total) && hm.size() > 1) {
+            if (total > out_cap) { *out_len = total; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+            const uint32_t n = (uint32_t)hm.size();
+            HIPCHK(c, c->members.ensure(n)); HIPCHK(c, c->mstatus.ensure(n));
+            HIPCHK(c, hipMemcpyAsync(c->members.p, hm.data(), (size_t)n * sizeof(ZaMember), hipMemcpyHostToDevice, c->stream));
+            { ProfScope ps(c, ZNGAMD_K_INFLATE);
+              hipLaunchKernelGGL(za_k_inflate_serial_members, dim3(n), dim3(64), 0, c->stream, c->st_in.p, in_len, c->members.p,
+                                 c->st_out.p, out_cap, c->d_crc_table, c->d_x8k, c->mstatus.p); }
+            HIPCHK(c, hipGetLastError());
+            std::vector<int32_t> st(n);
+            HIPCHK(c, hipMemcpyAsync(st.data(), c->mstatus.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            prof_collect(c);
+            uint32_t good = 0;
+            while (good < n && st[good] == ZA_I_OK) good++;
+            const uint64_t produced = good < n ? hm[good].out_off : total;
+            if (produced) HIPCHK(c, hipMemcpy(out, c->st_out.p, produced, hipMemcpyDeviceToHost));
+            *out_len = produced;
+            if (n_members) *n_members = good;
+            if (good == n) return ZNGAMD_OK;
+            const int code = st[good];
+            if (code == ZA_I_CRC) { c->err = "CRC check failed"; return ZNGAMD_E_GZ_CRC; }
+            if (code == ZA_I_LENGTH) { c->err = "Incorrect length of data produced"; return ZNGAMD_E_GZ_LENGTH; }
+            if (code == ZA_I_INPUT) return ZNGAMD_E_GZ_TRUNC;
+            c->err = "invalid deflate data";
+            return ZNGAMD_DATA_ERROR;
         }
     }
     for (;;) {

@@ -142,6 +142,7 @@ class Context:
             raise RuntimeError(
                 f"zng_amd: no usable GPU (zngamd_ctx_create({device}) -> {r}); this engine has no CPU path")
         self.L, self.h, self.device = L, h, device
+        self.last_needed = 0
 
     def close(self):
         if self.h:
@@ -242,7 +243,9 @@ class Context:
                                  C.byref(ol), C.byref(nm))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
-        return r, out.raw[:ol.value], nm.value
+        # BUF_ERROR with a size above the capacity = "this is how much room the stream needs"
+        self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
+        return r, out.raw[:min(ol.value, out_cap)], nm.value
 
     def gzip_members(self, data, block_size, level):
         p, keep = _addr(data)

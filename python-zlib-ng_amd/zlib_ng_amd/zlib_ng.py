@@ -445,8 +445,8 @@ class _GzipReader:
         cap = max(1 << 16, 4 * len(raw), isize + 64)
         while True:
             code, out, nm = ctx.gunzip(raw, cap)
-            if code == _lib.BUF_ERROR and len(out) >= cap:
-                cap *= 4
+            if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
+                cap = max(cap * 4, ctx.last_needed + 64)
                 continue
             break
         self._data = out

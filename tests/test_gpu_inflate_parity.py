@@ -129,3 +129,61 @@ def test_golden_vectors(ctx):
             if code:
                 continue
         assert len(out) == v["size"] and hashlib.sha256(out).hexdigest() == v["sha256"], v["name"]
+
+
+def _bgzf(data, block=60000, level=6):
+    """Minimal BGZF writer (SAM/BAM spec): members with a 'BC' subfield holding the member size - 1."""
+    import struct
+    out = []
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + [b""]
+    for ch in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(ch) + co.flush()
+        size = 18 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04" + bytes(4) + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, size - 1) +
+                   body + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    return b"".join(out)
+
+
+def test_bgzf_members_one_launch(ctx, fastq):
+    from oracle import oracle as O
+    data = fastq[:1500000]
+    blob = _bgzf(data)
+    assert gzip.decompress(blob) == data
+    code, out, nm = ctx.gunzip(blob, len(data))
+    assert (code, out, nm) == (0, data, -(-len(data) // 60000) + 1)
+    # too small an output buffer: the needed size comes back
+    code, out, nm = ctx.gunzip(blob, 1000)
+    assert code == -5 and ctx.last_needed == len(data)
+    # corrupt the 5th member's payload and the 9th member's CRC: output stops at the first bad member
+    bad = bytearray(blob)
+    offs, pos = [], 0
+    while pos < len(blob):
+        offs.append(pos)
+        pos += (blob[pos + 16] | blob[pos + 17] << 8) + 1
+    bad[offs[4] + 40] ^= 0x04
+    code, out, nm = ctx.gunzip(bytes(bad), len(data))
+    ocode, oout, onm = O.gunzip(bytes(bad), len(data) + 1)
+    assert code != 0 and ocode != 0 and nm == 4 and out == data[:4 * 60000]
+    bad = bytearray(blob)
+    bad[offs[9] - 8] ^= 1          # CRC field of member 8
+    code, out, nm = ctx.gunzip(bytes(bad), len(data))
+    assert code == -104 and nm == 8 and out == data[:8 * 60000]
+
+
+def test_indexed_stream_fuzz(ctx, fastq):
+    """Random single-byte corruptions of an indexed member stream (headers, index, payload, trailers):
+    the engine must answer like the oracle -- never crash, never return wrong bytes as good."""
+    from oracle import oracle as O
+    data = fastq[:300000]
+    stream = ctx.gzip_members(data, 131072, 6)
+    rng = np.random.default_rng(99)
+    for trial in range(120):
+        bad = bytearray(stream)
+        pos = int(rng.integers(0, len(bad))) if trial % 3 else int(rng.integers(0, 288))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        code, out, nm = ctx.gunzip(bytes(bad), len(data) + 4096)
+        ocode, oout, onm = O.gunzip(bytes(bad), len(data) + 4096)
+        assert (code == 0) == (ocode == 0), (pos, code, ocode)
+        if code == 0:
+            assert out == oout
