@@ -31,6 +31,18 @@ BLOCK = 131072
 HBM_PEAK_GBS = 8000.0
 
 
+def host_cores():
+    """CPUs this process may really use: the scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,9 +226,9 @@ def main():
     # ---- CPU baseline on this box's host cores (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = len(os.sched_getaffinity(0))
+        cores = host_cores()
         # bounded sample of the same workload: the distinct text tiled like the GPU shard, 8 MiB per core
-        sample = args.cpu_sample_mib << 20 if args.cpu_sample_mib else min(size, (8 << 20) * cores)
+        sample = args.cpu_sample_mib << 20 if args.cpu_sample_mib else min(size, (16 << 20) * cores)
         sample -= sample % BLOCK
         arr = np.ascontiguousarray(np.tile(host, (sample + uniq - 1) // uniq)[:sample])
         td, ti, cb = O.bench_blocks(arr, BLOCK, args.level, cores)

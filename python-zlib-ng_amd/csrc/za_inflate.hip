@@ -437,6 +437,25 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
         const uint64_t byte0 = my_start >> 3;                       // lane origin inside src
         const uint64_t readable = in_total - m.in_off;              // bytes that may be read from src
         bool done = !act || lane_err != 0 || pos >= end;
+        // Output of this lane is collected in a 16-byte block (two 64-bit halves) and stored once per block:
+        // literal bytes land in it, match bytes are left zero -- phase B overwrites them later, and no other
+        // lane owns bytes of this block (segment starts are multiples of 16 inside the member).  The block
+        // that holds the member's last bytes is stored bytewise so that nothing past `n` is touched.
+        uint64_t blk_lo = 0, blk_hi = 0;
+        bool blk_dirty = false;                                 // a literal was put into the block
+        int blk_base = pos;                                     // multiple of 16
+        auto flush_block = [&](int upto) {                      // store [blk_base, min(blk_base+16, upto))
+            if (blk_base + 16 <= n) {
+                za_u64u *d64 = (za_u64u *)(dst + blk_base);
+                d64[0] = blk_lo; d64[1] = blk_hi;
+            } else {
+                for (int k = blk_base; k < upto && k < n; k++) {
+                    const int o = k - blk_base;
+                    dst[k] = (uint8_t)(o < 8 ? blk_lo >> (8 * o) : blk_hi >> (8 * (o - 8)));
+                }
+            }
+            blk_lo = 0; blk_hi = 0; blk_dirty = false;
+        };
         uint32_t pre[ZA_IROW - 1];
         auto prefetch = [&](uint32_t r) {
 #pragma unroll
@@ -468,7 +487,15 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
                 if (!e) { lane_err = 2; break; }
                 int sym = (int)(e >> 4);
                 uint32_t used = e & 15u;
-                if (sym < 256) { dst[pos++] = (uint8_t)sym; bp += used; if (pos >= end) done = true; continue; }
+                if (sym < 256) {
+                    const int o = pos - blk_base;
+                    if (o < 8) blk_lo |= (uint64_t)(uint32_t)sym << (8 * o); else blk_hi |= (uint64_t)(uint32_t)sym << (8 * (o - 8));
+                    blk_dirty = true;
+                    pos++; bp += used;
+                    if (pos - blk_base == 16) { flush_block(pos); blk_base = pos; }
+                    if (pos >= end) done = true;
+                    continue;
+                }
                 if (sym == 256) { lane_err = 1; break; }
                 sym -= 257;
                 if (sym >= 29) { lane_err = 2; break; }
@@ -488,10 +515,16 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
                 if (pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG) { lane_err = 1; break; }
                 myq[nmatch++] = make_uint2((uint32_t)pos | ((uint32_t)len << 17), (uint32_t)dist);
                 pos += len; bp += used;
+                if (pos - blk_base >= 16) {
+                    // the block being filled holds literals only if something was put in it
+                    if (blk_dirty) flush_block(pos);
+                    blk_base = pos & ~15;
+                }
                 if (pos >= end) done = true;
             }
             if (lane_err) done = true;
         }
+        if (act && blk_dirty) flush_block(pos);
         if (act && !lane_err && bp != my_stop) lane_err = 1;
         if (act && !lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
             const uint64_t b = za_peek(src, bp);         // bp == my_stop <= in_bits
