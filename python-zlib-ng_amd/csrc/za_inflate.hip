@@ -41,7 +41,9 @@ struct ZaInfTabs {
 struct ZaInfResult {
     int32_t status; uint32_t pad;
     uint64_t out_len;
-    uint64_t in_bits;      // bits consumed
+    uint64_t in_bits;      // bits consumed (counted from bit 0 of the buffer)
+    uint64_t block_bits;   // bit offset of the header of the last block that was entered (resume point)
+    uint64_t block_out;    // bytes produced before that block
 };
 
 // bit-serial canonical decode of the low bits of v; returns (sym<<4)|len or 0
@@ -216,16 +218,19 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       uint8_t *__restrict__ out, uint64_t out_cap,
-                                      ZaInfTabs &T, uint8_t *win, int *scratch, uint64_t &bits_used, uint64_t &out_len)
+                                      ZaInfTabs &T, uint8_t *win, int *scratch, uint64_t &bits_used, uint64_t &out_len,
+                                      uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
-    uint64_t bitpos = 0, op = 0;
+    uint64_t bitpos = start_bit, op = 0;
+    uint64_t cp_bits = start_bit, cp_out = 0;
     int status = ZA_I_OK;
     for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) win[(ZA_WIN - dict_len + i) & (ZA_WIN - 1)] = dict[i];
     __syncthreads();
 
     for (;;) {
+        cp_bits = bitpos; cp_out = op;          // a decoder can restart here with the last 32 KiB of output as dictionary
         if (bitpos + 3 > in_bits) { status = ZA_I_INPUT; break; }
         uint64_t bits = za_peek(in, bitpos);
         const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
@@ -307,11 +312,13 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
         if (last) { status = ZA_I_END; break; }
     }
     bits_used = bitpos; out_len = op;
+    if (blk_bits) *blk_bits = cp_bits;
+    if (blk_out) *blk_out = cp_out;
     return status;
 }
 
 
-__global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len,
+__global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len, uint32_t start_bit,
                                                           const uint8_t *__restrict__ dict, uint32_t dict_len,
                                                           uint8_t *__restrict__ out, uint64_t out_cap,
                                                           ZaInfResult *__restrict__ res)
@@ -319,9 +326,9 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     __shared__ ZaInfTabs T;
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
-    uint64_t bits = 0, op = 0;
-    const int status = za_inflate_serial_core(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, bits, op);
-    if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; }
+    uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
+    const int status = za_inflate_serial_core(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, bits, op, start_bit, &cpb, &cpo);
+    if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -534,11 +534,11 @@ static int map_status(int s)
 
 // sequential decode of one raw stream that already sits (padded) on the device
 static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const uint8_t *d_dict, uint32_t dict_len,
-                              uint8_t *d_out, uint64_t out_cap, ZaInfResult *hres)
+                              uint8_t *d_out, uint64_t out_cap, ZaInfResult *hres, uint32_t start_bit = 0)
 {
     ZaInfResult *dres = (ZaInfResult *)((uint8_t *)c->d_small + 64);
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, d_in, in_len, d_dict, dict_len, d_out, out_cap, dres); }
+      hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, d_in, in_len, start_bit, d_dict, dict_len, d_out, out_cap, dres); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hres, dres, sizeof(ZaInfResult), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -572,6 +572,29 @@ int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const 
         if (crc) *crc = cv;
         if (adler) *adler = av;
     }
+    if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
+    return map_status(res.status);
+}
+
+
+int zngamd_inflate_resume(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint32_t start_bit, const uint8_t *dict, uint32_t dict_len,
+                          uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_bits, uint64_t *block_bits, uint64_t *block_out)
+{
+    if (!c || (!in && in_len) || (!out && out_cap) || !out_len || !in_bits || !block_bits || !block_out || start_bit > 7) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (dict_len > ZA_WIN) { dict += dict_len - ZA_WIN; dict_len = ZA_WIN; }
+    const uint64_t front = (dict_len + 63u) & ~63ull;
+    int r = stage_in(c, in, in_len, front);
+    if (r) return r;
+    if (dict_len) HIPCHK(c, hipMemcpyAsync(c->st_in.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->st_out.ensure(out_cap + 64));
+    ZaInfResult res;
+    r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res, start_bit);
+    if (r) return r;
+    *out_len = res.out_len; *in_bits = res.in_bits; *block_bits = res.block_bits; *block_out = res.block_out;
+    if (res.out_len) HIPCHK(c, hipMemcpyAsync(out, c->st_out.p, res.out_len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (res.status == ZA_I_OUTFULL) return ZNGAMD_E_OVERFLOW;          // out_cap reached: call again with more room
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
 }

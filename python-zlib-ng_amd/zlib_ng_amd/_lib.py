@@ -27,7 +27,7 @@ SYMBOLS = [
     "zngamd_set_stream", "zngamd_sync", "zngamd_dmalloc", "zngamd_dfree", "zngamd_h2d", "zngamd_d2h",
     "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
     "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
-    "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
+    "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gunzip", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
     "zngamd_kernel_times", "zngamd_debug_fetch",
 ]
@@ -91,6 +91,9 @@ def load():
         L.zngamd_inflate_raw.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint32, u8p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.zngamd_inflate_resume.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_uint64,
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]
         L.zngamd_gzip_scan_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint64)]
         L.zngamd_gzip_inflate_members_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp]
@@ -233,6 +236,18 @@ class Context:
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
         return r, out.raw[:ol.value], used.value, crc.value, ad.value
+
+    def inflate_resume(self, data, start_bit, zdict, out_cap):
+        """-> (code, out bytes, in_bits, block_bits, block_out); code E_OVERFLOW = out_cap reached"""
+        p, keep = _addr(data)
+        dp, dkeep = _addr(zdict) if len(zdict) else (None, None)
+        out = C.create_string_buffer(max(out_cap, 1))
+        ol, ib, bb, bo = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        r = self.L.zngamd_inflate_resume(self.h, p, memoryview(data).nbytes, start_bit, dp, len(zdict),
+                                         C.cast(out, C.c_void_p), out_cap, C.byref(ol), C.byref(ib), C.byref(bb), C.byref(bo))
+        if r in (E_HIP, E_ARG):
+            raise EngineError(r, self.err())
+        return r, out.raw[:ol.value], ib.value, bb.value, bo.value
 
     def gunzip(self, data, out_cap):
         """-> (code, out bytes, n_members)"""

@@ -98,3 +98,75 @@ def compress(data, compresslevel=_COMPRESS_LEVEL_BEST, *, mtime=None):
 def decompress(data):
     """One-shot gunzip of any number of members (gzip_ng.py:200-205)."""
     return _GzipReader(data).readall()
+
+
+# ---- command line (reference: python -m zlib_ng.gzip_ng, gzip_ng.py:208-317) -------------------------------------
+def _argument_parser():
+    import argparse
+    ap = argparse.ArgumentParser(
+        prog="python -m zlib_ng_amd.gzip_ng",
+        description="gzip-compatible (de)compression on the MI355X engine. Reads stdin when no file is given.")
+    ap.add_argument("file", nargs="?")
+    lv = ap.add_mutually_exclusive_group()
+    for n in range(1, 10):
+        names = [f"-{n}"] + (["--fast"] if n == 1 else ["--best"] if n == 9 else [])
+        lv.add_argument(*names, action="store_const", dest="compresslevel", const=n,
+                        help=f"compression level {n}" + (" (default 6)" if n == 6 else ""))
+    lv.add_argument("-d", "--decompress", action="store_true", help="decompress")
+    out = ap.add_mutually_exclusive_group()
+    out.add_argument("-c", "--stdout", action="store_true", help="write to standard output")
+    out.add_argument("-o", "--output", help="write to this file")
+    ap.add_argument("-n", "--no-name", action="store_true", help="do not store the file name and time stamp")
+    ap.add_argument("-f", "--force", action="store_true", help="overwrite existing output")
+    ap.add_argument("-b", "--buffer-size", type=int, default=READ_BUFFER_SIZE, help="bytes read per request")
+    ap.set_defaults(compresslevel=_COMPRESS_LEVEL_TRADEOFF)
+    return ap
+
+
+def main(argv=None):
+    import os
+    import shutil
+    import sys
+    args = _argument_parser().parse_args(argv)
+    global READ_BUFFER_SIZE
+    READ_BUFFER_SIZE = args.buffer_size
+    decompress_mode = args.decompress
+    src_name = args.file
+    if args.output:
+        dst_name = args.output
+    elif args.stdout or src_name is None:
+        dst_name = None
+    elif decompress_mode:
+        stem, ext = os.path.splitext(src_name)
+        if ext not in (".gz", ".tgz"):
+            sys.exit(f"filename doesn't end in .gz: {src_name!r}. Cannot determine output filename.")
+        dst_name = stem + (".tar" if ext == ".tgz" else "")
+    else:
+        dst_name = src_name + ".gz"
+    if dst_name is not None and os.path.exists(dst_name) and not args.force:
+        answer = input(f"{dst_name} already exists; do you wish to overwrite (y/n)? ")
+        if answer.strip().lower() not in ("y", "yes"):
+            sys.exit("not overwritten")
+    raw_in = sys.stdin.buffer if src_name is None else builtins_open(src_name, "rb")
+    raw_out = sys.stdout.buffer if dst_name is None else builtins_open(dst_name, "wb")
+    try:
+        if decompress_mode:
+            with GzipNGFile(fileobj=raw_in, mode="rb") as gz:
+                shutil.copyfileobj(gz, raw_out, args.buffer_size)
+        else:
+            kw = {"filename": "", "mtime": 0} if (args.no_name or src_name is None) else {"filename": os.path.basename(src_name)}
+            with GzipNGFile(fileobj=raw_out, mode="wb", compresslevel=args.compresslevel, **kw) as gz:
+                shutil.copyfileobj(raw_in, gz, args.buffer_size)
+    finally:
+        if raw_in is not sys.stdin.buffer:
+            raw_in.close()
+        if raw_out is not sys.stdout.buffer:
+            raw_out.close()
+
+
+import builtins as _builtins  # noqa: E402
+
+builtins_open = _builtins.open
+
+if __name__ == "__main__":  # pragma: no cover
+    main()

@@ -9,8 +9,8 @@ and a GPU these functions raise RuntimeError.
 
 Implemented: compress / decompress (a10), crc32 / adler32 /
 crc32_combine (a4, a5, a12), _ParallelCompress (a1, a2), _GzipReader (a8), compressobj (buffering
-writer used by gzip_ng.GzipNGFile).  decompressobj / _ZlibDecompressor (incremental, inherently
-sequential: SURVEY.md section 8f rank 2) are the next widening step and raise NotImplementedError.
+writer used by gzip_ng.GzipNGFile), decompressobj / _ZlibDecompressor (SURVEY.md section 8f rank 2:
+block-resumable decoding on the sequential wavefront decoder).
 """
 import gzip as _gzip
 import io as _io
@@ -383,19 +383,241 @@ def compressobj(level=Z_DEFAULT_COMPRESSION, method=DEFLATED, wbits=MAX_WBITS, m
     return _Compress(level, method, wbits, memLevel, strategy, zdict)
 
 
-def decompressobj(wbits=MAX_WBITS, zdict=b""):
-    raise NotImplementedError("decompressobj: incremental inflate is the next widening step (SURVEY.md 8f-2); "
-                              "use decompress() or _GzipReader")
+# ---- incremental inflate: decompressobj / _ZlibDecompressor (zlib_ngmodule.c:456-502, :622-716, :1040-1438) ----------
+class _InflateCore:
+    """Block-resumable inflate on the GPU engine.  Input is kept from the last deflate-block header onward;
+    every call decodes from there (start bit + up to 32 KiB of history) with the sequential wavefront decoder
+    (`zngamd_inflate_resume`) and hands out only what is new.  Container header / trailer bytes are handled
+    here; payload checksums are computed by the engine."""
+
+    def __init__(self, wbits, zdict):
+        if wbits == 0 or 8 <= wbits <= 15:
+            self.kind = "zlib"
+        elif -15 <= wbits <= -8:
+            self.kind = "raw"
+        elif 24 <= wbits <= 31:
+            self.kind = "gzip"
+        elif 40 <= wbits <= 47 or wbits == 32:
+            self.kind = "auto"
+        else:
+            raise ValueError("Invalid initialization option")
+        self.wbits = wbits
+        self.zdict = bytes(_view(zdict)) if zdict is not None else b""
+        self.window = self.zdict[-32768:] if self.kind == "raw" else b""
+        self.buf = bytearray()
+        self.start_bit = 0
+        self.skip = 0
+        self.header_done = self.kind == "raw"
+        self.deflate_done = False
+        self.eof = False
+        self.unused = b""
+        self.check = 1                    # running Adler-32 (zlib) or CRC-32 (gzip)
+        self.total = 0
+
+    def clone(self):
+        import copy as _copy
+        o = _copy.copy(self)
+        o.buf = bytearray(self.buf)
+        return o
+
+    def _header(self):
+        W = "while decompressing data"
+        b = self.buf
+        if self.kind == "auto" and len(b) >= 2:
+            self.kind = "gzip" if b[:2] == b"\x1f\x8b" else "zlib"
+            self.wbits = 15
+        if self.kind == "zlib":
+            if len(b) < 2:
+                return False
+            cmf, flg = b[0], b[1]
+            if (cmf & 15) != 8 or ((cmf << 8) | flg) % 31:
+                raise _zerr(_lib.DATA_ERROR, W, "incorrect header check")
+            if (cmf >> 4) + 8 > (self.wbits if self.wbits else 15):
+                raise _zerr(_lib.DATA_ERROR, W, "invalid window size")
+            need = 2
+            if flg & 0x20:
+                if len(b) < 6:
+                    return False
+                if not self.zdict:
+                    raise _zerr(_lib.NEED_DICT, W)
+                if _struct.unpack(">I", bytes(b[2:6]))[0] != adler32(self.zdict):
+                    raise _zerr(_lib.DATA_ERROR, "while setting zdict")
+                self.window = self.zdict[-32768:]
+                need = 6
+            del b[:need]
+            self.check = 1
+        elif self.kind == "gzip":
+            try:
+                start = _parse_gzip_header(bytes(b))
+            except EOFError:
+                return False
+            except BadGzipFile:
+                raise _zerr(_lib.DATA_ERROR, W, "incorrect header check") from None
+            del b[:start]
+            self.check = 0
+        else:
+            return False
+        self.header_done = True
+        return True
+
+    def _trailer(self):
+        need = {"zlib": 4, "gzip": 8, "raw": 0}[self.kind]
+        if len(self.buf) < need:
+            return
+        t = bytes(self.buf[:need])
+        W = "while decompressing data"
+        if self.kind == "zlib" and _struct.unpack(">I", t)[0] != self.check:
+            raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
+        if self.kind == "gzip":
+            crc, isize = _struct.unpack("<II", t)
+            if crc != self.check:
+                raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
+            if isize != self.total & 0xFFFFFFFF:
+                raise _zerr(_lib.DATA_ERROR, W, "incorrect length check")
+        self.unused = bytes(self.buf[need:])
+        self.buf.clear()
+        self.eof = True
+
+    def feed(self, data, limit=None):
+        """Append `data`, decode, return the new output (at most `limit` bytes when given) and the number of
+        input bytes of this call that zlib would report as still unconsumed."""
+        if self.eof:
+            self.unused += bytes(data)
+            return b"", 0
+        self.buf += data
+        if not self.header_done and not self._header():
+            return b"", 0
+        if self.deflate_done:
+            self._trailer()
+            return b"", 0
+        ctx = _ctx()
+        want = None if limit is None else self.skip + limit
+        cap = want if want is not None else max(1 << 16, 8 * len(self.buf) + self.skip)
+        while True:
+            code, out, in_bits, bb, bo = ctx.inflate_resume(bytes(self.buf), self.start_bit, self.window, max(cap, 1))
+            if code == _lib.E_OVERFLOW and want is None:
+                cap *= 4
+                continue
+            break
+        new = out[self.skip:]
+        if code == _lib.DATA_ERROR:
+            raise _zerr(_lib.DATA_ERROR, "while decompressing data")
+        if new:
+            self.check = crc32(new, self.check) if self.kind == "gzip" else adler32(new, self.check) if self.kind == "zlib" else 0
+            self.total += len(new)
+        left = 0
+        if code == _lib.STREAM_END:
+            del self.buf[:(in_bits + 7) // 8]
+            self.deflate_done = True
+            self.skip = 0
+            self._trailer()
+        elif code == _lib.E_OVERFLOW:
+            # output limit reached in the middle of a block: remember what was delivered, report the input
+            # beyond the stop position as unconsumed (it stays buffered here as well)
+            self.skip = len(out)
+            left = max(0, len(self.buf) - (in_bits + 7) // 8)
+        else:                                   # input ran out: move the resume point to the last block header
+            self.window = (self.window + out[:bo])[-32768:]
+            del self.buf[:bb // 8]
+            self.start_bit = bb & 7
+            self.skip = len(out) - bo
+        return new, left
 
 
 class _Decompress:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("incremental inflate is the next widening step (SURVEY.md 8f-2)")
+    """zlib.decompressobj look-alike (zlib_ngmodule.c:622-1037): decompress(data, max_length), flush, copy,
+    unused_data, unconsumed_tail, eof."""
+
+    def __init__(self, wbits=MAX_WBITS, zdict=b""):
+        self._core = _InflateCore(wbits, zdict)
+        self._lock = _threading.Lock()
+        self.unused_data = b""
+        self.unconsumed_tail = b""
+        self.eof = False
+        self._ahead = 0          # bytes at the end of the core buffer that were handed back as unconsumed_tail
+
+    def _sync(self):
+        self.eof = self._core.eof
+        self.unused_data = self._core.unused
+
+    def decompress(self, data, /, max_length=0):
+        if max_length < 0:
+            raise ValueError("max_length must be non-negative")
+        with self._lock:
+            data = bytes(_view(data))
+            if self._ahead:                     # the caller feeds unconsumed_tail back: already buffered
+                data = data[min(self._ahead, len(data)):]
+                self._ahead = 0
+            out, left = self._core.feed(data, max_length or None)
+            self.unconsumed_tail = bytes(self._core.buf[len(self._core.buf) - left:]) if left else b""
+            self._ahead = left
+            self._sync()
+            return out
+
+    def flush(self, length=DEF_BUF_SIZE, /):
+        if length <= 0:
+            raise ValueError("length must be greater than zero")
+        with self._lock:
+            self._ahead = 0
+            out, _ = self._core.feed(b"", None)
+            self.unconsumed_tail = b""
+            self._sync()
+            return out
+
+    def copy(self):
+        with self._lock:
+            o = _Decompress.__new__(_Decompress)
+            o._core = self._core.clone()
+            o._lock = _threading.Lock()
+            o.unused_data, o.unconsumed_tail, o.eof, o._ahead = self.unused_data, self.unconsumed_tail, self.eof, self._ahead
+            return o
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        return self.copy()
+
+
+_Decompress.__module__ = "zlib_ng"
+
+
+def decompressobj(wbits=MAX_WBITS, zdict=b""):
+    return _Decompress(wbits, zdict)
 
 
 class _ZlibDecompressor:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("incremental inflate is the next widening step (SURVEY.md 8f-2)")
+    """bz2/lzma-style decompressor (zlib_ngmodule.c:1040-1438): decompress(data, max_length=-1), eof,
+    unused_data, needs_input."""
+
+    def __init__(self, wbits=MAX_WBITS, zdict=b""):
+        self._core = _InflateCore(wbits, zdict)
+        self._lock = _threading.Lock()
+        self._held = b""
+        self.needs_input = True
+
+    @property
+    def eof(self):
+        return self._core.eof and not self._held
+
+    @property
+    def unused_data(self):
+        return self._core.unused
+
+    def decompress(self, data, max_length=-1):
+        with self._lock:
+            if self._core.eof and not self._held:
+                raise EOFError("End of stream already reached")
+            out, _ = self._core.feed(bytes(_view(data)), None)
+            out = self._held + out
+            if 0 <= max_length < len(out):
+                out, self._held = out[:max_length], out[max_length:]
+            else:
+                self._held = b""
+            self.needs_input = not self._held and not self._core.eof
+            return out
+
+
+_ZlibDecompressor.__module__ = "zlib_ng"
 
 
 # ---- _GzipReader (zlib_ngmodule.c:2215-2930) ------------------------------------------------------------------

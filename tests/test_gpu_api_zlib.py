@@ -174,3 +174,98 @@ def test_gzip_reader_errors(G, Z, fastq):
     assert r.read(30000) == fastq[:30000]          # good member is served, the error comes after it
     with pytest.raises(G.BadGzipFile):
         r.read(10)
+
+
+# ---- incremental objects, after tests/test_zlib_compliance.py / test_compat.py:118-189 --------
+def test_decompressobj_streaming(Z, fastq):
+    data = fastq[:700000]
+    for wbits, blob in ((15, zlib.compress(data, 6)), (-15, zlib.compressobj(9, 8, -15).compress(data) + zlib.compressobj(9, 8, -15).flush() if False else None),
+                        (31, gzip.compress(data, 6)), (47, zlib.compress(data, 1))):
+        if blob is None:
+            co = zlib.compressobj(9, zlib.DEFLATED, -15)
+            blob = co.compress(data) + co.flush()
+        for step in (1000, 65536, len(blob)):
+            d = Z.decompressobj(wbits)
+            out = b"".join(d.decompress(blob[i:i + step]) for i in range(0, len(blob), step)) + d.flush()
+            assert out == data and d.eof and d.unused_data == b"" and d.unconsumed_tail == b""
+    # unused_data after the end of the stream (test_compat.py:179-189)
+    d = Z.decompressobj()
+    assert d.decompress(zlib.compress(b"abcdef" * 100) + b"trailing") == b"abcdef" * 100
+    assert d.eof and d.unused_data == b"trailing"
+    assert d.decompress(b"more") == b"" and d.unused_data == b"trailingmore"
+    # max_length / unconsumed_tail loop (test_zlib_compliance.py:470-500)
+    blob = zlib.compress(data[:200000], 6)
+    d = Z.decompressobj()
+    chunks = [d.decompress(blob, 1000)]
+    assert len(chunks[0]) == 1000 and d.unconsumed_tail
+    while d.unconsumed_tail:
+        chunks.append(d.decompress(d.unconsumed_tail, 50000))
+        assert len(chunks[-1]) <= 50000
+    chunks.append(d.flush())
+    assert b"".join(chunks) == data[:200000] and d.eof
+    cdata = b"x\x9cKLJ\x06\x00\x02M\x01"            # "abc" without the last Adler byte, :497
+    d = Z.decompressobj()
+    got = d.decompress(cdata, 1)
+    got += d.decompress(d.unconsumed_tail)
+    assert got == b"abc" and d.unconsumed_tail == b""
+    with pytest.raises(ValueError):
+        Z.decompressobj().decompress(b"", -1)
+    # sync-flushed pieces decode as they arrive (test_zlib_compliance.py:503-533)
+    co = zlib.compressobj(6)
+    p1 = co.compress(data[:5000]) + co.flush(zlib.Z_SYNC_FLUSH)
+    p2 = co.compress(data[5000:9000]) + co.flush()
+    d = Z.decompressobj()
+    assert d.decompress(p1) == data[:5000] and not d.eof
+    assert d.decompress(p2) == data[5000:9000] and d.eof
+    # copy (test_zlib_compliance.py:750-779)
+    d = Z.decompressobj()
+    first = d.decompress(blob[:3000])
+    d2 = d.copy()
+    assert first + d.decompress(blob[3000:]) + d.flush() == data[:200000]
+    assert first + d2.decompress(blob[3000:]) + d2.flush() == data[:200000]
+    # zdict
+    zd = data[:20000]
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, 0, zd)
+    zblob = co.compress(data[10000:60000]) + co.flush()
+    assert Z.decompressobj(15, zd).decompress(zblob) == data[10000:60000]
+    with pytest.raises(Z.error):
+        Z.decompressobj().decompress(zblob)
+    with pytest.raises(Z.error):
+        Z.decompressobj().decompress(b"not a zlib stream at all")
+
+
+def test_zlib_decompressor(Z, fastq):
+    data = fastq[:300000]
+    blob = zlib.compress(data, 6) + b"tail"
+    d = Z._ZlibDecompressor()
+    out = []
+    assert d.needs_input and not d.eof
+    feed = [blob[:1000], blob[1000:]]
+    for _ in range(100):
+        if d.eof:
+            break
+        chunk = feed.pop(0) if (d.needs_input and feed) else b""
+        piece = d.decompress(chunk, 70000)
+        assert len(piece) <= 70000
+        out.append(piece)
+    assert b"".join(out) == data and d.eof and d.unused_data == b"tail"
+    with pytest.raises(EOFError):
+        d.decompress(b"x")
+    d = Z._ZlibDecompressor(wbits=31)
+    assert d.decompress(gzip.compress(data[:1000])) == data[:1000] and d.eof
+
+
+def test_compressobj_and_cli(Z, G, fastq, tmp_path):
+    data = fastq[:400000]
+    for wbits in (15, -15, 31):
+        co = Z.compressobj(6, Z.DEFLATED, wbits)
+        blob = b"".join(co.compress(data[i:i + 50000]) for i in range(0, len(data), 50000))
+        blob += co.flush(Z.Z_SYNC_FLUSH) + co.compress(b"tail") + co.flush()
+        assert zlib.decompress(blob, wbits) == data + b"tail"
+    src = tmp_path / "in.txt"
+    src.write_bytes(data)
+    G.main(["-6", "-n", "-f", str(src)])
+    assert gzip.open(str(src) + ".gz").read() == data
+    out = tmp_path / "back.txt"
+    G.main(["-d", "-f", "-o", str(out), str(src) + ".gz"])
+    assert out.read_bytes() == data
