@@ -1,0 +1,81 @@
+"""GPU: randomized parity.  Inputs are stitched from text / random / zero / periodic pieces with random
+lengths; levels, dictionary lengths and FINAL flags are random; every case must give the oracle's exact
+bytes from the HIP pipeline, inflate with the system zlib to the input, and decode identically on the HIP
+sequential decoder.  A second test forces several workspace chunks per call."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stitch(rng, fastq, total):
+    parts, n = [], 0
+    while n < total:
+        kind = int(rng.integers(0, 5))
+        ln = int(rng.integers(1, 40000))
+        if kind == 0:
+            o = int(rng.integers(0, len(fastq) - ln))
+            p = fastq[o:o + ln]
+        elif kind == 1:
+            p = rng.bytes(ln)
+        elif kind == 2:
+            p = bytes(ln)
+        elif kind == 3:
+            pat = rng.bytes(int(rng.integers(1, 40)))
+            p = (pat * (ln // len(pat) + 1))[:ln]
+        else:
+            p = bytes(rng.integers(0, 4, ln, dtype=np.uint8) + 65)      # 2-bit entropy "DNA"
+        parts.append(p)
+        n += ln
+    return b"".join(parts)[:total]
+
+
+def test_random_blocks_match_oracle(ctx, fastq):
+    from oracle import oracle as O
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        n = int(rng.choice([0, 1, 3, 4, 5, 17, 2047, 2048, 2049, 4096, 65535, 65536, 70001, 131071, 131072]))
+        dl = int(rng.choice([0, 0, 1, 100, 32767, 32768]))
+        level = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -1]))
+        if level in (8, 9) and n > 70001:
+            n = 70001
+        flags = int(rng.integers(0, 2))
+        buf = _stitch(rng, fastq, dl + n)
+        zd, data = buf[:dl], buf[dl:]
+        outs, crcs, ovf = ctx.deflate_blocks(buf, [(dl, n, dl, flags)], level, n + n // 8 + 600)
+        exp, ecrc = O.deflate_unit(data, zd, level, flags)
+        assert not ovf and outs[0] == exp and crcs[0] == ecrc == zlib.crc32(data), (case, n, dl, level, flags)
+        d = zlib.decompressobj(-15, zdict=zd) if dl else zlib.decompressobj(-15)
+        assert d.decompress(outs[0]) == data and d.eof == bool(flags)
+        code, back, used, crc, ad = ctx.inflate_raw(outs[0], n + 16, zd)
+        assert back == data and code == (1 if flags else -5) and crc == ecrc
+
+
+def test_many_units_over_several_workspace_chunks(fastq):
+    """ZNGAMD_CHUNK_UNITS=3: a 13-unit call runs the five kernels five times over a 3-unit workspace."""
+    from oracle import oracle as O
+    from zlib_ng_amd import _lib
+    old = os.environ.get("ZNGAMD_CHUNK_UNITS")
+    os.environ["ZNGAMD_CHUNK_UNITS"] = "3"
+    try:
+        c = _lib.Context(device=0)
+    finally:
+        if old is None:
+            os.environ.pop("ZNGAMD_CHUNK_UNITS", None)
+        else:
+            os.environ["ZNGAMD_CHUNK_UNITS"] = old
+    data = fastq[:13 * 131072 - 777]
+    blocks = [(off, min(131072, len(data) - off), min(32768, off), 0) for off in range(0, len(data), 131072)]
+    outs, crcs, ovf = c.deflate_blocks(data, blocks, 6, 131072 + 13107)
+    assert not ovf and len(outs) == 13
+    for (off, ln, dl, _), out, crc in zip(blocks, outs, crcs):
+        exp, ecrc = O.deflate_unit(data[off:off + ln], data[off - dl:off], 6, 0)
+        assert out == exp and crc == ecrc
+    assert zlib.decompress(b"".join(outs) + b"\x03\x00", -15) == data
+    stream = c.gzip_members(data, 131072, 1)
+    code, back, nm = c.gunzip(stream, len(data))
+    assert code == 0 and back == data and nm == 13
+    c.close()
