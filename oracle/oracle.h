@@ -44,6 +44,7 @@ extern "C" {
 #define ZA_WIN        32768
 #define ZA_HASH_BITS  15
 #define ZA_MIN_MATCH  4
+#define ZA_HASH_BYTES 6         /* bytes hashed into a chain bucket */
 #define ZA_MAX_MATCH  258
 #define ZA_TOO_FAR    4096      /* a minimum-length match farther than this is dropped */
 

@@ -10,7 +10,7 @@
  * this file byte for byte, stage by stage.
  *
  *   stage 1  hash chains        prevdist[p] = distance to the nearest earlier position whose
- *                               4-byte hash lands in the same 15-bit bucket (u16 head table)
+ *                               6-byte hash lands in the same 15-bit bucket (u16 head table)
  *   stage 2  match search       best[p] = longest match among the first `chain` chain entries,
  *                               nearest wins ties, truncated at the 2 KiB segment end
  *   stage 3  parse              per 2 KiB segment, greedy (levels 1-3) or one-step lazy (4-9)
@@ -29,8 +29,8 @@ typedef struct { int chain, nice, lazy; } za_level;
  * searched and a whole 128 KiB unit shares one Huffman block), so that the ratio at each level is at
  * least that of zlib 1.2.11 at the same level on the text / FASTQ / mixed corpora. */
 static const za_level LEVELS[10] = {
-    {0, 0, 0}, {4, 8, 0}, {6, 16, 0}, {8, 16, 0}, {8, 32, 8}, {12, 32, 16},
-    {16, 32, 16}, {32, 64, 16}, {64, 128, 32}, {512, 258, 128}
+    {0, 0, 0}, {1, 8, 0}, {2, 8, 0}, {3, 16, 0}, {2, 16, 8}, {3, 32, 16},
+    {4, 32, 16}, {8, 32, 16}, {16, 64, 16}, {128, 258, 128}
 };
 
 /* test-only: forced token-boundary granularity (default ZA_SEG) */
@@ -45,7 +45,13 @@ static inline uint32_t ld32(const uint8_t *p)
 {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
-static inline uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - ZA_HASH_BITS); }
+/* bucket of the 6 bytes at p: chains over 6-byte contexts carry far fewer junk candidates than 4-byte
+ * ones, so a few steps find what 4-byte chains need 16+ steps for */
+static inline uint32_t hash6(const uint8_t *p)
+{
+    uint32_t lo = ld32(p), hi = (uint32_t)p[4] | ((uint32_t)p[5] << 8);
+    return ((lo * 2654435761u) ^ (hi * 2246822519u)) >> (32 - ZA_HASH_BITS);
+}
 
 /* ---------------- stage 1 ---------------- */
 static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *prevdist)
@@ -55,9 +61,9 @@ static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *pr
     int pmin = ZA_WIN - dict_len;
     for (int p = -dict_len; p < n; p++) {
         int i = p + dict_len;
-        if (p + ZA_MIN_MATCH > n) { prevdist[i] = 0; continue; }
+        if (p + ZA_HASH_BYTES > n) { prevdist[i] = 0; continue; }
         uint32_t P = (uint32_t)(ZA_WIN + p);
-        uint32_t h = hash4(ld32(data + p));
+        uint32_t h = hash6(data + p);
         uint32_t d = (P - head[h]) & 0xFFFFu;
         prevdist[i] = (uint16_t)((d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin) ? d : 0);
         head[h] = (uint16_t)(P & 0xFFFFu);

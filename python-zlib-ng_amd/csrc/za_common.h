@@ -14,6 +14,7 @@
 #define ZA_WIN        32768
 #define ZA_HASH_BITS  15
 #define ZA_MIN_MATCH  4
+#define ZA_HASH_BYTES 6
 #define ZA_MAX_MATCH  258
 #define ZA_TOO_FAR    4096
 
@@ -52,7 +53,13 @@ typedef uint64_t __attribute__((aligned(1))) za_u64u;
 
 __device__ __forceinline__ uint32_t za_ld32(const uint8_t *p) { return *(const za_u32u *)p; }
 __device__ __forceinline__ uint64_t za_ld64(const uint8_t *p) { return *(const za_u64u *)p; }
-__device__ __forceinline__ uint32_t za_hash4(uint32_t v) { return (v * 2654435761u) >> (32 - ZA_HASH_BITS); }
+typedef uint16_t __attribute__((aligned(1))) za_u16u;
+__device__ __forceinline__ uint32_t za_ld16(const uint8_t *p) { return *(const za_u16u *)p; }
+// bucket of a 6-byte context: lo = bytes 0..3, hi = bytes 4..5
+__device__ __forceinline__ uint32_t za_hash6(uint32_t lo, uint32_t hi)
+{
+    return ((lo * 2654435761u) ^ (hi * 2246822519u)) >> (32 - ZA_HASH_BITS);
+}
 
 __device__ __forceinline__ int za_lane() { return (int)(threadIdx.x & 63); }
 

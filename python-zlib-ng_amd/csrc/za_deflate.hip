@@ -90,21 +90,22 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     uint32_t rd = 0, wr = 0;
     // software pipeline: a group of 4 tiles (256 positions) is in flight while the previous group is
     // classified -- one tile of look-ahead left the wave waiting on every load
-    uint32_t va[4], vb[4];
-    auto load_group = [&](int gbase, uint32_t (&v)[4]) {
+    uint2 va[4], vb[4];
+    auto load_group = [&](int gbase, uint2 (&v)[4]) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int i = gbase + 64 * t + lane, p = i - dict_len;
-            v[t] = ((i < total) && (p + ZA_MIN_MATCH <= n)) ? za_ld32(data + p) : 0u;
+            const bool ok = (i < total) && (p + ZA_HASH_BYTES <= n);
+            v[t] = ok ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
         }
     };
-    auto do_group = [&](int gbase, const uint32_t (&v)[4]) {
+    auto do_group = [&](int gbase, const uint2 (&v)[4]) {
         // classify the four tiles back to back (independent work), then drain the ring
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int i = gbase + 64 * t + lane, p = i - dict_len;
-            const bool valid = (i < total) && (p + ZA_MIN_MATCH <= n);
-            const uint32_t h = za_hash4(v[t]);
+            const bool valid = (i < total) && (p + ZA_HASH_BYTES <= n);
+            const uint32_t h = za_hash6(v[t].x, v[t].y);
             const bool mine = valid && (h >> ZA_CH_SUB) == wave;
             const unsigned long long mask = __ballot(mine);
             if (mine) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
         }
     };
     // three groups (768 positions) of loads stay in flight ahead of the one being classified
-    uint32_t vc[4], vd[4];
+    uint2 vc[4], vd[4];
     load_group(0, va); load_group(256, vb); load_group(512, vc);
     for (int gbase = 0; gbase < total; gbase += 1024) {
         load_group(gbase + 768, vd);
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
         do_group(gbase + 768, vd);
     }
     if (wr != rd) za_chains_dense(head, stage, rd, (int)(wr - rd), pmin, prevdist, dict_len);
-    // positions with fewer than 4 bytes left are never inserted: their link is 0
-    if (wave == 0 && lane < ZA_MIN_MATCH - 1) {
+    // positions with fewer than 6 bytes left are never inserted: their link is 0
+    if (wave == 0 && lane < ZA_HASH_BYTES - 1) {
         const int p = n - 1 - lane;
         if (p >= -dict_len) prevdist[p + dict_len] = 0;
     }
