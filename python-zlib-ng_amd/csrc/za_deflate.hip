@@ -51,8 +51,9 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
     __builtin_amdgcn_wave_barrier();
     const bool clash = valid && vhead[h] != P16;
     if (__ballot(clash) != 0ull) {
-        // Some bucket is hit twice in this tile: order the lanes exactly (15/13/12-ballot bit-slice
-        // match-any), link later lanes to the nearest earlier one and leave the last position in the table.
+        // Some bucket is hit twice in this tile: order the lanes exactly (bit-slice match-any over the
+        // table-index bits), link later lanes to the nearest earlier one and leave the last position in the
+        // table.  (A loop over the clashing buckets was measured slower: text has many per tile.)
         unsigned long long eq = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < ZA_CH_SUB; b++) {
@@ -65,7 +66,7 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
         const int j = lower ? 63 - __builtin_clzll(lower) : lane;
         const uint32_t Pj = __shfl(P, j, 64);
         if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
-        if (valid && !higher) head[h] = P16;
+        if (valid && !higher) vhead[h] = P16;
     }
     if (valid) prevdist[(int)P - ZA_WIN + dict_len] = (uint16_t)d;
 }
@@ -88,15 +89,19 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     const int total = dict_len + n;
     const int pmin = ZA_WIN - dict_len;
     uint32_t rd = 0, wr = 0;
+    const bool can_load = total >= ZA_HASH_BYTES;          // wave-uniform: the unit + dictionary hold at least one 6-byte context
     // software pipeline: a group of 4 tiles (256 positions) is in flight while the previous group is
     // classified -- one tile of look-ahead left the wave waiting on every load
     uint2 va[4], vb[4];
+    // loads are unconditional from a clamped position (no branch per tile); `valid` masks them later
+    const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available (may be < -dict_len)
     auto load_group = [&](int gbase, uint2 (&v)[4]) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int i = gbase + 64 * t + lane, p = i - dict_len;
-            const bool ok = (i < total) && (p + ZA_HASH_BYTES <= n);
-            v[t] = ok ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
+            int p = gbase + 64 * t + lane - dict_len;
+            p = p > pclamp_hi ? pclamp_hi : p;
+            p = p < -dict_len ? -dict_len : p;
+            v[t] = can_load ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
         }
     };
     auto do_group = [&](int gbase, const uint2 (&v)[4]) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
             const bool mine = valid && (h >> ZA_CH_SUB) == wave;
             const unsigned long long mask = __ballot(mine);
             if (mine) {
-                const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 stage[(wr + rank) & (ZA_CH_STAGE - 1u)] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
             }
             wr += (uint32_t)__builtin_popcountll(mask);
