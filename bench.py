@@ -5,7 +5,8 @@ One "step" = one pass of the hot path over this rank's shard of synthetic text a
   (1) compress: every 128 KiB block, primed with the previous 32 KiB of input as dictionary
       (reference semantics: gzip_ng_threaded.py:299-322 + zlib_ngmodule.c:1696-1782), through the five
       deflate kernels, gathered into one contiguous raw-deflate slice; with N > 1 ranks the slices are
-      exchanged with an RCCL all-gather and re-assembled into the member stream on every rank;
+      exchanged with an RCCL all-gather (issued asynchronously, overlapping leg 2) and re-assembled into the
+      member stream on every rank;
   (2) decompress: two-pass inflate (member scan, then one wavefront per member) of a pre-built stream
       of independent indexed gzip members of the same text (BASELINE.json configs[2]).
 value = uncompressed bytes of all ranks / (max over ranks of the step time): the rate at which data goes
@@ -133,16 +134,20 @@ def main():
                                         ptr(d_ucrc), None), "deflate_blocks_dev")
         chk(L.zngamd_gather_dev(h, ptr(d_slots), ptr(d_ulen), n_units, ptr(d_comp), 0, d_comp.numel(), None,
                                 C.byref(comp_total)), "gather_dev")
-        if exchange:
-            stream, total, _ = shard.allgather_stream(d_comp, comp_total.value, scratch=gathered)
-            gathered["total"] = total
+        pending = None
+        if exchange:      # the slices travel while this rank runs its inflate leg
             torch.cuda.synchronize()
+            pending = shard.allgather_stream_start(d_comp, comp_total.value, scratch=gathered)
         # (2) two-pass inflate of the pre-built member stream
         nm, tot = C.c_uint32(0), C.c_uint64(0)
         chk(L.zngamd_gzip_scan_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nblocks, C.byref(nm),
                                    C.byref(tot)), "gzip_scan_dev")
         chk(L.zngamd_gzip_inflate_members_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nm.value,
                                               ptr(d_out), size, ptr(d_mstat)), "gzip_inflate_members_dev")
+        if pending is not None:
+            stream, total, _ = shard.allgather_stream_finish(pending)
+            gathered["total"] = total
+            torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()

@@ -19,9 +19,10 @@ def shard_range(n_blocks, rank, world):
     return lo, hi
 
 
-def allgather_stream(local, local_len, group=None, scratch=None):
-    """All ranks contribute local[:local_len] (uint8, 1-D); every rank gets the slices concatenated in
-    rank order.  Returns (stream tensor, total length, per-rank sizes).  `scratch` caches buffers."""
+def allgather_stream_start(local, local_len, group=None, scratch=None):
+    """Start the exchange: sizes are all-gathered synchronously (8 bytes per rank), the payload all-gather
+    is issued asynchronously so that independent work (the inflate leg) can overlap it.  Returns a handle for
+    allgather_stream_finish."""
     world = dist.get_world_size(group)
     dev = local.device
     mine = torch.tensor([int(local_len)], dtype=torch.int64, device=dev)
@@ -40,12 +41,26 @@ def allgather_stream(local, local_len, group=None, scratch=None):
         scratch["stream"] = torch.empty(sum(hs) + sum(hs) // 8 + 64, dtype=torch.uint8, device=dev)
         scratch["scap"] = scratch["stream"].numel()
     parts = [scratch["buf"][r * mx:(r + 1) * mx] for r in range(world)]
-    dist.all_gather(parts, local[:mx].contiguous(), group=group)
+    work = dist.all_gather(parts, local[:mx].contiguous(), group=group, async_op=True)
+    return {"work": work, "parts": parts, "sizes": hs, "scratch": scratch}
+
+
+def allgather_stream_finish(h):
+    """Wait for the payload and re-assemble the slices in rank order (rank order == block order: ranges are
+    contiguous).  Returns (stream tensor, total length, per-rank sizes)."""
+    h["work"].wait()
     off = 0
-    for r, s in enumerate(hs):          # rank order == block order: ranges are contiguous
-        scratch["stream"][off:off + s] = parts[r][:s]
+    stream = h["scratch"]["stream"]
+    for r, s in enumerate(h["sizes"]):
+        stream[off:off + s] = h["parts"][r][:s]
         off += s
-    return scratch["stream"], off, hs
+    return stream, off, h["sizes"]
+
+
+def allgather_stream(local, local_len, group=None, scratch=None):
+    """All ranks contribute local[:local_len] (uint8, 1-D); every rank gets the slices concatenated in
+    rank order.  Returns (stream tensor, total length, per-rank sizes).  `scratch` caches buffers."""
+    return allgather_stream_finish(allgather_stream_start(local, local_len, group, scratch))
 
 
 def combine_crcs(crcs_and_lens):
