@@ -1,0 +1,18 @@
+"""Times the sequential wavefront decoder (ordinary single-member gzip) and the BGZF one-launch path."""
+import gzip, os, sys, time, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
+from zlib_ng_amd import _lib
+ctx = _lib.default_context()
+for name in ("test.fastq.gz", "test.fastq.bgzip.gz"):
+    raw = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+    exp = gzip.decompress(raw)
+    ctx.gunzip(raw, len(exp))
+    t = time.perf_counter(); code, out, nm = ctx.gunzip(raw, len(exp)); dt = time.perf_counter() - t
+    assert code == 0 and out == exp
+    t = time.perf_counter(); zlib.decompress(raw, 47) if nm == 1 else gzip.decompress(raw); dz = time.perf_counter() - t
+    print(f"{name}: {nm} members, {len(exp)/dt/1e6:.1f} MB/s on the GPU path ({dt*1e3:.1f} ms), system zlib {len(exp)/dz/1e6:.1f} MB/s")
+raw = open(os.path.join(ROOT, "tests", "golden", "test.fastq.gz"), "rb").read()
+ctx.profiling(True); ctx.kernel_times(True)
+t = time.perf_counter(); ctx.gunzip(raw, 3578369); dt = time.perf_counter() - t
+print("wall %.1f ms; kernel ms:" % (dt * 1e3), {k: round(v[0], 2) for k, v in ctx.kernel_times(True).items() if v[1]})

@@ -17,6 +17,7 @@
 #include "za_crc.h"
 
 #define ZA_LUT_L_BITS 10
+#define ZA_IBUF_DW 128             // dwords of bitstream staged in LDS by the sequential decoder
 #define ZA_LUT_D_BITS 9
 
 // internal status values (host maps them to ZNGAMD_* codes)
@@ -218,7 +219,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       uint8_t *__restrict__ out, uint64_t out_cap,
-                                      ZaInfTabs &T, uint8_t *win, int *scratch, uint64_t &bits_used, uint64_t &out_len,
+                                      ZaInfTabs &T, uint8_t *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
                                       uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr)
 {
     const int lane = za_lane();
@@ -260,52 +261,90 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
         } else {
             status = za_read_tables(in, in_bits, bitpos, type, T, scratch);
             if (status != ZA_I_OK) break;
-            for (;;) {
-                bits = za_peek(in, bitpos);
-                uint32_t e = za_decode_sym(bits, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
-                if (!e) { status = (bitpos + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
-                int sym = (int)(e >> 4);
-                uint32_t used = e & 15u;
-                if (bitpos + used > in_bits) { status = ZA_I_INPUT; break; }
-                if (sym < 256) {
-                    if (op >= out_cap) { status = ZA_I_OUTFULL; break; }
-                    if (lane == 0) { win[op & (ZA_WIN - 1)] = (uint8_t)sym; out[op] = (uint8_t)sym; }
-                    op++; bitpos += used;
-                    continue;
-                }
-                if (sym == 256) { bitpos += used; break; }
-                sym -= 257;
-                if (sym >= 29) { status = ZA_I_DATA; break; }
-                int nx;
-                int len = za_len_base(sym, nx);
-                len += (int)((bits >> used) & ((1u << nx) - 1u));
-                used += (uint32_t)nx;
-                e = za_decode_sym(bits >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
-                if (!e) { status = (bitpos + used + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
-                const int ds = (int)(e >> 4);
-                used += e & 15u;
-                if (ds >= 30) { status = ZA_I_DATA; break; }
-                int dist = za_dist_base(ds, nx);
-                dist += (int)((bits >> used) & ((1u << nx) - 1u));
-                used += (uint32_t)nx;
-                if (bitpos + used > in_bits) { status = ZA_I_INPUT; break; }
-                if ((uint64_t)dist > op + dict_len) { status = ZA_I_DATA; break; }
-                bool short_out = false;
-                if ((uint64_t)len > out_cap - op) { len = (int)(out_cap - op); short_out = true; }
-                for (int base = 0; base < len; base += 64) {
-                    const int i = base + lane;
-                    uint8_t b = 0;
-                    if (i < len) {
-                        const int k = dist < len ? i % dist : i;
-                        b = win[(op - (uint64_t)dist + (uint64_t)k) & (ZA_WIN - 1)];
+            // Symbol loop.  The bitstream is staged through LDS (512 bytes at a time).  Per round: one 64-bit
+            // window W at bitpos; lane l decodes, in one LDS round trip, the literal/length code and the
+            // distance code that would start at bit l of W; a scalar walker then follows the real token chain
+            // through the lanes' results with readlane, consuming every token that lies completely inside W.
+            // A token is at most 48 bits, so the first one of a window always fits: each round makes progress.
+            bool eob = false;
+            uint64_t ibase = ~0ull;                 // byte offset of ibuf[0] (multiple of 4); ~0 = nothing staged
+            while (!eob && status == ZA_I_OK) {
+                const uint64_t byte = bitpos >> 3;
+                if (ibase == ~0ull || byte < ibase || byte + 12 > ibase + 4ull * ZA_IBUF_DW) {
+                    ibase = byte & ~3ull;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = lane; i < ZA_IBUF_DW; i += 64) {
+                        const uint64_t o = ibase + 4ull * (unsigned)i;
+                        uint32_t v = 0;
+                        if (o + 4 <= in_len + 8) v = za_ld32(in + o);               // the buffer is padded by >= 8 bytes
+                        else for (int k = 0; k < 4; k++) if (o + (unsigned)k < in_len + 8) v |= (uint32_t)in[o + (unsigned)k] << (8 * k);
+                        ibuf[i] = v;
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (i < len) { win[(op + (uint64_t)i) & (ZA_WIN - 1)] = b; out[op + (uint64_t)i] = b; }
-                    __builtin_amdgcn_wave_barrier();
                 }
-                op += (uint64_t)len;
-                if (short_out) { status = ZA_I_OUTFULL; break; }
-                bitpos += used;
+                const uint32_t rel = (uint32_t)(byte - ibase), w = rel >> 2, sh = (rel & 3u) * 8u + (uint32_t)(bitpos & 7u);
+                const uint64_t lo64 = ((uint64_t)ibuf[w + 1] << 32) | ibuf[w];
+                const uint64_t Wv = sh ? ((lo64 >> sh) | ((uint64_t)ibuf[w + 2] << (64 - sh))) : lo64;
+                const uint64_t W = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(Wv >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)Wv);
+                // speculative decode at bit offset `lane`
+                const uint64_t mine = W >> lane;
+                // LUT only here: a code longer than the LUT (rare) is resolved by the walker when it is really met
+                const uint32_t eL = T.lut_l[mine & ((1u << ZA_LUT_L_BITS) - 1u)];
+                const uint32_t eD = T.lut_d[mine & ((1u << ZA_LUT_D_BITS) - 1u)];
+                uint32_t o = 0;
+                for (;;) {
+                    if (o > 64u - 15u) break;                                        // next code may be cut: new window
+                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)eL, (int)o);
+                    if (!e) e = za_slow_decode((uint32_t)(W >> o), T.cnt_l, T.sym_l, 15);         // o <= 49: 15 bits are there
+                    if (!e) { status = (bitpos + o + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
+                    int sym = (int)(e >> 4);
+                    const uint32_t l = e & 15u;
+                    if (bitpos + o + l > in_bits) { status = ZA_I_INPUT; break; }
+                    if (sym < 256) {
+                        if (op >= out_cap) { status = ZA_I_OUTFULL; break; }
+                        if (lane == 0) { win[op & (ZA_WIN - 1)] = (uint8_t)sym; out[op] = (uint8_t)sym; }
+                        op++; o += l;
+                        continue;
+                    }
+                    if (sym == 256) { o += l; eob = true; break; }
+                    sym -= 257;
+                    if (sym >= 29) { status = ZA_I_DATA; break; }
+                    int nx;
+                    int len = za_len_base(sym, nx);
+                    const uint32_t o2 = o + l + (uint32_t)nx;
+                    if (o2 > 64u - 15u) break;                                       // distance code may be cut: new window
+                    if (nx) len += (int)((W >> (o + l)) & ((1u << nx) - 1u));       // o + l < 64 here
+                    uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)eD, (int)o2);
+                    if (!e2) e2 = za_slow_decode((uint32_t)(W >> o2), T.cnt_d, T.sym_d, 15);
+                    if (!e2) { status = (bitpos + o2 + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
+                    const int ds = (int)(e2 >> 4);
+                    if (ds >= 30) { status = ZA_I_DATA; break; }
+                    int dnx;
+                    int dist = za_dist_base(ds, dnx);
+                    const uint32_t o3 = o2 + (e2 & 15u) + (uint32_t)dnx;
+                    if (o3 > 64u) break;                                             // extra bits cut: new window
+                    if (dnx) dist += (int)((W >> (o2 + (e2 & 15u))) & ((1u << dnx) - 1u));   // shift < 64 when dnx > 0
+                    if (bitpos + o3 > in_bits) { status = ZA_I_INPUT; break; }
+                    if ((uint64_t)dist > op + dict_len) { status = ZA_I_DATA; break; }
+                    bool short_out = false;
+                    if ((uint64_t)len > out_cap - op) { len = (int)(out_cap - op); short_out = true; }
+                    for (int base = 0; base < len; base += 64) {
+                        const int i = base + lane;
+                        uint8_t b = 0;
+                        if (i < len) {
+                            const int k = dist < len ? i % dist : i;
+                            b = win[(op - (uint64_t)dist + (uint64_t)k) & (ZA_WIN - 1)];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (i < len) { win[(op + (uint64_t)i) & (ZA_WIN - 1)] = b; out[op + (uint64_t)i] = b; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    op += (uint64_t)len;
+                    if (short_out) { status = ZA_I_OUTFULL; break; }
+                    o = o3;
+                }
+                bitpos += o;
             }
             if (status != ZA_I_OK) break;
         }
@@ -326,8 +365,9 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     __shared__ ZaInfTabs T;
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
+    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
     uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
-    const int status = za_inflate_serial_core(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, bits, op, start_bit, &cpb, &cpo);
+    const int status = za_inflate_serial_core(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, ibuf, bits, op, start_bit, &cpb, &cpo);
     if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
 
@@ -624,6 +664,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
+    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
@@ -635,7 +676,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, bits, op);
+    int status = za_inflate_serial_core(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, ibuf, bits, op);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
         if (((bits + 7) >> 3) != m.in_len) status = ZA_I_DATA;          // the member must end where its size says
