@@ -215,19 +215,32 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 // sequential decoder: one wave per stream
 // ------------------------------------------------------------------------------------------------
 // Wave-uniform sequential RFC 1951 decode of one stream (all 64 lanes call with identical arguments).
-// T / win / scratch are the caller's LDS; returns a ZA_I_* status, bits consumed and bytes produced.
+// T / win / scratch / ibuf are the caller's LDS; returns a ZA_I_* status, bits consumed and bytes produced.
+//   MODE 0  normal: SymT = u8, history ring `win` (32768 entries) and `out` hold bytes
+//   MODE 1  count only: nothing is stored (win / out unused); sizes a chunk and validates it
+//   MODE 2  markers: SymT = u16; the ring starts as 256 + j (j = index into the unknown previous 32 KiB), copies
+//           move symbols, so every output symbol is a byte (< 256) or names the byte of the previous window it
+//           equals; *max_back = farthest distance before the chunk start that was referenced
+// hist = bytes of history that may be referenced before out[0] (dict_len, or 32768 for a chunk in mid-stream);
+// stop_at_sync ends the decode right after an empty stored block (sync-flush point) with ZA_I_SYNC.
+#define ZA_I_SYNC 2
+template <int MODE, typename SymT>
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
-                                      uint8_t *__restrict__ out, uint64_t out_cap,
-                                      ZaInfTabs &T, uint8_t *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
-                                      uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr)
+                                      SymT *__restrict__ out, uint64_t out_cap,
+                                      ZaInfTabs &T, SymT *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
+                                      uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr,
+                                      uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
     uint64_t bitpos = start_bit, op = 0;
     uint64_t cp_bits = start_bit, cp_out = 0;
+    uint32_t far = 0;
     int status = ZA_I_OK;
-    for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) win[(ZA_WIN - dict_len + i) & (ZA_WIN - 1)] = dict[i];
+    if (hist == 0xFFFFFFFFu) hist = dict_len;
+    if (MODE == 0) for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) win[(ZA_WIN - dict_len + i) & (ZA_WIN - 1)] = (SymT)dict[i];
+    if (MODE == 2) for (uint32_t i = (uint32_t)lane; i < ZA_WIN; i += 64) win[i] = (SymT)(256u + i);
     __syncthreads();
 
     for (;;) {
@@ -249,15 +262,18 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             bool short_in = false, short_out = false;
             if ((uint64_t)can > availb) { can = (uint32_t)availb; short_in = true; }
             if ((uint64_t)can > out_cap - op) { can = (uint32_t)(out_cap - op); short_out = true; short_in = false; }
-            const uint8_t *src = in + (bitpos >> 3);
-            for (uint32_t i = (uint32_t)lane; i < can; i += 64) {
-                const uint8_t b = src[i];
-                win[(op + i) & (ZA_WIN - 1)] = b;
-                out[op + i] = b;
+            if (MODE != 1) {
+                const uint8_t *src = in + (bitpos >> 3);
+                for (uint32_t i = (uint32_t)lane; i < can; i += 64) {
+                    const SymT b = (SymT)src[i];
+                    win[(op + i) & (ZA_WIN - 1)] = b;
+                    out[op + i] = b;
+                }
             }
             op += can; bitpos += 8ull * can;
             if (short_out) { status = ZA_I_OUTFULL; break; }
             if (short_in) { status = ZA_I_INPUT; break; }
+            if (stop_at_sync && len == 0 && !last) { status = ZA_I_SYNC; break; }
         } else {
             status = za_read_tables(in, in_bits, bitpos, type, T, scratch);
             if (status != ZA_I_OK) break;
@@ -287,9 +303,9 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                 const uint64_t Wv = sh ? ((lo64 >> sh) | ((uint64_t)ibuf[w + 2] << (64 - sh))) : lo64;
                 const uint64_t W = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(Wv >> 32)) << 32) |
                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)Wv);
-                // speculative decode at bit offset `lane`
+                // speculative decode at bit offset `lane`; LUT only: a code longer than the LUT (rare) is resolved by
+                // the walker when it is really met
                 const uint64_t mine = W >> lane;
-                // LUT only here: a code longer than the LUT (rare) is resolved by the walker when it is really met
                 const uint32_t eL = T.lut_l[mine & ((1u << ZA_LUT_L_BITS) - 1u)];
                 const uint32_t eD = T.lut_d[mine & ((1u << ZA_LUT_D_BITS) - 1u)];
                 uint32_t o = 0;
@@ -303,7 +319,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     if (bitpos + o + l > in_bits) { status = ZA_I_INPUT; break; }
                     if (sym < 256) {
                         if (op >= out_cap) { status = ZA_I_OUTFULL; break; }
-                        if (lane == 0) { win[op & (ZA_WIN - 1)] = (uint8_t)sym; out[op] = (uint8_t)sym; }
+                        if (MODE != 1 && lane == 0) { win[op & (ZA_WIN - 1)] = (SymT)sym; out[op] = (SymT)sym; }
                         op++; o += l;
                         continue;
                     }
@@ -326,19 +342,22 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     if (o3 > 64u) break;                                             // extra bits cut: new window
                     if (dnx) dist += (int)((W >> (o2 + (e2 & 15u))) & ((1u << dnx) - 1u));   // shift < 64 when dnx > 0
                     if (bitpos + o3 > in_bits) { status = ZA_I_INPUT; break; }
-                    if ((uint64_t)dist > op + dict_len) { status = ZA_I_DATA; break; }
+                    if ((uint64_t)dist > op + hist) { status = ZA_I_DATA; break; }
+                    if ((uint64_t)dist > op && (uint32_t)((uint64_t)dist - op) > far) far = (uint32_t)((uint64_t)dist - op);
                     bool short_out = false;
                     if ((uint64_t)len > out_cap - op) { len = (int)(out_cap - op); short_out = true; }
-                    for (int base = 0; base < len; base += 64) {
-                        const int i = base + lane;
-                        uint8_t b = 0;
-                        if (i < len) {
-                            const int k = dist < len ? i % dist : i;
-                            b = win[(op - (uint64_t)dist + (uint64_t)k) & (ZA_WIN - 1)];
+                    if (MODE != 1) {
+                        for (int base = 0; base < len; base += 64) {
+                            const int i = base + lane;
+                            SymT b = 0;
+                            if (i < len) {
+                                const int k = dist < len ? i % dist : i;
+                                b = win[(op - (uint64_t)dist + (uint64_t)k) & (ZA_WIN - 1)];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            if (i < len) { win[(op + (uint64_t)i) & (ZA_WIN - 1)] = b; out[op + (uint64_t)i] = b; }
+                            __builtin_amdgcn_wave_barrier();
                         }
-                        __builtin_amdgcn_wave_barrier();
-                        if (i < len) { win[(op + (uint64_t)i) & (ZA_WIN - 1)] = b; out[op + (uint64_t)i] = b; }
-                        __builtin_amdgcn_wave_barrier();
                     }
                     op += (uint64_t)len;
                     if (short_out) { status = ZA_I_OUTFULL; break; }
@@ -353,6 +372,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
     bits_used = bitpos; out_len = op;
     if (blk_bits) *blk_bits = cp_bits;
     if (blk_out) *blk_out = cp_out;
+    if (max_back) *max_back = far;
     return status;
 }
 
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     __shared__ int scratch[2];
     __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
     uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
-    const int status = za_inflate_serial_core(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, ibuf, bits, op, start_bit, &cpb, &cpo);
+    const int status = za_inflate_serial_core<0, uint8_t>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, ibuf, bits, op, start_bit, &cpb, &cpo);
     if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
 
@@ -676,7 +696,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, ibuf, bits, op);
+    int status = za_inflate_serial_core<0, uint8_t>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, ibuf, bits, op);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
         if (((bits + 7) >> 3) != m.in_len) status = ZA_I_DATA;          // the member must end where its size says
@@ -697,6 +717,129 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
         }
     } else if (status == ZA_I_OUTFULL) status = ZA_I_LENGTH;
     if (lane == 0) status_out[blockIdx.x] = status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parallel inflate of ONE deflate stream that contains sync-flush points (what block-parallel writers emit:
+// the reference's gzip_ng_threaded, pigz, this engine's own writer).  SURVEY.md section 8f-3.
+//   za_k_scan_sync        byte positions that follow `00 00 FF FF` = candidate chunk starts
+//   za_k_chunk_count      one wave per candidate: decode without storing anything until the next in-stream sync
+//                         point / the final block; gives the chunk's compressed and uncompressed size and
+//                         weeds out false candidates (they fail to decode or are never reached by the chain)
+//   za_k_chunk_decode     one wave per chunk of the chain: decode with 16-bit symbols; what a chunk copies from
+//                         the (still unknown) 32 KiB before its start stays a marker naming that byte
+//   za_k_chunk_propagate  walks the chain once: from the window before chunk k and chunk k's symbols, the window
+//                         before chunk k+1 (one workgroup, 32 KiB per step)
+//   za_k_chunk_resolve    one workgroup per chunk: markers -> bytes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict__ in, uint64_t n,
+                                                      uint64_t *__restrict__ cands, uint32_t max_cands,
+                                                      uint32_t *__restrict__ n_cands)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t base = t * 16ull;
+    if (base >= n) return;
+    uint32_t w[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint64_t o = base + 4ull * k;
+        uint32_t v = 0;
+        if (o + 4 <= n) v = za_ld32(in + o);
+        else for (int j = 0; j < 4; j++) if (o + (unsigned)j < n) v |= (uint32_t)in[o + (unsigned)j] << (8 * j);
+        w[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int wi = k >> 2, sh = (k & 3) * 8;
+        const uint32_t v = sh ? ((w[wi] >> sh) | (w[wi + 1] << (32 - sh))) : w[wi];
+        if (v != 0xFFFF0000u) continue;
+        const uint64_t q = base + (uint64_t)k + 4ull;          // first byte after the marker
+        if (q > n) continue;
+        const uint32_t idx = atomicAdd(n_cands, 1u);
+        if (idx < max_cands) cands[idx] = q;
+    }
+}
+
+struct ZaChunkRes { int32_t status; uint32_t max_back; uint64_t bits; uint64_t out_len; };
+struct ZaChunk { uint64_t in_off; uint64_t out_off; uint64_t out_len; uint64_t bits; };
+
+__global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict__ in, uint64_t in_len,
+                                                       const uint64_t *__restrict__ cands, ZaChunkRes *__restrict__ res)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ int scratch[2];
+    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
+    const uint64_t off = cands[blockIdx.x];
+    uint64_t bits = 0, op = 0;
+    int status = ZA_I_DATA;
+    if (off <= in_len)
+        status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, 1ull << 40, T, nullptr, scratch, ibuf,
+                                                    bits, op, 0, nullptr, nullptr, off == 0 ? 0u : (uint32_t)ZA_WIN, true, nullptr);
+    if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = bits; r.out_len = op; res[blockIdx.x] = r; }
+}
+
+__global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restrict__ in, uint64_t in_len,
+                                                        const ZaChunk *__restrict__ chunks, uint16_t *__restrict__ out16,
+                                                        ZaChunkRes *__restrict__ res)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ uint16_t win[ZA_WIN];
+    __shared__ int scratch[2];
+    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
+    const ZaChunk ch = chunks[blockIdx.x];
+    uint64_t bits = 0, op = 0;
+    uint32_t far = 0;
+    int status = ZA_I_DATA;
+    if (ch.in_off <= in_len)
+        status = za_inflate_serial_core<2, uint16_t>(in + ch.in_off, in_len - ch.in_off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
+                                                     scratch, ibuf, bits, op, 0, nullptr, nullptr, ch.in_off == 0 ? 0u : (uint32_t)ZA_WIN, true, &far);
+    if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = bits; r.out_len = op; res[blockIdx.x] = r; }
+}
+
+__global__ __launch_bounds__(1024) void za_k_chunk_propagate(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
+                                                             uint32_t n, uint8_t *__restrict__ winbuf)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t wa[ZA_WIN];
+    __shared__ __attribute__((aligned(16))) uint8_t wb[ZA_WIN];
+    uint8_t *cur = wa, *nxt = wb;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t j = tid; j < ZA_WIN; j += 1024) cur[j] = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k < n; k++) {
+        const ZaChunk ch = chunks[k];
+        uint8_t *wout = winbuf + (size_t)k * ZA_WIN;
+        for (uint32_t j = tid * 4; j < ZA_WIN; j += 4096) *(uint32_t *)(wout + j) = *(const uint32_t *)(cur + j);
+        if (k + 1 == n) break;
+        const long long L = (long long)ch.out_len;
+        for (uint32_t j = tid; j < ZA_WIN; j += 1024) {
+            const long long p = L - ZA_WIN + (long long)j;       // position inside the chunk of window byte j
+            uint8_t b;
+            if (p < 0) b = cur[j + (uint32_t)L];                  // still a byte of the previous window
+            else {
+                const uint32_t sym = out16[ch.out_off + (uint64_t)p];
+                b = sym < 256u ? (uint8_t)sym : cur[(sym - 256u) & (ZA_WIN - 1)];
+            }
+            nxt[j] = b;
+        }
+        __syncthreads();
+        uint8_t *t = cur; cur = nxt; nxt = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void za_k_chunk_resolve(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
+                                                          const uint8_t *__restrict__ winbuf, uint8_t *__restrict__ out8)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t w[ZA_WIN];
+    const ZaChunk ch = chunks[blockIdx.x];
+    const uint8_t *wsrc = winbuf + (size_t)blockIdx.x * ZA_WIN;
+    for (uint32_t j = threadIdx.x * 4; j < ZA_WIN; j += 1024) *(uint32_t *)(w + j) = *(const uint32_t *)(wsrc + j);
+    __syncthreads();
+    const uint16_t *src = out16 + ch.out_off;
+    uint8_t *dst = out8 + ch.out_off;
+    for (uint64_t i = threadIdx.x; i < ch.out_len; i += 256) {
+        const uint32_t sym = src[i];
+        dst[i] = sym < 256u ? (uint8_t)sym : w[(sym - 256u) & (ZA_WIN - 1)];
+    }
 }
 
 // One workgroup per member: header with the segment index, deflate bytes from the unit slot, trailer.

@@ -59,6 +59,7 @@ struct zngamd_ctx {
     uint32_t last_units = 0; bool last_single_chunk = false;
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
+    DevBuf<uint64_t> ccand; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16; DevBuf<uint8_t> winbuf;
     DevBuf<ZaCkPart> ck; DevBuf<uint2> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
@@ -142,6 +143,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->prev.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
     c->plan.release(); c->units.release(); c->segbits.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
+    c->ccand.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->winbuf.release();
     c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
@@ -720,6 +722,86 @@ static int parse_gzip_header(const uint8_t *in, uint64_t in_len, uint64_t pos, u
     return ZNGAMD_OK;
 }
 
+// Parallel inflate of one member whose deflate stream contains sync-flush points.
+// d_def = device pointer to the first deflate byte (inside a padded staging buffer), avail = bytes from there to
+// the end of the input.  Returns 0 when the member was decoded (out_len / in_used set; CRC / ISIZE are checked by
+// the caller), 1 when this path does not apply or anything looked odd (caller uses the sequential decoder, which
+// also produces the exact error), <0 on engine errors, ZNGAMD_BUF_ERROR with *out_len = needed size when the
+// output does not fit.
+static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
+                               uint64_t *out_len, uint64_t *in_used)
+{
+    if (avail < (1u << 16)) return 1;
+    const uint32_t max_c = (uint32_t)std::min<uint64_t>(avail / 8 + 16, 1u << 24);
+    HIPCHK(c, c->ccand.ensure(max_c + 1));
+    uint32_t *d_n = (uint32_t *)((uint8_t *)c->d_small + 128);
+    HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
+    { ProfScope ps(c, ZNGAMD_K_SCAN);
+      const uint64_t threads = (avail + 15) / 16;
+      hipLaunchKernelGGL(za_k_scan_sync, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->ccand.p, max_c, d_n); }
+    HIPCHK(c, hipGetLastError());
+    uint32_t nc = 0;
+    HIPCHK(c, hipMemcpyAsync(&nc, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nc < 8 || nc > max_c) return 1;                  // too few sync points to be worth it
+    std::vector<uint64_t> cand(nc + 1);
+    HIPCHK(c, hipMemcpy(cand.data() + 1, c->ccand.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+    cand[0] = 0;
+    std::sort(cand.begin(), cand.end());
+    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    const uint32_t n = (uint32_t)cand.size();
+    HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->cres.ensure(n));
+    { ProfScope ps(c, ZNGAMD_K_INFLATE);
+      hipLaunchKernelGGL(za_k_chunk_count, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, c->cres.p); }
+    HIPCHK(c, hipGetLastError());
+    std::vector<ZaChunkRes> res(n);
+    HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)n * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // follow the chain of true sync points from the start of the stream
+    std::vector<ZaChunk> chain;
+    uint64_t acc = 0, end_byte = 0;
+    size_t i = 0;
+    bool ended = false;
+    for (uint32_t guard = 0; guard <= n; guard++) {
+        const ZaChunkRes &r = res[i];
+        if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return 1;
+        ZaChunk ch; ch.in_off = cand[i]; ch.out_off = acc; ch.out_len = r.out_len; ch.bits = r.bits;
+        chain.push_back(ch);
+        acc += r.out_len;
+        const uint64_t next = cand[i] + ((r.bits + 7) >> 3);
+        if (r.status == ZA_I_END) { end_byte = next; ended = true; break; }
+        auto it = std::lower_bound(cand.begin(), cand.end(), next);
+        if (it == cand.end() || *it != next) return 1;
+        i = (size_t)(it - cand.begin());
+    }
+    if (!ended || chain.size() < 4) return 1;
+    *out_len = acc; *in_used = end_byte;
+    if (acc > out_room) return ZNGAMD_BUF_ERROR;
+    const uint32_t m = (uint32_t)chain.size();
+    HIPCHK(c, c->cchunks.ensure(m)); HIPCHK(c, c->out16.ensure(acc + 64)); HIPCHK(c, c->winbuf.ensure((size_t)m * ZA_WIN));
+    HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->cres.ensure(m));
+    { ProfScope ps(c, ZNGAMD_K_INFLATE);
+      hipLaunchKernelGGL(za_k_chunk_decode, dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p); }
+    HIPCHK(c, hipGetLastError());
+    res.resize(m);
+    HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)m * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k < m; k++) {
+        const bool last = k + 1 == m;
+        if (res[k].status != (last ? ZA_I_END : ZA_I_SYNC) || res[k].out_len != chain[k].out_len || res[k].bits != chain[k].bits) return 1;
+        if (res[k].max_back > chain[k].out_off) return 1;       // reference before the start of the stream
+    }
+    { ProfScope ps(c, ZNGAMD_K_INFLATE);
+      hipLaunchKernelGGL(za_k_chunk_propagate, dim3(1), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->winbuf.p);
+      hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(256), 0, c->stream, c->out16.p, c->cchunks.p, c->winbuf.p, d_out); }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return 0;
+}
+
 // BGZF hop: every member must be `1f 8b 08 04`, carry a 'B','C' subfield of length 2 (block size - 1) and
 // tile the buffer exactly; anything else makes the caller use the general reader.
 static bool hop_bgzf(const uint8_t *in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out)
@@ -840,8 +922,17 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
             if ((hc & 0xFFFFu) != want) { ret = ZNGAMD_E_GZ_HCRC; break; }
         }
         ZaInfResult res;
-        r = inflate_serial_dev(c, c->st_in.p + doff, in_len - doff, nullptr, 0, c->st_out.p + op, out_cap - op, &res);
-        if (r) return r;
+        {   // streams with sync-flush points (block-parallel writers): chunk-parallel decode
+            uint64_t clen = 0, cused = 0;
+            const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused);
+            if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
+            if (cr == ZNGAMD_BUF_ERROR) { *out_len = op + clen; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+            if (cr == 0) { res.status = ZA_I_END; res.out_len = clen; res.in_bits = cused * 8; res.block_bits = 0; res.block_out = 0; }
+            else {
+                r = inflate_serial_dev(c, c->st_in.p + doff, in_len - doff, nullptr, 0, c->st_out.p + op, out_cap - op, &res);
+                if (r) return r;
+            }
+        }
         if (res.status != ZA_I_END) {
             *out_len = op + res.out_len;
             if (res.status == ZA_I_OUTFULL) ret = ZNGAMD_BUF_ERROR;

@@ -187,3 +187,72 @@ def test_indexed_stream_fuzz(ctx, fastq):
         assert (code == 0) == (ocode == 0), (pos, code, ocode)
         if code == 0:
             assert out == oout
+
+
+def _sync_flushed_gzip(data, step, level=6, mark=False):
+    """One gzip member whose deflate stream has a sync-flush point every `step` bytes and keeps its history
+    across them (what pigz / gzip_ng_threaded style writers produce; here made with the system zlib)."""
+    import struct
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    parts = [b"\x1f\x8b\x08\x00" + bytes(4) + b"\x00\xff"]
+    for i in range(0, len(data), step):
+        parts.append(co.compress(data[i:i + step]) + co.flush(zlib.Z_SYNC_FLUSH))
+    parts.append(co.flush() + struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF))
+    return b"".join(parts)
+
+
+def test_chunk_parallel_inflate_of_sync_flushed_stream(ctx, fastq):
+    """a single member with sync-flush points is decoded chunk-parallel (markers for references
+    into the previous chunk), result identical to the sequential decoders."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    data = fastq + fastq[:500000]
+    for step, level in ((100000, 6), (37000, 9), (250000, 1)):
+        blob = _sync_flushed_gzip(data, step, level)
+        assert gzip.decompress(blob) == data
+        ctx.profiling(True); ctx.kernel_times(True)
+        code, out, nm = ctx.gunzip(blob, len(data))
+        kt = ctx.kernel_times(True); ctx.profiling(False)
+        assert (code, nm) == (0, 1) and out == data
+        assert kt["inflate"][1] >= 3 and kt["scan"][1] >= 1, kt          # count, decode, propagate+resolve ran
+    # payload full of `00 00 FF FF` look-alikes: stored blocks (level 0) and compressed
+    tricky = (b"\x00\x00\xff\xff" * 50 + rng.bytes(3000)) * 400
+    for level in (0, 6):
+        blob = _sync_flushed_gzip(tricky, 90000, level)
+        code, out, nm = ctx.gunzip(blob, len(tricky))
+        assert code == 0 and out == tricky
+    # output buffer too small: needed size reported
+    blob = _sync_flushed_gzip(data, 100000, 6)
+    code, out, nm = ctx.gunzip(blob, 1000)
+    assert code == -5 and ctx.last_needed == len(data)
+    # two such members back to back + padding
+    code, out, nm = ctx.gunzip(blob + bytes(10) + blob, 2 * len(data))
+    assert code == 0 and nm == 2 and out == data + data
+    # corruption anywhere gives the oracle's verdict (the chunk path hands over to the sequential decoder)
+    for trial in range(25):
+        bad = bytearray(blob)
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        code, out, nm = ctx.gunzip(bytes(bad), len(data) + 4096)
+        ocode, oout, onm = O.gunzip(bytes(bad), len(data) + 4096)
+        assert (code == 0) == (ocode == 0), (pos, code, ocode)
+        if code == 0:
+            assert out == oout
+
+
+def test_threaded_writer_output_is_read_chunk_parallel(ctx, fastq):
+    """What our gzip_ng_threaded writer (reference framing: one member, dictionary-chained sync-flushed blocks,
+    trailing empty member) produces is read back through the chunk-parallel path."""
+    import io
+    from zlib_ng_amd import gzip_ng_threaded
+    data = fastq + fastq
+    bio = io.BytesIO()
+    with gzip_ng_threaded.open(bio, "wb", compresslevel=6, threads=8, block_size=128 * 1024) as f:
+        f.write(data)
+    blob = bio.getvalue()
+    ctx.profiling(True); ctx.kernel_times(True)
+    code, out, nm = ctx.gunzip(blob, len(data))
+    kt = ctx.kernel_times(True); ctx.profiling(False)
+    assert code == 0 and out == data and nm == 2 and kt["scan"][1] >= 1
+    with gzip_ng_threaded.open(io.BytesIO(blob), "rb") as f:
+        assert f.read() == data
