@@ -162,11 +162,16 @@ int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t 
                                     void *d_out, uint64_t out_cap, int32_t *d_status);
 
 /* Host-buffer gzip reader: any multi-member gzip stream (headers with FEXTRA/FNAME/FCOMMENT/FHCRC,
- * NUL padding between members).  Streams made of this engine's indexed members take the two-pass
- * lane-parallel path; BGZF-style streams ('B','C' block-size subfield in every member) are decoded one
- * wavefront per member in a single launch; anything else goes through the sequential decoder member by
- * member.  *out_len = bytes produced (also on error), except that ZNGAMD_BUF_ERROR with
- * *out_len > out_cap means "the stream needs *out_len bytes of output" (size known from the headers). */
+ * NUL padding between members).  Four decode paths, picked per stream / member:
+ *   1. this engine's indexed members          -> two-pass, lane-parallel inside each member
+ *   2. BGZF-style members ('B','C' subfield)  -> one wavefront per member, one launch
+ *   3. a member with sync-flush points (block-parallel writers: gzip_ng_threaded, pigz) -> chunk-parallel:
+ *      count-only pass sizes and validates the chunks, a marker pass decodes them independently, the 32 KiB
+ *      windows are propagated along the chain and the markers resolved
+ *   4. anything else -> the sequential wavefront decoder
+ * Paths 1-3 hand over to 4 whenever something does not check out, so errors are always the sequential
+ * reader's.  *out_len = bytes produced (also on error), except that ZNGAMD_BUF_ERROR with
+ * *out_len > out_cap means "the stream needs *out_len bytes of output" (size known up front). */
 int zngamd_gunzip(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
                   uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members);
 

@@ -16,3 +16,21 @@ raw = open(os.path.join(ROOT, "tests", "golden", "test.fastq.gz"), "rb").read()
 ctx.profiling(True); ctx.kernel_times(True)
 t = time.perf_counter(); ctx.gunzip(raw, 3578369); dt = time.perf_counter() - t
 print("wall %.1f ms; kernel ms:" % (dt * 1e3), {k: round(v[0], 2) for k, v in ctx.kernel_times(True).items() if v[1]})
+
+# chunk-parallel path on a larger stream: 256 MiB of text in the reference's threaded-writer framing
+import struct
+from zlib_ng_amd import corpus, shard
+data = corpus.text(64 << 20, seed=1).tobytes() * 4
+B = 131072
+blocks = [(off, B, min(32768, off), 0) for off in range(0, len(data), B)]
+outs, crcs, ovf = ctx.deflate_blocks(data, blocks, 6, B + B // 10)
+crc = shard.combine_crcs([(c, B) for c in crcs])
+hdr, trl = shard.gzip_frame(0, crc, len(data), 6)
+blob = hdr + b"".join(outs) + trl
+ctx.gunzip(blob, len(data))
+ctx.profiling(True); ctx.kernel_times(True)
+t = time.perf_counter(); code, out, nm = ctx.gunzip(blob, len(data)); dt = time.perf_counter() - t
+kt = ctx.kernel_times(True)
+assert code == 0 and out == data
+print("threaded-writer framing, %d MiB, %d blocks: %.1f MB/s wall incl. PCIe (%.1f ms); kernel ms: %s" % (
+    len(data) >> 20, len(blocks), len(data) / dt / 1e6, dt * 1e3, {k: round(v[0], 2) for k, v in kt.items() if v[1]}))
