@@ -200,6 +200,15 @@ int zngamd_profiling(zngamd_ctx *ctx, int on);
 /* accumulated milliseconds and launch counts per kernel class since the last reset */
 int zngamd_kernel_times(zngamd_ctx *ctx, double *ms /*[ZNGAMD_K_COUNT]*/, uint64_t *launches /*[ZNGAMD_K_COUNT]*/, int reset);
 
+/* how many gzip members zngamd_gunzip decoded through each of its paths since the last reset:
+ * ZA-indexed two-pass, BGZF one-launch, chunk-parallel (sync points / block finder), one sequential wavefront */
+#define ZNGAMD_PATH_INDEXED    0
+#define ZNGAMD_PATH_BGZF       1
+#define ZNGAMD_PATH_CHUNKED    2
+#define ZNGAMD_PATH_SEQUENTIAL 3
+#define ZNGAMD_PATH_COUNT      4
+int zngamd_decode_paths(zngamd_ctx *ctx, uint64_t *members /*[ZNGAMD_PATH_COUNT]*/, int reset);
+
 /* ---- debugging aid for the parity tests: copy a stage's intermediate of unit `u` of the last
  * deflate call to the host.  what: 0 prevdist(u16) 1 best(u32) 2 tokens(u32) 3 seg_ntok(u32)
  * 4 hist(u32) 5 codes(u32) 6 seg_bits(u32) 7 plan(4 x u32) */

@@ -34,3 +34,16 @@ kt = ctx.kernel_times(True)
 assert code == 0 and out == data
 print("threaded-writer framing, %d MiB, %d blocks: %.1f MB/s wall incl. PCIe (%.1f ms); kernel ms: %s" % (
     len(data) >> 20, len(blocks), len(data) / dt / 1e6, dt * 1e3, {k: round(v[0], 2) for k, v in kt.items() if v[1]}))
+
+# ordinary gzip (no sync points): chunk starts from the block finder
+for lvl in (1, 6, 9):
+    d = data[:128 << 20]
+    blob = gzip.compress(d, lvl)
+    ctx.gunzip(blob, len(d))
+    ctx.profiling(True); ctx.kernel_times(True)
+    t = time.perf_counter(); code, out, nm = ctx.gunzip(blob, len(d)); dt = time.perf_counter() - t
+    kt = ctx.kernel_times(True)
+    assert code == 0 and out == d
+    t = time.perf_counter(); zlib.decompress(blob, 47); dz = time.perf_counter() - t
+    print("ordinary gzip -%d, %d MiB: %.1f MB/s wall incl. PCIe (%.1f ms), system zlib 1 core %.1f MB/s; kernel ms: %s" % (
+        lvl, len(d) >> 20, len(d) / dt / 1e6, dt * 1e3, len(d) / dz / 1e6, {k: (round(v[0], 2), v[1]) for k, v in kt.items() if v[1]}))

@@ -230,7 +230,8 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                                       SymT *__restrict__ out, uint64_t out_cap,
                                       ZaInfTabs &T, SymT *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
                                       uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr,
-                                      uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr)
+                                      uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr,
+                                      const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0, uint64_t abs_bit0 = 0)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
@@ -245,6 +246,13 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
 
     for (;;) {
         cp_bits = bitpos; cp_out = op;          // a decoder can restart here with the last 32 KiB of output as dictionary
+        if (nstops && bitpos != start_bit) {
+            // chunk mode: stop at a block boundary that is a listed chunk start (binary search, uniform)
+            const uint64_t a = abs_bit0 + bitpos;
+            uint32_t lo = 0, hi = nstops;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (stops[mid] < a) lo = mid + 1; else hi = mid; }
+            if (lo < nstops && stops[lo] == a) { status = ZA_I_SYNC; break; }
+        }
         if (bitpos + 3 > in_bits) { status = ZA_I_INPUT; break; }
         uint64_t bits = za_peek(in, bitpos);
         const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
@@ -761,21 +769,25 @@ __global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict_
 }
 
 struct ZaChunkRes { int32_t status; uint32_t max_back; uint64_t bits; uint64_t out_len; };
-struct ZaChunk { uint64_t in_off; uint64_t out_off; uint64_t out_len; uint64_t bits; };
+struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t end_bit; };   // absolute bit offsets in the deflate stream
 
 __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict__ in, uint64_t in_len,
-                                                       const uint64_t *__restrict__ cands, ZaChunkRes *__restrict__ res)
+                                                       const uint64_t *__restrict__ cands, uint32_t ncands,
+                                                       ZaChunkRes *__restrict__ res)
 {
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
     __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
-    const uint64_t off = cands[blockIdx.x];
+    const uint64_t abit = cands[blockIdx.x];                 // absolute bit offset of a possible block header
+    const uint64_t off = abit >> 3;
     uint64_t bits = 0, op = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
         status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, 1ull << 40, T, nullptr, scratch, ibuf,
-                                                    bits, op, 0, nullptr, nullptr, off == 0 ? 0u : (uint32_t)ZA_WIN, true, nullptr);
-    if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = bits; r.out_len = op; res[blockIdx.x] = r; }
+                                                    bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == 0 ? 0u : (uint32_t)ZA_WIN, true, nullptr,
+                                                    cands, ncands, off * 8ull);
+    // bits = position relative to byte `off`; report the absolute end
+    if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
 
 __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restrict__ in, uint64_t in_len,
@@ -787,13 +799,117 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     __shared__ int scratch[2];
     __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
     const ZaChunk ch = chunks[blockIdx.x];
+    const uint64_t off = ch.in_bit >> 3;
     uint64_t bits = 0, op = 0;
     uint32_t far = 0;
     int status = ZA_I_DATA;
-    if (ch.in_off <= in_len)
-        status = za_inflate_serial_core<2, uint16_t>(in + ch.in_off, in_len - ch.in_off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
-                                                     scratch, ibuf, bits, op, 0, nullptr, nullptr, ch.in_off == 0 ? 0u : (uint32_t)ZA_WIN, true, &far);
-    if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = bits; r.out_len = op; res[blockIdx.x] = r; }
+    if (off <= in_len)
+        status = za_inflate_serial_core<2, uint16_t>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
+                                                     scratch, ibuf, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
+                                                     ch.in_bit == 0 ? 0u : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull);
+    if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
+}
+
+// ---- block finder: where could a dynamic-Huffman block header start? ----------------------------------------
+// Phase A tests every bit offset cheaply: BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29 and a COMPLETE code-length
+// code (Kraft sum exactly 1 over the HCLEN+4 three-bit lengths).  Survivors (about 1 offset in 10^3) are compacted.
+__global__ __launch_bounds__(256) void za_k_find_blocks_a(const uint8_t *__restrict__ in, uint64_t n,
+                                                          uint64_t *__restrict__ surv, uint32_t max_surv, uint32_t *__restrict__ n_surv)
+{
+    const uint64_t byte = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (byte + 12 > n) return;                                   // a real header is followed by far more than 12 bytes
+    const uint64_t lo = za_ld64(in + byte);
+    const uint32_t hi = za_ld32(in + byte + 8);
+    auto field = [&](uint32_t bitoff, uint32_t nb) -> uint32_t {     // nb bits at bit `bitoff` of the 96-bit window
+        const uint32_t mask = (1u << nb) - 1u;
+        if (bitoff + nb <= 64u) return (uint32_t)(lo >> bitoff) & mask;
+        if (bitoff >= 64u) return (hi >> (bitoff - 64u)) & mask;
+        return (uint32_t)((lo >> bitoff) | ((uint64_t)hi << (64u - bitoff))) & mask;
+    };
+#pragma unroll 1
+    for (uint32_t b = 0; b < 8; b++) {
+        if (field(b, 3) != 4u) continue;                         // BFINAL = 0, BTYPE = 10b
+        if (field(b + 3, 5) > 29u || field(b + 8, 5) > 29u) continue;
+        const uint32_t hclen = field(b + 13, 4) + 4u;
+        uint32_t kraft = 0;                                      // in units of 2^-7
+        for (uint32_t k = 0; k < hclen; k++) {
+            const uint32_t v = field(b + 17u + 3u * k, 3);       // last one ends at bit 7+17+57 = 81 < 96
+            if (v) kraft += 128u >> v;
+        }
+        if (kraft != 128u) continue;
+        const uint32_t idx = atomicAdd(n_surv, 1u);
+        if (idx < max_surv) surv[idx] = byte * 8ull + (uint64_t)b;
+    }
+}
+
+// Phase B, one lane per survivor: decode the HLIT+HDIST code lengths with the code-length code and require what
+// a decoder requires (no bad repeats, end-of-block present, both codes complete -- or a single 1-bit code).
+__global__ __launch_bounds__(64) void za_k_find_blocks_b(const uint8_t *__restrict__ in, uint64_t n,
+                                                         const uint64_t *__restrict__ surv, uint32_t n_surv,
+                                                         uint64_t *__restrict__ cands, uint32_t max_cands, uint32_t *__restrict__ n_cands)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n_surv) return;
+    const uint64_t abit = surv[i];
+    const uint64_t in_bits = n * 8ull;
+    uint64_t bp = abit + 3;
+    const uint64_t hdr = za_peek(in, bp);
+    const int nlen = (int)(hdr & 31u) + 257, ndist = (int)((hdr >> 5) & 31u) + 1, ncode = (int)((hdr >> 10) & 15u) + 4;
+    bp += 14;
+    // code-length code: canonical (count, first code, first index) per length from the 3-bit lengths
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint32_t cll = 0, clh = 0;                                    // 19 x 3 bits packed: symbol s at bits 3s
+    for (int k = 0; k < ncode; k++) {
+        const uint32_t v = (uint32_t)(za_peek(in, bp) & 7u); bp += 3;
+        const int sft = 3 * order[k];
+        if (sft < 30) cll |= v << sft; else clh |= v << (sft - 30);
+    }
+    auto cl_len = [&](int s) -> uint32_t { const int sft = 3 * s; return sft < 30 ? (cll >> sft) & 7u : (clh >> (sft - 30)) & 7u; };
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s2 = 0; s2 < 19; s2++) cnt[cl_len(s2)]++;
+    // decode nlen + ndist lengths; track Kraft sums (units 2^-15) and the presence of symbol 256
+    uint32_t kl = 0, kd = 0, nl_nonzero = 0, nd_nonzero = 0, maxl = 0, maxd = 0;
+    bool eob = false, bad = false;
+    int idx = 0, prev = 0;
+    while (idx < nlen + ndist && !bad) {
+        if (bp + 7 > in_bits) { bad = true; break; }
+        const uint32_t bitsv = (uint32_t)za_peek(in, bp);
+        // canonical decode over the 19-symbol code, bit by bit
+        int code = 0, first = 0, index = 0, sym = -1, l = 1;
+        uint32_t v = bitsv;
+        for (; l <= 7; l++) {
+            code |= (int)(v & 1u); v >>= 1;
+            const int c = (int)cnt[l];
+            if (code - c < first) {
+                // the (code - first)-th symbol, in symbol order, among those of length l
+                const int want = code - first;
+                int seen = 0;
+                for (int s2 = 0; s2 < 19; s2++) if ((int)cl_len(s2) == l) { if (seen == want) { sym = s2; break; } seen++; }
+                break;
+            }
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        if (sym < 0) { bad = true; break; }
+        bp += (unsigned)l;
+        int rep = 1, val = sym;
+        if (sym == 16) { if (idx == 0) { bad = true; break; } val = prev; rep = 3 + (int)((bitsv >> l) & 3u); bp += 2; }
+        else if (sym == 17) { val = 0; rep = 3 + (int)((bitsv >> l) & 7u); bp += 3; }
+        else if (sym == 18) { val = 0; rep = 11 + (int)((bitsv >> l) & 127u); bp += 7; }
+        if (idx + rep > nlen + ndist) { bad = true; break; }
+        for (int r = 0; r < rep; r++, idx++) {
+            if (val) {
+                if (idx < nlen) { kl += 32768u >> val; nl_nonzero++; if ((uint32_t)val > maxl) maxl = (uint32_t)val; if (idx == 256) eob = true; }
+                else { kd += 32768u >> val; nd_nonzero++; if ((uint32_t)val > maxd) maxd = (uint32_t)val; }
+            }
+        }
+        prev = val;
+    }
+    if (bad || !eob || bp > in_bits) return;
+    const bool lit_ok = kl == 32768u || (kl < 32768u && maxl == 1);
+    const bool dist_ok = nd_nonzero == 0 || kd == 32768u || (kd < 32768u && maxd == 1);
+    if (!lit_ok || !dist_ok) return;
+    const uint32_t o = atomicAdd(n_cands, 1u);
+    if (o < max_cands) cands[o] = abit;
 }
 
 __global__ __launch_bounds__(1024) void za_k_chunk_propagate(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,

@@ -59,10 +59,11 @@ struct zngamd_ctx {
     uint32_t last_units = 0; bool last_single_chunk = false;
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
-    DevBuf<uint64_t> ccand; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16; DevBuf<uint8_t> winbuf;
+    DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16; DevBuf<uint8_t> winbuf;
     DevBuf<ZaCkPart> ck; DevBuf<uint2> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
+    uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
     bool prof = false; std::vector<EvPair> evs; std::vector<hipEvent_t> pool;
     double ms[ZNGAMD_K_COUNT] = {0}; uint64_t launches[ZNGAMD_K_COUNT] = {0};
 };
@@ -143,7 +144,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->prev.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
     c->plan.release(); c->units.release(); c->segbits.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
-    c->ccand.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->winbuf.release();
+    c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->winbuf.release();
     c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
@@ -191,6 +192,13 @@ int zngamd_d2h(zngamd_ctx *c, void *dst, const void *src, size_t bytes)
     return ZNGAMD_OK;
 }
 
+int zngamd_decode_paths(zngamd_ctx *c, uint64_t *members, int reset)
+{
+    if (!c || !members) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    for (int i = 0; i < ZNGAMD_PATH_COUNT; i++) { members[i] = c->paths[i]; if (reset) c->paths[i] = 0; }
+    return ZNGAMD_OK;
+}
 int zngamd_profiling(zngamd_ctx *c, int on) { if (!c) return ZNGAMD_E_ARG; c->prof = on != 0; return ZNGAMD_OK; }
 int zngamd_kernel_times(zngamd_ctx *c, double *ms, uint64_t *launches, int reset)
 {
@@ -722,7 +730,17 @@ static int parse_gzip_header(const uint8_t *in, uint64_t in_len, uint64_t pos, u
     return ZNGAMD_OK;
 }
 
-// Parallel inflate of one member whose deflate stream contains sync-flush points.
+// why the chunk-parallel path handed over to the sequential decoder (ZNGAMD_DEBUG=1 prints it)
+static int chunk_bail(int why)
+{
+    static const bool dbg = getenv("ZNGAMD_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "zng_amd: chunk-parallel inflate not used (reason %d)\n", why);
+    return 1;
+}
+
+// Chunk-parallel inflate of one member: candidate chunk starts = positions after sync-flush
+// markers and bit offsets where a dynamic block header parses; a count-only pass sizes every candidate up to the
+// next listed boundary, the host follows the chain of real block boundaries and groups blocks into chunks.
 // d_def = device pointer to the first deflate byte (inside a padded staging buffer), avail = bytes from there to
 // the end of the input.  Returns 0 when the member was decoded (out_len / in_used set; CRC / ISIZE are checked by
 // the caller), 1 when this path does not apply or anything looked odd (caller uses the sequential decoder, which
@@ -731,52 +749,75 @@ static int parse_gzip_header(const uint8_t *in, uint64_t in_len, uint64_t pos, u
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
                                uint64_t *out_len, uint64_t *in_used)
 {
-    if (avail < (1u << 16)) return 1;
-    const uint32_t max_c = (uint32_t)std::min<uint64_t>(avail / 8 + 16, 1u << 24);
-    HIPCHK(c, c->ccand.ensure(max_c + 1));
-    uint32_t *d_n = (uint32_t *)((uint8_t *)c->d_small + 128);
-    HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
-    { ProfScope ps(c, ZNGAMD_K_SCAN);
-      const uint64_t threads = (avail + 15) / 16;
-      hipLaunchKernelGGL(za_k_scan_sync, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->ccand.p, max_c, d_n); }
+    if (avail < (1u << 16) || avail > (1ull << 36)) return chunk_bail(1);
+    const uint32_t max_c = (uint32_t)std::min<uint64_t>(avail / 8 + 64, 1u << 24);
+    const uint32_t max_s = (uint32_t)std::min<uint64_t>(avail / 4 + 1024, 1u << 25);
+    HIPCHK(c, c->ccand.ensure((size_t)max_c + 1)); HIPCHK(c, c->csurv.ensure(max_s));
+    uint32_t *d_n = (uint32_t *)((uint8_t *)c->d_small + 128);          // [0] candidates, [1] survivors
+    HIPCHK(c, hipMemsetAsync(d_n, 0, 8, c->stream));
+    {   ProfScope ps(c, ZNGAMD_K_SCAN);
+        const uint64_t threads = (avail + 15) / 16;
+        hipLaunchKernelGGL(za_k_scan_sync, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->ccand.p, max_c, d_n);
+        hipLaunchKernelGGL(za_k_find_blocks_a, dim3((uint32_t)((avail + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->csurv.p, max_s, d_n + 1);
+    }
     HIPCHK(c, hipGetLastError());
-    uint32_t nc = 0;
-    HIPCHK(c, hipMemcpyAsync(&nc, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t cnt[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt, d_n, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nc < 8 || nc > max_c) return 1;                  // too few sync points to be worth it
-    std::vector<uint64_t> cand(nc + 1);
-    HIPCHK(c, hipMemcpy(cand.data() + 1, c->ccand.p, (size_t)nc * 8, hipMemcpyDeviceToHost));
-    cand[0] = 0;
+    if (cnt[0] > max_c) return chunk_bail(2);
+    // sync-scan hits are byte positions: turn them into bit offsets on the host while phase B runs
+    std::vector<uint64_t> cand(cnt[0]);
+    if (cnt[0]) HIPCHK(c, hipMemcpy(cand.data(), c->ccand.p, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
+    for (auto &q : cand) q *= 8ull;
+    if (cnt[1] > 0 && cnt[1] <= max_s) {
+        HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
+        { ProfScope ps(c, ZNGAMD_K_SCAN);
+          hipLaunchKernelGGL(za_k_find_blocks_b, dim3((cnt[1] + 63) / 64), dim3(64), 0, c->stream, d_def, avail, c->csurv.p, cnt[1], c->ccand.p, max_c, d_n); }
+        HIPCHK(c, hipGetLastError());
+        uint32_t nb = 0;
+        HIPCHK(c, hipMemcpyAsync(&nb, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nb > 0 && nb <= max_c) {
+            const size_t old = cand.size();
+            cand.resize(old + nb);
+            HIPCHK(c, hipMemcpy(cand.data() + old, c->ccand.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    cand.push_back(0);
     std::sort(cand.begin(), cand.end());
     cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
     const uint32_t n = (uint32_t)cand.size();
+    if (getenv("ZNGAMD_DEBUG")) fprintf(stderr, "zng_amd: chunk finder: %u sync hits, %u header survivors, %u candidates\n", cnt[0], cnt[1], n);
+    if (n < 8 || n > max_c) return chunk_bail(3);                    // too few boundaries to be worth it
     HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(n));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_chunk_count, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, c->cres.p); }
+      hipLaunchKernelGGL(za_k_chunk_count, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, n, c->cres.p); }
     HIPCHK(c, hipGetLastError());
     std::vector<ZaChunkRes> res(n);
     HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)n * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // follow the chain of true sync points from the start of the stream
+    // follow the chain of real block boundaries from the start of the stream; group blocks into chunks
+    const uint64_t target = 256u << 10;
     std::vector<ZaChunk> chain;
-    uint64_t acc = 0, end_byte = 0;
+    uint64_t acc = 0, end_bit = 0;
     size_t i = 0;
-    bool ended = false;
+    bool ended = false, open = false;
+    ZaChunk cur; cur.in_bit = 0; cur.out_off = 0; cur.out_len = 0; cur.end_bit = 0;
     for (uint32_t guard = 0; guard <= n; guard++) {
         const ZaChunkRes &r = res[i];
-        if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return 1;
-        ZaChunk ch; ch.in_off = cand[i]; ch.out_off = acc; ch.out_len = r.out_len; ch.bits = r.bits;
-        chain.push_back(ch);
+        if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return chunk_bail(4);
+        if (!open) { cur.in_bit = cand[i]; cur.out_off = acc; cur.out_len = 0; open = true; }
+        cur.out_len += r.out_len; cur.end_bit = r.bits;
         acc += r.out_len;
-        const uint64_t next = cand[i] + ((r.bits + 7) >> 3);
-        if (r.status == ZA_I_END) { end_byte = next; ended = true; break; }
-        auto it = std::lower_bound(cand.begin(), cand.end(), next);
-        if (it == cand.end() || *it != next) return 1;
+        if (r.status == ZA_I_END) { chain.push_back(cur); end_bit = r.bits; ended = true; break; }
+        if (cur.out_len >= target) { chain.push_back(cur); open = false; }
+        auto it = std::lower_bound(cand.begin(), cand.end(), r.bits);
+        if (it == cand.end() || *it != r.bits) return chunk_bail(5);
         i = (size_t)(it - cand.begin());
     }
-    if (!ended || chain.size() < 4) return 1;
-    *out_len = acc; *in_used = end_byte;
+    if (!ended || chain.size() < 4) return chunk_bail(6);
+    *out_len = acc; *in_used = (end_bit + 7) >> 3;
     if (acc > out_room) return ZNGAMD_BUF_ERROR;
     const uint32_t m = (uint32_t)chain.size();
     HIPCHK(c, c->cchunks.ensure(m)); HIPCHK(c, c->out16.ensure(acc + 64)); HIPCHK(c, c->winbuf.ensure((size_t)m * ZA_WIN));
@@ -790,8 +831,8 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (uint32_t k = 0; k < m; k++) {
         const bool last = k + 1 == m;
-        if (res[k].status != (last ? ZA_I_END : ZA_I_SYNC) || res[k].out_len != chain[k].out_len || res[k].bits != chain[k].bits) return 1;
-        if (res[k].max_back > chain[k].out_off) return 1;       // reference before the start of the stream
+        if (res[k].status != (last ? ZA_I_END : ZA_I_SYNC) || res[k].out_len != chain[k].out_len || res[k].bits != chain[k].end_bit) return chunk_bail(7);
+        if (res[k].max_back > chain[k].out_off) return chunk_bail(8);       // reference before the start of the stream
     }
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
       hipLaunchKernelGGL(za_k_chunk_propagate, dim3(1), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->winbuf.p);
@@ -870,6 +911,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
                     if (total) HIPCHK(c, hipMemcpy(out, c->st_out.p, total, hipMemcpyDeviceToHost));
                     *out_len = total;
                     if (n_members) *n_members = (uint32_t)hm.size();
+                    c->paths[ZNGAMD_PATH_INDEXED] += hm.size();
                     return ZNGAMD_OK;
                 }
                 // anything unexpected (foreign 'ZA' field, stored blocks, corruption): the sequential
@@ -900,6 +942,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
             if (produced) HIPCHK(c, hipMemcpy(out, c->st_out.p, produced, hipMemcpyDeviceToHost));
             *out_len = produced;
             if (n_members) *n_members = good;
+            c->paths[ZNGAMD_PATH_BGZF] += good;
             if (good == n) return ZNGAMD_OK;
             const int code = st[good];
             if (code == ZA_I_CRC) { c->err = "CRC check failed"; return ZNGAMD_E_GZ_CRC; }
@@ -922,12 +965,13 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
             if ((hc & 0xFFFFu) != want) { ret = ZNGAMD_E_GZ_HCRC; break; }
         }
         ZaInfResult res;
-        {   // streams with sync-flush points (block-parallel writers): chunk-parallel decode
+        bool chunked = false;
+        {   // chunk-parallel decode where the stream offers enough block boundaries, else one wavefront
             uint64_t clen = 0, cused = 0;
             const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused);
             if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
             if (cr == ZNGAMD_BUF_ERROR) { *out_len = op + clen; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
-            if (cr == 0) { res.status = ZA_I_END; res.out_len = clen; res.in_bits = cused * 8; res.block_bits = 0; res.block_out = 0; }
+            if (cr == 0) { chunked = true; res.status = ZA_I_END; res.out_len = clen; res.in_bits = cused * 8; res.block_bits = 0; res.block_out = 0; }
             else {
                 r = inflate_serial_dev(c, c->st_in.p + doff, in_len - doff, nullptr, 0, c->st_out.p + op, out_cap - op, &res);
                 if (r) return r;
@@ -953,6 +997,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
         if (tc != crc) { ret = ZNGAMD_E_GZ_CRC; char b[96]; snprintf(b, sizeof b, "CRC check failed %u != %u", tc, crc); c->err = b; break; }
         if (tl != (uint32_t)(res.out_len & 0xFFFFFFFFull)) { ret = ZNGAMD_E_GZ_LENGTH; c->err = "Incorrect length of data produced"; break; }
         cur += 8; op += res.out_len; members++;
+        c->paths[chunked ? ZNGAMD_PATH_CHUNKED : ZNGAMD_PATH_SEQUENTIAL]++;
         while (cur < in_len && in[cur] == 0) cur++;
         pos = cur;
     }

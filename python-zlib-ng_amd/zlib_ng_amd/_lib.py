@@ -29,7 +29,7 @@ SYMBOLS = [
     "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gunzip", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_debug_fetch",
+    "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch",
 ]
 
 
@@ -105,6 +105,7 @@ def load():
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.zngamd_profiling.argtypes = [vp, C.c_int]
         L.zngamd_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.zngamd_decode_paths.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
         _lib = L
         return L
@@ -282,6 +283,12 @@ class Context:
         ln = (C.c_uint64 * len(K_NAMES))()
         self._chk(self.L.zngamd_kernel_times(self.h, ms, ln, 1 if reset else 0))
         return {k: (ms[i], ln[i]) for i, k in enumerate(K_NAMES)}
+
+    def decode_paths(self, reset=True):
+        """Members gunzip() decoded per path since the last reset: indexed, bgzf, chunked, sequential."""
+        m = (C.c_uint64 * 4)()
+        self._chk(self.L.zngamd_decode_paths(self.h, m, 1 if reset else 0))
+        return dict(zip(("indexed", "bgzf", "chunked", "sequential"), (int(x) for x in m)))
 
 
 _default = None

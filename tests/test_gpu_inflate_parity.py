@@ -210,11 +210,13 @@ def test_chunk_parallel_inflate_of_sync_flushed_stream(ctx, fastq):
     for step, level in ((100000, 6), (37000, 9), (250000, 1)):
         blob = _sync_flushed_gzip(data, step, level)
         assert gzip.decompress(blob) == data
+        ctx.decode_paths(True)
         ctx.profiling(True); ctx.kernel_times(True)
         code, out, nm = ctx.gunzip(blob, len(data))
         kt = ctx.kernel_times(True); ctx.profiling(False)
         assert (code, nm) == (0, 1) and out == data
         assert kt["inflate"][1] >= 3 and kt["scan"][1] >= 1, kt          # count, decode, propagate+resolve ran
+        assert ctx.decode_paths(True)["chunked"] == 1
     # payload full of `00 00 FF FF` look-alikes: stored blocks (level 0) and compressed
     tricky = (b"\x00\x00\xff\xff" * 50 + rng.bytes(3000)) * 400
     for level in (0, 6):
@@ -256,3 +258,37 @@ def test_threaded_writer_output_is_read_chunk_parallel(ctx, fastq):
     assert code == 0 and out == data and nm == 2 and kt["scan"][1] >= 1
     with gzip_ng_threaded.open(io.BytesIO(blob), "rb") as f:
         assert f.read() == data
+
+
+def test_chunk_parallel_inflate_of_ordinary_gzip(ctx, fastq):
+    """SURVEY.md 8f-3, general case: a plain `gzip` member has no sync points; chunk starts come from the
+    bit-level dynamic-block-header finder.  The result is the system zlib's, and the chunk kernels really ran."""
+    from zlib_ng_amd import corpus
+    rng = np.random.default_rng(33)
+    text = corpus.text(12 << 20, seed=9).tobytes()
+    mixed = corpus.mixed(12 << 20, seed=4).tobytes()
+    cases = [(text, 6), (text, 1), (text, 9), (mixed, 6), (fastq + fastq + fastq, 6)]
+    ran = 0
+    for data, level in cases:
+        blob = gzip.compress(data, level)
+        ctx.decode_paths(True)
+        code, out, nm = ctx.gunzip(blob, len(data))
+        assert (code, nm) == (0, 1) and out == data
+        ran += ctx.decode_paths(True)["chunked"]
+    assert ran == len(cases), ran
+    # the golden single-member file, as shipped by the reference's tests
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "test.fastq.gz"), "rb").read()
+    code, out, nm = ctx.gunzip(raw, len(fastq))
+    assert code == 0 and out == fastq
+    # corrupted ordinary streams: same verdict as the oracle
+    from oracle import oracle as O
+    blob = gzip.compress(text[:3 << 20], 6)
+    for trial in range(20):
+        bad = bytearray(blob)
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        code, out, nm = ctx.gunzip(bytes(bad), (3 << 20) + 4096)
+        ocode, oout, onm = O.gunzip(bytes(bad), (3 << 20) + 4096)
+        assert (code == 0) == (ocode == 0), (pos, code, ocode)
+        if code == 0:
+            assert out == oout
