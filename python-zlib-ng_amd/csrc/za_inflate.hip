@@ -224,7 +224,9 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 // hist = bytes of history that may be referenced before out[0] (dict_len, or 32768 for a chunk in mid-stream);
 // stop_at_sync ends the decode right after an empty stored block (sync-flush point) with ZA_I_SYNC.
 #define ZA_I_SYNC 2
-template <int MODE, typename SymT>
+// MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
+// start), RING symbols in LDS; older sources are read back from `out` (written many rounds ago) or are markers.
+template <int MODE, typename SymT, int RING = ZA_WIN>
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       SymT *__restrict__ out, uint64_t out_cap,
@@ -241,7 +243,12 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
     int status = ZA_I_OK;
     if (hist == 0xFFFFFFFFu) hist = dict_len;
     if (MODE == 0) for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) win[(ZA_WIN - dict_len + i) & (ZA_WIN - 1)] = (SymT)dict[i];
-    if (MODE == 2) for (uint32_t i = (uint32_t)lane; i < ZA_WIN; i += 64) win[i] = (SymT)(256u + i);
+    // MODE 2: the ring starts out holding the markers of the RING positions before the start
+    if (MODE == 2) for (uint32_t i = (uint32_t)lane; i < (uint32_t)RING; i += 64) win[i] = (SymT)(256u + (uint32_t)(ZA_WIN - RING) + i);
+    // symbol at position q (may be negative: before the start) that is no longer in the ring -- MODE 2 only
+    auto far_sym = [&](long long q) -> SymT {
+        return q >= 0 ? out[q] : (SymT)(256u + (uint32_t)(ZA_WIN + q));
+    };
     __syncthreads();
 
     for (;;) {
@@ -274,7 +281,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                 const uint8_t *src = in + (bitpos >> 3);
                 for (uint32_t i = (uint32_t)lane; i < can; i += 64) {
                     const SymT b = (SymT)src[i];
-                    win[(op + i) & (ZA_WIN - 1)] = b;
+                    win[(op + i) & (RING - 1)] = b;
                     out[op + i] = b;
                 }
             }
@@ -294,7 +301,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             uint64_t ibase = ~0ull;                 // byte offset of ibuf[0] (multiple of 4); ~0 = nothing staged
             while (!eob && status == ZA_I_OK) {
                 const uint64_t byte = bitpos >> 3;
-                if (ibase == ~0ull || byte < ibase || byte + 12 > ibase + 4ull * ZA_IBUF_DW) {
+                if (ibase == ~0ull || byte < ibase || byte + 24 > ibase + 4ull * ZA_IBUF_DW) {
                     ibase = byte & ~3ull;
                     __builtin_amdgcn_wave_barrier();
                     for (int i = lane; i < ZA_IBUF_DW; i += 64) {
@@ -305,6 +312,153 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                         ibuf[i] = v;
                     }
                     __builtin_amdgcn_wave_barrier();
+                }
+                // ---- fast round: every lane decodes the COMPLETE token (literal, end of block, or length + distance
+                // with their extra bits: at most 48 bits) that would start at bit `lane`; a short scalar loop then
+                // follows the real chain 0 -> next -> ... through the lanes (one readlane per token) and everything
+                // on the chain is emitted together: literals with one store, matches one after the other.  A round
+                // consumes at least 64 bits.  Windows that touch the end of the input or of the output, codes longer
+                // than the LUT and invalid data are left to the careful walker below, which also produces the status.
+                if (bitpos + 128ull <= in_bits && out_cap - op >= 64ull * 258ull) {
+                    const uint32_t relbit = (uint32_t)(bitpos - ibase * 8ull) + (uint32_t)lane;
+                    const uint32_t fw = relbit >> 5, fsh = relbit & 31u;
+                    const uint64_t flo = ((uint64_t)ibuf[fw + 1] << 32) | ibuf[fw];
+                    const uint64_t mine = fsh ? ((flo >> fsh) | ((uint64_t)ibuf[fw + 2] << (64u - fsh))) : flo;
+                    const uint32_t eL = T.lut_l[mine & ((1u << ZA_LUT_L_BITS) - 1u)];
+                    const uint32_t l = eL & 15u, sym = eL >> 4;
+                    uint32_t nk = (uint32_t)lane + l;            // (kind << 8) | offset of the next token; kind 0 literal
+                    uint32_t olen = 1, dist = 0;
+                    if (eL == 0) nk = 0xFFFFu;                   // not in the LUT: careful walker
+                    else if (sym == 256u) { nk |= 2u << 8; olen = 0; }
+                    else if (sym > 256u) {
+                        const int ls = (int)sym - 257;
+                        if (ls >= 29) nk = 0xFFFFu;
+                        else {
+                            int nx;
+                            int len = za_len_base(ls, nx);
+                            len += (int)((mine >> l) & ((1u << nx) - 1u));
+                            const uint32_t o2 = l + (uint32_t)nx;                        // <= 20
+                            const uint32_t eD = T.lut_d[(mine >> o2) & ((1u << ZA_LUT_D_BITS) - 1u)];
+                            const int ds = (int)(eD >> 4);
+                            if (eD == 0 || ds >= 30) nk = 0xFFFFu;
+                            else {
+                                int dnx;
+                                int d = za_dist_base(ds, dnx);
+                                const uint32_t o3 = o2 + (eD & 15u);                     // <= 35
+                                d += (int)((mine >> o3) & ((1u << dnx) - 1u));
+                                nk = (1u << 8) | ((uint32_t)lane + o3 + (uint32_t)dnx);  // offset <= 63 + 48
+                                olen = (uint32_t)len; dist = (uint32_t)d;
+                            }
+                        }
+                    }
+                    uint64_t vis = 0;
+                    uint32_t fo = 0;
+                    bool feob = false;
+                    for (;;) {
+                        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nk, (int)fo);
+                        if (n == 0xFFFFu) break;
+                        vis |= 1ull << fo;
+                        fo = n & 0xFFu;
+                        if ((n >> 8) == 2u) { feob = true; break; }
+                        if (fo >= 64u) break;
+                    }
+                    if (vis) {
+                        bool on = (vis >> lane) & 1ull;
+                        uint32_t incl = za_wave_incl_scan(on ? olen : 0u);
+                        uint32_t pre = incl - (on ? olen : 0u);
+                        const bool ismatch = (nk >> 8) == 1u && nk != 0xFFFFu;
+                        // a distance that reaches before the start of the history ends the round in front of it
+                        const uint64_t bad = __ballot(on && ismatch && (uint64_t)dist > op + (uint64_t)pre + (uint64_t)hist);
+                        if (bad) {
+                            const uint32_t b = (uint32_t)__builtin_ctzll(bad);
+                            vis &= (1ull << b) - 1ull;
+                            fo = b; feob = false;
+                            on = (vis >> lane) & 1ull;
+                        }
+                        if (vis) {
+                            uint32_t total = bad ? (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)fo)
+                                                 : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            // Literals are put into the 32 KiB ring before the matches are copied: a literal behind a
+                            // match whose distance is within this round's output of 32 KiB would overwrite bytes that
+                            // match still has to read.  Such a match ends the round (or is a round of its own).
+                            // (with a small ring a match that far back reads `out` instead; then only the round's
+                            // output is bounded so that whatever is read there was written in an earlier round)
+                            const uint64_t hz = RING == ZA_WIN ? __ballot(on && ismatch && dist + (total - pre) > (uint32_t)ZA_WIN)
+                                                               : __ballot(on && pre + olen > (uint32_t)(RING / 4));
+                            if (hz) {
+                                const uint32_t h = (uint32_t)__builtin_ctzll(hz);
+                                feob = false;
+                                if (h == 0) {
+                                    vis = 1ull; fo = (uint32_t)__builtin_amdgcn_readlane((int)nk, 0) & 0xFFu;
+                                    total = (uint32_t)__builtin_amdgcn_readlane((int)olen, 0);
+                                } else {
+                                    vis &= (1ull << h) - 1ull; fo = h;
+                                    total = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)h);
+                                }
+                                on = (vis >> lane) & 1ull;
+                            }
+                            if (max_back && op < (uint64_t)ZA_WIN) {
+                                uint32_t fv = (on && ismatch && (uint64_t)dist > op + pre) ? (uint32_t)((uint64_t)dist - op - pre) : 0u;
+                                for (int sft = 32; sft; sft >>= 1) { const uint32_t ov = (uint32_t)__shfl_xor((int)fv, sft, 64); fv = ov > fv ? ov : fv; }
+                                if (fv > far) far = fv;
+                            }
+                            if (MODE != 1) {
+                                if (on && !ismatch && olen) {
+                                    const uint64_t q = op + (uint64_t)pre;
+                                win[q & (RING - 1)] = (SymT)sym; out[q] = (SymT)sym;
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                                uint64_t mm = __ballot(on && ismatch);
+                                while (mm) {
+                                    const int ml = __builtin_ctzll(mm);
+                                    mm &= mm - 1ull;
+                                    const int len = __builtin_amdgcn_readlane((int)olen, ml);
+                                    const int d = __builtin_amdgcn_readlane((int)dist, ml);
+                                    const uint32_t mpre = (uint32_t)__builtin_amdgcn_readlane((int)pre, ml);
+                                    const uint64_t mp = op + (uint64_t)mpre;
+                                    if (RING != ZA_WIN && (uint32_t)d + (total - mpre) > (uint32_t)RING) {
+                                        // source older than the ring (d > 3/4 RING, so d > len: no overlap)
+                                        for (int base = 0; base < len; base += 64) {
+                                            const int i = base + lane;
+                                            if (i < len) {
+                                                const SymT b = far_sym((long long)mp - d + i);
+                                                win[(mp + (uint64_t)i) & (RING - 1)] = b; out[mp + (uint64_t)i] = b;
+                                            }
+                                        }
+                                    } else if (d >= len) {
+                                        for (int base = 0; base < len; base += 64) {
+                                            const int i = base + lane;
+                                            if (i < len) {
+                                                const SymT b = win[(mp - (uint64_t)d + (uint64_t)i) & (RING - 1)];
+                                                win[(mp + (uint64_t)i) & (RING - 1)] = b; out[mp + (uint64_t)i] = b;
+                                            }
+                                        }
+                                    } else {
+                                        // overlapping copy: byte i comes from position i mod d of the period; the period
+                                        // itself lies completely before the match, so every lane can read at once
+                                        const float rd = 1.0f / (float)d;
+                                        for (int base = 0; base < len; base += 64) {
+                                            const int i = base + lane;
+                                            if (i < len) {
+                                                int k = i - d * (int)((float)i * rd);
+                                                if (k < 0) k += d;
+                                                if (k >= d) k -= d;
+                                                const SymT b = win[(mp - (uint64_t)d + (uint64_t)k) & (RING - 1)];
+                                                out[mp + (uint64_t)i] = b;
+                                                __builtin_amdgcn_wave_barrier();
+                                                win[(mp + (uint64_t)i) & (RING - 1)] = b;
+                                            }
+                                        }
+                                    }
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            }
+                            op += (uint64_t)total;
+                            bitpos += (uint64_t)fo;
+                            if (feob) eob = true;
+                            continue;
+                        }
+                    }
                 }
                 const uint32_t rel = (uint32_t)(byte - ibase), w = rel >> 2, sh = (rel & 3u) * 8u + (uint32_t)(bitpos & 7u);
                 const uint64_t lo64 = ((uint64_t)ibuf[w + 1] << 32) | ibuf[w];
@@ -327,7 +481,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     if (bitpos + o + l > in_bits) { status = ZA_I_INPUT; break; }
                     if (sym < 256) {
                         if (op >= out_cap) { status = ZA_I_OUTFULL; break; }
-                        if (MODE != 1 && lane == 0) { win[op & (ZA_WIN - 1)] = (SymT)sym; out[op] = (SymT)sym; }
+                        if (MODE != 1 && lane == 0) { win[op & (RING - 1)] = (SymT)sym; out[op] = (SymT)sym; }
                         op++; o += l;
                         continue;
                     }
@@ -360,10 +514,11 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                             SymT b = 0;
                             if (i < len) {
                                 const int k = dist < len ? i % dist : i;
-                                b = win[(op - (uint64_t)dist + (uint64_t)k) & (ZA_WIN - 1)];
+                                if (RING != ZA_WIN && dist > RING) b = far_sym((long long)op - dist + k);
+                                else b = win[(op - (uint64_t)dist + (uint64_t)k) & (RING - 1)];
                             }
                             __builtin_amdgcn_wave_barrier();
-                            if (i < len) { win[(op + (uint64_t)i) & (ZA_WIN - 1)] = b; out[op + (uint64_t)i] = b; }
+                            if (i < len) { win[(op + (uint64_t)i) & (RING - 1)] = b; out[op + (uint64_t)i] = b; }
                             __builtin_amdgcn_wave_barrier();
                         }
                     }
@@ -736,8 +891,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
 //                         weeds out false candidates (they fail to decode or are never reached by the chain)
 //   za_k_chunk_decode     one wave per chunk of the chain: decode with 16-bit symbols; what a chunk copies from
 //                         the (still unknown) 32 KiB before its start stays a marker naming that byte
-//   za_k_chunk_propagate  walks the chain once: from the window before chunk k and chunk k's symbols, the window
-//                         before chunk k+1 (one workgroup, 32 KiB per step)
+//   za_k_chunk_compose / _chain   the 32 KiB window before every chunk, as a blocked scan over the chunk chain
 //   za_k_chunk_resolve    one workgroup per chunk: markers -> bytes
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict__ in, uint64_t n,
@@ -768,6 +922,7 @@ __global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict_
     }
 }
 
+#define ZA_CHUNK_RING 4096          // symbols of history the marker decode keeps in LDS (8 KiB: 12 waves per CU)
 struct ZaChunkRes { int32_t status; uint32_t max_back; uint64_t bits; uint64_t out_len; };
 struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t end_bit; };   // absolute bit offsets in the deflate stream
 
@@ -795,7 +950,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
                                                         ZaChunkRes *__restrict__ res)
 {
     __shared__ ZaInfTabs T;
-    __shared__ uint16_t win[ZA_WIN];
+    __shared__ uint16_t win[ZA_CHUNK_RING];
     __shared__ int scratch[2];
     __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
     const ZaChunk ch = chunks[blockIdx.x];
@@ -804,7 +959,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     uint32_t far = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<2, uint16_t>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
+        status = za_inflate_serial_core<2, uint16_t, ZA_CHUNK_RING>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
                                                      scratch, ibuf, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
                                                      ch.in_bit == 0 ? 0u : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull);
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
@@ -912,30 +1067,63 @@ __global__ __launch_bounds__(64) void za_k_find_blocks_b(const uint8_t *__restri
     if (o < max_cands) cands[o] = abit;
 }
 
-__global__ __launch_bounds__(1024) void za_k_chunk_propagate(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
-                                                             uint32_t n, uint8_t *__restrict__ winbuf)
+// Window propagation.  W(k) = the 32 KiB before chunk k.  W(k+1) = tail(k) applied to W(k), where tail(k) is the
+// last 32 Ki symbols of chunk k (markers name bytes of W(k)).  Walking that chain chunk by chunk is serial, so it
+// is done as a blocked scan over groups of ZA_CHUNK_GROUP chunks:
+//   za_k_chunk_compose  one workgroup per group: comp[k] = tail(k) o ... o tail(first of group), still in markers
+//                       of W(first of group)
+//   za_k_chunk_chain    one workgroup: W(first of group g+1) = comp[last of group g] applied to W(first of group g)
+//   za_k_chunk_resolve  one workgroup per chunk: W(k) from comp[k-1] and its group's window, then markers -> bytes
+#define ZA_CHUNK_GROUP 64
+
+__device__ __forceinline__ uint16_t za_tail_sym(const uint16_t *__restrict__ out16, const ZaChunk &ch, uint32_t j)
+{
+    // symbol at window position j of the window that follows chunk `ch`, in terms of the window before it
+    const long long p = (long long)ch.out_len - ZA_WIN + (long long)j;
+    return p < 0 ? (uint16_t)(256u + j + (uint32_t)ch.out_len) : out16[ch.out_off + (uint64_t)p];
+}
+
+__global__ __launch_bounds__(1024) void za_k_chunk_compose(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
+                                                           uint32_t n, uint16_t *__restrict__ comp)
+{
+    __shared__ uint16_t cur[ZA_WIN];                 // 64 KiB: composed map so far, updated in place
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k0 = blockIdx.x * ZA_CHUNK_GROUP;
+    const uint32_t k1 = min(n, k0 + ZA_CHUNK_GROUP);
+    for (uint32_t k = k0; k < k1; k++) {
+        const ZaChunk ch = chunks[k];
+        uint16_t *dst = comp + (size_t)k * ZA_WIN;
+        uint16_t vals[ZA_WIN / 1024];
+#pragma unroll
+        for (uint32_t t = 0; t < ZA_WIN / 1024; t++) {
+            uint32_t sy = za_tail_sym(out16, ch, tid + 1024u * t);
+            if (k != k0 && sy >= 256u) sy = cur[sy - 256u];
+            vals[t] = (uint16_t)sy;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < ZA_WIN / 1024; t++) { cur[tid + 1024u * t] = vals[t]; dst[tid + 1024u * t] = vals[t]; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void za_k_chunk_chain(const uint16_t *__restrict__ comp, uint32_t n, uint8_t *__restrict__ winbuf)
 {
     __shared__ __attribute__((aligned(16))) uint8_t wa[ZA_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t wb[ZA_WIN];
     uint8_t *cur = wa, *nxt = wb;
     const uint32_t tid = threadIdx.x;
+    const uint32_t groups = (n + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
     for (uint32_t j = tid; j < ZA_WIN; j += 1024) cur[j] = 0;
     __syncthreads();
-    for (uint32_t k = 0; k < n; k++) {
-        const ZaChunk ch = chunks[k];
-        uint8_t *wout = winbuf + (size_t)k * ZA_WIN;
+    for (uint32_t g = 0; g < groups; g++) {
+        uint8_t *wout = winbuf + (size_t)g * ZA_WIN;
         for (uint32_t j = tid * 4; j < ZA_WIN; j += 4096) *(uint32_t *)(wout + j) = *(const uint32_t *)(cur + j);
-        if (k + 1 == n) break;
-        const long long L = (long long)ch.out_len;
+        if (g + 1 == groups) break;
+        const uint16_t *cm = comp + (size_t)((g + 1) * ZA_CHUNK_GROUP - 1) * ZA_WIN;
         for (uint32_t j = tid; j < ZA_WIN; j += 1024) {
-            const long long p = L - ZA_WIN + (long long)j;       // position inside the chunk of window byte j
-            uint8_t b;
-            if (p < 0) b = cur[j + (uint32_t)L];                  // still a byte of the previous window
-            else {
-                const uint32_t sym = out16[ch.out_off + (uint64_t)p];
-                b = sym < 256u ? (uint8_t)sym : cur[(sym - 256u) & (ZA_WIN - 1)];
-            }
-            nxt[j] = b;
+            const uint32_t sy = cm[j];
+            nxt[j] = sy < 256u ? (uint8_t)sy : cur[sy - 256u];
         }
         __syncthreads();
         uint8_t *t = cur; cur = nxt; nxt = t;
@@ -943,13 +1131,26 @@ __global__ __launch_bounds__(1024) void za_k_chunk_propagate(const uint16_t *__r
 }
 
 __global__ __launch_bounds__(256) void za_k_chunk_resolve(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
-                                                          const uint8_t *__restrict__ winbuf, uint8_t *__restrict__ out8)
+                                                          const uint16_t *__restrict__ comp, const uint8_t *__restrict__ winbuf,
+                                                          uint8_t *__restrict__ out8)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t w[ZA_WIN];
-    const ZaChunk ch = chunks[blockIdx.x];
-    const uint8_t *wsrc = winbuf + (size_t)blockIdx.x * ZA_WIN;
-    for (uint32_t j = threadIdx.x * 4; j < ZA_WIN; j += 1024) *(uint32_t *)(w + j) = *(const uint32_t *)(wsrc + j);
+    __shared__ __attribute__((aligned(16))) uint8_t wg[ZA_WIN];     // window before the group's first chunk
+    __shared__ __attribute__((aligned(16))) uint8_t w[ZA_WIN];      // window before this chunk
+    const uint32_t k = blockIdx.x, g = k / ZA_CHUNK_GROUP;
+    const ZaChunk ch = chunks[k];
+    const uint8_t *wsrc = winbuf + (size_t)g * ZA_WIN;
+    const bool first = k == g * ZA_CHUNK_GROUP;
+    uint8_t *wdst = first ? w : wg;
+    for (uint32_t j = threadIdx.x * 4; j < ZA_WIN; j += 1024) *(uint32_t *)(wdst + j) = *(const uint32_t *)(wsrc + j);
     __syncthreads();
+    if (!first) {
+        const uint16_t *cm = comp + (size_t)(k - 1) * ZA_WIN;
+        for (uint32_t j = threadIdx.x; j < ZA_WIN; j += 256) {
+            const uint32_t sy = cm[j];
+            w[j] = sy < 256u ? (uint8_t)sy : wg[sy - 256u];
+        }
+        __syncthreads();
+    }
     const uint16_t *src = out16 + ch.out_off;
     uint8_t *dst = out8 + ch.out_off;
     for (uint64_t i = threadIdx.x; i < ch.out_len; i += 256) {

@@ -59,7 +59,7 @@ struct zngamd_ctx {
     uint32_t last_units = 0; bool last_single_chunk = false;
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
-    DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16; DevBuf<uint8_t> winbuf;
+    DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
     DevBuf<ZaCkPart> ck; DevBuf<uint2> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
@@ -144,7 +144,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->prev.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
     c->plan.release(); c->units.release(); c->segbits.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
-    c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->winbuf.release();
+    c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
     c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
@@ -797,30 +797,43 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     std::vector<ZaChunkRes> res(n);
     HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)n * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // follow the chain of real block boundaries from the start of the stream; group blocks into chunks
-    const uint64_t target = 256u << 10;
-    std::vector<ZaChunk> chain;
+    // follow the chain of real block boundaries from the start of the stream, then group blocks into chunks:
+    // about 4096 of them (12 marker decoders fit a CU), none below 32 KiB (a chunk's tail is the next window)
+    std::vector<ZaChunk> blocks;
     uint64_t acc = 0, end_bit = 0;
-    size_t i = 0;
-    bool ended = false, open = false;
-    ZaChunk cur; cur.in_bit = 0; cur.out_off = 0; cur.out_len = 0; cur.end_bit = 0;
-    for (uint32_t guard = 0; guard <= n; guard++) {
-        const ZaChunkRes &r = res[i];
-        if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return chunk_bail(4);
-        if (!open) { cur.in_bit = cand[i]; cur.out_off = acc; cur.out_len = 0; open = true; }
-        cur.out_len += r.out_len; cur.end_bit = r.bits;
-        acc += r.out_len;
-        if (r.status == ZA_I_END) { chain.push_back(cur); end_bit = r.bits; ended = true; break; }
-        if (cur.out_len >= target) { chain.push_back(cur); open = false; }
-        auto it = std::lower_bound(cand.begin(), cand.end(), r.bits);
-        if (it == cand.end() || *it != r.bits) return chunk_bail(5);
-        i = (size_t)(it - cand.begin());
+    bool ended = false;
+    {
+        size_t i = 0;
+        for (uint32_t guard = 0; guard <= n; guard++) {
+            const ZaChunkRes &r = res[i];
+            if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return chunk_bail(4);
+            ZaChunk b; b.in_bit = cand[i]; b.out_off = acc; b.out_len = r.out_len; b.end_bit = r.bits;
+            blocks.push_back(b);
+            acc += r.out_len;
+            if (r.status == ZA_I_END) { end_bit = r.bits; ended = true; break; }
+            auto it = std::lower_bound(cand.begin(), cand.end(), r.bits);
+            if (it == cand.end() || *it != r.bits) return chunk_bail(5);
+            i = (size_t)(it - cand.begin());
+        }
+    }
+    const uint64_t target = std::max<uint64_t>(32u << 10, acc / 4096);
+    std::vector<ZaChunk> chain;
+    for (size_t b = 0; b < blocks.size();) {
+        ZaChunk cur = blocks[b++];
+        while (b < blocks.size() && cur.out_len < target) { cur.out_len += blocks[b].out_len; cur.end_bit = blocks[b].end_bit; b++; }
+        chain.push_back(cur);
+    }
+    if (chain.size() > 1 && chain.back().out_len < target) {       // short last chunk: merge into its predecessor
+        ZaChunk last = chain.back(); chain.pop_back();
+        chain.back().out_len += last.out_len; chain.back().end_bit = last.end_bit;
     }
     if (!ended || chain.size() < 4) return chunk_bail(6);
     *out_len = acc; *in_used = (end_bit + 7) >> 3;
     if (acc > out_room) return ZNGAMD_BUF_ERROR;
     const uint32_t m = (uint32_t)chain.size();
-    HIPCHK(c, c->cchunks.ensure(m)); HIPCHK(c, c->out16.ensure(acc + 64)); HIPCHK(c, c->winbuf.ensure((size_t)m * ZA_WIN));
+    const uint32_t groups = (m + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
+    HIPCHK(c, c->cchunks.ensure(m)); HIPCHK(c, c->out16.ensure(acc + 64)); HIPCHK(c, c->winbuf.ensure((size_t)groups * ZA_WIN));
+    HIPCHK(c, c->ccomp.ensure((size_t)m * ZA_WIN));
     HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(m));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
@@ -835,8 +848,9 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         if (res[k].max_back > chain[k].out_off) return chunk_bail(8);       // reference before the start of the stream
     }
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_chunk_propagate, dim3(1), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->winbuf.p);
-      hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(256), 0, c->stream, c->out16.p, c->cchunks.p, c->winbuf.p, d_out); }
+      hipLaunchKernelGGL(za_k_chunk_compose, dim3(groups), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->ccomp.p);
+      hipLaunchKernelGGL(za_k_chunk_chain, dim3(1), dim3(1024), 0, c->stream, c->ccomp.p, m, c->winbuf.p);
+      hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(256), 0, c->stream, c->out16.p, c->cchunks.p, c->ccomp.p, c->winbuf.p, d_out); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
