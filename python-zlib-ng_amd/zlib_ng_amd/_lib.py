@@ -130,6 +130,24 @@ def _addr(buf):
     return C.cast(arr, C.c_void_p), arr
 
 
+_py = C.pythonapi
+_py.PyBytes_FromStringAndSize.restype = C.py_object
+_py.PyBytes_FromStringAndSize.argtypes = [C.c_void_p, C.c_ssize_t]
+_py.PyBytes_AsString.restype = C.c_void_p
+_py.PyBytes_AsString.argtypes = [C.py_object]
+
+
+def _new_bytes(n):
+    """A fresh, uninitialised bytes object of n >= 1 bytes for the engine to fill, and its address: no zero fill,
+    and no copy when the engine fills it completely."""
+    obj = _py.PyBytes_FromStringAndSize(None, max(int(n), 1))
+    return obj, C.c_void_p(_py.PyBytes_AsString(obj))
+
+
+def _take(obj, n):
+    return obj if n == len(obj) else obj[:n]
+
+
 class Context:
     """One engine context = one GPU + one HIP stream + grow-only device workspaces."""
 
@@ -191,19 +209,18 @@ class Context:
         for i, (off, ln, dl, fl) in enumerate(blocks):
             arr[i] = Block(off, ln, dl, fl, 0)
         p, keep = _addr(buf)
-        out = C.create_string_buffer(max(n, 1) * out_cap)
+        out, op = _new_bytes(max(n, 1) * out_cap)
         lens = (C.c_uint32 * max(n, 1))()
         crcs = (C.c_uint32 * max(n, 1))()
         r = self.L.zngamd_deflate_blocks(self.h, p, memoryview(buf).nbytes, arr, n, level,
-                                         C.cast(out, C.c_void_p), out_cap, C.cast(lens, C.c_void_p),
-                                         C.cast(crcs, C.c_void_p))
+                                         op, out_cap, C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p))
         self._chk(r, (OK, E_OVERFLOW))
         res = []
         for i in range(n):
             if lens[i] == 0xFFFFFFFF:
                 res.append(None)
             else:
-                res.append(out.raw[i * out_cap:i * out_cap + lens[i]])
+                res.append(out[i * out_cap:i * out_cap + lens[i]])
         return res, list(crcs[:n]), r == E_OVERFLOW
 
     def deflate_stream(self, data, level, window_bits=15):
@@ -211,12 +228,12 @@ class Context:
         p, keep = _addr(data)
         n = memoryview(data).nbytes
         cap = n + (n // UNIT_MAX + 1) * 64 + 64
-        out = C.create_string_buffer(cap)
+        out, op = _new_bytes(cap)
         ol = C.c_uint64(0)
         crc, ad = C.c_uint32(0), C.c_uint32(1)
-        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, window_bits, C.cast(out, C.c_void_p), cap,
+        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, window_bits, op, cap,
                                                C.byref(ol), C.byref(crc), C.byref(ad)))
-        return out.raw[:ol.value], crc.value, ad.value
+        return _take(out, ol.value), crc.value, ad.value
 
     def debug_fetch(self, what, unit, nbytes):
         b = C.create_string_buffer(nbytes)
@@ -228,51 +245,50 @@ class Context:
         """-> (code, out bytes, in_used, crc32, adler32)"""
         p, keep = _addr(data)
         dp, dkeep = _addr(zdict) if len(zdict) else (None, None)
-        out = C.create_string_buffer(max(out_cap, 1))
+        out, op = _new_bytes(out_cap)
         ol, used = C.c_uint64(0), C.c_uint64(0)
         crc, ad = C.c_uint32(0), C.c_uint32(1)
         r = self.L.zngamd_inflate_raw(self.h, p, memoryview(data).nbytes, dp, len(zdict),
-                                      C.cast(out, C.c_void_p), out_cap, C.byref(ol), C.byref(used),
+                                      op, out_cap, C.byref(ol), C.byref(used),
                                       C.byref(crc), C.byref(ad))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
-        return r, out.raw[:ol.value], used.value, crc.value, ad.value
+        return r, _take(out, min(ol.value, out_cap)), used.value, crc.value, ad.value
 
     def inflate_resume(self, data, start_bit, zdict, out_cap):
         """-> (code, out bytes, in_bits, block_bits, block_out); code E_OVERFLOW = out_cap reached"""
         p, keep = _addr(data)
         dp, dkeep = _addr(zdict) if len(zdict) else (None, None)
-        out = C.create_string_buffer(max(out_cap, 1))
+        out, op = _new_bytes(out_cap)
         ol, ib, bb, bo = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         r = self.L.zngamd_inflate_resume(self.h, p, memoryview(data).nbytes, start_bit, dp, len(zdict),
-                                         C.cast(out, C.c_void_p), out_cap, C.byref(ol), C.byref(ib), C.byref(bb), C.byref(bo))
+                                         op, out_cap, C.byref(ol), C.byref(ib), C.byref(bb), C.byref(bo))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
-        return r, out.raw[:ol.value], ib.value, bb.value, bo.value
+        return r, _take(out, min(ol.value, out_cap)), ib.value, bb.value, bo.value
 
     def gunzip(self, data, out_cap):
         """-> (code, out bytes, n_members)"""
         p, keep = _addr(data)
-        out = C.create_string_buffer(max(out_cap, 1))
+        out, op = _new_bytes(out_cap)
         ol, nm = C.c_uint64(0), C.c_uint32(0)
-        r = self.L.zngamd_gunzip(self.h, p, memoryview(data).nbytes, C.cast(out, C.c_void_p), out_cap,
+        r = self.L.zngamd_gunzip(self.h, p, memoryview(data).nbytes, op, out_cap,
                                  C.byref(ol), C.byref(nm))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
         # BUF_ERROR with a size above the capacity = "this is how much room the stream needs"
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
-        return r, out.raw[:min(ol.value, out_cap)], nm.value
+        return r, _take(out, min(ol.value, out_cap)), nm.value
 
     def gzip_members(self, data, block_size, level):
         p, keep = _addr(data)
         n = memoryview(data).nbytes
         nb = max(1, (n + block_size - 1) // max(block_size, 1))
         cap = n + nb * 400 + 64
-        out = C.create_string_buffer(cap)
+        out, op = _new_bytes(cap)
         ol = C.c_uint64(0)
-        self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, C.cast(out, C.c_void_p), cap,
-                                             C.byref(ol)))
-        return out.raw[:ol.value]
+        self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, op, cap, C.byref(ol)))
+        return _take(out, ol.value)
 
     # ---- measurement
     def profiling(self, on):
