@@ -42,22 +42,23 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
     const uint32_t hv = head[h];
     uint32_t d = (P - hv) & 0xFFFFu;
     if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
-    // Fast path: every valid lane stores its position and reads the bucket back.  If all of them read
-    // their own value no two lanes share a bucket, the links above are final and so is the table.
+    // Every valid lane stores its LANE NUMBER into its bucket and reads the bucket back: all lanes of one bucket
+    // read the same number (whichever store landed last), so that number names the bucket group with 6 bits.
+    // If every lane reads its own number no two lanes share a bucket and the links above are final.
     // (volatile: the read-back must come from LDS, where another lane's store may have landed, not from
     // this lane's own store forwarded by the compiler)
     volatile uint16_t *vhead = head;
-    if (valid) vhead[h] = P16;
+    if (valid) vhead[h] = (uint16_t)lane;
     __builtin_amdgcn_wave_barrier();
-    const bool clash = valid && vhead[h] != P16;
-    if (__ballot(clash) != 0ull) {
-        // Some bucket is hit twice in this tile: order the lanes exactly (bit-slice match-any over the
-        // table-index bits), link later lanes to the nearest earlier one and leave the last position in the
-        // table.  (A loop over the clashing buckets was measured slower: text has many per tile.)
+    const uint32_t rep = valid ? (uint32_t)vhead[h] : (uint32_t)lane;
+    bool last = true;                                // highest lane of my bucket: leaves its position in the table
+    if (__ballot(rep != (uint32_t)lane) != 0ull) {
+        // Some bucket is hit twice in this tile: order its lanes exactly (bit-slice match-any over the 6 bits of
+        // the group number) and link later lanes to the nearest earlier one.
         unsigned long long eq = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < ZA_CH_SUB; b++) {
-            const bool bit = (h >> b) & 1u;
+        for (int b = 0; b < 6; b++) {
+            const bool bit = (rep >> b) & 1u;
             const unsigned long long B = __ballot(bit);
             eq &= bit ? B : ~B;
         }
@@ -66,8 +67,10 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
         const int j = lower ? 63 - __builtin_clzll(lower) : lane;
         const uint32_t Pj = __shfl(P, j, 64);
         if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
-        if (valid && !higher) vhead[h] = P16;
+        last = !higher;
     }
+    __builtin_amdgcn_wave_barrier();
+    if (valid && last) vhead[h] = P16;
     if (valid) prevdist[(int)P - ZA_WIN + dict_len] = (uint16_t)d;
 }
 
