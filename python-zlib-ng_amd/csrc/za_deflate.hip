@@ -20,14 +20,16 @@
 // ------------------------------------------------------------------------------------------------
 // k_chains
 // ------------------------------------------------------------------------------------------------
-// One 512-thread workgroup per unit.  The 15-bit bucket space is split into 8 classes by the top 3 hash
-// bits; wave w owns class w and a private 4096-entry u16 head table (8 x 8 KiB of LDS).  Every wave
-// sweeps all positions 64 at a time, keeps the ones of its class, compacts them (ballot + mbcnt) into a
-// small LDS ring in position order, and whenever 64 are pending inserts them as one dense tile:
-// same-bucket lanes are ordered by a 12-ballot bit-slice match-any, so the result is exactly the
-// sequential insertion order -- with no barrier between waves, since no two waves share a bucket.
+// One 256-thread workgroup per unit.  The 14-bit bucket space is split into 4 classes by the top 2 hash
+// bits; wave w owns class w and a private 4096-entry u16 head table (4 x 8 KiB of LDS; with the rings
+// 42 KiB per workgroup: three per CU -- the dense insert is a chain of dependent LDS round trips, and the
+// kernel scales almost linearly with resident waves).  Positions are
+// hashed once, 256 per tile (64 per wave), and handed to the owning wave through a per-class LDS ring in
+// position order (per-wave class counts -> offsets -> ranks: two barriers per tile).  Whenever 64 entries
+// are pending in its ring a wave inserts them as one dense tile: same-bucket lanes are ordered by a
+// bit-slice match-any, so the result is exactly the sequential insertion order.
 #define ZA_CH_WAVES 4
-#define ZA_CH_STAGE 512u                      // pending-entry ring per wave: 63 left over + 256 of one group
+#define ZA_CH_STAGE 320u                      // pending-entry ring per class: 63 left over + one tile of 256; cursors are kept mod 320
 #define ZA_CH_SUB   (ZA_HASH_BITS - 2)        // bits of the per-wave table index
 
 __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, uint32_t rd, int m, int pmin,
@@ -35,7 +37,9 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
 {
     const int lane = za_lane();
     const bool valid = lane < m;
-    const uint32_t e = stage[(rd + (uint32_t)lane) & (ZA_CH_STAGE - 1u)];
+    uint32_t slot = rd + (uint32_t)lane;              // rd < ZA_CH_STAGE
+    slot -= slot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+    const uint32_t e = stage[slot];
     const uint32_t P = e & 0x3FFFFu, h = (e >> 18) & ((1u << ZA_CH_SUB) - 1u);
     const uint16_t P16 = (uint16_t)(P & 0xFFFFu);
     // link through the table state left by the earlier tiles
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
                                                                 uint16_t *__restrict__ prev_ws)
 {
     __shared__ uint16_t head_all[ZA_CH_WAVES][1 << ZA_CH_SUB];
-    __shared__ uint32_t stage_all[ZA_CH_WAVES][ZA_CH_STAGE];
+    __shared__ uint32_t ring_all[ZA_CH_WAVES][ZA_CH_STAGE];
+    __shared__ uint32_t cnt[2][ZA_CH_WAVES][ZA_CH_WAVES];    // [tile parity][producer wave][class] entries of a tile
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
@@ -86,65 +91,91 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     const int lane = za_lane();
     const uint32_t wave = threadIdx.x >> 6;
     uint16_t *head = head_all[wave];
-    uint32_t *stage = stage_all[wave];
     for (int i = lane; i < (1 << ZA_CH_SUB) / 2; i += 64) ((uint32_t *)head)[i] = 0;
-    __builtin_amdgcn_wave_barrier();
     const int total = dict_len + n;
     const int pmin = ZA_WIN - dict_len;
-    uint32_t rd = 0, wr = 0;
-    const bool can_load = total >= ZA_HASH_BYTES;          // wave-uniform: the unit + dictionary hold at least one 6-byte context
-    // software pipeline: a group of 4 tiles (256 positions) is in flight while the previous group is
-    // classified -- one tile of look-ahead left the wave waiting on every load
-    uint2 va[4], vb[4];
-    // loads are unconditional from a clamped position (no branch per tile); `valid` masks them later
+    const bool can_load = total >= ZA_HASH_BYTES;          // uniform: the unit + dictionary hold at least one 6-byte context
     const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available (may be < -dict_len)
-    auto load_group = [&](int gbase, uint2 (&v)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            int p = gbase + 64 * t + lane - dict_len;
-            p = p > pclamp_hi ? pclamp_hi : p;
-            p = p < -dict_len ? -dict_len : p;
-            v[t] = can_load ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
-        }
+    // A tile is 256 positions: wave w hashes positions [64 w, 64 w + 64) of it -- every position is hashed once.
+    // loads are unconditional from a clamped position (no branch per tile); `valid` masks them later
+    auto load_tile = [&](int tbase) -> uint2 {
+        int p = tbase + 64 * (int)wave + lane - dict_len;
+        p = p > pclamp_hi ? pclamp_hi : p;
+        p = p < -dict_len ? -dict_len : p;
+        return can_load ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
     };
-    auto do_group = [&](int gbase, const uint2 (&v)[4]) {
-        // classify the four tiles back to back (independent work), then drain the ring
+    // Two barriers per tile: class counts visible -> every wave places its entries -> rings complete -> consume.
+    uint32_t wrv = 0;          // lane c < 4: entries ever put into class c's ring (every wave keeps the same copy)
+    uint32_t wslot = 0;        // lane c < 4: wrv mod ZA_CH_STAGE
+    uint32_t rd = 0, rslot = 0;   // consumed entries of my class, and that number mod ZA_CH_STAGE
+    uint32_t par = 0;
+    auto consume = [&](uint32_t upto, bool flush) {
+        while (upto - rd >= 64u) {
+            za_chains_dense(head, ring_all[wave], rslot, 64, pmin, prevdist, dict_len);
+            rd += 64u; rslot += 64u; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+        }
+        if (flush && upto != rd) za_chains_dense(head, ring_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len);
+    };
+    auto do_tile = [&](int tbase, const uint2 v) {
+        // ---- classify: class = top two hash bits; rank = my place among this wave's entries of my class
+        const int i = tbase + 64 * (int)wave + lane, p = i - dict_len;
+        const bool valid = (i < total) && (p + ZA_HASH_BYTES <= n);
+        const uint32_t h = za_hash6(v.x, v.y);
+        const uint32_t cls = h >> ZA_CH_SUB;
+        const unsigned long long V = __ballot(valid);
+        const unsigned long long B0 = __ballot((cls & 1u) != 0u), B1 = __ballot((cls & 2u) != 0u);
+        const unsigned long long m0 = V & ~B0 & ~B1, m1 = V & B0 & ~B1, m2 = V & ~B0 & B1, m3 = V & B0 & B1;
+        unsigned long long eq = (cls & 1u) ? B0 : ~B0;
+        eq &= (cls & 2u) ? B1 : ~B1;
+        eq &= V;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(eq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)eq, 0u));
+        if (lane < ZA_CH_WAVES) {
+            const uint32_t c01 = lane == 0 ? (uint32_t)__builtin_popcountll(m0) : (uint32_t)__builtin_popcountll(m1);
+            const uint32_t c23 = lane == 2 ? (uint32_t)__builtin_popcountll(m2) : (uint32_t)__builtin_popcountll(m3);
+            cnt[par][wave][lane] = lane < 2 ? c01 : c23;
+        }
+        __syncthreads();
+        // ---- lane c < 4 adds up class c over the producer waves: where my wave's entries start, and the new cursor
+        uint32_t base = 0;
+        if (lane < ZA_CH_WAVES) {
+            uint32_t before = 0, all = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int i = gbase + 64 * t + lane, p = i - dict_len;
-            const bool valid = (i < total) && (p + ZA_HASH_BYTES <= n);
-            const uint32_t h = za_hash6(v[t].x, v[t].y);
-            const bool mine = valid && (h >> ZA_CH_SUB) == wave;
-            const unsigned long long mask = __ballot(mine);
-            if (mine) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                stage[(wr + rank) & (ZA_CH_STAGE - 1u)] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+            for (uint32_t w = 0; w < ZA_CH_WAVES; w++) {
+                const uint32_t c = cnt[par][w][lane];
+                before += w < wave ? c : 0u;
+                all += c;
             }
-            wr += (uint32_t)__builtin_popcountll(mask);
+            base = wslot + before;                         // < 320 + 256
+            wrv += all;
+            wslot += all; wslot -= wslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
         }
-        __builtin_amdgcn_wave_barrier();
-        while (wr - rd >= 64u) {
-            za_chains_dense(head, stage, rd, 64, pmin, prevdist, dict_len);
-            rd += 64u;
-        }
+        par ^= 1u;
+        uint32_t myslot = (uint32_t)__shfl((int)base, (int)cls, 64) + rank;   // < 320 + 256 + 64
+        myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+        myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+        if (valid)
+            ring_all[cls][myslot] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+        __syncthreads();
+        // ---- consume my class in dense groups of 64, in position order
+        consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), false);
     };
-    // three groups (768 positions) of loads stay in flight ahead of the one being classified
-    uint2 vc[4], vd[4];
-    load_group(0, va); load_group(256, vb); load_group(512, vc);
-    for (int gbase = 0; gbase < total; gbase += 1024) {
-        load_group(gbase + 768, vd);
-        do_group(gbase, va);
-        if (gbase + 256 >= total) break;
-        load_group(gbase + 1024, va);
-        do_group(gbase + 256, vb);
-        if (gbase + 512 >= total) break;
-        load_group(gbase + 1280, vb);
-        do_group(gbase + 512, vc);
-        if (gbase + 768 >= total) break;
-        load_group(gbase + 1536, vc);
-        do_group(gbase + 768, vd);
+    // four tiles of loads stay in flight ahead of the one being classified
+    uint2 va = load_tile(0), vb = load_tile(256), vc = load_tile(512), vd = load_tile(768);
+    __syncthreads();
+    for (int tbase = 0; tbase < total; tbase += 1024) {
+        do_tile(tbase, va);
+        if (tbase + 256 >= total) break;
+        va = load_tile(tbase + 1024);
+        do_tile(tbase + 256, vb);
+        if (tbase + 512 >= total) break;
+        vb = load_tile(tbase + 1280);
+        do_tile(tbase + 512, vc);
+        if (tbase + 768 >= total) break;
+        vc = load_tile(tbase + 1536);
+        do_tile(tbase + 768, vd);
+        vd = load_tile(tbase + 1792);
     }
-    if (wr != rd) za_chains_dense(head, stage, rd, (int)(wr - rd), pmin, prevdist, dict_len);
+    consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), true);
     // positions with fewer than 6 bytes left are never inserted: their link is 0
     if (wave == 0 && lane < ZA_HASH_BYTES - 1) {
         const int p = n - 1 - lane;
