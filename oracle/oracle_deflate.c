@@ -24,13 +24,16 @@
 #include <pthread.h>
 #include <time.h>
 
-typedef struct { int chain, nice, lazy; } za_level;
+typedef struct { int chain, nice, lazy, cap; } za_level;
 /* (max_chain, nice_length, max_lazy) per level.  Calibrated for this codec (every position is
  * searched and a whole 128 KiB unit shares one Huffman block), so that the ratio at each level is at
  * least that of zlib 1.2.11 at the same level on the text / FASTQ / mixed corpora. */
+/* cap: candidates are compared on their first `cap` bytes only while the chain is walked (longest wins, nearest
+ * wins ties, the walk ends at min(nice, cap) equal bytes); the winner is then extended to its true length.
+ * 16 on the fast levels (one 16-byte compare per candidate on the GPU), 258 = compare in full. */
 static const za_level LEVELS[10] = {
-    {0, 0, 0}, {1, 8, 0}, {2, 8, 0}, {3, 16, 0}, {2, 16, 8}, {3, 32, 16},
-    {4, 32, 16}, {8, 32, 16}, {16, 64, 16}, {128, 258, 128}
+    {0, 0, 0, 0}, {1, 8, 0, 16}, {2, 8, 0, 16}, {3, 16, 0, 16}, {2, 16, 8, 16}, {3, 32, 16, 16},
+    {4, 32, 16, 16}, {8, 32, 16, 258}, {16, 64, 16, 258}, {128, 258, 128, 258}
 };
 
 /* test-only: forced token-boundary granularity (default ZA_SEG) */
@@ -38,8 +41,9 @@ static int g_cut = ZA_SEG;
 void za_o_set_cut(int cut) { g_cut = cut; }
 
 /* test-only override of the level table (parameter studies); chain <= 0 switches it off */
-static za_level g_override = {0, 0, 0};
+static za_level g_override = {0, 0, 0, 258};
 void za_o_override_level(int chain, int nice, int lazy) { g_override.chain = chain; g_override.nice = nice; g_override.lazy = lazy; }
+void za_o_override_cap(int cap) { g_override.cap = cap; }
 
 static inline uint32_t ld32(const uint8_t *p)
 {
@@ -79,7 +83,8 @@ static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const ui
     int maxlen = seg_end - p;
     if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
     if (maxlen < ZA_MIN_MATCH) return 0;
-    int nice = L->nice < maxlen ? L->nice : maxlen;
+    const int cap = L->cap < maxlen ? L->cap : maxlen;      /* bytes compared per candidate */
+    const int nice = L->nice < cap ? L->nice : cap;
     int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
     int q = p, depth = L->chain;
     while (depth-- > 0) {
@@ -90,13 +95,15 @@ static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const ui
         if (dist > max_dist) break;
         if (data[q + best_len] != data[p + best_len]) continue;
         int len = 0;
-        while (len < maxlen && data[q + len] == data[p + len]) len++;
+        while (len < cap && data[q + len] == data[p + len]) len++;
         if (len > best_len) {
             best_len = len; best_dist = dist;
             if (len >= nice) break;
         }
     }
     if (best_len < ZA_MIN_MATCH) return 0;
+    if (best_len == cap)                                      /* the winner's true length */
+        while (best_len < maxlen && data[p - best_dist + best_len] == data[p + best_len]) best_len++;
     if (best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR) return 0;
     return ((uint32_t)best_len << 16) | (uint32_t)best_dist;
 }

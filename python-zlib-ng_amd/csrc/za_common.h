@@ -46,7 +46,8 @@ struct ZaPlan {
     uint32_t pad0, pad1;
 };
 
-struct ZaLevel { int chain, nice, lazy, max_dist; };
+// cap: bytes compared per candidate while the chain is walked (16 or 258); the winner is extended afterwards
+struct ZaLevel { int chain, nice, lazy, max_dist, cap; };
 
 typedef uint32_t __attribute__((aligned(1))) za_u32u;
 typedef uint64_t __attribute__((aligned(1))) za_u64u;

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             uint32_t result = 0;
             if (maxlen >= ZA_MIN_MATCH) {
                 const uint32_t P = (uint32_t)(ZA_WIN + p);
-                const int nice = L.nice < maxlen ? L.nice : maxlen;
+                const int cap = L.cap < maxlen ? L.cap : maxlen;             // bytes compared per candidate
+                const int nice = L.nice < cap ? L.nice : cap;
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
                 // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
                 // against them without branches (this also plays the role of zlib's quick-reject byte)
@@ -292,19 +293,29 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     const uint32_t hi = n2 < 4u ? 8u + n2 : 12u + n3;
                     const uint32_t lo = n0 < 4u ? n0 : 4u + n1;
                     int len = (int)((n0 < 4u || n1 < 4u) ? lo : hi);
-                    if (len == 16 && maxlen > 16 && best_len < maxlen) {
-                        // rare: at least 16 equal bytes -- finish the compare the long way
+                    if (len == 16 && cap > 16 && best_len < cap) {
+                        // levels that compare in full: at least 16 equal bytes -- finish the compare the long way
                         while (len < maxlen) {
                             const uint32_t x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
                             if (x) { len += (int)(__builtin_ctz(x) >> 3); break; }
                             len += 4;
                         }
                     }
-                    len = len < maxlen ? len : maxlen;
+                    len = len < cap ? len : cap;
                     const bool better = len > best_len;
                     best_len = better ? len : best_len;
                     best_dist = better ? dist : best_dist;
                     if (best_len >= nice) break;
+                }
+                if (best_len == cap && cap < maxlen) {
+                    // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
+                    const uint32_t qb = P - (uint32_t)best_dist;
+                    while (best_len < maxlen) {
+                        const uint32_t x = za_lds_ld32(win32, qb + (uint32_t)best_len) ^ za_lds_ld32(win32, P + (uint32_t)best_len);
+                        if (x) { best_len += (int)(__builtin_ctz(x) >> 3); break; }
+                        best_len += 4;
+                    }
+                    best_len = best_len < maxlen ? best_len : maxlen;
                 }
                 if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
                     result = ((uint32_t)best_len << 16) | (uint32_t)best_dist;
