@@ -773,6 +773,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
     // loads of a batch are independent, so they overlap); a self-overlapping match (dist < len) reads its
     // period byte-wise, which lies entirely below its destination.
     const uint64_t out_room = out_cap - m.out_off;     // bytes of dst that may be touched
+#ifndef ZA_ABL_NO_B
     for (int s = 0; s < nseg; s++) {
         const uint32_t cnt = __shfl(nmatch, s, 64);
         const uint2 *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
@@ -783,41 +784,71 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
             const uint32_t mdst = mm.x & 0x1FFFFu, mlen = mm.x >> 17, mdist = mm.y;
             bool done = !has;
             unsigned long long pending = __ballot(!done);
+            // Which matches of this group write bytes that mine reads?  Destinations are disjoint and ascending with
+            // the lane, so they are the lanes [jlo, jhi): jhi = matches that start below the end of my source,
+            // jlo = matches that end at or below its start (two 6-step binary searches with shuffles; both counts
+            // are at most my own lane).  A match is ready as soon as none of those is pending -- the lowest
+            // pending one always is.
+            const uint32_t sdst = has ? mdst : 0xFFFFFFFFu, send = has ? mdst + mlen : 0xFFFFFFFFu;
+            const uint32_t src_a = mdst - mdist, src_b = src_a + (mlen < mdist ? mlen : mdist);
+            uint32_t jhi = 0, jlo = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t vd = (uint32_t)__shfl((int)sdst, (int)(jhi + step - 1u), 64);
+                const uint32_t ve = (uint32_t)__shfl((int)send, (int)(jlo + step - 1u), 64);
+                if (vd < src_b) jhi += step;
+                if (ve <= src_a) jlo += step;
+            }
+            const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+            // short non-overlapping matches (nearly all) are copied by their own lane, at most two 16-byte batches;
+            // long or self-overlapping ones would keep the other 63 lanes waiting, so the whole wave copies those
+            const bool simple = mdist >= mlen && mlen <= 32u && (uint64_t)mdst + mlen + 4 <= out_room;
             while (pending) {
-                const int lowest = __builtin_ctzll(pending);
-                const uint32_t frontier = __shfl(mdst, lowest, 64);
-                const uint32_t srcend = mdst - mdist + (mlen < mdist ? mlen : mdist);
-                const bool ready = !done && (srcend <= frontier || lane == lowest);
-                if (ready) {
+                const bool ready = !done && (pending & deps) == 0ull;
+                if (ready && simple) {
                     uint8_t *o = dst + mdst;
                     const uint8_t *sp = o - mdist;
-                    if (mdist >= mlen && (uint64_t)mdst + mlen + 4 <= out_room) {
-                        for (uint32_t i = 0; i < mlen; i += 16) {
-                            const uint32_t rem = mlen - i;
-                            uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                            v0 = za_ld32(sp + i);
-                            if (rem > 4) v1 = za_ld32(sp + i + 4);
-                            if (rem > 8) v2 = za_ld32(sp + i + 8);
-                            if (rem > 12) v3 = za_ld32(sp + i + 12);
-                            const uint32_t vv[4] = {v0, v1, v2, v3};
+                    for (uint32_t i = 0; i < mlen; i += 16) {
+                        const uint32_t rem = mlen - i;
+                        uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                        v0 = za_ld32(sp + i);
+                        if (rem > 4) v1 = za_ld32(sp + i + 4);
+                        if (rem > 8) v2 = za_ld32(sp + i + 8);
+                        if (rem > 12) v3 = za_ld32(sp + i + 12);
+                        const uint32_t vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const int left = (int)rem - 4 * k;
-                                if (left >= 4) *(za_u32u *)(o + i + 4 * k) = vv[k];
-                                else if (left > 0) {
-                                    o[i + 4 * k] = (uint8_t)vv[k];
-                                    if (left > 1) o[i + 4 * k + 1] = (uint8_t)(vv[k] >> 8);
-                                    if (left > 2) o[i + 4 * k + 2] = (uint8_t)(vv[k] >> 16);
-                                }
+                        for (int k = 0; k < 4; k++) {
+                            const int left = (int)rem - 4 * k;
+                            if (left >= 4) *(za_u32u *)(o + i + 4 * k) = vv[k];
+                            else if (left > 0) {
+                                o[i + 4 * k] = (uint8_t)vv[k];
+                                if (left > 1) o[i + 4 * k + 1] = (uint8_t)(vv[k] >> 8);
+                                if (left > 2) o[i + 4 * k + 2] = (uint8_t)(vv[k] >> 16);
                             }
                         }
-                    } else {
-                        for (uint32_t i = 0; i < mlen; i += 4) {
-                            uint8_t b[4];
-#pragma unroll
-                            for (int k = 0; k < 4; k++) b[k] = (i + k < mlen) ? sp[(i + k) % mdist] : (uint8_t)0;
-#pragma unroll
-                            for (int k = 0; k < 4; k++) if (i + k < mlen) o[i + k] = b[k];
+                    }
+                }
+                unsigned long long coop = __ballot(ready && !simple);
+                while (coop) {
+                    const int j = __builtin_ctzll(coop);
+                    coop &= coop - 1ull;
+                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
+                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
+                    const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
+                    uint8_t *o = dst + cd;
+                    const uint8_t *sp = o - cdist;
+                    const float rd = 1.0f / (float)cdist;
+                    for (uint32_t base = 0; base < cl; base += 64) {
+                        const uint32_t i = base + (uint32_t)lane;
+                        if (i < cl) {
+                            // byte i of a self-overlapping match is byte (i mod dist) of its period, which lies below it
+                            int k = (int)i;
+                            if (cdist < cl) {
+                                k = (int)i - (int)cdist * (int)((float)i * rd);
+                                if (k < 0) k += (int)cdist;
+                                if (k >= (int)cdist) k -= (int)cdist;
+                            }
+                            o[i] = sp[k];
                         }
                     }
                 }
@@ -827,8 +858,13 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
             }
         }
     }
+#endif
     // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
+#ifdef ZA_ABL_NO_CRC
+    const uint32_t c = za_ld32(src + m.in_len);
+#else
     const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
+#endif
     const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
     if (lane == 0) status_out[blockIdx.x] = (c != want_crc) ? ZA_I_CRC : (want_len != (uint32_t)n) ? ZA_I_LENGTH : ZA_I_OK;
 }
