@@ -165,10 +165,12 @@ int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t 
  * NUL padding between members).  Four decode paths, picked per stream / member:
  *   1. this engine's indexed members          -> two-pass, lane-parallel inside each member
  *   2. BGZF-style members ('B','C' subfield)  -> one wavefront per member, one launch
- *   3. a member with sync-flush points (block-parallel writers: gzip_ng_threaded, pigz) -> chunk-parallel:
- *      count-only pass sizes and validates the chunks, a marker pass decodes them independently, the 32 KiB
- *      windows are propagated along the chain and the markers resolved
- *   4. anything else -> the sequential wavefront decoder
+ *   3. any other member of at least 64 KiB with enough block boundaries -> chunk-parallel: chunk starts are
+ *      the positions after sync-flush markers (block-parallel writers: gzip_ng_threaded, pigz) and the bit
+ *      offsets where a dynamic block header parses (ordinary gzip files); a count-only pass sizes and
+ *      validates them, a marker pass decodes the chunks independently, the 32 KiB windows are propagated
+ *      along the chain and the markers resolved
+ *   4. anything else (small members, stored / fixed-Huffman only streams) -> the sequential wavefront decoder
  * Paths 1-3 hand over to 4 whenever something does not check out, so errors are always the sequential
  * reader's.  *out_len = bytes produced (also on error), except that ZNGAMD_BUF_ERROR with
  * *out_len > out_cap means "the stream needs *out_len bytes of output" (size known up front). */
