@@ -285,14 +285,20 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     // keep all four compares unconditional: hipcc otherwise sinks the loads into nested
                     // branches, one LDS round trip per level
                     asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-                    uint32_t n0 = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : 4u;
-                    uint32_t n1 = x1 ? (uint32_t)__builtin_ctz(x1) >> 3 : 4u;
-                    uint32_t n2 = x2 ? (uint32_t)__builtin_ctz(x2) >> 3 : 4u;
-                    uint32_t n3 = x3 ? (uint32_t)__builtin_ctz(x3) >> 3 : 4u;
-                    asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3));
-                    const uint32_t hi = n2 < 4u ? 8u + n2 : 12u + n3;
-                    const uint32_t lo = n0 < 4u ? n0 : 4u + n1;
-                    int len = (int)((n0 < 4u || n1 < 4u) ? lo : hi);
+                    // first differing bit of the 128: v_ffbl gives 0xFFFFFFFF for "none", which the saturating adds
+                    // keep as "none"; 4 ffbl + 3 add + min3 + min + shift + min
+                    // (written out: the compiler otherwise turns each "none" into a compare + select)
+                    uint32_t f0, f1, f2, f3, fbit;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(x0));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(x1));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(x2));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(x3));
+                    asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(f1) : "v"(f1));
+                    asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(f2) : "v"(f2));
+                    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(f3) : "v"(f3), "s"(96u));     // 96 is not an inline constant
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(fbit) : "v"(f0), "v"(f1), "v"(f2));
+                    fbit = min(fbit, f3);
+                    int len = (int)min(fbit >> 3, 16u);
                     if (len == 16 && cap > 16 && best_len < cap) {
                         // levels that compare in full: at least 16 equal bytes -- finish the compare the long way
                         while (len < maxlen) {
