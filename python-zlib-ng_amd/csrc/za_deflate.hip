@@ -202,6 +202,8 @@ __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t 
     return __builtin_amdgcn_alignbyte(win32[w + 1], win32[w], idx & 3u);     // win32 has 4 mirrored pad dwords
 }
 
+// FULL: candidates are compared in full (levels with cap 258); otherwise on 16 bytes, winner extended afterwards
+template <bool FULL>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                  const ZaUnit *__restrict__ units,
                                                                  const uint16_t *__restrict__ prev_ws,
@@ -268,12 +270,11 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 uint32_t d = ring[qs];
                 int depth = L.chain;
                 while (depth-- > 0) {
-                    if (d == 0) break;
                     q -= d;
                     qs -= (int)d;
                     qs += qs < 0 ? ZA_RING : 0;
                     const int dist = (int)(P - q);
-                    if (dist > L.max_dist) break;
+                    if (d == 0 || dist > L.max_dist) break;
                     // one LDS round trip per chain step: next link + 5 aligned dwords of the candidate
                     d = ring[qs];
                     const uint32_t idx = q & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     asm("v_min3_u32 %0, %1, %2, %3" : "=v"(fbit) : "v"(f0), "v"(f1), "v"(f2));
                     fbit = min(fbit, f3);
                     int len = (int)min(fbit >> 3, 16u);
-                    if (len == 16 && cap > 16 && best_len < cap) {
+                    if (FULL && len == 16 && cap > 16 && best_len < cap) {
                         // levels that compare in full: at least 16 equal bytes -- finish the compare the long way
                         while (len < maxlen) {
                             const uint32_t x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     best_dist = better ? dist : best_dist;
                     if (best_len >= nice) break;
                 }
-                if (best_len == cap && cap < maxlen) {
+                if (!FULL && best_len == cap && cap < maxlen) {
                     // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
                     const uint32_t qb = P - (uint32_t)best_dist;
                     while (best_len < maxlen) {

@@ -357,7 +357,8 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
               hipLaunchKernelGGL(za_k_chains, dim3(m), dim3(64 * ZA_CH_WAVES), 0, c->stream, d_in, du, c->prev.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
-              hipLaunchKernelGGL(za_k_search, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L); }
+              if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L);
+              else hipLaunchKernelGGL(za_k_search<false>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L); }
         }
         { ProfScope ps(c, ZNGAMD_K_PARSE);
           hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, d_in, in_len, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
