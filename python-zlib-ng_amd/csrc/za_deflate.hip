@@ -317,10 +317,17 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 if (!FULL && best_len == cap && cap < maxlen) {
                     // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
                     const uint32_t qb = P - (uint32_t)best_dist;
-                    while (best_len < maxlen) {
-                        const uint32_t x = za_lds_ld32(win32, qb + (uint32_t)best_len) ^ za_lds_ld32(win32, P + (uint32_t)best_len);
-                        if (x) { best_len += (int)(__builtin_ctz(x) >> 3); break; }
-                        best_len += 4;
+                    for (;;) {                                   // 8 bytes per round; most winners end in the first
+                        const uint32_t o = (uint32_t)best_len;
+                        const uint32_t a0 = za_lds_ld32(win32, qb + o) ^ za_lds_ld32(win32, P + o);
+                        const uint32_t a1 = za_lds_ld32(win32, qb + o + 4u) ^ za_lds_ld32(win32, P + o + 4u);
+                        uint32_t g0, g1;
+                        asm("v_ffbl_b32 %0, %1" : "=v"(g0) : "v"(a0));
+                        asm("v_ffbl_b32 %0, %1" : "=v"(g1) : "v"(a1));
+                        asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(g1) : "v"(g1));
+                        const int nb = (int)min(min(g0, g1) >> 3, 8u);
+                        best_len += nb;
+                        if (nb < 8 || best_len >= maxlen) break;
                     }
                     best_len = best_len < maxlen ? best_len : maxlen;
                 }
