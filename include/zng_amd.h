@@ -122,7 +122,10 @@ int zngamd_deflate_stream(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, i
 /* ---- inflate ---- */
 /* Raw RFC 1951 stream from a host buffer, optional preset dictionary.  Returns ZNGAMD_STREAM_END when
  * a final block ended, ZNGAMD_BUF_ERROR when input ran out or out_cap was reached (distinguish with
- * *out_len == out_cap), ZNGAMD_DATA_ERROR on invalid data.  *in_used = bytes consumed. */
+ * *out_len == out_cap), ZNGAMD_DATA_ERROR on invalid data.  *in_used = bytes consumed.
+ * Complete streams of at least 64 KiB without a dictionary are decoded chunk-parallel (see zngamd_gunzip,
+ * path 3); for those an output buffer that is too small gives ZNGAMD_BUF_ERROR with *out_len > out_cap =
+ * the size the stream needs, and nothing is copied. */
 int zngamd_inflate_raw(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
                        const uint8_t *dict, uint32_t dict_len,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used,

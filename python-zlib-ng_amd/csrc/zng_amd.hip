@@ -557,6 +557,9 @@ static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_le
     return ZNGAMD_OK;
 }
 
+static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
+                               uint64_t *out_len, uint64_t *in_used);
+
 int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used, uint32_t *crc, uint32_t *adler)
 {
@@ -570,8 +573,19 @@ int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const 
     if (dict_len) HIPCHK(c, hipMemcpyAsync(c->st_in.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->st_out.ensure(out_cap + 64));
     ZaInfResult res;
-    r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res);
-    if (r) return r;
+    bool chunked = false;
+    if (dict_len == 0) {
+        // large complete streams: chunk-parallel (sync-flush points / dynamic block headers), see zngamd_gunzip
+        uint64_t clen = 0, cused = 0;
+        const int cr = inflate_chunked_dev(c, c->st_in.p + front, in_len, c->st_out.p, out_cap, &clen, &cused);
+        if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
+        if (cr == ZNGAMD_BUF_ERROR) { *out_len = clen; if (in_used) *in_used = 0; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+        if (cr == 0) { chunked = true; res.status = ZA_I_END; res.out_len = clen; res.in_bits = cused * 8; res.block_bits = 0; res.block_out = 0; }
+    }
+    if (!chunked) {
+        r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res);
+        if (r) return r;
+    }
     *out_len = res.out_len;
     if (in_used) *in_used = (res.in_bits + 7) >> 3;
     if (res.out_len) HIPCHK(c, hipMemcpyAsync(out, c->st_out.p, res.out_len, hipMemcpyDeviceToHost, c->stream));

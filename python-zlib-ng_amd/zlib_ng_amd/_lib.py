@@ -253,6 +253,10 @@ class Context:
                                       C.byref(crc), C.byref(ad))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
+        # BUF_ERROR with a size above the capacity = "this is how much room the stream needs" (nothing was copied)
+        self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
+        if self.last_needed:
+            return r, b"", 0, 0, 1
         return r, _take(out, min(ol.value, out_cap)), used.value, crc.value, ad.value
 
     def inflate_resume(self, data, start_bit, zdict, out_cap):

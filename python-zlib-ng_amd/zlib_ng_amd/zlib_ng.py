@@ -135,6 +135,9 @@ def _inflate_all(body, zdict=b"", hint=0):
     cap = max(hint, 4 * len(body), 1 << 16)
     while True:
         code, out, used, crc, ad = ctx.inflate_raw(body, cap, zdict)
+        if code == _lib.BUF_ERROR and ctx.last_needed > cap:      # the engine already knows the size
+            cap = ctx.last_needed
+            continue
         if code == _lib.BUF_ERROR and len(out) >= cap:
             cap *= 4
             continue
