@@ -205,7 +205,7 @@ int zngamd_profiling(zngamd_ctx *ctx, int on);
 /* accumulated milliseconds and launch counts per kernel class since the last reset */
 int zngamd_kernel_times(zngamd_ctx *ctx, double *ms /*[ZNGAMD_K_COUNT]*/, uint64_t *launches /*[ZNGAMD_K_COUNT]*/, int reset);
 
-/* how many gzip members zngamd_gunzip decoded through each of its paths since the last reset:
+/* how many gzip members zngamd_gunzip (and whole streams zngamd_inflate_raw) decoded through each path since the last reset:
  * ZA-indexed two-pass, BGZF one-launch, chunk-parallel (sync points / block finder), one sequential wavefront */
 #define ZNGAMD_PATH_INDEXED    0
 #define ZNGAMD_PATH_BGZF       1

@@ -428,7 +428,8 @@ int zngamd_gather_dev(zngamd_ctx *c, const void *d_slots, const uint32_t *d_unit
 // shared by the two host-buffer entry points: input already staged at st_in.p
 static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks, int level,
                                std::vector<ZaUnit> &hu, std::vector<uint32_t> &ulen, std::vector<uint32_t> &ucrc,
-                               std::vector<uint8_t> &packed, int max_dist = ZA_WIN)
+                               std::vector<uint8_t> &packed, int max_dist = ZA_WIN,
+                               uint8_t *direct_out = nullptr, uint64_t direct_cap = 0, uint64_t *direct_len = nullptr)
 {
     int r = build_units(c, blocks, n_blocks, in_len, hu);
     if (r) return r;
@@ -441,12 +442,16 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
     uint64_t total = 0;
     r = gather_dev(c, c->st_slots.p, c->st_len.p, n, 0, c->st_out.p, 0, (uint64_t)n * ZNGAMD_SLOT_STRIDE, nullptr, &total, true);
     if (r) return r;
-    ulen.resize(n); ucrc.resize(n); packed.resize(total);
+    // one-shot callers take the packed stream straight into their buffer (no intermediate copy)
+    const bool direct = direct_out != nullptr;
+    if (direct) { *direct_len = total; if (total > direct_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+    ulen.resize(n); ucrc.resize(n);
+    if (!direct) packed.resize(total);
     std::vector<uint32_t> st(n);
     HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-    if (total) HIPCHK(c, hipMemcpyAsync(packed.data(), c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (total) HIPCHK(c, hipMemcpyAsync(direct ? direct_out : packed.data(), c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_OVERFLOW, "unit overflowed its slot");
@@ -495,11 +500,8 @@ int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int
     zngamd_block B; B.off = 0; B.len = (uint32_t)in_len; B.dict_len = 0; B.flags = ZNGAMD_FLAG_FINAL; B.reserved = 0;
     std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
     if (window_bits < 9 || window_bits > 15) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
-    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, packed, 1 << window_bits);
+    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, packed, 1 << window_bits, out, out_cap, out_len);
     if (r) return r;
-    *out_len = packed.size();
-    if (packed.size() > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small");
-    memcpy(out, packed.data(), packed.size());
     if (crc) { uint32_t v = 0; for (size_t u = 0; u < hu.size(); u++) v = u ? zngamd_crc32_combine(v, ucrc[u], hu[u].in_len) : ucrc[u]; *crc = v; }
     if (adler) { uint32_t a = 1; r = checksum_dev(c, c->st_in.p, in_len, nullptr, &a); if (r) return r; *adler = a; }
     return ZNGAMD_OK;
@@ -586,6 +588,7 @@ int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const 
         r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res);
         if (r) return r;
     }
+    c->paths[chunked ? ZNGAMD_PATH_CHUNKED : ZNGAMD_PATH_SEQUENTIAL]++;
     *out_len = res.out_len;
     if (in_used) *in_used = (res.in_bits + 7) >> 3;
     if (res.out_len) HIPCHK(c, hipMemcpyAsync(out, c->st_out.p, res.out_len, hipMemcpyDeviceToHost, c->stream));

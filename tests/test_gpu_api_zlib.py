@@ -269,3 +269,29 @@ def test_compressobj_and_cli(Z, G, fastq, tmp_path):
     out = tmp_path / "back.txt"
     G.main(["-d", "-f", "-o", str(out), str(src) + ".gz"])
     assert out.read_bytes() == data
+
+
+def test_large_one_shot_streams_decode_chunk_parallel():
+    """zlib_ng.decompress of a large zlib / raw / gzip stream: the engine decodes it chunk-parallel, learns the
+    output size from its count pass and asks for exactly that much room (no geometric regrowth)."""
+    import zlib
+    from zlib_ng_amd import _lib, corpus, zlib_ng
+    ctx = _lib.default_context()
+    data = corpus.text(24 << 20, seed=12).tobytes()
+    for wbits, blob in ((15, zlib.compress(data, 6)), (-15, zlib.compressobj(9, zlib.DEFLATED, -15)),
+                        (31, None), (15, zlib_ng.compress(data, 6))):
+        if wbits == -15:
+            blob = blob.compress(data) + blob.flush()
+        if wbits == 31:
+            co = zlib.compressobj(6, zlib.DEFLATED, 31); blob = co.compress(data) + co.flush()
+        ctx.decode_paths(True)
+        assert zlib_ng.decompress(blob, wbits) == data
+        paths = ctx.decode_paths(True)
+        assert paths["chunked"] >= 1, paths
+    # an explicit buffer that is too small: needed size comes back, nothing is copied
+    raw = zlib.compress(data, 6)[2:-4]
+    code, out, used, _, _ = ctx.inflate_raw(raw, 1 << 20)
+    assert code == _lib.BUF_ERROR and out == b"" and ctx.last_needed == len(data)
+    code, out, used, crc, ad = ctx.inflate_raw(raw, len(data))
+    assert code == _lib.STREAM_END and out == data and used == len(raw)
+    assert crc == zlib.crc32(data) and ad == zlib.adler32(data)
