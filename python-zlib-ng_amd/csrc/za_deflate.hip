@@ -419,12 +419,6 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     // tokens leave in groups of four (one 16-byte store): single dword stores from 64 lanes to 64 different
     // lines cost 3-4x their bytes in HBM write traffic
     uint32_t tb0 = 0, tb1 = 0, tb2 = 0;
-    auto emit = [&](uint32_t t) {
-        const uint32_t k = ntok & 3u;
-        if (k == 0) tb0 = t; else if (k == 1) tb1 = t; else if (k == 2) tb2 = t;
-        else *(uint4 *)(tok + (ntok & ~3u)) = make_uint4(tb0, tb1, tb2, t);
-        ntok++;
-    };
     prefetch(s0);
 #pragma unroll 1
     for (int c = 0; c < ZA_SEG / ZA_PCH; c++) {
@@ -447,25 +441,26 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
             const uint8_t *bytes = (const uint8_t *)myd;
             for (int k = cb; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb]) & 0xFF] ^ (crc_r >> 8);
             if (do_parse) {
+                // one token per lane and round, literal and match on one predicated path (no divergent if/else)
                 while (p < ce) {
-                    const uint32_t b = myb[p - cb];
-                    const int len = (int)(b >> 16);
-                    if (len >= ZA_MIN_MATCH &&
-                        !(L.lazy && len < L.lazy && p + 1 < s1 && (int)(myb[p + 1 - cb] >> 16) > len)) {
-                        const int dist = (int)(b & 0xFFFFu);
-                        int lc, ln, le, dc, dn, de;
-                        za_len_sym(len, lc, ln, le);
-                        za_dist_sym(dist, dc, dn, de);
-                        emit(0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1));
-                        atomicAdd(&hist[257 + lc], 1u);
-                        atomicAdd(&hist[288 + dc], 1u);
-                        p += len;
-                    } else {
-                        const uint32_t lit = bytes[p - cb];
-                        emit(lit);
-                        atomicAdd(&hist[lit], 1u);
-                        p++;
-                    }
+                    const uint32_t b = myb[p - cb], bn = myb[p + 1 - cb];      // row has one look-ahead entry
+                    const int len = (int)(b >> 16), nlen = (int)(bn >> 16);
+                    const bool deferred = L.lazy && len < L.lazy && p + 1 < s1 && nlen > len;
+                    const bool is_match = len >= ZA_MIN_MATCH && !deferred;
+                    const uint32_t lit = bytes[p - cb];
+                    const int dist = is_match ? (int)(b & 0xFFFFu) : 1;
+                    int lc, ln, le, dc, dn, de;
+                    za_len_sym(is_match ? len : 3, lc, ln, le);
+                    za_dist_sym(dist, dc, dn, de);
+                    const uint32_t t = is_match ? (0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1)) : lit;
+                    // rotating group of four tokens, stored as one 16-byte write
+                    const uint32_t k = ntok & 3u;
+                    if (k == 3u) *(uint4 *)(tok + (ntok & ~3u)) = make_uint4(tb0, tb1, tb2, t);
+                    tb0 = k == 0u ? t : tb0; tb1 = k == 1u ? t : tb1; tb2 = k == 2u ? t : tb2;
+                    ntok++;
+                    atomicAdd(&hist[is_match ? 257u + (uint32_t)lc : lit], 1u);
+                    if (is_match) atomicAdd(&hist[288 + dc], 1u);
+                    p += is_match ? len : 1;
                 }
             }
         }

@@ -958,6 +958,10 @@ __global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict_
     }
 }
 
+// the count pass gives up on a candidate after this much output without reaching a listed boundary: bounds the work a
+// false candidate can cause; a real block that large (none of the common encoders emits one) sends the member to the
+// sequential decoder
+#define ZA_COUNT_CAP (64ull << 20)
 #define ZA_CHUNK_RING 4096          // symbols of history the marker decode keeps in LDS (8 KiB: 12 waves per CU)
 struct ZaChunkRes { int32_t status; uint32_t max_back; uint64_t bits; uint64_t out_len; };
 struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t end_bit; };   // absolute bit offsets in the deflate stream
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
     uint64_t bits = 0, op = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, 1ull << 40, T, nullptr, scratch, ibuf,
+        status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, ibuf,
                                                     bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == 0 ? 0u : (uint32_t)ZA_WIN, true, nullptr,
                                                     cands, ncands, off * 8ull);
     // bits = position relative to byte `off`; report the absolute end
