@@ -881,13 +881,14 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
 
     // pass A: bit length of my segment
     uint32_t bits = 0;
+    // (literal and match on one predicated path: a literal is "length part only")
     for_each_token([&](uint32_t t) {
-        if (t & 0x80000000u) {
-            int lc, ln, le, dc, dn, de;
-            za_len_sym((int)((t >> 16) & 0xFF) + 3, lc, ln, le);
-            za_dist_sym((int)(t & 0x7FFF) + 1, dc, dn, de);
-            bits += (codes[257 + lc] >> 16) + (uint32_t)ln + (codes[288 + dc] >> 16) + (uint32_t)dn;
-        } else bits += codes[t] >> 16;
+        const bool m = (t & 0x80000000u) != 0u;
+        int lc, ln, le, dc, dn, de;
+        za_len_sym(m ? (int)((t >> 16) & 0xFF) + 3 : 3, lc, ln, le);
+        za_dist_sym(m ? (int)(t & 0x7FFF) + 1 : 1, dc, dn, de);
+        const uint32_t c1 = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], c2 = codes[288 + dc];
+        bits += (c1 >> 16) + (m ? (uint32_t)ln + (c2 >> 16) + (uint32_t)dn : 0u);
     });
     const uint32_t incl = za_wave_incl_scan(bits);
     const uint32_t start = plan.header_bits + incl - bits;
@@ -900,18 +901,14 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     ZaLaneW w;
     w.init(slot32, cap_words, start);
     for_each_token([&](uint32_t t) {
-        if (t & 0x80000000u) {
-            int lc, ln, le, dc, dn, de;
-            za_len_sym((int)((t >> 16) & 0xFF) + 3, lc, ln, le);
-            za_dist_sym((int)(t & 0x7FFF) + 1, dc, dn, de);
-            const uint32_t cl = codes[257 + lc], cd = codes[288 + dc];
-            // length code + extra fit in 20 bits, distance code + extra in 28
-            w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
-            w.put((cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)), (int)(cd >> 16) + dn);
-        } else {
-            const uint32_t c = codes[t];
-            w.put(c & 0xFFFF, (int)(c >> 16));
-        }
+        const bool m = (t & 0x80000000u) != 0u;
+        int lc, ln, le, dc, dn, de;
+        za_len_sym(m ? (int)((t >> 16) & 0xFF) + 3 : 3, lc, ln, le);
+        za_dist_sym(m ? (int)(t & 0x7FFF) + 1 : 1, dc, dn, de);
+        const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
+        // literal / length code + extra fit in 20 bits, distance code + extra in 28 (0 bits for a literal)
+        w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
+        w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : 0u, m ? (int)(cd >> 16) + dn : 0);
     });
     w.finish();
     ovf = w.ovf;
