@@ -32,7 +32,7 @@
 #define ZA_CH_STAGE 320u                      // pending-entry ring per class: 63 left over + one tile of 256; cursors are kept mod 320
 #define ZA_CH_SUB   (ZA_HASH_BITS - 2)        // bits of the per-wave table index
 
-__device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, uint32_t rd, int m, int pmin,
+__device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, unsigned long long *gmask, uint32_t rd, int m, int pmin,
                                                 uint16_t *__restrict__ prevdist, int dict_len)
 {
     const int lane = za_lane();
@@ -57,15 +57,15 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
     const uint32_t rep = valid ? (uint32_t)vhead[h] : (uint32_t)lane;
     bool last = true;                                // highest lane of my bucket: leaves its position in the table
     if (__ballot(rep != (uint32_t)lane) != 0ull) {
-        // Some bucket is hit twice in this tile: order its lanes exactly (bit-slice match-any over the 6 bits of
-        // the group number) and link later lanes to the nearest earlier one.
-        unsigned long long eq = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 6; b++) {
-            const bool bit = (rep >> b) & 1u;
-            const unsigned long long B = __ballot(bit);
-            eq &= bit ? B : ~B;
-        }
+        // Some bucket is hit twice in this tile: order its lanes exactly and link later lanes to the nearest
+        // earlier one.  The lanes of a group collect their lane bits in a 64-bit LDS word named by the group
+        // number (three LDS operations instead of a 6-ballot bit-slice match-any: this kernel is VALU-bound).
+        volatile unsigned long long *vg = gmask;
+        vg[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) atomicOr(&gmask[rep], 1ull << lane);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long eq = valid ? vg[rep] : 0ull;
         const unsigned long long lower = eq & ((1ull << lane) - 1ull);
         const unsigned long long higher = (eq >> lane) >> 1;
         const int j = lower ? 63 - __builtin_clzll(lower) : lane;
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
 {
     __shared__ uint16_t head_all[ZA_CH_WAVES][1 << ZA_CH_SUB];
     __shared__ uint32_t ring_all[ZA_CH_WAVES][ZA_CH_STAGE];
+    __shared__ unsigned long long gmask_all[ZA_CH_WAVES][64];   // scratch of the dense insert
     __shared__ uint32_t cnt[2][ZA_CH_WAVES][ZA_CH_WAVES];    // [tile parity][producer wave][class] entries of a tile
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
@@ -111,10 +112,10 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     uint32_t par = 0;
     auto consume = [&](uint32_t upto, bool flush) {
         while (upto - rd >= 64u) {
-            za_chains_dense(head, ring_all[wave], rslot, 64, pmin, prevdist, dict_len);
+            za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, 64, pmin, prevdist, dict_len);
             rd += 64u; rslot += 64u; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
         }
-        if (flush && upto != rd) za_chains_dense(head, ring_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len);
+        if (flush && upto != rd) za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len);
     };
     auto do_tile = [&](int tbase, const uint2 v) {
         // ---- classify: class = top two hash bits; rank = my place among this wave's entries of my class
