@@ -13,6 +13,8 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row.get("Kernel_Name", "")
+            if k.startswith("void "):            # template instantiations are printed with their return type
+                k = k[5:]
             if not k.startswith("za_k_"):
                 continue
             k = k.split("(")[0]
