@@ -265,6 +265,16 @@ def main():
                            "library": "zlib " + zlib.ZLIB_RUNTIME_VERSION,
                            "compress_MBps": round(sample / tzc / 1e6, 1), "decompress_MBps": round(sample / tzd / 1e6, 1),
                            "ratio": round(sample / sum(map(len, comp)), 4)}
+        # a real zlib-ng on this host would be the true reference CPU path; say plainly if there is none
+        try:
+            from zlib_ng import zlib_ng as _real                              # the reference's wheel, if the box has one
+            zc_ng = lambda b: _real.compress(mv[b * BLOCK:(b + 1) * BLOCK], args.level, -15)
+            with ThreadPoolExecutor(cores) as ex:
+                t = time.perf_counter(); comp = list(ex.map(zc_ng, range(nb))); tn = time.perf_counter() - t
+            out["cpu_zlib_ng"] = {"available": True, "compress_MBps": round(sample / tn / 1e6, 1), "cores": cores,
+                                  "note": "independent blocks, no dictionary"}
+        except Exception:
+            out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
     if exchange:
         # the re-assembled stream must be the concatenation of the rank slices: check this rank's slice in place
         assert gathered["total"] >= comp_total.value
