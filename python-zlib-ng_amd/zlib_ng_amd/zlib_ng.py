@@ -298,7 +298,7 @@ _ParallelCompress.__module__ = "zlib_ng"
 class _Compress:
     """Incremental compressor with zlib.compressobj's surface (compress / flush).  Input is collected
     and handed to the engine in large dictionary-chained batches; every batch ends on a sync-flush
-    boundary, so the concatenation is one valid deflate stream.  copy() is not supported."""
+    boundary, so the concatenation is one valid deflate stream."""
 
     _BATCH = 8 << 20
 
@@ -370,7 +370,19 @@ class _Compress:
             return self._emit(mode == Z_FINISH)
 
     def copy(self):
-        raise NotImplementedError("copy() of a compression object is not supported by the GPU engine yet")
+        """zlib_Compress_copy_impl (zlib_ngmodule.c:790-850): an independent compressor in the same state.  All stream
+        state lives here (pending input, 32 KiB dictionary tail, running checksums), so the copy is exact."""
+        with self._lock:
+            if self._finished:
+                raise ValueError("Inconsistent stream state")
+            o = _Compress.__new__(_Compress)
+            o._kind, o._wb, o._level = self._kind, self._wb, self._level
+            o._pending = bytearray(self._pending)
+            o._tail = self._tail
+            o._started, o._finished = self._started, self._finished
+            o._crc, o._adler, o._size = self._crc, self._adler, self._size
+            o._lock = _threading.Lock()
+            return o
 
     __copy__ = copy
 

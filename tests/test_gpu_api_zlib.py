@@ -295,3 +295,32 @@ def test_large_one_shot_streams_decode_chunk_parallel():
     code, out, used, crc, ad = ctx.inflate_raw(raw, len(data))
     assert code == _lib.STREAM_END and out == data and used == len(raw)
     assert crc == zlib.crc32(data) and ad == zlib.adler32(data)
+
+
+def test_compress_copy():
+    """After the reference's test_compresscopy / test_badcompresscopy (tests/test_zlib_compliance.py:700-740)."""
+    import copy
+    import zlib
+    from zlib_ng_amd import zlib_ng
+    data0 = b"To be, or not to be, that is the question:\n" * 4000
+    data1 = data0.swapcase()
+    for func in (lambda c: c.copy(), copy.copy, copy.deepcopy):
+        c0 = zlib_ng.compressobj(zlib_ng.Z_BEST_COMPRESSION)
+        bufs0 = [c0.compress(data0)]
+        c1 = func(c0)
+        bufs1 = bufs0[:]
+        bufs0 += [c0.compress(data0), c0.flush()]
+        bufs1 += [c1.compress(data1), c1.flush()]
+        assert zlib.decompress(b"".join(bufs0)) == data0 + data0
+        assert zlib.decompress(b"".join(bufs1)) == data0 + data1
+    # a copy taken after a sync flush continues the same stream with its own dictionary tail
+    c0 = zlib_ng.compressobj(6, zlib_ng.DEFLATED, 31)
+    head = c0.compress(data0) + c0.flush(zlib_ng.Z_SYNC_FLUSH)
+    c1 = c0.copy()
+    a = head + c0.compress(data1) + c0.flush()
+    b = head + c1.compress(data0) + c1.flush()
+    assert zlib.decompress(a, 31) == data0 + data1 and zlib.decompress(b, 31) == data0 + data0
+    c = zlib_ng.compressobj()
+    c.compress(data0); c.flush()
+    with pytest.raises(ValueError):
+        c.copy()
