@@ -180,6 +180,15 @@ int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t 
 int zngamd_gunzip(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
                   uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members);
 
+/* The same reader for a WINDOW of a longer stream (bounded-memory readers: GzipReader_read_into_buffer keeps a fixed
+ * input buffer, zlib_ngmodule.c:2426-2450): every member that is complete inside the window is decoded; an incomplete
+ * last member (cut header, deflate data or trailer) is left alone.  Returns ZNGAMD_OK with *in_consumed = offset of the
+ * first byte not consumed: feed the stream from there next time, with more input behind it.  *in_consumed == 0 means the
+ * window holds no complete member yet.  Real errors are reported as by zngamd_gunzip. */
+int zngamd_gunzip_partial(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                          uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members,
+                          uint64_t *in_consumed);
+
 /* Build one indexed gzip member stream (one member per block, FINAL blocks, 'ZA' index) from a host
  * buffer.  level as above; block_size <= 128 KiB. */
 int zngamd_gzip_members(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, uint32_t block_size,

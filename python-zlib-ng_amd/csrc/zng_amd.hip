@@ -560,7 +560,7 @@ static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_le
 }
 
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
-                               uint64_t *out_len, uint64_t *in_used);
+                               uint64_t *out_len, uint64_t *in_used, bool *cut = nullptr);
 
 int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used, uint32_t *crc, uint32_t *adler)
@@ -628,7 +628,10 @@ int zngamd_inflate_resume(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uin
 }
 
 // ---- two-pass reader for indexed members -----------------------------------------------------
-static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out)
+// allow_tail: the chain may stop before the end of the buffer (what follows is an incomplete member, or not an indexed
+// one); *covered = bytes the chain spans.
+static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out,
+                            bool allow_tail = false, uint64_t *covered = nullptr)
 {
     hm.clear(); *total_out = 0;
     if (in_len < ZA_MEMBER_HDR + 8) return ZNGAMD_E_ARG;
@@ -653,14 +656,15 @@ static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
     size_t i = 0;
     while (pos < in_len) {
         while (i < hc.size() && hc[i].off < pos) i++;
-        if (i == hc.size() || hc[i].off != pos) return ZNGAMD_E_ARG;
+        if (i == hc.size() || hc[i].off != pos) { if (allow_tail && !hm.empty()) break; return ZNGAMD_E_ARG; }
         ZaMember m;
         m.in_off = pos + ZA_MEMBER_HDR; m.in_len = hc[i].size - ZA_MEMBER_HDR - 8; m.out_off = outp;
         m.out_len = hc[i].isize; m.crc = 0; m.index_off = ZA_MEMBER_HDR - 28; m.nseg = (hc[i].isize + ZA_SEG - 1) / ZA_SEG;
         hm.push_back(m);
         pos += hc[i].size; outp += hc[i].isize;
     }
-    if (pos != in_len) return ZNGAMD_E_ARG;
+    if (pos != in_len && !allow_tail) return ZNGAMD_E_ARG;
+    if (covered) *covered = pos;
     *total_out = outp;
     return ZNGAMD_OK;
 }
@@ -764,8 +768,9 @@ static int chunk_bail(int why)
 // the caller), 1 when this path does not apply or anything looked odd (caller uses the sequential decoder, which
 // also produces the exact error), <0 on engine errors, ZNGAMD_BUF_ERROR with *out_len = needed size when the
 // output does not fit.
+// *cut (optional) is set when the chain of blocks runs into the end of the input: the stream is longer than the buffer.
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
-                               uint64_t *out_len, uint64_t *in_used)
+                               uint64_t *out_len, uint64_t *in_used, bool *cut)
 {
     if (avail < (1u << 16) || avail > (1ull << 36)) return chunk_bail(1);
     const uint32_t max_c = (uint32_t)std::min<uint64_t>(avail / 8 + 64, 1u << 24);
@@ -824,6 +829,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         size_t i = 0;
         for (uint32_t guard = 0; guard <= n; guard++) {
             const ZaChunkRes &r = res[i];
+            if (r.status == ZA_I_INPUT && cut) *cut = true;
             if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return chunk_bail(4);
             ZaChunk b; b.in_bit = cand[i]; b.out_off = acc; b.out_len = r.out_len; b.end_bit = r.bits;
             blocks.push_back(b);
@@ -877,29 +883,31 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
 
 // BGZF hop: every member must be `1f 8b 08 04`, carry a 'B','C' subfield of length 2 (block size - 1) and
 // tile the buffer exactly; anything else makes the caller use the general reader.
-static bool hop_bgzf(const uint8_t *in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out)
+static bool hop_bgzf(const uint8_t *in, uint64_t in_len, std::vector<ZaMember> &hm, uint64_t *total_out,
+                     bool allow_tail = false, uint64_t *covered = nullptr)
 {
     auto le16 = [&](uint64_t o) { return (uint32_t)in[o] | ((uint32_t)in[o + 1] << 8); };
     auto le32 = [&](uint64_t o) { return (uint32_t)in[o] | ((uint32_t)in[o + 1] << 8) | ((uint32_t)in[o + 2] << 16) | ((uint32_t)in[o + 3] << 24); };
     uint64_t pos = 0, outp = 0;
     hm.clear();
     while (pos < in_len) {
-        if (in_len - pos < 12 + 6 + 8) return false;
-        if (in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8 || in[pos + 3] != 4) return false;
+        if (in_len - pos < 12 + 6 + 8) { if (allow_tail && !hm.empty()) break; return false; }
+        if (in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8 || in[pos + 3] != 4) { if (allow_tail && !hm.empty()) break; return false; }
         const uint64_t xlen = le16(pos + 10);
         uint64_t cur = pos + 12;
         const uint64_t end = cur + xlen;
-        if (end + 8 > in_len) return false;
+        if (end + 8 > in_len) { if (allow_tail && !hm.empty()) break; return false; }
         long bsize = -1;
+        bool bad = false;
         while (cur + 4 <= end) {
             const uint32_t sl = le16(cur + 2);
-            if (cur + 4 + sl > end) return false;
+            if (cur + 4 + sl > end) { bad = true; break; }
             if (in[cur] == 'B' && in[cur + 1] == 'C' && sl == 2) bsize = (long)le16(cur + 4);
             cur += 4 + sl;
         }
-        if (bsize < 0) return false;
+        if (bad || bsize < 0) { if (allow_tail && !hm.empty()) break; return false; }
         const uint64_t msize = (uint64_t)bsize + 1;
-        if (msize < (end - pos) + 8 || pos + msize > in_len) return false;
+        if (msize < (end - pos) + 8 || pos + msize > in_len) { if (allow_tail && !hm.empty()) break; return false; }
         ZaMember m;
         m.in_off = end; m.in_len = msize - (end - pos) - 8; m.out_off = outp;
         m.out_len = le32(pos + msize - 4); m.crc = le32(pos + msize - 8); m.index_off = 0; m.nseg = 0;
@@ -907,14 +915,17 @@ static bool hop_bgzf(const uint8_t *in, uint64_t in_len, std::vector<ZaMember> &
         pos += msize; outp += m.out_len;
     }
     *total_out = outp;
-    return pos == in_len;
+    if (covered) *covered = pos;
+    return pos == in_len || (allow_tail && !hm.empty());
 }
 
-int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
+// partial: more input may follow -- complete members are decoded, an incomplete last one is left alone and
+// *in_consumed tells where it starts (ZNGAMD_OK; nothing consumed = the window holds no complete member yet).
+static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool partial, uint8_t *out, uint64_t out_cap,
+                       uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
 {
-    if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
-    std::lock_guard<std::mutex> g(c->mu);
     *out_len = 0;
+    *in_consumed = 0;
     if (n_members) *n_members = 0;
     int r = stage_in(c, in, in_len);
     if (r) return r;
@@ -927,7 +938,8 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
         uint64_t doff; bool za; uint32_t hl;
         if (in_len >= ZA_MEMBER_HDR + 8 && parse_gzip_header(in, in_len, 0, &doff, &za, &hl) == ZNGAMD_OK && za) {
             std::vector<ZaMember> hm; uint64_t total = 0;
-            if (scan_members_dev(c, c->st_in.p, in_len, hm, &total) == ZNGAMD_OK) {
+            uint64_t covered = 0;
+            if (scan_members_dev(c, c->st_in.p, in_len, hm, &total, partial, &covered) == ZNGAMD_OK) {
                 if (total > out_cap) { *out_len = total; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
                 HIPCHK(c, c->members.ensure(hm.size())); HIPCHK(c, c->mstatus.ensure(hm.size()));
                 HIPCHK(c, hipMemcpyAsync(c->members.p, hm.data(), hm.size() * sizeof(ZaMember), hipMemcpyHostToDevice, c->stream));
@@ -944,6 +956,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
                     *out_len = total;
                     if (n_members) *n_members = (uint32_t)hm.size();
                     c->paths[ZNGAMD_PATH_INDEXED] += hm.size();
+                    *in_consumed = covered;          // == in_len unless partial
                     return ZNGAMD_OK;
                 }
                 // anything unexpected (foreign 'ZA' field, stored blocks, corruption): the sequential
@@ -955,7 +968,8 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
     // header hop over the host copy; all members are then decoded in one launch, one wavefront each.
     {
         std::vector<ZaMember> hm; uint64_t total = 0;
-        if (hop_bgzf(in, in_len, hm, &total) && hm.size() > 1) {
+        uint64_t covered = 0;
+        if (hop_bgzf(in, in_len, hm, &total, partial, &covered) && hm.size() > 1) {
             if (total > out_cap) { *out_len = total; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
             const uint32_t n = (uint32_t)hm.size();
             HIPCHK(c, c->members.ensure(n)); HIPCHK(c, c->mstatus.ensure(n));
@@ -975,7 +989,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
             *out_len = produced;
             if (n_members) *n_members = good;
             c->paths[ZNGAMD_PATH_BGZF] += good;
-            if (good == n) return ZNGAMD_OK;
+            if (good == n) { *in_consumed = covered; return ZNGAMD_OK; }
             const int code = st[good];
             if (code == ZA_I_CRC) { c->err = "CRC check failed"; return ZNGAMD_E_GZ_CRC; }
             if (code == ZA_I_LENGTH) { c->err = "Incorrect length of data produced"; return ZNGAMD_E_GZ_LENGTH; }
@@ -988,6 +1002,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
         if (pos == in_len) break;
         uint64_t doff = 0; bool za = false; uint32_t hl = 0;
         r = parse_gzip_header(in, in_len, pos, &doff, &za, &hl);
+        if (r == ZNGAMD_E_GZ_TRUNC && partial) break;                     // incomplete header: wait for more input
         if (r) { ret = r; break; }
         if (hl) {
             uint32_t hc = 0;
@@ -1000,15 +1015,18 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
         bool chunked = false;
         {   // chunk-parallel decode where the stream offers enough block boundaries, else one wavefront
             uint64_t clen = 0, cused = 0;
-            const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused);
+            bool cut = false;
+            const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused, &cut);
             if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
             if (cr == ZNGAMD_BUF_ERROR) { *out_len = op + clen; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
             if (cr == 0) { chunked = true; res.status = ZA_I_END; res.out_len = clen; res.in_bits = cused * 8; res.block_bits = 0; res.block_out = 0; }
+            else if (cut && partial) break;                               // the member runs past the window: wait for more input
             else {
                 r = inflate_serial_dev(c, c->st_in.p + doff, in_len - doff, nullptr, 0, c->st_out.p + op, out_cap - op, &res);
                 if (r) return r;
             }
         }
+        if (res.status == ZA_I_INPUT && partial) break;
         if (res.status != ZA_I_END) {
             *out_len = op + res.out_len;
             if (res.status == ZA_I_OUTFULL) ret = ZNGAMD_BUF_ERROR;
@@ -1023,7 +1041,7 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
         r = checksum_dev(c, c->st_out.p + op, res.out_len, &crc, nullptr);
         if (r) return r;
         uint64_t cur = doff + ((res.in_bits + 7) >> 3);
-        if (in_len - cur < 8) { ret = ZNGAMD_E_GZ_TRUNC; break; }
+        if (in_len - cur < 8) { if (!partial) ret = ZNGAMD_E_GZ_TRUNC; break; }
         const uint32_t tc = in[cur] | (in[cur + 1] << 8) | (in[cur + 2] << 16) | ((uint32_t)in[cur + 3] << 24);
         const uint32_t tl = in[cur + 4] | (in[cur + 5] << 8) | (in[cur + 6] << 16) | ((uint32_t)in[cur + 7] << 24);
         if (tc != crc) { ret = ZNGAMD_E_GZ_CRC; char b[96]; snprintf(b, sizeof b, "CRC check failed %u != %u", tc, crc); c->err = b; break; }
@@ -1035,8 +1053,25 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
     }
     if (op) HIPCHK(c, hipMemcpy(out, c->st_out.p, op, hipMemcpyDeviceToHost));
     *out_len = op;
+    *in_consumed = pos;
     if (n_members) *n_members = members;
     return ret;
+}
+
+int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
+{
+    if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    uint64_t used = 0;
+    return gunzip_impl(c, in, in_len, false, out, out_cap, out_len, n_members, &used);
+}
+
+int zngamd_gunzip_partial(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                          uint32_t *n_members, uint64_t *in_consumed)
+{
+    if (!c || (!in && in_len) || (!out && out_cap) || !out_len || !in_consumed) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    return gunzip_impl(c, in, in_len, true, out, out_cap, out_len, n_members, in_consumed);
 }
 
 // ---- indexed member writer ---------------------------------------------------------------------

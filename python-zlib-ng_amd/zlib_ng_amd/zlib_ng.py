@@ -14,6 +14,7 @@ block-resumable decoding on the sequential wavefront decoder).
 """
 import gzip as _gzip
 import io as _io
+import os as _os
 import struct as _struct
 import threading as _threading
 
@@ -646,75 +647,134 @@ _GZ_ERR = {
 
 
 class _GzipReader:
-    """Multi-member gzip reader with the surface of the reference's C type.  The compressed input is taken
-    whole (bytes-like, or everything `fp` yields), decoded on the GPU -- two-pass for indexed members, the
-    sequential wavefront decoder otherwise -- and served from memory; an error found after N good bytes is
-    raised when the reader reaches byte N, as the streaming reference does."""
+    """Multi-member gzip reader with the surface of the reference's C type (zlib_ngmodule.c:2215-2930).
+    The compressed input is read in windows (ZNGAMD_READ_WINDOW bytes, default 64 MiB; a bytes-like `fp` is one
+    window).  Every window goes to the GPU engine, which decodes all members that are complete inside it -- two-pass
+    for indexed members, one launch for BGZF members, chunk-parallel for ordinary ones -- and says where the first
+    incomplete member starts; that tail is kept and the next window appended.  A member larger than the window makes
+    the window grow until it fits.  An error found after N good bytes is raised when the reader reaches byte N, as
+    the streaming reference does."""
 
     def __init__(self, fp, /, buffersize=32 * 1024):
         if buffersize < 1:
             raise ValueError(f"buffersize must be at least 1, got {buffersize}")
         self._fp = fp
-        self._data = None
-        self._error = None
-        self._pos = 0
-        self._size = -1
+        self._is_file = hasattr(fp, "read")
+        self._start = None
+        if self._is_file:
+            try:
+                self._start = fp.tell()
+            except (AttributeError, OSError, ValueError):
+                self._start = None
         self._closed = False
         self._last_mtime = 0
         self._lock = _threading.Lock()
+        self._size = -1
+        self._reset()
 
-    # -- decoding, once
-    def _load(self):
-        if self._data is not None:
-            return
-        raw = self._fp.read() if hasattr(self._fp, "read") else bytes(_view(self._fp))
-        raw = bytes(raw)
-        if len(raw) >= 8:
-            self._last_mtime = _struct.unpack_from("<I", raw, 4)[0]
-        if not raw:
-            self._data = b""
-            return
-        if raw[:2] != b"\x1f\x8b" and len(raw) >= 2:
-            self._data, self._error = b"", BadGzipFile(f"Not a gzipped file ({raw[:2]!r})")
-            return
-        ctx = _ctx()
-        isize = _struct.unpack_from("<I", raw, len(raw) - 4)[0] if len(raw) >= 18 else 0
-        cap = max(1 << 16, 4 * len(raw), isize + 64)
-        while True:
-            code, out, nm = ctx.gunzip(raw, cap)
-            if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
-                cap = max(cap * 4, ctx.last_needed + 64)
-                continue
-            break
-        self._data = out
-        if code == _lib.OK:
-            return
+    def _reset(self):
+        self._window = max(1 << 16, int(_os.environ.get("ZNGAMD_READ_WINDOW", 64 << 20)))
+        self._buf = b""          # decoded, not yet handed out
+        self._boff = 0
+        self._pos = 0            # position in the decompressed stream
+        self._carry = b""        # compressed bytes of a member that was not complete yet
+        self._in_eof = False
+        self._done = False       # nothing more to decode
+        self._error = None       # raised once the buffered good bytes are gone
+        self._first = True
+
+    # -- compressed input, one window at a time
+    def _read_window(self):
+        if not self._is_file:
+            self._in_eof = True
+            return bytes(_view(self._fp)) if self._first else b""
+        parts, got = [], 0
+        while got < self._window:
+            chunk = self._fp.read(self._window - got)
+            if not chunk:
+                self._in_eof = True
+                break
+            parts.append(bytes(chunk))
+            got += len(chunk)
+        return b"".join(parts)
+
+    def _set_error(self, code, data, ctx):
         msg = ctx.err()
         if code == _lib.E_GZ_MAGIC:
             # locate the offending bytes the way the reference reports them
-            self._error = BadGzipFile("Not a gzipped file (b'??')")
-            self._error = _magic_error(raw, ctx) or self._error
+            self._error = _magic_error(data, ctx) or BadGzipFile("Not a gzipped file (b'??')")
         elif code in _GZ_ERR:
             self._error = _GZ_ERR[code](msg)
         else:
             self._error = _zerr(code if code in _MSG else _lib.DATA_ERROR, "while decompressing data")
 
+    def _fill(self):
+        """Decode until some output is buffered, the stream ends, or an error is pending."""
+        ctx = _ctx()
+        while not self._done and self._boff >= len(self._buf):
+            new = b"" if self._in_eof else self._read_window()
+            data = self._carry + new if self._carry else new
+            self._carry = b""
+            if self._first:
+                self._first = False
+                if len(data) >= 8:
+                    self._last_mtime = _struct.unpack_from("<I", data, 4)[0]
+                if len(data) >= 2 and data[:2] != b"\x1f\x8b":
+                    self._buf, self._boff, self._done = b"", 0, True
+                    self._error = BadGzipFile(f"Not a gzipped file ({data[:2]!r})")
+                    return
+            if not data:
+                self._done = True
+                return
+            final = self._in_eof
+            isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
+            cap = max(1 << 16, 4 * len(data), isize + 64)
+            while True:
+                if final:
+                    code, out, nm = ctx.gunzip(data, cap)
+                    used = len(data)
+                else:
+                    code, out, nm, used = ctx.gunzip_partial(data, cap)
+                if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
+                    cap = max(cap * 4, ctx.last_needed + 64)
+                    continue
+                break
+            if code != _lib.OK:
+                self._buf, self._boff, self._done = out, 0, True
+                self._set_error(code, data, ctx)
+                return
+            if final:
+                self._buf, self._boff, self._done = out, 0, True
+                return
+            if used == 0:
+                # not even one complete member in the window: take a larger one
+                self._carry = data
+                self._window *= 2
+                continue
+            self._buf, self._boff = out, 0
+            self._carry = data[used:]
+
     def _check(self):
         if self._closed:
             raise ValueError("I/O operation on closed file.")
 
+    def _avail(self):
+        if self._boff >= len(self._buf) and not self._done:
+            self._fill()
+        return len(self._buf) - self._boff
+
     def readinto(self, b, /):
         self._check()
         with self._lock:
-            self._load()
             mv = _view(b)
-            n = min(mv.nbytes, len(self._data) - self._pos)
+            n = min(mv.nbytes, self._avail())
             if n <= 0:
                 if self._error is not None:
                     raise self._error
                 self._size = self._pos
                 return 0
-            mv[:n] = self._data[self._pos:self._pos + n]
+            mv[:n] = self._buf[self._boff:self._boff + n]
+            self._boff += n
             self._pos += n
             return n
 
@@ -729,29 +789,54 @@ class _GzipReader:
     def readall(self):
         self._check()
         with self._lock:
-            self._load()
+            parts = []
+            while self._avail() > 0:
+                parts.append(self._buf[self._boff:] if self._boff else self._buf)
+                self._pos += len(self._buf) - self._boff
+                self._boff = len(self._buf)
             if self._error is not None:
                 raise self._error
-            out = self._data[self._pos:]
-            self._pos = len(self._data)
             self._size = self._pos
-            return out
+            return parts[0] if len(parts) == 1 else b"".join(parts)
+
+    def _skip_to(self, target):
+        while self._pos < target and self._avail() > 0:
+            n = min(target - self._pos, len(self._buf) - self._boff)
+            self._boff += n
+            self._pos += n
 
     def seek(self, offset, whence=0, /):
         self._check()
         with self._lock:
-            self._load()
             if whence == 0:
-                pos = offset
+                target = offset
             elif whence == 1:
-                pos = self._pos + offset
+                target = self._pos + offset
             elif whence == 2:
+                # the size is only known at the end of the stream
+                self._skip_to(1 << 62)
                 if self._error is not None:
                     raise self._error
-                pos = len(self._data) + offset
+                self._size = self._pos
+                target = self._size + offset
             else:
                 raise ValueError(f"Invalid format for whence: {whence}")
-            self._pos = max(0, min(pos, len(self._data)))
+            target = max(0, target)
+            if target < self._pos:
+                # backwards: decode again from the start (what the reference's reader does as well)
+                back = self._pos - target
+                if back <= self._boff:
+                    self._boff -= back
+                    self._pos = target
+                    return self._pos
+                if self._is_file:
+                    if self._start is None:
+                        raise _io.UnsupportedOperation("underlying stream is not seekable")
+                    self._fp.seek(self._start)
+                size = self._size
+                self._reset()
+                self._size = size
+            self._skip_to(target)
             return self._pos
 
     def tell(self):

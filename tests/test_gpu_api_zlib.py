@@ -324,3 +324,57 @@ def test_compress_copy():
     c.compress(data0); c.flush()
     with pytest.raises(ValueError):
         c.copy()
+
+
+def test_gzip_reader_streams_in_windows(monkeypatch, fastq):
+    """_GzipReader reads the compressed file in windows (bounded memory): members complete inside a window are
+    decoded, the incomplete tail is carried over; a member larger than the window makes the window grow.  Small
+    windows force every case; results are the stdlib's."""
+    import gzip
+    import io
+    from conftest import GOLDEN
+    from zlib_ng_amd import _lib, corpus, gzip_ng, zlib_ng
+    ctx = _lib.default_context()
+    monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(128 << 10))
+    text = corpus.text(6 << 20, seed=21).tobytes()
+    blobs = {
+        "bgzf fixture": open(os.path.join(GOLDEN, "test.fastq.bgzip.gz"), "rb").read(),
+        "two members": open(os.path.join(GOLDEN, "concatenated.fastq.gz"), "rb").read(),
+        "indexed members": ctx.gzip_members(text, 131072, 6),
+        "one big member": gzip.compress(text, 6),
+        "mixed": gzip.compress(text[:300000], 1) + bytes(7) + ctx.gzip_members(text[:1 << 20], 65536, 6) + gzip.compress(text[:70000], 9),
+    }
+    for name, blob in blobs.items():
+        want = gzip.decompress(blob)
+        r = zlib_ng._GzipReader(io.BytesIO(blob))
+        got = bytearray()
+        while True:
+            piece = r.read(1000003)
+            if not piece:
+                break
+            got += piece
+        assert bytes(got) == want, name
+        assert r.tell() == len(want)
+        # seeking: backwards re-decodes from the start, whence=2 runs to the end
+        assert r.seek(12345) == 12345 and r.read(100) == want[12345:12445]
+        assert r.seek(-50, 2) == len(want) - 50 and r.read() == want[-50:]
+        assert r.seek(len(want) // 2) == len(want) // 2 and r.read(64) == want[len(want) // 2:len(want) // 2 + 64]
+        assert zlib_ng._GzipReader(io.BytesIO(blob)).readall() == want
+        with gzip_ng.open(io.BytesIO(blob), "rb") as f:
+            assert f.read() == want
+    # corruption in a late member: everything before it is served, then the error
+    blob = bytearray(blobs["indexed members"])
+    blob[len(blob) - 20000] ^= 0x10
+    r = zlib_ng._GzipReader(io.BytesIO(bytes(blob)))
+    got = bytearray()
+    with pytest.raises((gzip.BadGzipFile, zlib_ng.error, EOFError)):
+        while True:
+            piece = r.read(1 << 20)
+            if not piece:
+                break
+            got += piece
+    assert len(got) >= len(text) - (256 << 10) and bytes(got) == text[:len(got)]
+    # truncated file: EOFError after the good bytes
+    r = zlib_ng._GzipReader(io.BytesIO(blobs["one big member"][:-5000]))
+    with pytest.raises(EOFError):
+        r.readall()
