@@ -22,7 +22,7 @@
 // ------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per unit.  The 13-bit bucket space is split into 4 classes by the top 2 hash
 // bits; wave w owns class w and a private 2048-entry u16 head table (4 x 4 KiB of LDS; with the rings
-// 23 KiB per workgroup: seven per CU -- the dense insert is a chain of dependent LDS round trips, and the
+// 23 KiB per workgroup: six per CU -- the dense insert is a chain of dependent LDS round trips, and the
 // kernel scales almost linearly with resident waves).  Positions are
 // hashed once, 256 per tile (64 per wave), and handed to the owning wave through a per-class LDS ring in
 // position order (per-wave class counts -> offsets -> ranks: two barriers per tile).  Whenever 64 entries
