@@ -189,6 +189,24 @@ int zngamd_gunzip_partial(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
                           uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members,
                           uint64_t *in_consumed);
 
+/* The windowed reader with state: also a member LARGER than the window is decoded, block-wise.  *st starts zeroed.
+ * At a member boundary this is zngamd_gunzip_partial; when not even the first member of the window is complete, the
+ * complete deflate blocks of that member are decoded (chunk-parallel) and handed out, and *st remembers the bit offset
+ * of the next block header, the last 32 KiB of output (the history that block may reference), the CRC-32 and length so
+ * far.  The next call continues there: `in` must start at byte *in_consumed of the previous input.  last != 0: no more
+ * input exists (a stream that does not end is an error).  *in_consumed == 0 with ZNGAMD_OK: supply a larger window. */
+typedef struct zngamd_gz_state {
+    uint32_t in_member;      /* 0 at a member boundary, 1 inside a member's deflate data */
+    uint32_t start_bit;      /* bit (0..7) of in[0] where the next block header starts */
+    uint32_t crc;            /* CRC-32 of the member's output so far */
+    uint32_t window_len;     /* valid bytes in window[] */
+    uint64_t out_total;      /* bytes the member has produced so far */
+    uint8_t  window[32768];  /* the last window_len bytes of the member's output */
+} zngamd_gz_state;
+int zngamd_gunzip_stream(zngamd_ctx *ctx, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, int last,
+                         uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members,
+                         uint64_t *in_consumed);
+
 /* Build one indexed gzip member stream (one member per block, FINAL blocks, 'ZA' index) from a host
  * buffer.  level as above; block_size <= 128 KiB. */
 int zngamd_gzip_members(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, uint32_t block_size,

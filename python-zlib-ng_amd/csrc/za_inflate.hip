@@ -968,7 +968,8 @@ struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t e
 
 __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict__ in, uint64_t in_len,
                                                        const uint64_t *__restrict__ cands, uint32_t ncands,
-                                                       ZaChunkRes *__restrict__ res)
+                                                       ZaChunkRes *__restrict__ res,
+                                                       uint64_t first_bit, uint32_t first_hist)   // where the stream (re)starts, and how much history it has there
 {
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
     int status = ZA_I_DATA;
     if (off <= in_len)
         status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, ibuf,
-                                                    bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == 0 ? 0u : (uint32_t)ZA_WIN, true, nullptr,
+                                                    bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == first_bit ? first_hist : (uint32_t)ZA_WIN, true, nullptr,
                                                     cands, ncands, off * 8ull);
     // bits = position relative to byte `off`; report the absolute end
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
 
 __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restrict__ in, uint64_t in_len,
                                                         const ZaChunk *__restrict__ chunks, uint16_t *__restrict__ out16,
-                                                        ZaChunkRes *__restrict__ res)
+                                                        ZaChunkRes *__restrict__ res, uint64_t first_bit, uint32_t first_hist)
 {
     __shared__ ZaInfTabs T;
     __shared__ uint16_t win[ZA_CHUNK_RING];
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     if (off <= in_len)
         status = za_inflate_serial_core<2, uint16_t, ZA_CHUNK_RING>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
                                                      scratch, ibuf, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
-                                                     ch.in_bit == 0 ? 0u : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull);
+                                                     ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull);
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
 
@@ -1147,14 +1148,15 @@ __global__ __launch_bounds__(1024) void za_k_chunk_compose(const uint16_t *__res
     }
 }
 
-__global__ __launch_bounds__(1024) void za_k_chunk_chain(const uint16_t *__restrict__ comp, uint32_t n, uint8_t *__restrict__ winbuf)
+__global__ __launch_bounds__(1024) void za_k_chunk_chain(const uint16_t *__restrict__ comp, uint32_t n, uint8_t *__restrict__ winbuf,
+                                                         const uint8_t *__restrict__ dict, uint32_t dict_len)   // history before chunk 0 (a resumed stream)
 {
     __shared__ __attribute__((aligned(16))) uint8_t wa[ZA_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t wb[ZA_WIN];
     uint8_t *cur = wa, *nxt = wb;
     const uint32_t tid = threadIdx.x;
     const uint32_t groups = (n + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
-    for (uint32_t j = tid; j < ZA_WIN; j += 1024) cur[j] = 0;
+    for (uint32_t j = tid; j < ZA_WIN; j += 1024) cur[j] = j >= ZA_WIN - dict_len ? dict[j - (ZA_WIN - dict_len)] : (uint8_t)0;
     __syncthreads();
     for (uint32_t g = 0; g < groups; g++) {
         uint8_t *wout = winbuf + (size_t)g * ZA_WIN;

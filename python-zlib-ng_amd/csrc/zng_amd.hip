@@ -559,8 +559,11 @@ static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_le
     return ZNGAMD_OK;
 }
 
+// a stream that is resumed at a block header (bit offset + history) and / or may run past the end of the buffer
+struct ChunkOpts { uint32_t start_bit = 0; const uint8_t *d_dict = nullptr; uint32_t dict_len = 0; bool allow_cut = false; };
+struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; };
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
-                               uint64_t *out_len, uint64_t *in_used, bool *cut = nullptr);
+                               uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o = ChunkOpts(), ChunkInfo *info = nullptr);
 
 int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used, uint32_t *crc, uint32_t *adler)
@@ -768,10 +771,15 @@ static int chunk_bail(int why)
 // the caller), 1 when this path does not apply or anything looked odd (caller uses the sequential decoder, which
 // also produces the exact error), <0 on engine errors, ZNGAMD_BUF_ERROR with *out_len = needed size when the
 // output does not fit.
-// *cut (optional) is set when the chain of blocks runs into the end of the input: the stream is longer than the buffer.
+// Options: the stream may start at a bit offset inside the first byte with up to 32 KiB of history (a stream resumed at
+// a block header), and with allow_cut a stream that runs past the end of the buffer is decoded up to its last complete
+// block (info->cut, info->end_bit = where the next block header starts; *in_used = that bit's byte).
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
-                               uint64_t *out_len, uint64_t *in_used, bool *cut)
+                               uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o, ChunkInfo *info)
 {
+    ChunkInfo dummy; if (!info) info = &dummy;
+    *info = ChunkInfo();
+    const bool resumed = o.start_bit != 0 || o.dict_len != 0 || o.allow_cut;
     if (avail < (1u << 16) || avail > (1ull << 36)) return chunk_bail(1);
     const uint32_t max_c = (uint32_t)std::min<uint64_t>(avail / 8 + 64, 1u << 24);
     const uint32_t max_s = (uint32_t)std::min<uint64_t>(avail / 4 + 1024, 1u << 25);
@@ -806,7 +814,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
             HIPCHK(c, hipMemcpy(cand.data() + old, c->ccand.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
         }
     }
-    cand.push_back(0);
+    cand.push_back(o.start_bit);
     std::sort(cand.begin(), cand.end());
     cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
     const uint32_t n = (uint32_t)cand.size();
@@ -815,7 +823,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(n));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_chunk_count, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, n, c->cres.p); }
+      hipLaunchKernelGGL(za_k_chunk_count, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, n, c->cres.p, (uint64_t)o.start_bit, o.dict_len); }
     HIPCHK(c, hipGetLastError());
     std::vector<ZaChunkRes> res(n);
     HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)n * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
@@ -826,10 +834,13 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     uint64_t acc = 0, end_bit = 0;
     bool ended = false;
     {
-        size_t i = 0;
+        size_t i = (size_t)(std::lower_bound(cand.begin(), cand.end(), (uint64_t)o.start_bit) - cand.begin());
         for (uint32_t guard = 0; guard <= n; guard++) {
             const ZaChunkRes &r = res[i];
-            if (r.status == ZA_I_INPUT && cut) *cut = true;
+            if (r.status == ZA_I_INPUT) {
+                info->cut = true;
+                if (o.allow_cut && !blocks.empty()) { end_bit = cand[i]; break; }      // stop in front of the incomplete block
+            }
             if (r.status != ZA_I_SYNC && r.status != ZA_I_END) return chunk_bail(4);
             ZaChunk b; b.in_bit = cand[i]; b.out_off = acc; b.out_len = r.out_len; b.end_bit = r.bits;
             blocks.push_back(b);
@@ -851,8 +862,10 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         ZaChunk last = chain.back(); chain.pop_back();
         chain.back().out_len += last.out_len; chain.back().end_bit = last.end_bit;
     }
-    if (!ended || chain.size() < 4) return chunk_bail(6);
-    *out_len = acc; *in_used = (end_bit + 7) >> 3;
+    if (!ended && !(o.allow_cut && info->cut && !chain.empty())) return chunk_bail(6);
+    if (chain.size() < (resumed ? 1u : 4u)) return chunk_bail(6);
+    info->ended = ended; info->end_bit = end_bit;
+    *out_len = acc; *in_used = ended ? (end_bit + 7) >> 3 : end_bit >> 3;
     if (acc > out_room) return ZNGAMD_BUF_ERROR;
     const uint32_t m = (uint32_t)chain.size();
     const uint32_t groups = (m + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
@@ -861,19 +874,19 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(m));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_chunk_decode, dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p); }
+      hipLaunchKernelGGL(za_k_chunk_decode, dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len); }
     HIPCHK(c, hipGetLastError());
     res.resize(m);
     HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)m * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (uint32_t k = 0; k < m; k++) {
         const bool last = k + 1 == m;
-        if (res[k].status != (last ? ZA_I_END : ZA_I_SYNC) || res[k].out_len != chain[k].out_len || res[k].bits != chain[k].end_bit) return chunk_bail(7);
-        if (res[k].max_back > chain[k].out_off) return chunk_bail(8);       // reference before the start of the stream
+        if (res[k].status != ((last && ended) ? ZA_I_END : ZA_I_SYNC) || res[k].out_len != chain[k].out_len || res[k].bits != chain[k].end_bit) return chunk_bail(7);
+        if (res[k].max_back > chain[k].out_off + o.dict_len) return chunk_bail(8);       // reference before the start of the stream
     }
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
       hipLaunchKernelGGL(za_k_chunk_compose, dim3(groups), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->ccomp.p);
-      hipLaunchKernelGGL(za_k_chunk_chain, dim3(1), dim3(1024), 0, c->stream, c->ccomp.p, m, c->winbuf.p);
+      hipLaunchKernelGGL(za_k_chunk_chain, dim3(1), dim3(1024), 0, c->stream, c->ccomp.p, m, c->winbuf.p, o.d_dict, o.dict_len);
       hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(256), 0, c->stream, c->out16.p, c->cchunks.p, c->ccomp.p, c->winbuf.p, d_out); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1015,8 +1028,9 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
         bool chunked = false;
         {   // chunk-parallel decode where the stream offers enough block boundaries, else one wavefront
             uint64_t clen = 0, cused = 0;
-            bool cut = false;
-            const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused, &cut);
+            ChunkInfo ci;
+            const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused, ChunkOpts(), &ci);
+            const bool cut = ci.cut;
             if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
             if (cr == ZNGAMD_BUF_ERROR) { *out_len = op + clen; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
             if (cr == 0) { chunked = true; res.status = ZA_I_END; res.out_len = clen; res.in_bits = cused * 8; res.block_bits = 0; res.block_out = 0; }
@@ -1064,6 +1078,115 @@ int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *ou
     std::lock_guard<std::mutex> g(c->mu);
     uint64_t used = 0;
     return gunzip_impl(c, in, in_len, false, out, out_cap, out_len, n_members, &used);
+}
+
+// ---- one member that is larger than the caller's window: decoded block-wise across calls -------------------
+struct StreamRun { int status; uint64_t out_len; uint64_t in_bits; bool chunked; };
+
+// Decodes the deflate stream that starts at bit `start_bit` of d_def[0] with `dict_len` bytes of history.  With allow_cut a
+// stream that runs past the buffer is decoded up to its last complete block: status ZA_I_INPUT, in_bits = where the next
+// block header starts.
+static int decode_stream_prefix(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint32_t start_bit, const uint8_t *d_dict, uint32_t dict_len,
+                                uint8_t *d_out, uint64_t out_room, bool allow_cut, StreamRun *run, uint64_t *needed)
+{
+    ChunkOpts o; o.start_bit = start_bit; o.d_dict = d_dict; o.dict_len = dict_len; o.allow_cut = allow_cut;
+    ChunkInfo ci;
+    uint64_t clen = 0, cused = 0;
+    const int cr = inflate_chunked_dev(c, d_def, avail, d_out, out_room, &clen, &cused, o, &ci);
+    if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
+    if (cr == ZNGAMD_BUF_ERROR) { *needed = clen; return ZNGAMD_BUF_ERROR; }
+    if (cr == 0) { run->status = ci.ended ? ZA_I_END : ZA_I_INPUT; run->out_len = clen; run->in_bits = ci.end_bit; run->chunked = true; return ZNGAMD_OK; }
+    ZaInfResult res;
+    int r = inflate_serial_dev(c, d_def, avail, d_dict, dict_len, d_out, out_room, &res, start_bit);
+    if (r) return r;
+    run->chunked = false;
+    if (res.status == ZA_I_OUTFULL) { *needed = 0; return ZNGAMD_BUF_ERROR; }
+    if (res.status == ZA_I_INPUT && allow_cut) { run->status = ZA_I_INPUT; run->out_len = res.block_out; run->in_bits = res.block_bits; }   // the last block header entered
+    else { run->status = res.status; run->out_len = res.out_len; run->in_bits = res.in_bits; }
+    return ZNGAMD_OK;
+}
+
+static int stream_step(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, uint64_t doff, bool last,
+                       uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
+{
+    const uint64_t front = ZA_WIN + 64;                     // staging: [history][pad][window of the stream]
+    int r = stage_in(c, in, in_len, front);
+    if (r) return r;
+    const uint32_t dl = st->window_len > ZA_WIN ? (uint32_t)ZA_WIN : st->window_len;
+    if (dl) HIPCHK(c, hipMemcpyAsync(c->st_in.p, st->window, dl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->st_out.ensure(out_cap + 64));
+    StreamRun run; uint64_t needed = 0;
+    r = decode_stream_prefix(c, c->st_in.p + front + doff, in_len - doff, st->start_bit & 7u, c->st_in.p, dl, c->st_out.p, out_cap, !last, &run, &needed);
+    if (r == ZNGAMD_BUF_ERROR) { *out_len = needed > out_cap ? needed : out_cap; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+    if (r) return r;
+    if (run.status != ZA_I_END && run.status != ZA_I_INPUT) { c->err = "invalid deflate data"; return map_status(run.status); }
+    if (run.status == ZA_I_INPUT && last) {
+        if (run.out_len) HIPCHK(c, hipMemcpy(out, c->st_out.p, run.out_len, hipMemcpyDeviceToHost));
+        *out_len = run.out_len; c->err = "gzip member did not end"; return ZNGAMD_E_GZ_TRUNC;
+    }
+    if (run.status == ZA_I_INPUT && run.out_len == 0 && run.in_bits <= (st->start_bit & 7u)) return ZNGAMD_OK;   // not one whole block yet
+    uint32_t cnew = 0;
+    r = checksum_dev(c, c->st_out.p, run.out_len, &cnew, nullptr);
+    if (r) return r;
+    const uint32_t crc = st->out_total ? zngamd_crc32_combine(st->crc, cnew, run.out_len) : cnew;
+    if (run.status == ZA_I_END) {
+        uint64_t cur = doff + ((run.in_bits + 7) >> 3);
+        if (in_len - cur < 8) { if (last) return ZNGAMD_E_GZ_TRUNC; return ZNGAMD_OK; }      // trailer not in the window yet
+        const uint32_t tc = in[cur] | (in[cur + 1] << 8) | (in[cur + 2] << 16) | ((uint32_t)in[cur + 3] << 24);
+        const uint32_t tl = in[cur + 4] | (in[cur + 5] << 8) | (in[cur + 6] << 16) | ((uint32_t)in[cur + 7] << 24);
+        if (run.out_len) HIPCHK(c, hipMemcpy(out, c->st_out.p, run.out_len, hipMemcpyDeviceToHost));
+        *out_len = run.out_len;
+        if (tc != crc) { char b[96]; snprintf(b, sizeof b, "CRC check failed %u != %u", tc, crc); c->err = b; return ZNGAMD_E_GZ_CRC; }
+        if (tl != (uint32_t)((st->out_total + run.out_len) & 0xFFFFFFFFull)) { c->err = "Incorrect length of data produced"; return ZNGAMD_E_GZ_LENGTH; }
+        cur += 8;
+        while (cur < in_len && in[cur] == 0) cur++;
+        *in_consumed = cur;
+        if (n_members) *n_members = 1;
+        c->paths[run.chunked ? ZNGAMD_PATH_CHUNKED : ZNGAMD_PATH_SEQUENTIAL]++;
+        st->in_member = 0; st->start_bit = 0; st->crc = 0; st->window_len = 0; st->out_total = 0;
+        return ZNGAMD_OK;
+    }
+    // the member goes on: hand out the complete blocks, remember where and with what history to continue
+    if (run.out_len) HIPCHK(c, hipMemcpy(out, c->st_out.p, run.out_len, hipMemcpyDeviceToHost));
+    if (run.out_len >= ZA_WIN) { memcpy(st->window, out + run.out_len - ZA_WIN, ZA_WIN); st->window_len = ZA_WIN; }
+    else {
+        const uint32_t keep = std::min<uint32_t>(dl, (uint32_t)(ZA_WIN - run.out_len));
+        memmove(st->window, st->window + (dl - keep), keep);
+        memcpy(st->window + keep, out, run.out_len);
+        st->window_len = keep + (uint32_t)run.out_len;
+    }
+    st->crc = crc; st->out_total += run.out_len; st->start_bit = (uint32_t)(run.in_bits & 7u); st->in_member = 1;
+    *out_len = run.out_len;
+    *in_consumed = doff + (run.in_bits >> 3);
+    return ZNGAMD_OK;
+}
+
+int zngamd_gunzip_stream(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, int last, uint8_t *out, uint64_t out_cap,
+                         uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
+{
+    if (!c || !st || (!in && in_len) || (!out && out_cap) || !out_len || !in_consumed) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    *out_len = 0; *in_consumed = 0;
+    if (n_members) *n_members = 0;
+    if (st->in_member) return stream_step(c, st, in, in_len, 0, last != 0, out, out_cap, out_len, n_members, in_consumed);
+    int r = gunzip_impl(c, in, in_len, !last, out, out_cap, out_len, n_members, in_consumed);
+    if (r != ZNGAMD_OK || last || *in_consumed > 0 || in_len == 0) return r;
+    // not even the first member is complete in this window: start it and hand out the blocks that are
+    uint64_t doff = 0; bool za = false; uint32_t hl = 0;
+    r = parse_gzip_header(in, in_len, 0, &doff, &za, &hl);
+    if (r == ZNGAMD_E_GZ_TRUNC) return ZNGAMD_OK;                      // the header itself is cut: more input first
+    if (r) return r;
+    if (hl) {
+        int rs = stage_in(c, in, in_len);
+        if (rs) return rs;
+        uint32_t hc = 0;
+        rs = checksum_dev(c, c->st_in.p, hl, &hc, nullptr);
+        if (rs) return rs;
+        const uint32_t want = in[hl] | (in[hl + 1] << 8);
+        if ((hc & 0xFFFFu) != want) return ZNGAMD_E_GZ_HCRC;
+    }
+    st->in_member = 0; st->start_bit = 0; st->crc = 0; st->window_len = 0; st->out_total = 0;
+    return stream_step(c, st, in, in_len, doff, false, out, out_cap, out_len, n_members, in_consumed);
 }
 
 int zngamd_gunzip_partial(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,

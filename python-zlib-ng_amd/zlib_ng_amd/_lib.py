@@ -28,9 +28,14 @@ SYMBOLS = [
     "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
     "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
-    "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
+    "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
     "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch",
 ]
+
+
+class GzState(C.Structure):                    # zngamd_gz_state
+    _fields_ = [("in_member", C.c_uint32), ("start_bit", C.c_uint32), ("crc", C.c_uint32), ("window_len", C.c_uint32),
+                ("out_total", C.c_uint64), ("window", C.c_uint8 * 32768)]
 
 
 class Block(C.Structure):
@@ -101,6 +106,8 @@ def load():
                                     C.POINTER(C.c_uint32)]
         L.zngamd_gunzip_partial.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.zngamd_gunzip_stream.argtypes = [vp, C.POINTER(GzState), u8p, C.c_uint64, C.c_int, u8p, C.c_uint64,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.zngamd_gzip_members.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, C.c_int, u8p, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
         L.zngamd_gzip_members_dev.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, C.c_uint64,
@@ -293,6 +300,18 @@ class Context:
         ol, nm, used = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
         r = self.L.zngamd_gunzip_partial(self.h, p, memoryview(data).nbytes, op, out_cap,
                                          C.byref(ol), C.byref(nm), C.byref(used))
+        if r in (E_HIP, E_ARG):
+            raise EngineError(r, self.err())
+        self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
+        return r, _take(out, min(ol.value, out_cap)), nm.value, used.value
+
+    def gunzip_stream(self, state, data, out_cap, last):
+        """Stateful window of a longer stream -> (code, out bytes, n_members, in_consumed); see zngamd_gunzip_stream."""
+        p, keep = _addr(data)
+        out, op = _new_bytes(out_cap)
+        ol, nm, used = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
+        r = self.L.zngamd_gunzip_stream(self.h, C.byref(state), p, memoryview(data).nbytes, 1 if last else 0, op, out_cap,
+                                        C.byref(ol), C.byref(nm), C.byref(used))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0

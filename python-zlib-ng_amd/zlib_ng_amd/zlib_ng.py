@@ -651,8 +651,9 @@ class _GzipReader:
     The compressed input is read in windows (ZNGAMD_READ_WINDOW bytes, default 64 MiB; a bytes-like `fp` is one
     window).  Every window goes to the GPU engine, which decodes all members that are complete inside it -- two-pass
     for indexed members, one launch for BGZF members, chunk-parallel for ordinary ones -- and says where the first
-    incomplete member starts; that tail is kept and the next window appended.  A member larger than the window makes
-    the window grow until it fits.  An error found after N good bytes is raised when the reader reaches byte N, as
+    incomplete member starts; that tail is kept and the next window appended.  A member larger than the window is
+    decoded block-wise across windows (the engine keeps the bit offset of the next block header, the last 32 KiB of
+    output, CRC and length in a small state).  An error found after N good bytes is raised when the reader reaches byte N, as
     the streaming reference does."""
 
     def __init__(self, fp, /, buffersize=32 * 1024):
@@ -682,6 +683,7 @@ class _GzipReader:
         self._done = False       # nothing more to decode
         self._error = None       # raised once the buffered good bytes are gone
         self._first = True
+        self._state = _lib.GzState()      # where a member larger than the window is being continued
 
     # -- compressed input, one window at a time
     def _read_window(self):
@@ -730,11 +732,7 @@ class _GzipReader:
             isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
             cap = max(1 << 16, 4 * len(data), isize + 64)
             while True:
-                if final:
-                    code, out, nm = ctx.gunzip(data, cap)
-                    used = len(data)
-                else:
-                    code, out, nm, used = ctx.gunzip_partial(data, cap)
+                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final)
                 if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
                     cap = max(cap * 4, ctx.last_needed + 64)
                     continue
@@ -744,10 +742,16 @@ class _GzipReader:
                 self._set_error(code, data, ctx)
                 return
             if final:
-                self._buf, self._boff, self._done = out, 0, True
-                return
+                self._buf, self._boff = out, 0
+                if 0 < used < len(data):
+                    self._carry = data[used:]      # a continued member ended inside the last window: the rest follows
+                else:
+                    self._done = True
+                if self._boff < len(self._buf) or self._done:
+                    return
+                continue
             if used == 0:
-                # not even one complete member in the window: take a larger one
+                # neither a complete member nor a complete deflate block in the window: take a larger one
                 self._carry = data
                 self._window *= 2
                 continue

@@ -378,3 +378,62 @@ def test_gzip_reader_streams_in_windows(monkeypatch, fastq):
     r = zlib_ng._GzipReader(io.BytesIO(blobs["one big member"][:-5000]))
     with pytest.raises(EOFError):
         r.readall()
+
+
+def test_gzip_reader_continues_a_giant_member_across_windows(monkeypatch):
+    """One ordinary gzip member much larger than the read window: its complete deflate blocks are decoded window by
+    window (bit offset of the next block header + 32 KiB of history + CRC carried in zngamd_gz_state); the window does
+    not grow to the size of the member."""
+    import gzip
+    import io
+    from zlib_ng_amd import _lib, corpus, zlib_ng
+    ctx = _lib.default_context()
+    text = corpus.text(40 << 20, seed=33).tobytes()
+    mixed = corpus.mixed(24 << 20, seed=34).tobytes()
+    for data, level, window in ((text, 6, 1 << 20), (text, 1, 3 << 20), (mixed, 9, 1 << 20), (text[:3 << 20], 6, 128 << 10)):
+        monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(window))
+        blob = gzip.compress(data, level) + bytes(5) + gzip.compress(b"tail member", 6)
+        want = data + b"tail member"
+        ctx.decode_paths(True)
+        r = zlib_ng._GzipReader(io.BytesIO(blob))
+        got = bytearray()
+        while True:
+            piece = r.read(4 << 20)
+            if not piece:
+                break
+            got += piece
+        assert bytes(got) == want
+        assert r._window <= 4 * window, (r._window, window)          # bounded: the member is several times larger
+        assert r.seek(len(data) - 10) == len(data) - 10
+        tail = b""
+        while len(tail) < 30:                                        # a raw reader may return short at a member end
+            piece = r.read(30 - len(tail))
+            if not piece:
+                break
+            tail += piece
+        assert tail == want[len(data) - 10:len(data) + 20]
+    # damage in the middle of the giant member: the bytes before it arrive, then the error
+    monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(1 << 20))
+    blob = bytearray(gzip.compress(text, 6))
+    blob[len(blob) // 2] ^= 0x55
+    r = zlib_ng._GzipReader(io.BytesIO(bytes(blob)))
+    got = bytearray()
+    with pytest.raises((gzip.BadGzipFile, zlib_ng.error, EOFError)):
+        while True:
+            piece = r.read(4 << 20)
+            if not piece:
+                break
+            got += piece
+    # (like the streaming reference, bytes decoded from damaged data may be handed out before the trailer check fails)
+    q = len(text) // 4
+    assert len(got) > q and bytes(got[:q]) == text[:q]
+    # cut short: EOFError at the end of what could be decoded
+    r = zlib_ng._GzipReader(io.BytesIO(gzip.compress(text, 6)[:-100000]))
+    got = bytearray()
+    with pytest.raises(EOFError):
+        while True:
+            piece = r.read(4 << 20)
+            if not piece:
+                break
+            got += piece
+    assert len(got) > len(text) // 2 and bytes(got) == text[:len(got)]
