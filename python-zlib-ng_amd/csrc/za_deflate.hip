@@ -405,11 +405,17 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                 for (int j = 0; j < ZA_PCH / 4; j++) pb[j] = *(const uint4 *)(best + cb + 4 * j);   // workspace rows are 16 B aligned
                 if (cb + ZA_PCH < n) pla = best[cb + ZA_PCH];
             }
+            if ((long long)cb + ZA_PCH <= readable) {          // everywhere but at the very end of the caller's buffer
 #pragma unroll
-            for (int j = 0; j < ZA_PCH / 4; j++) {
-                const int o = cb + 4 * j;
-                if ((long long)o + 4 <= readable) pd[j] = za_ld32(data + o);
-                else for (int k = 0; k < 4; k++) if ((long long)(o + k) < readable) pd[j] |= (uint32_t)data[o + k] << (8 * k);
+                for (int j = 0; j < ZA_PCH / 4; j++) pd[j] = za_ld32(data + cb + 4 * j);
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < ZA_PCH / 4; j++) {
+                    const int o = cb + 4 * j;
+                    uint32_t v = 0;
+                    for (int k = 0; k < 4; k++) if ((long long)(o + k) < readable) v |= (uint32_t)data[o + k] << (8 * k);
+                    pd[j] = v;
+                }
             }
         }
     };
