@@ -446,7 +446,17 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
         if (active) {
             // CRC-32 over this chunk's bytes (zng_crc32_z at zlib_ngmodule.c:1741)
             const uint8_t *bytes = (const uint8_t *)myd;
-            for (int k = cb; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb]) & 0xFF] ^ (crc_r >> 8);
+            {
+                int k = cb;
+                for (; k + 4 <= ce; k += 4) {                     // one row dword, four table steps
+                    const uint32_t w4 = myd[(k - cb) >> 2];
+                    crc_r = crct[(crc_r ^ w4) & 0xFF] ^ (crc_r >> 8);
+                    crc_r = crct[(crc_r ^ (w4 >> 8)) & 0xFF] ^ (crc_r >> 8);
+                    crc_r = crct[(crc_r ^ (w4 >> 16)) & 0xFF] ^ (crc_r >> 8);
+                    crc_r = crct[(crc_r ^ (w4 >> 24)) & 0xFF] ^ (crc_r >> 8);
+                }
+                for (; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb]) & 0xFF] ^ (crc_r >> 8);
+            }
             if (do_parse) {
                 // one token per lane and round, literal and match on one predicated path (no divergent if/else)
                 while (p < ce) {
