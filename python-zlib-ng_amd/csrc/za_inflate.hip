@@ -726,23 +726,22 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
                     if (pos >= end) done = true;
                     continue;
                 }
-                if (sym == 256) { lane_err = 1; break; }
-                sym -= 257;
-                if (sym >= 29) { lane_err = 2; break; }
+                // match: every validity test of the token is collected and branched on once (the fields of an invalid
+                // token are computed from clamped symbols, never used)
+                const int ls = sym - 257;                               // 256 (end of block inside a segment) gives -1
                 int nx;
-                int len = za_len_base(sym, nx);
+                int len = za_len_base(ls < 0 ? 0 : (ls > 28 ? 28 : ls), nx);
                 len += (int)((b >> used) & ((1u << nx) - 1u));
                 used += (uint32_t)nx;
                 e = za_decode_sym(b >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
-                if (!e) { lane_err = 2; break; }
                 const int ds = (int)(e >> 4);
                 used += e & 15u;
-                if (ds >= 30) { lane_err = 2; break; }
-                int dist = za_dist_base(ds, nx);
+                int dist = za_dist_base(ds > 29 ? 29 : ds, nx);
                 dist += (int)((b >> used) & ((1u << nx) - 1u));
                 used += (uint32_t)nx;
-                if (dist > pos) { lane_err = 2; break; }
-                if (pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG) { lane_err = 1; break; }
+                const bool bad_data = ls > 28 || e == 0u || ds >= 30 || dist > pos;
+                const bool bad_index = ls < 0 || pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG;
+                if (bad_data || bad_index) { lane_err = (ls < 0 || !bad_data) ? 1 : 2; break; }    // same verdict order as a test at a time
                 myq[nmatch++] = make_uint2((uint32_t)pos | ((uint32_t)len << 17), (uint32_t)dist);
                 pos += len; bp += used;
                 if (pos - blk_base >= 16) {
