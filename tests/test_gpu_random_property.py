@@ -79,3 +79,53 @@ def test_many_units_over_several_workspace_chunks(fastq):
     code, back, nm = c.gunzip(stream, len(data))
     assert code == 0 and back == data and nm == 13
     c.close()
+
+
+def test_windowed_reader_random_streams(monkeypatch, fastq):
+    """Random concatenations of member kinds (ordinary at several levels, stored-only, sync-flushed, indexed, BGZF
+    fixture, empty, NUL padding) read through _GzipReader with random window sizes equal the stdlib's result."""
+    import gzip
+    import io
+    import zlib
+    from conftest import GOLDEN
+    from zlib_ng_amd import _lib, corpus, zlib_ng
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(77)
+    text = corpus.text(8 << 20, seed=3).tobytes()
+    mixed = corpus.mixed(4 << 20, seed=4).tobytes()
+    bgzf = open(os.path.join(GOLDEN, "test.fastq.bgzip.gz"), "rb").read()
+
+    def piece():
+        kind = int(rng.integers(0, 8))
+        src = text if rng.integers(0, 2) else mixed
+        n = int(rng.integers(1, 3 << 20))
+        o = int(rng.integers(0, len(src) - n))
+        d = src[o:o + n]
+        if kind == 0:
+            return gzip.compress(d, int(rng.integers(1, 10)))
+        if kind == 1:
+            return gzip.compress(d[:200000], 0)                       # stored blocks only
+        if kind == 2:                                                  # sync-flushed every ~100 KB
+            co = zlib.compressobj(6, zlib.DEFLATED, 31)
+            return b"".join(co.compress(d[i:i + 100000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(d), 100000)) + co.flush()
+        if kind == 3:
+            return ctx.gzip_members(d, int(rng.choice([4096, 65536, 131072])), int(rng.integers(1, 10)))
+        if kind == 4:
+            return bgzf
+        if kind == 5:
+            return gzip.compress(b"", 6)
+        if kind == 6:
+            return gzip.compress(d[:int(rng.integers(1, 3000))], 9) + bytes(int(rng.integers(0, 40)))
+        return gzip.compress(d, 1)
+    for trial in range(40):
+        blob = b"".join(piece() for _ in range(int(rng.integers(1, 6))))
+        want = gzip.decompress(blob)
+        monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(int(rng.choice([65536, 100000, 262144, 1 << 20, 3 << 20]))))
+        r = zlib_ng._GzipReader(io.BytesIO(blob))
+        got = bytearray()
+        while True:
+            part = r.read(int(rng.integers(1, 2 << 20)))
+            if not part:
+                break
+            got += part
+        assert bytes(got) == want, (trial, len(got), len(want))
