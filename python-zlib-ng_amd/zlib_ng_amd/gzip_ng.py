@@ -67,6 +67,18 @@ class GzipNGFile(gzip.GzipFile):
     def __repr__(self):
         return "<gzip_ng " + repr(self.fileobj)[1:-1] + " " + hex(id(self)) + ">"
 
+    # gzip.GzipFile.close() writes `self.crc` after flushing the compressor.  The deflate kernels already produce the
+    # CRC-32 of every block they compress, so the running value is taken from the compressor (complete once it has been
+    # flushed) instead of sending every write() to the GPU a second time.
+    @property
+    def crc(self):
+        c = getattr(self, "compress", None)
+        return c._crc if (getattr(self, "mode", None) == WRITE and isinstance(c, zlib_ng._Compress)) else self._crc_read
+
+    @crc.setter
+    def crc(self, value):
+        self._crc_read = value
+
     def write(self, data):
         self._check_not_closed()
         if self.mode != WRITE:
@@ -79,7 +91,6 @@ class GzipNGFile(gzip.GzipFile):
         if nbytes:
             self.fileobj.write(self.compress.compress(view))
             self.size += nbytes
-            self.crc = zlib_ng.crc32(view, self.crc)
             self.offset += nbytes
         return nbytes
 

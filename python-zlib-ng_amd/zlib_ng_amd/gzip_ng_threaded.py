@@ -170,7 +170,12 @@ class _ThreadedGzipWriter(io.RawIOBase):
         # incompressible data grows a little; 10 % head-room as in gzip_ng_threaded.py:229-231
         self.compressors = [zlib_ng._ParallelCompress(buffersize=block_size + max(block_size // 10, 500), level=level)]
         self.threads = threads
-        self.input_queues = [queue.Queue(queue_size) for _ in range(threads)]
+        # The reference keeps queue_size blocks per worker thread in flight.  One engine batch replaces the N worker
+        # threads, and a batch of 8 blocks is all launch overhead: the queues are made deep enough for about 32 MiB
+        # of pending input per batch (a memory bound of the same kind as the reference's threads * queue_size blocks).
+        depth = max(queue_size, -(-(32 << 20) // (max(block_size, 1) * threads)))
+        self._batch_blocks = threads * depth
+        self.input_queues = [queue.Queue(depth) for _ in range(threads)]
         self.output_queues = []
         self.compression_workers = []
         self.output_worker = threading.Thread(target=self._compress_and_write)
@@ -271,7 +276,7 @@ class _ThreadedGzipWriter(io.RawIOBase):
                 continue
             origins.append(q)
             self._drain_index += 1
-            while len(batch) < nq:
+            while len(batch) < self._batch_blocks:
                 q = self.input_queues[self._drain_index % nq]
                 try:
                     batch.append(q.get_nowait())
