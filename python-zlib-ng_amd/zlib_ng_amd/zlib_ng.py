@@ -777,7 +777,7 @@ class _GzipReader:
                     raise self._error
                 self._size = self._pos
                 return 0
-            mv[:n] = self._buf[self._boff:self._boff + n]
+            mv[:n] = memoryview(self._buf)[self._boff:self._boff + n]      # one copy, no intermediate bytes object
             self._boff += n
             self._pos += n
             return n
