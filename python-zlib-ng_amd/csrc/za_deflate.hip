@@ -224,30 +224,52 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     int links_loaded = -dict_len;        // positions p < links_loaded have their chain link in the ring
     int bytes_loaded = -dict_len;        // positions p < bytes_loaded have their byte in the byte ring
     bytes_loaded &= ~3;                  // staged in aligned dwords (P is a multiple of 4 when p is)
-    for (int base = 0; base < n; base += ZA_SEARCH_TILE) {
-        // ---- stage chain links up to the tile end, bytes up to tile end + lookahead
-        int need_links = base + ZA_SEARCH_TILE;
-        if (need_links > n) need_links = n;
+    auto load_bytes = [&](int p) -> uint32_t {          // dword of input at p (a multiple of 4), zero outside the unit
+        if (p >= -dict_len && (long long)p + 4 <= readable) return za_ld32(data + p);
+        uint32_t v = 0;                                   // edges: before the dictionary start or past the caller's buffer
+        for (int k = 0; k < 4; k++)
+            if (p + k >= -dict_len && (long long)(p + k) < readable) v |= (uint32_t)data[p + k] << (8 * k);
+        return v;
+    };
+    auto store_bytes = [&](int p, uint32_t v) {
+        const uint32_t w = ((uint32_t)(ZA_WIN + p) & (ZA_BYTES - 1)) >> 2;
+        win32[w] = v;
+        if (w < 8) win32[w + ZA_BYTES / 4] = v;
+    };
+    // ---- the first tile is staged up front: chain links up to the tile end, bytes up to tile end + lookahead
+    {
+        int need_links = ZA_SEARCH_TILE < n ? ZA_SEARCH_TILE : n;
         for (int p = links_loaded + tid; p < need_links; p += ZA_SEARCH_THREADS)
             ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = prevdist[p + dict_len];
         links_loaded = need_links;
-        int need_bytes = base + ZA_SEARCH_TILE + ZA_LOOKAHEAD;
+        int need_bytes = ZA_SEARCH_TILE + ZA_LOOKAHEAD;
         if (need_bytes > n) need_bytes = n;
         need_bytes = (need_bytes + 3) & ~3;
-        for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) {
-            uint32_t v;
-            if (p >= -dict_len && (long long)p + 4 <= readable) v = za_ld32(data + p);
-            else {      // edges: before the dictionary start or past the caller's buffer
-                v = 0;
-                for (int k = 0; k < 4; k++)
-                    if (p + k >= -dict_len && (long long)(p + k) < readable) v |= (uint32_t)data[p + k] << (8 * k);
-            }
-            const uint32_t w = ((uint32_t)(ZA_WIN + p) & (ZA_BYTES - 1)) >> 2;
-            win32[w] = v;
-            if (w < 8) win32[w + ZA_BYTES / 4] = v;
-        }
+        for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, load_bytes(p));
         bytes_loaded = need_bytes;
-        __syncthreads();
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += ZA_SEARCH_TILE) {
+        // ---- the NEXT tile's links and bytes are fetched into registers now and put into the rings after this tile's
+        // search: the global-memory latency hides behind the search instead of stalling all 16 waves in front of it
+        // (at most 4 links and 2 dwords per thread: one tile of each)
+        int need_links = base + 2 * ZA_SEARCH_TILE;
+        if (need_links > n) need_links = n;
+        int need_bytes = base + 2 * ZA_SEARCH_TILE + ZA_LOOKAHEAD;
+        if (need_bytes > n) need_bytes = n;
+        need_bytes = (need_bytes + 3) & ~3;
+        uint16_t nl[4];
+        uint32_t nb[2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = links_loaded + tid + k * ZA_SEARCH_THREADS;
+            nl[k] = p < need_links ? prevdist[p + dict_len] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
+            nb[k] = p < need_bytes ? load_bytes(p) : 0u;
+        }
 #pragma unroll 1
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
@@ -337,11 +359,21 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             }
             best[p] = result;
         }
-        // one barrier per tile is enough for the rings: the next tile's stores land at least
-        // 65536-4096-272-32768 byte slots / 40960-4096-32768 link slots behind any walk still running,
-        // and nobody reads positions that are not staged yet.  The barrier below orders the NEXT
-        // staging pass after this tile's reads of slots that it will overwrite only if the margin
-        // were smaller than one tile; with the sizes above it is not needed.
+        // ---- put the next tile into the rings.  No barrier is needed in front of these stores: they land at least
+        // 65536-4096-272-32768 byte slots / 40960-4096-32768 link slots behind any walk of this tile that is still
+        // running in another wave.  The barrier behind them makes the next tile visible.
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = links_loaded + tid + k * ZA_SEARCH_THREADS;
+            if (p < need_links) ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = nl[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
+            if (p < need_bytes) store_bytes(p, nb[k]);
+        }
+        links_loaded = need_links; bytes_loaded = need_bytes;
+        __syncthreads();
     }
 }
 
