@@ -691,7 +691,7 @@ int zngamd_gzip_scan_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, zngam
 static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const ZaMember *d_members, uint32_t n,
                                uint8_t *d_out, uint64_t out_cap, int32_t *d_status)
 {
-    const uint32_t ch = std::min<uint32_t>(n, 8192);
+    const uint32_t ch = std::min<uint32_t>(n, 32768);          // members per launch: 352 KiB of match queue each (11.5 GB)
     HIPCHK(c, c->matchq.ensure((size_t)ch * 64 * ZA_MATCHQ_PER_SEG));
     for (uint32_t c0 = 0; c0 < n; c0 += ch) {
         const uint32_t m = std::min(ch, n - c0);
