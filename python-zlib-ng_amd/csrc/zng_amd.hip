@@ -52,7 +52,7 @@ struct zngamd_ctx {
     // constant tables
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
     // deflate workspaces (per chunk of units)
-    uint32_t chunk_units = 8192;                 // units per launch: 1.4 MiB of workspace each (11.5 GiB); fewer, fuller launches
+    uint32_t chunk_units = 16384;                // units per launch: 1.4 MiB of workspace each (23 GB); fewer, fuller launches
     DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     // per call
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, status;
