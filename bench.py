@@ -202,7 +202,9 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roofline["traffic"] = json.load(open(pmc)).get(roofline["kernel"])
+            per_unit = json.load(open(pmc)).get(roofline["kernel"])          # HBM bytes per unit from the PMC passes
+            if per_unit:
+                roofline["traffic"] = int(per_unit * nblocks / launches_per_step)
         except Exception:
             pass
 
