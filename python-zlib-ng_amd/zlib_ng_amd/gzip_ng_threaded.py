@@ -14,6 +14,7 @@ byte order), sync-flushed raw-deflate blocks, `03 00`, CRC32, ISIZE; `flush()` e
 starts a new one; `close()` after the buffered writer's implicit flush leaves a trailing empty member.
 """
 import builtins
+import collections
 import io
 import multiprocessing
 import os
@@ -59,83 +60,96 @@ def open_as_binary_stream(filename, open_mode):
 
 
 class _ThreadedGzipReader(io.RawIOBase):
-    """Background thread pulls `block_size` chunks out of a `_GzipReader` into a bounded queue
-    (gzip_ng_threaded.py:90-167)."""
+    """Streamed reading with one pump thread: it pulls `block_size` pieces out of the windowed GPU reader
+    (`zlib_ng._GzipReader`) and parks at most `queue_size` of them; readinto() takes them in order.  Same role as the
+    reference's prefetching reader (gzip_ng_threaded.py:90-167); the decode itself is chunk-parallel on the GPU."""
 
     def __init__(self, filename, queue_size=2, block_size=1024 * 1024):
-        self.raw, self.closefd = open_as_binary_stream(filename, "rb")
-        self.fileobj = zlib_ng._GzipReader(self.raw, buffersize=8 * block_size)
-        self.pos = 0
-        self.read_file = False
-        self.queue = queue.Queue(queue_size)
-        self.eof = False
-        self.exception = None
-        self.buffer = io.BytesIO()
+        source, owns = open_as_binary_stream(filename, "rb")
+        self.raw, self.closefd = source, owns
+        self.fileobj = zlib_ng._GzipReader(source, buffersize=8 * block_size)
         self.block_size = block_size
+        self.pos = 0
+        # (the reference's tests pass a mode string in this position; anything that is not a positive count means 2)
+        self._depth = queue_size if isinstance(queue_size, int) and queue_size > 0 else 2
+        self._parked = collections.deque()           # decoded pieces waiting for the consumer
+        self._cv = threading.Condition()
+        self._finished = False                       # pump has ended (end of stream or failure)
+        self._failure = None
+        self._current = memoryview(b"")
         self._closed = False
-        self.running = True
-        self._calling_thread = threading.current_thread()
-        self.worker = threading.Thread(target=self._decompress)
-        self.worker.start()
+        self._stop = False
+        self._owner = threading.current_thread()
+        self._pump_thread = threading.Thread(target=self._pump, name="zng-amd-reader")
+        self._pump_thread.start()
 
-    def _check_closed(self, msg=None):
-        if self._closed:
-            raise ValueError("I/O operation on closed file")
+    def _wanted(self):
+        return not self._stop and self._owner.is_alive()
 
-    def _alive(self):
-        return self.running and self._calling_thread.is_alive()
-
-    def _decompress(self):
-        while self._alive():
-            try:
-                chunk = self.fileobj.read(self.block_size)
-            except Exception as exc:
-                self.exception = exc
-                return
-            if not chunk:
-                return
-            while self._alive():
-                try:
-                    self.queue.put(chunk, timeout=0.05)
+    def _pump(self):
+        try:
+            while self._wanted():
+                piece = self.fileobj.read(self.block_size)
+                if not piece:
                     break
-                except queue.Full:
-                    continue
+                with self._cv:
+                    while len(self._parked) >= self._depth and self._wanted():
+                        self._cv.wait(0.05)
+                    self._parked.append(piece)
+                    self._cv.notify_all()
+        except Exception as exc:                     # handed to the consumer once the good pieces are gone
+            self._failure = exc
+        finally:
+            with self._cv:
+                self._finished = True
+                self._cv.notify_all()
+
+    def _next_piece(self):
+        with self._cv:
+            while not self._parked and not self._finished:
+                self._cv.wait(0.05)
+            if self._parked:
+                piece = self._parked.popleft()
+                self._cv.notify_all()
+                return piece
+        if self._failure is not None:
+            raise self._failure
+        return None
 
     def readinto(self, b):
-        self._check_closed()
-        got = self.buffer.readinto(b)
-        while got == 0:
-            try:
-                chunk = self.queue.get(timeout=0.01)
-            except queue.Empty:
-                if self.worker.is_alive():
-                    continue
-                if not self.queue.empty():
-                    continue
-                if self.exception:
-                    raise self.exception
+        if self._closed:
+            raise ValueError("I/O operation on closed file")
+        out = memoryview(b).cast("B")
+        if not len(self._current):
+            piece = self._next_piece()
+            if piece is None:
                 return 0
-            self.buffer = io.BytesIO(chunk)
-            got = self.buffer.readinto(b)
-        self.pos += got
-        return got
+            self._current = memoryview(piece)
+        n = min(len(out), len(self._current))
+        out[:n] = self._current[:n]
+        self._current = self._current[n:]
+        self.pos += n
+        return n
 
     def readable(self):
         return True
 
     def tell(self):
-        self._check_closed()
+        if self._closed:
+            raise ValueError("I/O operation on closed file")
         return self.pos
 
     def close(self):
         if self._closed:
             return
-        self.running = False
-        self.worker.join()
+        self._closed = True
+        self._stop = True
+        with self._cv:
+            self._cv.notify_all()
+        self._pump_thread.join()
         self.fileobj.close()
         if self.closefd:
             self.raw.close()
-        self._closed = True
 
     @property
     def closed(self):
