@@ -87,3 +87,43 @@ def test_device_resident_round_trip(ctx):
         for d in (d_slots, d_len, d_crc, d_dst, d_ms, d_tab, d_stat, d_out):
             d.free()
     d_in.free()
+
+
+def test_gunzip_partial_and_stream_entry_points(ctx):
+    """zngamd_gunzip_partial (member-granular window) and zngamd_gunzip_stream (stateful) called directly."""
+    from zlib_ng_amd import _lib, corpus
+    text = corpus.text(3 << 20, seed=5).tobytes()
+    a, b, c = gzip.compress(text[:1 << 20], 6), gzip.compress(text[1 << 20:2 << 20], 1), gzip.compress(text[2 << 20:], 9)
+    blob = a + b + c
+    # a window that ends inside the third member: two members come out, the third is left alone
+    cut = len(a) + len(b) + len(c) // 2
+    code, out, nm, used = ctx.gunzip_partial(blob[:cut], 4 << 20)
+    assert (code, nm, used) == (0, 2, len(a) + len(b)) and out == text[:2 << 20]
+    code, out, nm, used = ctx.gunzip_partial(blob[used:], 4 << 20)
+    assert (code, nm, used) == (0, 1, len(c)) and out == text[2 << 20:]
+    # a window that holds no complete member
+    code, out, nm, used = ctx.gunzip_partial(blob[:len(a) // 2], 4 << 20)
+    assert (code, nm, used, out) == (0, 0, 0, b"")
+    # the stateful form walks through one member in 200 KB windows
+    st = _lib.GzState()
+    pos, got = 0, bytearray()
+    big = gzip.compress(text, 6)
+    win = 200000
+    while pos < len(big):
+        last = pos + win >= len(big)
+        code, out, nm, used = ctx.gunzip_stream(st, big[pos:pos + win], 8 << 20, last)
+        assert code == 0, (code, pos)
+        got += out
+        if used == 0:
+            win *= 2
+            continue
+        pos += used
+    assert bytes(got) == text and st.in_member == 0
+
+
+def test_caller_stream_and_sync(ctx):
+    """zngamd_set_stream(NULL) restores the context's own stream; zngamd_sync waits for it."""
+    assert ctx.L.zngamd_set_stream(ctx.h, None) == 0
+    assert ctx.crc32(b"penguin") == zlib.crc32(b"penguin")
+    assert ctx.L.zngamd_sync(ctx.h) == 0
+    assert ctx.L.zngamd_level_ok(6) == 1 and ctx.L.zngamd_level_ok(10) == 0 and ctx.L.zngamd_level_ok(-1) == 1
