@@ -103,12 +103,14 @@ def _container(wbits):
     raise error("Bad compression level")    # Z_STREAM_ERROR from init is reported with this text (:224-226)
 
 
-def _zlib_header(level, window_bits):
+def _zlib_header(level, window_bits, dictid=None):
+    """RFC 1950 header; with a preset dictionary FDICT is set and DICTID (Adler-32 of the dictionary) follows."""
     lv = 6 if level == -1 else level
     flevel = 0 if lv < 2 else 1 if lv < 6 else 2 if lv == 6 else 3
-    head = (((window_bits - 8) << 4) | 8) << 8 | (flevel << 6)
+    head = (((window_bits - 8) << 4) | 8) << 8 | (flevel << 6) | (0x20 if dictid is not None else 0)
     head += 31 - head % 31
-    return _struct.pack(">H", head)
+    out = _struct.pack(">H", head)
+    return out if dictid is None else out + _struct.pack(">I", dictid & 0xFFFFFFFF)
 
 
 def _gzip_header(level):
@@ -318,15 +320,15 @@ class _Compress:
         self._finished = False
         self._crc, self._adler, self._size = 0, 1, 0
         self._lock = _threading.Lock()
-        if zdict is not None and self._kind == "zlib":
-            raise NotImplementedError("preset dictionary with a zlib container (FDICT) is not supported yet")
+        # zlib container with a preset dictionary: FDICT + DICTID in the header (deflateSetDictionary, zlib_ngmodule.c:401)
+        self._dictid = adler32(_view(zdict)) if (zdict is not None and self._kind == "zlib") else None
 
     def _emit(self, final):
         out = []
         if not self._started:
             self._started = True
             if self._kind == "zlib":
-                out.append(_zlib_header(self._level, self._wb))
+                out.append(_zlib_header(self._level, self._wb, self._dictid))
             elif self._kind == "gzip":
                 out.append(_gzip_header(self._level))
         data = bytes(self._pending)
@@ -377,7 +379,7 @@ class _Compress:
             if self._finished:
                 raise ValueError("Inconsistent stream state")
             o = _Compress.__new__(_Compress)
-            o._kind, o._wb, o._level = self._kind, self._wb, self._level
+            o._kind, o._wb, o._level, o._dictid = self._kind, self._wb, self._level, self._dictid
             o._pending = bytearray(self._pending)
             o._tail = self._tail
             o._started, o._finished = self._started, self._finished

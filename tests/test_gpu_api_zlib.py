@@ -437,3 +437,29 @@ def test_gzip_reader_continues_a_giant_member_across_windows(monkeypatch):
                 break
             got += piece
     assert len(got) > len(text) // 2 and bytes(got) == text[:len(got)]
+
+
+def test_compressobj_zlib_container_with_preset_dictionary():
+    """zdict with the default (zlib) container: FDICT + DICTID in the header, the data primed with the dictionary
+    (test_zlib_compliance.py test_dictionary / test_dictionary_streaming)."""
+    import zlib
+    from zlib_ng_amd import zlib_ng
+    words = b"the quick brown fox jumps over the lazy dog and runs away with the spoon ".split()
+    zdict = b" ".join(words * 40)
+    data = b" ".join(reversed(words * 300))
+    co = zlib_ng.compressobj(6, zdict=zdict)
+    blob = co.compress(data[:5000]) + co.compress(data[5000:]) + co.flush()
+    assert blob[1] & 0x20 and int.from_bytes(blob[2:6], "big") == zlib.adler32(zdict)
+    assert zlib.decompressobj(zdict=zdict).decompress(blob) == data
+    with pytest.raises(zlib.error):
+        zlib.decompress(blob)                                     # needs the dictionary
+    do = zlib_ng.decompressobj(zdict=zdict)
+    assert do.decompress(blob) + do.flush() == data
+    # the dictionary pays: smaller than without it
+    plain = zlib_ng.compress(data, 6)
+    assert len(blob) < len(plain)
+    # and the system's dictionary streams decode here
+    c2 = zlib.compressobj(9, zdict=zdict)
+    theirs = c2.compress(data) + c2.flush()
+    do = zlib_ng.decompressobj(zdict=zdict)
+    assert do.decompress(theirs) == data
