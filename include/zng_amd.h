@@ -135,7 +135,9 @@ int zngamd_inflate_raw(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
  * in[0] with `dict` as history.  Besides the totals it reports the last deflate-block header that was
  * entered (*block_bits from bit 0 of `in`, *block_out bytes produced before it): when the call ends with
  * ZNGAMD_BUF_ERROR (input ran out), the caller keeps in[*block_bits/8 ..], the last 32 KiB of output up to
- * *block_out, and calls again once more input has arrived.  ZNGAMD_E_OVERFLOW = out_cap reached. */
+ * *block_out, and calls again once more input has arrived.  ZNGAMD_E_OVERFLOW = out_cap reached.
+ * Pieces of at least 64 KiB are decoded chunk-parallel up to their last complete block (then *out_len == *block_out:
+ * the incomplete block is not decoded at all); smaller pieces run on the sequential wavefront decoder. */
 int zngamd_inflate_resume(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, uint32_t start_bit,
                           const uint8_t *dict, uint32_t dict_len, uint8_t *out, uint64_t out_cap,
                           uint64_t *out_len, uint64_t *in_bits, uint64_t *block_bits, uint64_t *block_out);

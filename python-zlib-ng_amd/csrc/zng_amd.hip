@@ -620,8 +620,25 @@ int zngamd_inflate_resume(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uin
     if (dict_len) HIPCHK(c, hipMemcpyAsync(c->st_in.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->st_out.ensure(out_cap + 64));
     ZaInfResult res;
-    r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res, start_bit);
-    if (r) return r;
+    bool chunked = false;
+    if (in_len >= (1u << 16)) {
+        // a large piece of a stream: its complete blocks are decoded chunk-parallel; what follows the last complete block
+        // stays for the next call (the checkpoint is exactly that boundary)
+        ChunkOpts o; o.start_bit = start_bit; o.d_dict = c->st_in.p; o.dict_len = dict_len; o.allow_cut = true;
+        ChunkInfo ci;
+        uint64_t clen = 0, cused = 0;
+        const int cr = inflate_chunked_dev(c, c->st_in.p + front, in_len, c->st_out.p, out_cap, &clen, &cused, o, &ci);
+        if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
+        if (cr == 0) {
+            chunked = true;
+            res.status = ci.ended ? ZA_I_END : ZA_I_INPUT; res.out_len = clen; res.in_bits = ci.end_bit;
+            res.block_bits = ci.end_bit; res.block_out = clen;
+        }   // (not enough room, or nothing to gain: the sequential decoder below fills out_cap / gives the verdict)
+    }
+    if (!chunked) {
+        r = inflate_serial_dev(c, c->st_in.p + front, in_len, c->st_in.p, dict_len, c->st_out.p, out_cap, &res, start_bit);
+        if (r) return r;
+    }
     *out_len = res.out_len; *in_bits = res.in_bits; *block_bits = res.block_bits; *block_out = res.block_out;
     if (res.out_len) HIPCHK(c, hipMemcpyAsync(out, c->st_out.p, res.out_len, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
