@@ -310,9 +310,13 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
                         continue;
                     }
                     int dist = (int)(b & 0xFFFF);
-                    t[nt++] = 0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1);
-                    hist[257 + len_code(len)]++;
-                    hist[288 + dist_code(dist)]++;
+                    /* a match token carries its symbols: bit 31, length code << 26, length extra << 21, distance
+                     * code << 16, distance extra (the packer needs no symbol arithmetic) */
+                    int lc = len_code(len), dc = dist_code(dist);
+                    t[nt++] = 0x80000000u | ((uint32_t)lc << 26) | ((uint32_t)(len - len_base[lc]) << 21) |
+                              ((uint32_t)dc << 16) | (uint32_t)(dist - dist_base[dc]);
+                    hist[257 + lc]++;
+                    hist[288 + dc]++;
                     p += len;
                 } else {
                     t[nt++] = data[p]; hist[data[p]]++; p++;
@@ -426,12 +430,11 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
             for (uint32_t k = 0; k < seg_ntok[s]; k++) {
                 uint32_t tk = t[k];
                 if (tk & 0x80000000u) {
-                    int len = (int)((tk >> 16) & 0xFF) + 3, dist = (int)(tk & 0x7FFF) + 1;
-                    int lc = len_code(len), dc = dist_code(dist);
+                    int lc = (int)((tk >> 26) & 31), dc = (int)((tk >> 16) & 31);
                     putbits(&w, codes[257 + lc], lens[257 + lc]);
-                    putbits(&w, (uint32_t)(len - len_base[lc]), len_extra[lc]);
+                    putbits(&w, (tk >> 21) & 31u, len_extra[lc]);
                     putbits(&w, codes[288 + dc], lens[288 + dc]);
-                    putbits(&w, (uint32_t)(dist - dist_base[dc]), dist_extra[dc]);
+                    putbits(&w, tk & 0x1FFFu, dist_extra[dc]);
                 } else putbits(&w, codes[tk], lens[tk]);
             }
         }

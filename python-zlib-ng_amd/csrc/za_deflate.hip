@@ -501,7 +501,9 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                     int lc, ln, le, dc, dn, de;
                     za_len_sym(is_match ? len : 3, lc, ln, le);
                     za_dist_sym(dist, dc, dn, de);
-                    const uint32_t t = is_match ? (0x80000000u | ((uint32_t)(len - 3) << 16) | (uint32_t)(dist - 1)) : lit;
+                    // a match token carries its symbols (length code << 26, extra << 21, distance code << 16, extra): the
+                    // packer, which is VALU-bound, needs no symbol arithmetic
+                    const uint32_t t = is_match ? (0x80000000u | ((uint32_t)lc << 26) | ((uint32_t)le << 21) | ((uint32_t)dc << 16) | (uint32_t)de) : lit;
                     // rotating group of four tokens, stored as one 16-byte write
                     const uint32_t k = ntok & 3u;
                     if (k == 3u) *(uint4 *)(tok + (ntok & ~3u)) = make_uint4(tb0, tb1, tb2, t);
@@ -933,11 +935,9 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     // (literal and match on one predicated path: a literal is "length part only")
     for_each_token([&](uint32_t t) {
         const bool m = (t & 0x80000000u) != 0u;
-        int lc, ln, le, dc, dn, de;
-        za_len_sym(m ? (int)((t >> 16) & 0xFF) + 3 : 3, lc, ln, le);
-        za_dist_sym(m ? (int)(t & 0x7FFF) + 1 : 1, dc, dn, de);
+        const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
         const uint32_t c1 = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], c2 = codes[288 + dc];
-        bits += (c1 >> 16) + (m ? (uint32_t)ln + (c2 >> 16) + (uint32_t)dn : 0u);
+        bits += (c1 >> 16) + (m ? (uint32_t)za_len_extra_bits(lc) + (c2 >> 16) + (uint32_t)za_dist_extra_bits(dc) : 0u);
     });
     const uint32_t incl = za_wave_incl_scan(bits);
     const uint32_t start = plan.header_bits + incl - bits;
@@ -951,9 +951,9 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     w.init(slot32, cap_words, start);
     for_each_token([&](uint32_t t) {
         const bool m = (t & 0x80000000u) != 0u;
-        int lc, ln, le, dc, dn, de;
-        za_len_sym(m ? (int)((t >> 16) & 0xFF) + 3 : 3, lc, ln, le);
-        za_dist_sym(m ? (int)(t & 0x7FFF) + 1 : 1, dc, dn, de);
+        const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
+        const int ln = m ? za_len_extra_bits(lc) : 0, dn = za_dist_extra_bits(dc);
+        const uint32_t le = m ? (t >> 21) & 31u : 0u, de = t & 0x1FFFu;
         const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
         // literal / length code + extra fit in 20 bits, distance code + extra in 28 (0 bits for a literal)
         w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
