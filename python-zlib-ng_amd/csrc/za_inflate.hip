@@ -242,12 +242,14 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
     uint32_t far = 0;
     int status = ZA_I_OK;
     if (hist == 0xFFFFFFFFu) hist = dict_len;
-    if (MODE == 0) for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) win[(ZA_WIN - dict_len + i) & (ZA_WIN - 1)] = (SymT)dict[i];
+    if (MODE == 0) for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) if (dict_len - i <= (uint32_t)RING) win[(ZA_WIN - dict_len + i) & (RING - 1)] = (SymT)dict[i];
     // MODE 2: the ring starts out holding the markers of the RING positions before the start
     if (MODE == 2) for (uint32_t i = (uint32_t)lane; i < (uint32_t)RING; i += 64) win[i] = (SymT)(256u + (uint32_t)(ZA_WIN - RING) + i);
-    // symbol at position q (may be negative: before the start) that is no longer in the ring -- MODE 2 only
+    // symbol at position q (may be negative: before the start) that is no longer in a small ring: read back from the
+    // output (written many rounds ago); before the start it is a marker (MODE 2) or a dictionary byte (MODE 0)
     auto far_sym = [&](long long q) -> SymT {
-        return q >= 0 ? out[q] : (SymT)(256u + (uint32_t)(ZA_WIN + q));
+        if (q >= 0) return out[q];
+        return MODE == 2 ? (SymT)(256u + (uint32_t)(ZA_WIN + q)) : (SymT)dict[(long long)dict_len + q];
     };
     __syncthreads();
 
@@ -871,6 +873,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__rest
 // Members whose extent is known up front without this engine's index (BGZF: 'B','C' subfield with the
 // block size; reference fixture tests/data/test.fastq.bgzip.gz): one wavefront per member runs the
 // sequential decoder, then checks CRC-32 and ISIZE against the trailer (zlib_ngmodule.c:2577-2599).
+#define ZA_MEMBER_RING 4096
 __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                   const ZaMember *__restrict__ members,
                                                                   uint8_t *__restrict__ out, uint64_t out_cap,
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
                                                                   int32_t *__restrict__ status_out)
 {
     __shared__ ZaInfTabs T;
-    __shared__ uint8_t win[ZA_WIN];
+    __shared__ uint8_t win[ZA_MEMBER_RING];       // 4 KiB of history in LDS (16 members per CU); older sources come from the output
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
     __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core<0, uint8_t>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, ibuf, bits, op);
+    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, ibuf, bits, op);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
         if (((bits + 7) >> 3) != m.in_len) status = ZA_I_DATA;          // the member must end where its size says
