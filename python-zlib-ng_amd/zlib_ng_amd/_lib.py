@@ -305,7 +305,7 @@ class Context:
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
         return r, _take(out, min(ol.value, out_cap)), nm.value, used.value
 
-    def gunzip_stream(self, state, data, out_cap, last):
+    def gunzip_stream(self, state, data, out_cap, last, view=False):
         """Stateful window of a longer stream -> (code, out bytes, n_members, in_consumed); see zngamd_gunzip_stream."""
         p, keep = _addr(data)
         out, op = _new_bytes(out_cap)
@@ -315,7 +315,10 @@ class Context:
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
-        return r, _take(out, min(ol.value, out_cap)), nm.value, used.value
+        n = min(ol.value, out_cap)
+        if view:                                # the caller only reads from it: no copy of the filled part
+            return r, memoryview(out)[:n], nm.value, used.value
+        return r, _take(out, n), nm.value, used.value
 
     def gzip_members(self, data, block_size, level):
         p, keep = _addr(data)

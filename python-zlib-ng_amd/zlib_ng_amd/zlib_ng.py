@@ -688,19 +688,33 @@ class _GzipReader:
         self._state = _lib.GzState()      # where a member larger than the window is being continued
 
     # -- compressed input, one window at a time
-    def _read_window(self):
+    def _read_window(self, carry):
+        """The unconsumed tail of the previous window followed by up to one window of new input, in one buffer."""
         if not self._is_file:
             self._in_eof = True
-            return bytes(_view(self._fp)) if self._first else b""
-        parts, got = [], 0
-        while got < self._window:
-            chunk = self._fp.read(self._window - got)
-            if not chunk:
-                self._in_eof = True
-                break
-            parts.append(bytes(chunk))
-            got += len(chunk)
-        return b"".join(parts)
+            return carry + bytes(_view(self._fp)) if self._first else carry
+        keep = len(carry)
+        buf = bytearray(keep + self._window)
+        buf[:keep] = carry
+        got = keep
+        into = getattr(self._fp, "readinto", None)
+        while got < len(buf):
+            if into is not None:
+                n = into(memoryview(buf)[got:])
+                if not n:
+                    self._in_eof = True
+                    break
+            else:
+                chunk = self._fp.read(len(buf) - got)
+                if not chunk:
+                    self._in_eof = True
+                    break
+                n = len(chunk)
+                buf[got:got + n] = chunk
+            got += n
+        if got < len(buf):
+            del buf[got:]
+        return buf
 
     def _set_error(self, code, data, ctx):
         msg = ctx.err()
@@ -716,8 +730,7 @@ class _GzipReader:
         """Decode until some output is buffered, the stream ends, or an error is pending."""
         ctx = _ctx()
         while not self._done and self._boff >= len(self._buf):
-            new = b"" if self._in_eof else self._read_window()
-            data = self._carry + new if self._carry else new
+            data = self._carry if self._in_eof else self._read_window(self._carry)
             self._carry = b""
             if self._first:
                 self._first = False
@@ -725,7 +738,7 @@ class _GzipReader:
                     self._last_mtime = _struct.unpack_from("<I", data, 4)[0]
                 if len(data) >= 2 and data[:2] != b"\x1f\x8b":
                     self._buf, self._boff, self._done = b"", 0, True
-                    self._error = BadGzipFile(f"Not a gzipped file ({data[:2]!r})")
+                    self._error = BadGzipFile(f"Not a gzipped file ({bytes(data[:2])!r})")
                     return
             if not data:
                 self._done = True
@@ -734,7 +747,7 @@ class _GzipReader:
             isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
             cap = max(1 << 16, 4 * len(data), isize + 64)
             while True:
-                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final)
+                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, view=True)
                 if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
                     cap = max(cap * 4, ctx.last_needed + 64)
                     continue
@@ -746,7 +759,7 @@ class _GzipReader:
             if final:
                 self._buf, self._boff = out, 0
                 if 0 < used < len(data):
-                    self._carry = data[used:]      # a continued member ended inside the last window: the rest follows
+                    self._carry = bytes(memoryview(data)[used:])   # a continued member ended inside the last window: the rest follows
                 else:
                     self._done = True
                 if self._boff < len(self._buf) or self._done:
@@ -758,7 +771,7 @@ class _GzipReader:
                 self._window *= 2
                 continue
             self._buf, self._boff = out, 0
-            self._carry = data[used:]
+            self._carry = bytes(memoryview(data)[used:])
 
     def _check(self):
         if self._closed:
@@ -797,7 +810,7 @@ class _GzipReader:
         with self._lock:
             parts = []
             while self._avail() > 0:
-                parts.append(self._buf[self._boff:] if self._boff else self._buf)
+                parts.append(bytes(self._buf[self._boff:]))
                 self._pos += len(self._buf) - self._boff
                 self._boff = len(self._buf)
             if self._error is not None:
@@ -886,6 +899,7 @@ class _GzipReader:
 
 def _magic_error(raw, ctx):
     """Walk the good members with the engine to find the two bytes that are not a gzip magic."""
+    raw = bytes(raw)
     pos, n = 0, len(raw)
     try:
         while pos < n:
