@@ -153,6 +153,9 @@ def _new_bytes(n):
     return obj, C.c_void_p(_py.PyBytes_AsString(obj))
 
 
+new_buffer = _new_bytes          # for callers that keep an output buffer across calls (see Context.gunzip_stream)
+
+
 def _take(obj, n):
     return obj if n == len(obj) else obj[:n]
 
@@ -305,10 +308,14 @@ class Context:
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
         return r, _take(out, min(ol.value, out_cap)), nm.value, used.value
 
-    def gunzip_stream(self, state, data, out_cap, last, view=False):
+    def gunzip_stream(self, state, data, out_cap, last, view=False, into=None):
         """Stateful window of a longer stream -> (code, out bytes, n_members, in_consumed); see zngamd_gunzip_stream."""
         p, keep = _addr(data)
-        out, op = _new_bytes(out_cap)
+        if into is not None:                    # (object, address) from new_buffer(): reused from window to window, so
+            out, op = into                      # its pages are faulted in once
+            view = True
+        else:
+            out, op = _new_bytes(out_cap)
         ol, nm, used = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
         r = self.L.zngamd_gunzip_stream(self.h, C.byref(state), p, memoryview(data).nbytes, 1 if last else 0, op, out_cap,
                                         C.byref(ol), C.byref(nm), C.byref(used))

@@ -686,6 +686,7 @@ class _GzipReader:
         self._error = None       # raised once the buffered good bytes are gone
         self._first = True
         self._state = _lib.GzState()      # where a member larger than the window is being continued
+        self._out = None                  # decoded window (object, address); reused, so its pages are faulted in once
 
     # -- compressed input, one window at a time
     def _read_window(self, carry):
@@ -747,7 +748,11 @@ class _GzipReader:
             isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
             cap = max(1 << 16, 4 * len(data), isize + 64)
             while True:
-                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, view=True)
+                if self._out is None or len(self._out[0]) < cap:
+                    self._buf = b""                      # drop the view of the old buffer before replacing it
+                    self._out = _lib.new_buffer(cap + cap // 4)   # head-room: windows differ a little in size
+                cap = len(self._out[0])
+                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, into=self._out)
                 if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
                     cap = max(cap * 4, ctx.last_needed + 64)
                     continue
