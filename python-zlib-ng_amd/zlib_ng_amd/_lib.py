@@ -127,16 +127,43 @@ class EngineError(RuntimeError):
         self.msg = msg
 
 
+class _PyBuffer(C.Structure):                  # Py_buffer (CPython's buffer protocol view)
+    _fields_ = [("buf", C.c_void_p), ("obj", C.c_void_p), ("len", C.c_ssize_t), ("itemsize", C.c_ssize_t),
+                ("readonly", C.c_int), ("ndim", C.c_int), ("format", C.c_char_p), ("shape", C.c_void_p),
+                ("strides", C.c_void_p), ("suboffsets", C.c_void_p), ("internal", C.c_void_p)]
+
+
+C.pythonapi.PyObject_GetBuffer.argtypes = [C.py_object, C.POINTER(_PyBuffer), C.c_int]
+C.pythonapi.PyObject_GetBuffer.restype = C.c_int
+C.pythonapi.PyBuffer_Release.argtypes = [C.POINTER(_PyBuffer)]
+C.pythonapi.PyBuffer_Release.restype = None
+
+
+class _Pinned:
+    """Holds a buffer-protocol view of an object (read-only ones included) for the duration of an engine call."""
+
+    def __init__(self, obj):
+        self.view = _PyBuffer()
+        self.ok = C.pythonapi.PyObject_GetBuffer(obj, C.byref(self.view), 0) == 0      # PyBUF_SIMPLE
+
+    def __del__(self):
+        if getattr(self, "ok", False):
+            C.pythonapi.PyBuffer_Release(C.byref(self.view))
+            self.ok = False
+
+
 def _addr(buf):
-    """Address + keep-alive object of a bytes-like without copying when possible."""
+    """Address + keep-alive object of a bytes-like, without copying (contiguous buffers of any kind)."""
     if isinstance(buf, bytes):
         return C.cast(C.c_char_p(buf), C.c_void_p), buf
-    mv = memoryview(buf)
-    if mv.readonly or not mv.contiguous:
-        b = mv.tobytes()
-        return C.cast(C.c_char_p(b), C.c_void_p), b
-    arr = (C.c_char * mv.nbytes).from_buffer(mv)
-    return C.cast(arr, C.c_void_p), arr
+    try:
+        pin = _Pinned(buf)                       # raises BufferError for non-contiguous exporters
+    except Exception:
+        pin = None
+    if pin is not None and pin.ok:
+        return C.c_void_p(pin.view.buf), (pin, buf)
+    b = memoryview(buf).tobytes()
+    return C.cast(C.c_char_p(b), C.c_void_p), b
 
 
 _py = C.pythonapi
@@ -176,6 +203,7 @@ class Context:
             raise RuntimeError(
                 f"zng_amd: no usable GPU (zngamd_ctx_create({device}) -> {r}); this engine has no CPU path")
         self.L, self.h, self.device = L, h, device
+        self._scratch, self._scratch_lock = None, threading.Lock()
         self.last_needed = 0
 
     def close(self):
@@ -214,25 +242,45 @@ class Context:
         return self.L.zngamd_crc32_combine(crc1 & 0xFFFFFFFF, crc2 & 0xFFFFFFFF, len2)
 
     # ---- deflate
-    def deflate_blocks(self, buf, blocks, level, out_cap):
-        """blocks: list of (off, len, dict_len, flags).  -> (list of bytes|None, list of crc, overflowed)"""
+    def deflate_blocks(self, buf, blocks, level, out_cap, joined=False):
+        """blocks: list of (off, len, dict_len, flags).  -> (list of bytes|None, list of crc, overflowed); with joined=True
+        the first element is ONE bytes object, the blocks' outputs back to back (a writer that only concatenates them
+        saves the allocation and release of one object per block) and a list of lengths is appended to the result."""
         n = len(blocks)
         arr = (Block * max(n, 1))()
         for i, (off, ln, dl, fl) in enumerate(blocks):
             arr[i] = Block(off, ln, dl, fl, 0)
         p, keep = _addr(buf)
-        out, op = _new_bytes(max(n, 1) * out_cap)
         lens = (C.c_uint32 * max(n, 1))()
         crcs = (C.c_uint32 * max(n, 1))()
-        r = self.L.zngamd_deflate_blocks(self.h, p, memoryview(buf).nbytes, arr, n, level,
-                                         op, out_cap, C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p))
-        self._chk(r, (OK, E_OVERFLOW))
-        res = []
-        for i in range(n):
-            if lens[i] == 0xFFFFFFFF:
-                res.append(None)
-            else:
-                res.append(out[i * out_cap:i * out_cap + lens[i]])
+        need = max(n, 1) * out_cap
+        # The per-block outputs land in a buffer that lives with the context: device-to-host copies into memory that has
+        # been touched (and registered by the runtime) before run several times faster than into fresh pages.  The lock
+        # covers the call and the slicing (engine calls of one context are serial anyway).
+        with self._scratch_lock:
+            if self._scratch is None or len(self._scratch) < need:
+                self._scratch = bytearray(need + need // 4)
+            out = self._scratch
+            arr_out = (C.c_char * len(out)).from_buffer(out)
+            r = self.L.zngamd_deflate_blocks(self.h, p, memoryview(buf).nbytes, arr, n, level,
+                                             C.cast(arr_out, C.c_void_p), out_cap, C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p))
+            del arr_out
+            self._chk(r, (OK, E_OVERFLOW))
+            res = []
+            mv = memoryview(out)
+            if joined:
+                if r == E_OVERFLOW:
+                    res = None
+                else:
+                    res = b"".join([mv[i * out_cap:i * out_cap + lens[i]] for i in range(n)])
+                del mv
+                return res, list(crcs[:n]), r == E_OVERFLOW, list(lens[:n])
+            for i in range(n):
+                if lens[i] == 0xFFFFFFFF:
+                    res.append(None)
+                else:
+                    res.append(bytes(mv[i * out_cap:i * out_cap + lens[i]]))
+            del mv
         return res, list(crcs[:n]), r == E_OVERFLOW
 
     def deflate_stream(self, data, level, window_bits=15):

@@ -227,6 +227,8 @@ class _ThreadedGzipWriter(io.RawIOBase):
             if self.exception:
                 raise self.exception
         nbytes = b.nbytes if isinstance(b, memoryview) else len(b)
+        if nbytes >= 8 * self.block_size:
+            return self._write_bulk(memoryview(b).cast("B"), nbytes)
         if nbytes > self.block_size:
             view = memoryview(b)
             done = 0
@@ -240,6 +242,47 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self.index += 1
         self.input_queues[slot].put((data, zdict))
         return len(data)
+
+    def _write_bulk(self, view, nbytes):
+        """A write of many blocks at once: same cutting and priming as block by block, but the blocks go to the engine as
+        slices of one buffer (no per-block objects, no queue round trips).  Queued blocks are finished first."""
+        for q in self.input_queues:
+            q.join()
+        with self.lock:
+            if self.exception:
+                raise self.exception
+        tail = bytes(memoryview(self.previous_block)[-DEFLATE_WINDOW_SIZE:])
+        bs = self.block_size
+        cap = bs + max(bs // 10, 500)
+        ctx = zlib_ng._ctx()
+
+        def emit(buf, blocks):
+            packed, crcs, overflowed, _ = ctx.deflate_blocks(buf, blocks, self.level, cap, joined=True)
+            if overflowed:
+                raise OverflowError(f"Compressed output exceeds buffer size of {cap}")
+            for (_, ln, _, _), crc in zip(blocks, crcs):
+                self._crc = zlib_ng.crc32_combine(self._crc, crc, ln)
+            self.raw.write(packed)
+
+        # the first block needs the tail of what was written before: a small buffer of its own; every later block is primed
+        # by the bytes in front of it in the caller's buffer, which goes to the engine as it is (no copy of the payload)
+        first = min(bs, nbytes)
+        emit(tail + bytes(view[:first]), [(len(tail), first, len(tail), 0)])
+        step = max(bs, (256 << 20) // bs * bs)                       # engine batches of at most 256 MiB
+        src = view.obj if isinstance(view.obj, bytes) and len(view.obj) == nbytes else view
+        lo = first
+        while lo < nbytes:
+            hi = min(nbytes, lo + step)
+            if hi - first == nbytes - first:                          # everything in one batch: the caller's buffer itself
+                emit(src, [(o, min(bs, hi - o), min(DEFLATE_WINDOW_SIZE, o), 0) for o in range(lo, hi, bs)])
+            else:                                                      # a slice with 32 KiB of history in front
+                d = min(DEFLATE_WINDOW_SIZE, lo)
+                emit(view[lo - d:hi], [(d + o - lo, min(bs, hi - o), min(DEFLATE_WINDOW_SIZE, d + o - lo), 0) for o in range(lo, hi, bs)])
+            lo = hi
+        self._size += nbytes
+        last = nbytes - ((nbytes - 1) // bs) * bs                    # the next block is primed with the last block, as always
+        self.previous_block = bytes(view[nbytes - last:nbytes])
+        return nbytes
 
     def _end_gzip_stream(self):
         self._check_closed()
@@ -305,10 +348,11 @@ class _ThreadedGzipWriter(io.RawIOBase):
                     q.task_done()
                 self._set_error_and_empty_queue(exc)
                 return
-            for (data, _), (compressed, crc), q in zip(batch, results, origins):
+            for (data, _), (compressed, crc) in zip(batch, results):
                 self._crc = zlib_ng.crc32_combine(self._crc, crc, len(data))
                 self._size += len(data)
-                self.raw.write(compressed)
+            self.raw.write(b"".join(c for c, _ in results))          # one write per batch, blocks in order
+            for q in origins:
                 q.task_done()
 
     def _set_error_and_empty_queue(self, error, q=None):

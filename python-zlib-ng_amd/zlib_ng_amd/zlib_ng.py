@@ -275,17 +275,28 @@ class _ParallelCompress:
         return self.compress_and_crc_batch([args])[0]
 
     def compress_and_crc_batch(self, items):
-        """items: iterable of (data, zdict) -> list of (compressed bytes, crc32)."""
+        """items: iterable of (data, zdict) -> list of (compressed bytes, crc32).  When a block's dictionary is exactly the
+        tail of the block before it (what the threaded writer produces) it is not copied again: the block is laid directly
+        behind its predecessor and primed from there."""
         parts, blocks, pos = [], [], 0
+        prev = None                                  # data of the previous item (memoryview)
         for data, zdict in items:
             d, z = _view(data), _view(zdict)
             if d.nbytes + z.nbytes > 0xFFFFFFFF:
                 raise OverflowError(f"Can only compress {0xFFFFFFFF} bytes of data")
             z = z[-32768:] if z.nbytes > 32768 else z
-            parts.append(z)
-            parts.append(d)
-            blocks.append((pos + z.nbytes, d.nbytes, z.nbytes, 0))
-            pos += z.nbytes + d.nbytes
+            chained = (prev is not None and z.nbytes and z.nbytes == min(prev.nbytes, 32768)
+                       and z == prev[prev.nbytes - z.nbytes:])
+            if chained:                              # the dictionary is what already lies in front of this block
+                parts.append(d)
+                blocks.append((pos, d.nbytes, z.nbytes, 0))
+                pos += d.nbytes
+            else:
+                parts.append(z)
+                parts.append(d)
+                blocks.append((pos + z.nbytes, d.nbytes, z.nbytes, 0))
+                pos += z.nbytes + d.nbytes
+            prev = d
         if not blocks:
             return []
         outs, crcs, overflowed = _ctx().deflate_blocks(b"".join(parts), blocks, self._level, max(self._buffersize, 1))
