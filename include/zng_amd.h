@@ -49,6 +49,9 @@ typedef struct zngamd_ctx zngamd_ctx;
 #define ZNGAMD_E_OVERFLOW    (-203)   /* a block's compressed output reached its buffer size */
 
 #define ZNGAMD_FLAG_FINAL      1u     /* block ends the deflate stream (BFINAL=1, no sync flush) */
+/* window of the stream the blocks belong to: match distances stay within 2^bits (deflateInit2's windowBits 9..15).
+ * Taken from the FIRST block of a call and applied to all of them; 0 = 15. */
+#define ZNGAMD_FLAG_WBITS(bits) (((uint32_t)(bits) & 15u) << 8)
 
 #define ZNGAMD_UNIT_MAX        131072u  /* largest span one kernel unit covers */
 #define ZNGAMD_SLOT_STRIDE     131136u  /* bytes reserved per unit in a device slot buffer */
@@ -84,7 +87,7 @@ typedef struct {
     uint64_t off;        /* offset of the block's first byte in `in` */
     uint32_t len;        /* block length (any size; cut into <=128 KiB units inside) */
     uint32_t dict_len;   /* bytes of `in` directly before `off` that prime the window (<= 32768) */
-    uint32_t flags;      /* ZNGAMD_FLAG_FINAL */
+    uint32_t flags;      /* ZNGAMD_FLAG_FINAL | ZNGAMD_FLAG_WBITS(n) */
     uint32_t reserved;
 } zngamd_block;
 

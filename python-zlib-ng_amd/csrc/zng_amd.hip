@@ -467,7 +467,9 @@ int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, con
     int r = stage_in(c, in, in_len);
     if (r) return r;
     std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
-    r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, packed);
+    const uint32_t wb = n_blocks ? (blocks[0].flags >> 8) & 15u : 0u;
+    if (wb != 0 && wb < 9) return fail(c, ZNGAMD_STREAM_ERROR, "window bits must be 9..15");
+    r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, packed, wb ? (1 << wb) : ZA_WIN);
     if (r) return r;
     int ret = ZNGAMD_OK;
     size_t pos = 0, u = 0;

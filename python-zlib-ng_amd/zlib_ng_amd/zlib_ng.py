@@ -347,7 +347,7 @@ class _Compress:
         if data or final:
             ctx = _ctx()
             buf = self._tail + data
-            flags = _lib.FLAG_FINAL if final else 0
+            flags = (_lib.FLAG_FINAL if final else 0) | ((self._wb & 15) << 8)      # ZNGAMD_FLAG_WBITS: stay inside the declared window
             outs, crcs, _ = ctx.deflate_blocks(buf, [(len(self._tail), len(data), len(self._tail), flags)],
                                                self._level, len(data) + len(data) // 8 + (len(data) // 131072 + 2) * 64)
             out.append(outs[0])

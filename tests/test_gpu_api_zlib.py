@@ -463,3 +463,18 @@ def test_compressobj_zlib_container_with_preset_dictionary():
     theirs = c2.compress(data) + c2.flush()
     do = zlib_ng.decompressobj(zdict=zdict)
     assert do.decompress(theirs) == data
+
+
+def test_compressobj_respects_small_windows():
+    """compressobj(wbits=9..14 / raw / gzip forms): no match may reach further back than the declared window -- the
+    system zlib opened with the same wbits must decode it (test_zlib_compliance.py test_wbits)."""
+    import zlib
+    from zlib_ng_amd import corpus, zlib_ng
+    data = corpus.text(3 << 20, seed=3).tobytes()
+    for wb in (9, 10, 12, 14, 15, -9, -12, -15, 25, 28, 31):
+        co = zlib_ng.compressobj(6, zlib_ng.DEFLATED, wb)
+        blob = co.compress(data[:1000]) + co.compress(data[1000:]) + co.flush()
+        assert zlib.decompress(blob, wb) == data, wb
+        assert zlib.decompress(zlib_ng.compress(data, 6, wb), wb) == data, wb
+        if 9 <= wb <= 15:
+            assert (blob[0] >> 4) + 8 == wb                       # CINFO says what was used
