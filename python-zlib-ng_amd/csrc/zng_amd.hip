@@ -64,6 +64,7 @@ struct zngamd_ctx {
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
     uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
+    uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // pinned host staging for device-to-host results (grow-only)
     bool prof = false; std::vector<EvPair> evs; std::vector<hipEvent_t> pool;
     double ms[ZNGAMD_K_COUNT] = {0}; uint64_t launches[ZNGAMD_K_COUNT] = {0};
 };
@@ -146,6 +147,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
     c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
     if (c->d_small) (void)hipFree(c->d_small);
@@ -426,9 +428,24 @@ int zngamd_gather_dev(zngamd_ctx *c, const void *d_slots, const uint32_t *d_unit
 }
 
 // shared by the two host-buffer entry points: input already staged at st_in.p
+// pinned host memory for results that are re-distributed on the host afterwards: a device-to-host copy into pinned memory
+// runs at link speed, into fresh pageable memory several times slower
+static int host_stage(zngamd_ctx *c, size_t bytes, uint8_t **p)
+{
+    if (bytes > c->h_stage_cap) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        const size_t want = bytes + bytes / 4 + (1u << 20);
+        HIPCHK(c, hipHostMalloc((void **)&c->h_stage, want, hipHostMallocDefault));
+        c->h_stage_cap = want;
+    }
+    *p = c->h_stage;
+    return ZNGAMD_OK;
+}
+
 static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks, int level,
                                std::vector<ZaUnit> &hu, std::vector<uint32_t> &ulen, std::vector<uint32_t> &ucrc,
-                               std::vector<uint8_t> &packed, int max_dist = ZA_WIN,
+                               const uint8_t **packed, int max_dist = ZA_WIN,
                                uint8_t *direct_out = nullptr, uint64_t direct_cap = 0, uint64_t *direct_len = nullptr)
 {
     int r = build_units(c, blocks, n_blocks, in_len, hu);
@@ -446,12 +463,13 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
     const bool direct = direct_out != nullptr;
     if (direct) { *direct_len = total; if (total > direct_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
     ulen.resize(n); ucrc.resize(n);
-    if (!direct) packed.resize(total);
+    uint8_t *stage = nullptr;
+    if (!direct) { int rs = host_stage(c, total, &stage); if (rs) return rs; *packed = stage; }
     std::vector<uint32_t> st(n);
     HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-    if (total) HIPCHK(c, hipMemcpyAsync(direct ? direct_out : packed.data(), c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (total) HIPCHK(c, hipMemcpyAsync(direct ? direct_out : stage, c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_OVERFLOW, "unit overflowed its slot");
@@ -466,10 +484,10 @@ int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, con
     std::lock_guard<std::mutex> g(c->mu);
     int r = stage_in(c, in, in_len);
     if (r) return r;
-    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
+    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; const uint8_t *packed = nullptr;
     const uint32_t wb = n_blocks ? (blocks[0].flags >> 8) & 15u : 0u;
     if (wb != 0 && wb < 9) return fail(c, ZNGAMD_STREAM_ERROR, "window bits must be 9..15");
-    r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, packed, wb ? (1 << wb) : ZA_WIN);
+    r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, &packed, wb ? (1 << wb) : ZA_WIN);
     if (r) return r;
     int ret = ZNGAMD_OK;
     size_t pos = 0, u = 0;
@@ -483,7 +501,7 @@ int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, con
         }
         crc[b] = bc;
         if (tot >= out_cap_per_block) { out_len[b] = 0xFFFFFFFFu; ret = ZNGAMD_E_OVERFLOW; continue; }
-        memcpy(out + (size_t)b * out_cap_per_block, packed.data() + start, tot);
+        memcpy(out + (size_t)b * out_cap_per_block, packed + start, tot);
         out_len[b] = (uint32_t)tot;
     }
     if (ret) c->err = "Compressed output exceeds buffer size";
@@ -500,9 +518,9 @@ int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int
     int r = stage_in(c, in, in_len);
     if (r) return r;
     zngamd_block B; B.off = 0; B.len = (uint32_t)in_len; B.dict_len = 0; B.flags = ZNGAMD_FLAG_FINAL; B.reserved = 0;
-    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; std::vector<uint8_t> packed;
+    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; const uint8_t *packed = nullptr;
     if (window_bits < 9 || window_bits > 15) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
-    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, packed, 1 << window_bits, out, out_cap, out_len);
+    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, &packed, 1 << window_bits, out, out_cap, out_len);
     if (r) return r;
     if (crc) { uint32_t v = 0; for (size_t u = 0; u < hu.size(); u++) v = u ? zngamd_crc32_combine(v, ucrc[u], hu[u].in_len) : ucrc[u]; *crc = v; }
     if (adler) { uint32_t a = 1; r = checksum_dev(c, c->st_in.p, in_len, nullptr, &a); if (r) return r; *adler = a; }

@@ -364,11 +364,40 @@ class _Compress:
                 out.append(_struct.pack("<II", self._crc, self._size & 0xFFFFFFFF))
         return b"".join(out)
 
+    def _emit_direct(self, view):
+        """A large piece with nothing pending: its first 128 KiB go through a small buffer behind the dictionary tail, the
+        rest is compressed where it lies in the caller's buffer (each unit primed by the bytes in front of it)."""
+        out = []
+        if not self._started:
+            out.append(self._emit(False))                   # header only (nothing pending)
+        ctx = _ctx()
+        n = view.nbytes
+        first = min(131072, n)
+        wflag = (self._wb & 15) << 8
+        head = self._tail + bytes(view[:first])
+        outs, crcs, _ = ctx.deflate_blocks(head, [(len(self._tail), first, len(self._tail), wflag)], self._level, first + first // 8 + 256)
+        out.append(outs[0])
+        self._crc = crc32_combine(self._crc, crcs[0], first)
+        if n > first:
+            rest = n - first
+            packed, crcs, _, _ = ctx.deflate_blocks(view, [(first, rest, 32768, wflag)], self._level,
+                                                    rest + rest // 8 + (rest // 131072 + 2) * 64, joined=True)
+            out.append(packed)
+            self._crc = crc32_combine(self._crc, crcs[0], rest)
+        if self._kind == "zlib":
+            self._adler = ctx.adler32(view, self._adler)
+        self._size += n
+        self._tail = bytes(view[-32768:]) if n >= 32768 else (self._tail + bytes(view))[-32768:]
+        return b"".join(out)
+
     def compress(self, data, /):
         with self._lock:
             if self._finished:
                 raise _zerr(_lib.STREAM_ERROR, "while compressing data")
-            self._pending += _view(data)
+            view = _view(data)
+            if not self._pending and view.nbytes >= self._BATCH and view.contiguous:
+                return self._emit_direct(view)
+            self._pending += view
             if len(self._pending) >= self._BATCH:
                 return self._emit(False)
             return b""
