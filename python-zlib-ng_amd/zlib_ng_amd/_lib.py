@@ -183,6 +183,52 @@ def _new_bytes(n):
 new_buffer = _new_bytes          # for callers that keep an output buffer across calls (see Context.gunzip_stream)
 
 
+# raw-pointer views of four C-API functions: the object below is owned through a bare pointer until it is handed over
+_raw_new = C.PYFUNCTYPE(C.c_void_p, C.c_void_p, C.c_ssize_t)(("PyBytes_FromStringAndSize", C.pythonapi))
+_raw_buf = C.PYFUNCTYPE(C.c_void_p, C.c_void_p)(("PyBytes_AsString", C.pythonapi))
+_raw_resize = C.PYFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_ssize_t)(("_PyBytes_Resize", C.pythonapi))
+_raw_decref = C.PYFUNCTYPE(None, C.c_void_p)(("Py_DecRef", C.pythonapi))
+
+
+class _Out:
+    """An engine output buffer on its way to becoming the result: a fresh bytes object that Python has not seen yet (it is
+    held through a bare pointer with its single reference), so it can be cut to the produced length in place
+    (_PyBytes_Resize, what CPython's own zlib module does) instead of being copied into a second object."""
+    __slots__ = ("ptr", "cap")
+
+    def __init__(self, n):
+        self.cap = max(int(n), 1)
+        self.ptr = C.c_void_p(_raw_new(None, self.cap))
+        if not self.ptr.value:
+            raise MemoryError("cannot allocate the result")
+
+    def addr(self):
+        return C.c_void_p(_raw_buf(self.ptr))
+
+    def take(self, n):
+        n = min(int(n), self.cap)
+        if n == 0:
+            self._drop()
+            return b""
+        if n != self.cap and _raw_resize(C.byref(self.ptr), n) != 0:
+            self.ptr = C.c_void_p(None)          # _PyBytes_Resize released the object on failure
+            raise MemoryError("cannot resize the result")
+        res = C.cast(self.ptr, C.py_object).value     # a new reference for Python ...
+        self._drop()                                   # ... and ours is given up
+        return res
+
+    def _drop(self):
+        if self.ptr is not None and self.ptr.value:
+            _raw_decref(self.ptr)
+        self.ptr = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self._drop()
+        except Exception:
+            pass
+
+
 def _take(obj, n):
     return obj if n == len(obj) else obj[:n]
 
@@ -288,12 +334,12 @@ class Context:
         p, keep = _addr(data)
         n = memoryview(data).nbytes
         cap = n + (n // UNIT_MAX + 1) * 64 + 64
-        out, op = _new_bytes(cap)
+        out = _Out(cap)
         ol = C.c_uint64(0)
         crc, ad = C.c_uint32(0), C.c_uint32(1)
-        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, window_bits, op, cap,
+        self._chk(self.L.zngamd_deflate_stream(self.h, p, n, level, window_bits, out.addr(), cap,
                                                C.byref(ol), C.byref(crc), C.byref(ad)))
-        return _take(out, ol.value), crc.value, ad.value
+        return out.take(ol.value), crc.value, ad.value
 
     def debug_fetch(self, what, unit, nbytes):
         b = C.create_string_buffer(nbytes)
@@ -305,11 +351,11 @@ class Context:
         """-> (code, out bytes, in_used, crc32, adler32)"""
         p, keep = _addr(data)
         dp, dkeep = _addr(zdict) if len(zdict) else (None, None)
-        out, op = _new_bytes(out_cap)
+        out = _Out(out_cap)
         ol, used = C.c_uint64(0), C.c_uint64(0)
         crc, ad = C.c_uint32(0), C.c_uint32(1)
         r = self.L.zngamd_inflate_raw(self.h, p, memoryview(data).nbytes, dp, len(zdict),
-                                      op, out_cap, C.byref(ol), C.byref(used),
+                                      out.addr(), out_cap, C.byref(ol), C.byref(used),
                                       C.byref(crc), C.byref(ad))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
@@ -317,44 +363,44 @@ class Context:
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
         if self.last_needed:
             return r, b"", 0, 0, 1
-        return r, _take(out, min(ol.value, out_cap)), used.value, crc.value, ad.value
+        return r, out.take(min(ol.value, out_cap)), used.value, crc.value, ad.value
 
     def inflate_resume(self, data, start_bit, zdict, out_cap):
         """-> (code, out bytes, in_bits, block_bits, block_out); code E_OVERFLOW = out_cap reached"""
         p, keep = _addr(data)
         dp, dkeep = _addr(zdict) if len(zdict) else (None, None)
-        out, op = _new_bytes(out_cap)
+        out = _Out(out_cap)
         ol, ib, bb, bo = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         r = self.L.zngamd_inflate_resume(self.h, p, memoryview(data).nbytes, start_bit, dp, len(zdict),
-                                         op, out_cap, C.byref(ol), C.byref(ib), C.byref(bb), C.byref(bo))
+                                         out.addr(), out_cap, C.byref(ol), C.byref(ib), C.byref(bb), C.byref(bo))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
-        return r, _take(out, min(ol.value, out_cap)), ib.value, bb.value, bo.value
+        return r, out.take(min(ol.value, out_cap)), ib.value, bb.value, bo.value
 
     def gunzip(self, data, out_cap):
         """-> (code, out bytes, n_members)"""
         p, keep = _addr(data)
-        out, op = _new_bytes(out_cap)
+        out = _Out(out_cap)
         ol, nm = C.c_uint64(0), C.c_uint32(0)
-        r = self.L.zngamd_gunzip(self.h, p, memoryview(data).nbytes, op, out_cap,
+        r = self.L.zngamd_gunzip(self.h, p, memoryview(data).nbytes, out.addr(), out_cap,
                                  C.byref(ol), C.byref(nm))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
         # BUF_ERROR with a size above the capacity = "this is how much room the stream needs"
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
-        return r, _take(out, min(ol.value, out_cap)), nm.value
+        return r, out.take(min(ol.value, out_cap)), nm.value
 
     def gunzip_partial(self, data, out_cap):
         """Window of a longer stream -> (code, out bytes, n_members, in_consumed); see zngamd_gunzip_partial."""
         p, keep = _addr(data)
-        out, op = _new_bytes(out_cap)
+        out = _Out(out_cap)
         ol, nm, used = C.c_uint64(0), C.c_uint32(0), C.c_uint64(0)
-        r = self.L.zngamd_gunzip_partial(self.h, p, memoryview(data).nbytes, op, out_cap,
+        r = self.L.zngamd_gunzip_partial(self.h, p, memoryview(data).nbytes, out.addr(), out_cap,
                                          C.byref(ol), C.byref(nm), C.byref(used))
         if r in (E_HIP, E_ARG):
             raise EngineError(r, self.err())
         self.last_needed = ol.value if (r == BUF_ERROR and ol.value > out_cap) else 0
-        return r, _take(out, min(ol.value, out_cap)), nm.value, used.value
+        return r, out.take(min(ol.value, out_cap)), nm.value, used.value
 
     def gunzip_stream(self, state, data, out_cap, last, view=False, into=None):
         """Stateful window of a longer stream -> (code, out bytes, n_members, in_consumed); see zngamd_gunzip_stream."""
@@ -380,10 +426,10 @@ class Context:
         n = memoryview(data).nbytes
         nb = max(1, (n + block_size - 1) // max(block_size, 1))
         cap = n + nb * 400 + 64
-        out, op = _new_bytes(cap)
+        out = _Out(cap)
         ol = C.c_uint64(0)
-        self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, op, cap, C.byref(ol)))
-        return _take(out, ol.value)
+        self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, out.addr(), cap, C.byref(ol)))
+        return out.take(ol.value)
 
     # ---- measurement
     def profiling(self, on):
