@@ -167,7 +167,11 @@ def _parse_gzip_header(buf, pos=0):
             raise trunc
     for bit in (8, 16):
         if flags & bit:
-            z = bytes(buf[cur:]).find(b"\0")
+            z, span, seen = -1, 4096, cur           # NUL-terminated field: look in growing pieces, not in a copy of the rest
+            while z < 0 and seen < n:
+                seen = min(n, cur + span)
+                z = bytes(buf[cur:seen]).find(b"\0")
+                span *= 16
             if z < 0:
                 raise trunc
             cur += z + 1
@@ -186,7 +190,7 @@ def decompress(data, /, wbits=MAX_WBITS, bufsize=DEF_BUF_SIZE):
     """Returns a bytes object containing the uncompressed data (zlib_decompress_impl, :275-373)."""
     if bufsize < 0:
         raise ValueError("bufsize must be non-negative")
-    buf = bytes(_view(data))
+    buf = _view(data)                        # a view: the payload is never copied on the host
     W = "while decompressing data"
     if wbits == 0 or 8 <= wbits <= 15:
         kind = "zlib"
@@ -220,7 +224,7 @@ def decompress(data, /, wbits=MAX_WBITS, bufsize=DEF_BUF_SIZE):
         code, out, used, _, ad = _inflate_all(buf[2:], hint=bufsize)
         if code != _lib.STREAM_END:
             raise _zerr(code if code in _MSG else _lib.DATA_ERROR, W)
-        tail = buf[2 + used:2 + used + 4]
+        tail = bytes(buf[2 + used:2 + used + 4])
         if len(tail) < 4:
             raise _zerr(_lib.BUF_ERROR, W)
         if _struct.unpack(">I", tail)[0] != ad:
@@ -242,7 +246,7 @@ def decompress(data, /, wbits=MAX_WBITS, bufsize=DEF_BUF_SIZE):
     code, out, used, crc, _ = _inflate_all(buf[start:], hint=bufsize)
     if code != _lib.STREAM_END:
         raise _zerr(code if code in _MSG else _lib.DATA_ERROR, W)
-    tail = buf[start + used:start + used + 8]
+    tail = bytes(buf[start + used:start + used + 8])
     if len(tail) < 8:
         raise _zerr(_lib.BUF_ERROR, W)
     tcrc, tlen = _struct.unpack("<II", tail)
