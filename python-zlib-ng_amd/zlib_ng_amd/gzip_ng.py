@@ -107,7 +107,23 @@ def compress(data, compresslevel=_COMPRESS_LEVEL_BEST, *, mtime=None):
 
 
 def decompress(data):
-    """One-shot gunzip of any number of members (gzip_ng.py:200-205)."""
+    """One-shot gunzip of any number of members (gzip_ng.py:200-205).  The whole input goes to the engine in one call
+    and the result is the engine's output object; anything but a clean decode is replayed through the reader, which
+    raises the reference's exceptions."""
+    mv = memoryview(data)
+    if mv.contiguous and mv.nbytes >= 18:
+        mv = mv.cast("B") if (mv.format != "B" or mv.ndim != 1) else mv
+        ctx = zlib_ng._ctx()
+        isize = int.from_bytes(mv[mv.nbytes - 4:], "little")
+        cap = max(1 << 16, isize + 64, 2 * mv.nbytes)
+        for _ in range(3):
+            code, out, _n = ctx.gunzip(mv, cap)
+            if code == 0:
+                return out
+            if code == zlib_ng._lib.BUF_ERROR and ctx.last_needed > cap:
+                cap = ctx.last_needed + 64
+                continue
+            break
     return _GzipReader(data).readall()
 
 
