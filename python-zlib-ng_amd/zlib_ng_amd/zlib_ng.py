@@ -14,8 +14,10 @@ block-resumable decoding on the sequential wavefront decoder).
 """
 import gzip as _gzip
 import io as _io
+import operator as _operator
 import os as _os
 import struct as _struct
+import sys as _sys
 import threading as _threading
 
 from . import _lib
@@ -64,6 +66,15 @@ def _view(data):
     if not mv.contiguous:
         raise BufferError("memoryview: underlying buffer is not C-contiguous")
     return mv.cast("B") if mv.format != "B" or mv.ndim != 1 else mv
+
+
+def _ssize(value):
+    """An argument Argument Clinic converts with its ssize_t converter (zlib_ngmodule.c: bufsize, max_length, length):
+    anything with __index__, OverflowError beyond sys.maxsize."""
+    value = _operator.index(value)
+    if not (-_sys.maxsize - 1 <= value <= _sys.maxsize):
+        raise OverflowError("Python int too large to convert to C ssize_t")
+    return value
 
 
 # ---- checksums (zlib_ngmodule.c:1455-1596) -----------------------------------------------------------
@@ -135,7 +146,7 @@ def compress(data, /, level=Z_DEFAULT_COMPRESSION, wbits=MAX_WBITS):
 def _inflate_all(body, zdict=b"", hint=0):
     """Raw inflate with geometric growth of the output buffer -> (code, out, used, crc, adler)."""
     ctx = _ctx()
-    cap = max(hint, 4 * len(body), 1 << 16)
+    cap = max(min(hint, 1032 * len(body) + 64), 4 * len(body), 1 << 16)     # deflate expands at most ~1032:1
     while True:
         code, out, used, crc, ad = ctx.inflate_raw(body, cap, zdict)
         if code == _lib.BUF_ERROR and ctx.last_needed > cap:      # the engine already knows the size
@@ -188,15 +199,16 @@ def _parse_gzip_header(buf, pos=0):
 
 def decompress(data, /, wbits=MAX_WBITS, bufsize=DEF_BUF_SIZE):
     """Returns a bytes object containing the uncompressed data (zlib_decompress_impl, :275-373)."""
+    buf = _view(data)                        # a view: the payload is never copied on the host
+    bufsize = _ssize(bufsize)
     if bufsize < 0:
         raise ValueError("bufsize must be non-negative")
-    buf = _view(data)                        # a view: the payload is never copied on the host
     W = "while decompressing data"
     if wbits == 0 or 8 <= wbits <= 15:
         kind = "zlib"
     elif -15 <= wbits <= -8:
         kind = "raw"
-    elif 24 <= wbits <= 31:
+    elif 24 <= wbits <= 31 or wbits == 16:
         kind = "gzip"
     elif 40 <= wbits <= 47 or wbits == 32:
         kind = "auto"
@@ -204,7 +216,7 @@ def decompress(data, /, wbits=MAX_WBITS, bufsize=DEF_BUF_SIZE):
         raise _zerr(_lib.STREAM_ERROR, "while preparing to decompress data")
     if kind == "auto":
         kind = "gzip" if buf[:2] == b"\x1f\x8b" else "zlib"
-        wbits = 15
+        wbits = wbits - 32                   # 0: take the window from the zlib header
     if kind == "raw":
         code, out, used, _, _ = _inflate_all(buf, hint=bufsize)
         if code == _lib.STREAM_END:
@@ -321,7 +333,10 @@ class _Compress:
     _BATCH = 8 << 20
 
     def __init__(self, level, method, wbits, memLevel, strategy, zdict):
-        _check_level(level)
+        try:
+            _check_level(level)
+        except error:
+            raise ValueError("Invalid initialization option") from None
         if method != DEFLATED or not (1 <= memLevel <= 9) or strategy not in (0, 1, 2, 3, 4):
             raise ValueError("Invalid initialization option")
         try:
@@ -407,13 +422,12 @@ class _Compress:
             return b""
 
     def flush(self, mode=Z_FINISH, /):
+        mode = _operator.index(mode)
         with self._lock:
             if mode == Z_NO_FLUSH:
                 return b""
-            if self._finished:
-                if mode == Z_FINISH:
-                    raise _zerr(_lib.STREAM_ERROR, "while flushing")
-                return b""
+            if self._finished or not (0 <= mode <= Z_BLOCK):       # deflate() answers Z_STREAM_ERROR to both
+                raise _zerr(_lib.STREAM_ERROR, "while flushing")
             return self._emit(mode == Z_FINISH)
 
     def copy(self):
@@ -457,7 +471,7 @@ class _InflateCore:
             self.kind = "zlib"
         elif -15 <= wbits <= -8:
             self.kind = "raw"
-        elif 24 <= wbits <= 31:
+        elif 24 <= wbits <= 31 or wbits == 16:
             self.kind = "gzip"
         elif 40 <= wbits <= 47 or wbits == 32:
             self.kind = "auto"
@@ -487,7 +501,7 @@ class _InflateCore:
         b = self.buf
         if self.kind == "auto" and len(b) >= 2:
             self.kind = "gzip" if b[:2] == b"\x1f\x8b" else "zlib"
-            self.wbits = 15
+            self.wbits -= 32                 # 0: take the window from the zlib header
         if self.kind == "zlib":
             if len(b) < 2:
                 return False
@@ -554,11 +568,13 @@ class _InflateCore:
             return b"", 0
         ctx = _ctx()
         want = None if limit is None else self.skip + limit
-        cap = want if want is not None else max(1 << 16, 8 * len(self.buf) + self.skip)
+        cap = max(1 << 16, 8 * len(self.buf) + self.skip)
+        if want is not None and want < cap:
+            cap = want
         while True:
             code, out, in_bits, bb, bo = ctx.inflate_resume(bytes(self.buf), self.start_bit, self.window, max(cap, 1))
-            if code == _lib.E_OVERFLOW and want is None:
-                cap *= 4
+            if code == _lib.E_OVERFLOW and (want is None or cap < want):      # our guess was short, not the caller's limit
+                cap = cap * 4 if want is None else min(cap * 4, want)
                 continue
             break
         new = out[self.skip:]
@@ -597,16 +613,18 @@ class _Decompress:
         self.unconsumed_tail = b""
         self.eof = False
         self._ahead = 0          # bytes at the end of the core buffer that were handed back as unconsumed_tail
+        self._ended = False      # flush() after the end of the stream releases it (inflateEnd): no copy() afterwards
 
     def _sync(self):
         self.eof = self._core.eof
         self.unused_data = self._core.unused
 
     def decompress(self, data, /, max_length=0):
+        data = bytes(_view(data))
+        max_length = _ssize(max_length)
         if max_length < 0:
             raise ValueError("max_length must be non-negative")
         with self._lock:
-            data = bytes(_view(data))
             if self._ahead:                     # the caller feeds unconsumed_tail back: already buffered
                 data = data[min(self._ahead, len(data)):]
                 self._ahead = 0
@@ -617,21 +635,25 @@ class _Decompress:
             return out
 
     def flush(self, length=DEF_BUF_SIZE, /):
-        if length <= 0:
+        if _ssize(length) <= 0:
             raise ValueError("length must be greater than zero")
         with self._lock:
             self._ahead = 0
             out, _ = self._core.feed(b"", None)
             self.unconsumed_tail = b""
             self._sync()
+            self._ended = self._ended or self.eof
             return out
 
     def copy(self):
         with self._lock:
+            if self._ended:
+                raise ValueError("Inconsistent stream state")
             o = _Decompress.__new__(_Decompress)
             o._core = self._core.clone()
             o._lock = _threading.Lock()
             o.unused_data, o.unconsumed_tail, o.eof, o._ahead = self.unused_data, self.unconsumed_tail, self.eof, self._ahead
+            o._ended = False
             return o
 
     __copy__ = copy
@@ -666,6 +688,7 @@ class _ZlibDecompressor:
         return self._core.unused
 
     def decompress(self, data, max_length=-1):
+        max_length = _ssize(max_length)
         with self._lock:
             if self._core.eof and not self._held:
                 raise EOFError("End of stream already reached")
