@@ -737,10 +737,16 @@ class _GzipReader:
             except (AttributeError, OSError, ValueError):
                 self._start = None
         self._closed = False
-        self._last_mtime = 0
+        self._mtime = 0
         self._lock = _threading.Lock()
         self._size = -1
         self._reset()
+
+    @property
+    def _last_mtime(self):
+        """MTIME of the stream's header once it has been read, None before that or when it is zero
+        (GzipReader_get_last_mtime, zlib_ngmodule.c:2887-2893)."""
+        return self._mtime or None
 
     def _reset(self):
         self._window = max(1 << 16, int(_os.environ.get("ZNGAMD_READ_WINDOW", 64 << 20)))
@@ -803,7 +809,7 @@ class _GzipReader:
             if self._first:
                 self._first = False
                 if len(data) >= 8:
-                    self._last_mtime = _struct.unpack_from("<I", data, 4)[0]
+                    self._mtime = _struct.unpack_from("<I", data, 4)[0]
                 if len(data) >= 2 and data[:2] != b"\x1f\x8b":
                     self._buf, self._boff, self._done = b"", 0, True
                     self._error = BadGzipFile(f"Not a gzipped file ({bytes(data[:2])!r})")

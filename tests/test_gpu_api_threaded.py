@@ -211,3 +211,33 @@ def test_large_blocks_default_size(T, fastq):
     with T.open(bio, "wb", threads=4) as f:
         f.write(fastq)
     assert gzip.decompress(bio.getvalue()) == fastq
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_writer_write_after_close(T, threads):
+    # reference tests/test_gzip_ng_threaded.py:166-172
+    f = T._ThreadedGzipWriter(io.BytesIO(), threads=threads)
+    f.close()
+    with pytest.raises(ValueError, match="closed"):
+        f.write(b"abc")
+
+
+@pytest.mark.parametrize("mode,threads", list(itertools.product(["rb", "wb"], [1, 2])))
+def test_program_exits_when_it_fails_with_an_open_file(T, tmp_path, mode, threads):
+    """A script that opens a threaded file without a context manager and then raises must still terminate: the worker
+    threads may not keep the interpreter alive (reference tests/test_gzip_ng_threaded.py:216-232)."""
+    import subprocess
+    import sys
+    from conftest import PKG_DIR
+    target = tmp_path / "output.gz"
+    target.write_bytes(gzip.compress(b"test" * (10 * 1024 * 1024)))
+    program = tmp_path / "no_context_manager.py"
+    program.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {PKG_DIR!r})\n"
+        "from zlib_ng_amd import gzip_ng_threaded\n"
+        f"f = gzip_ng_threaded.open({str(target)!r}, mode={mode!r}, threads={threads})\n"
+        + ("f.read(100)\n" if mode == "rb" else "f.write(b'x' * 3000000)\n") +
+        "raise Exception('Error')\n")
+    done = subprocess.run([sys.executable, str(program)], capture_output=True, timeout=120)
+    assert done.returncode == 1 and b"Exception: Error" in done.stderr
