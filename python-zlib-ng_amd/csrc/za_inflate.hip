@@ -60,35 +60,73 @@ __device__ __forceinline__ uint32_t za_slow_decode(uint32_t v, const uint16_t *c
     return 0;
 }
 
-// Build count/symbol arrays (lane 0) and the LUT (all lanes) from lens[0..n).  Returns <0 for an
-// over-subscribed set, >0 for an incomplete one, 0 otherwise; *maxlen_out = longest code.
+// Build count/symbol arrays and the LUT from lens[0..n), n <= 320, by the whole wave.  Returns <0 for an
+// over-subscribed set, >0 for an incomplete one, 0 otherwise; *shared_maxlen = longest code.
+// Every lane holds the lengths of symbols lane, lane + 64, ...; the number of codes of each length is a sum of
+// ballot population counts (wave-uniform, so it lives in scalar registers), and a symbol's slot in the canonical
+// order is the offset of its length plus the number of lower symbols of that length, again from the ballots.
 __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *lut, int lut_bits,
                               int *shared_status, int *shared_maxlen)
 {
     const int lane = za_lane();
     __syncthreads();
+    int L[5];
+#pragma unroll
+    for (int b = 0; b < 5; b++) { const int i = b * 64 + lane; L[b] = i < n ? (int)lens[i] : 0; }
+    int c[16];
+    c[0] = 0;
+    int maxlen = 0, coded = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+        int t = 0;
+#pragma unroll
+        for (int b = 0; b < 5; b++) t += __popcll(__ballot(L[b] == l));
+        c[l] = t; coded += t;
+        if (t) maxlen = l;
+    }
+    int st = 0;
+    if (coded) {
+        int left = 1;
+#pragma unroll
+        for (int l = 1; l <= 15; l++) { if (left >= 0) { left <<= 1; left -= c[l]; } }
+        st = left;
+    }
     if (lane == 0) {
-        uint16_t offs[16];
-        for (int i = 0; i < 16; i++) cnt[i] = 0;
-        for (int i = 0; i < n; i++) cnt[lens[i]]++;
-        int maxlen = 0, left = 1, st = 0;
-        for (int l = 1; l <= 15; l++) if (cnt[l]) maxlen = l;
-        if (cnt[0] != n) {
-            for (int l = 1; l <= 15; l++) { left <<= 1; left -= cnt[l]; if (left < 0) break; }
-            st = left;
-        }
-        cnt[0] = 0;
-        if (st >= 0) {
-            offs[1] = 0;
-            for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]);
-            for (int i = 0; i < n; i++) if (lens[i]) sym[offs[lens[i]]++] = (uint16_t)i;
-        }
+#pragma unroll
+        for (int l = 0; l <= 15; l++) cnt[l] = (uint16_t)c[l];
         *shared_status = st; *shared_maxlen = maxlen;
     }
-    __syncthreads();
-    const int st = *shared_status;
     if (st >= 0) {
-        for (int e = lane; e < (1 << lut_bits); e += 64) lut[e] = (uint16_t)za_slow_decode((uint32_t)e, cnt, sym, lut_bits);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int base = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; l++) {
+            if (c[l]) {
+#pragma unroll
+                for (int b = 0; b < 5; b++) {
+                    const unsigned long long m = __ballot(L[b] == l);
+                    if (L[b] == l) sym[base + __popcll(m & below)] = (uint16_t)(b * 64 + lane);
+                    base += __popcll(m);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (st >= 0) {
+        // LUT entry for the low lut_bits bits e: canonical decode with the counts in registers
+        for (int e = lane; e < (1 << lut_bits); e += 64) {
+            uint32_t v = (uint32_t)e, r = 0;
+            int code = 0, first = 0, index = 0;
+#pragma unroll
+            for (int l = 1; l <= 10; l++) {
+                if (l <= lut_bits && r == 0) {
+                    code |= (int)(v & 1u); v >>= 1;
+                    if (code - c[l] < first) r = ((uint32_t)sym[index + (code - first)] << 4) | (uint32_t)l;
+                    index += c[l]; first += c[l]; first <<= 1; code <<= 1;
+                }
+            }
+            lut[e] = (uint16_t)r;
+        }
     }
     __syncthreads();
     return st;
@@ -127,7 +165,9 @@ __constant__ uint8_t za_i_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 
 // Parse a fixed or dynamic block header at `bitpos` (uniform across the wave) and build the decode
 // tables.  Returns ZA_I_OK / ZA_I_DATA / ZA_I_INPUT; advances bitpos past the header.
-__device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bitpos, int type, ZaInfTabs &T, int *scratch /*2 ints LDS*/)
+#define ZA_HDR_DW 148     // dwords of LDS that hold a whole dynamic header behind its three counts: 57 + 316 * 14 bits, + alignment and look-ahead
+__device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bitpos, int type, ZaInfTabs &T, int *scratch /*2 ints LDS*/,
+                              uint32_t *hb = nullptr /* ZA_HDR_DW dwords of LDS, or none: the header is then read from memory bit by bit */)
 {
     const int lane = za_lane();
     if (type == 1) {
@@ -146,10 +186,29 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
     if (bitpos + 3ull * (unsigned)ncode > in_bits) return ZA_I_INPUT;
     __syncthreads();
     if (lane < 19) T.lens[lane] = 0;
+    // The code lengths are decoded by one lane, one dependent read per symbol: from LDS that is a fraction of a microsecond
+    // for the whole header, from memory about a microsecond per symbol.
+    const uint64_t hbyte = (bitpos >> 3) & ~3ull;
+    if (hb) {
+        const uint64_t in_len8 = (in_bits >> 3) + 8ull;                  // the buffer is padded by >= 8 bytes
+        for (int i = lane; i < ZA_HDR_DW; i += 64) {
+            const uint64_t o = hbyte + 4ull * (unsigned)i;
+            uint32_t v = 0;
+            if (o + 4 <= in_len8) v = za_ld32(in + o);
+            else for (int k = 0; k < 4; k++) if (o + (unsigned)k < in_len8) v |= (uint32_t)in[o + (unsigned)k] << (8 * k);
+            hb[i] = v;
+        }
+    }
     __syncthreads();
+    auto peek = [&](uint64_t bp) -> uint64_t {
+        if (!hb) return za_peek(in, bp);
+        const uint32_t rel = (uint32_t)(bp - hbyte * 8ull), w = rel >> 5, sh = rel & 31u;
+        const uint64_t lo = ((uint64_t)hb[w + 1] << 32) | hb[w];
+        return sh ? ((lo >> sh) | ((uint64_t)hb[w + 2] << (64 - sh))) : lo;
+    };
     if (lane == 0) {
         uint64_t bp = bitpos;
-        for (int i = 0; i < ncode; i++) { T.lens[za_i_cl_order[i]] = (uint8_t)(za_peek(in, bp) & 7u); bp += 3; }
+        for (int i = 0; i < ncode; i++) { T.lens[za_i_cl_order[i]] = (uint8_t)(peek(bp) & 7u); bp += 3; }
     }
     bitpos += 3ull * (unsigned)ncode;
     // code-length code: tables go to the distance slots for now (7-bit LUT)
@@ -164,7 +223,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         uint8_t tmp_prev = 0;
         while (idx < nlen + ndist) {
             if (bp > in_bits) { err = ZA_I_INPUT; break; }
-            const uint64_t b = za_peek(in, bp);
+            const uint64_t b = peek(bp);
             const uint32_t e = za_decode_sym(b, T.lut_d, 7, T.cnt_d, T.sym_d);
             if (!e) { err = ZA_I_DATA; break; }
             const int s = (int)(e >> 4), l = (int)(e & 15u);
@@ -222,6 +281,284 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 //           move symbols, so every output symbol is a byte (< 256) or names the byte of the previous window it
 //           equals; *max_back = farthest distance before the chunk start that was referenced
 // hist = bytes of history that may be referenced before out[0] (dict_len, or 32768 for a chunk in mid-stream);
+
+// ------------------------------------------------------------------------------------------------
+// Parallel decode inside ONE Huffman block of a foreign stream (no index): self-synchronising sub-sequences.
+// The next 64 x S bits of the block are cut into 64 sub-sequences, one per lane.  Only lane 0 knows a real token
+// boundary; the others start at a guess.  Every lane decodes from its start up to the first token boundary at or
+// behind the next lane's nominal start and hands that boundary on as the next lane's start; lanes whose start
+// changed decode again.  Deflate's prefix codes re-synchronise after a few tokens, so nearly always the second
+// pass changes nothing and all starts are exact (lane 0 is exact, and a lane whose start and predecessors did not
+// change is exact by induction).  After ZA_PS_MAXIT passes the lanes below the first one that still changed are
+// exact and the sweep covers only those.  The counting passes give each lane's output length and number of
+// matches; a last pass stores literals at their final place and queues the matches in LDS, and the queue is
+// resolved in output order, 64 matches at a time, exactly like phase B of za_k_inflate_members.
+// Anything unusual (end of input near, output nearly full, invalid code on the true chain, a distance before
+// the history, more output / matches than the LDS queue addresses) shortens the sweep or leaves the position
+// untouched; the sequential rounds of the caller then deal with it and produce the status.
+#define ZA_PS_BITS   1024          // longest sub-sequence (bits per lane)
+#define ZA_PS_MINBITS 64
+#define ZA_PS_DW     (64 * ZA_PS_BITS / 32 + 8)
+#define ZA_PS_Q      3072          // matches of one sweep
+#define ZA_PS_MAXIT  6
+#define ZA_PS_NONE   0xFFFFFFFFu
+#ifdef ZA_PS_STATS
+__device__ unsigned long long za_ps_stat[16];
+#define ZA_STAT_ADD(i, v) do { if (za_lane() == 0) atomicAdd(&za_ps_stat[i], (unsigned long long)(v)); } while (0)
+#define ZA_STAT_T() wall_clock64()
+#else
+#define ZA_STAT_ADD(i, v) do { } while (0)
+#define ZA_STAT_T() 0ull
+#endif
+struct ZaParStage {
+    uint32_t stage[ZA_PS_DW];      // the sweep's compressed bytes (also the sequential decoder's 512-byte staging area)
+};
+struct ZaParBuf : ZaParStage {     // the match queue is only touched when something is stored (MODE != 1): a counting
+    uint32_t qa[ZA_PS_Q];          // kernel passes a ZaParStage.  position relative to the sweep's first output symbol
+    uint8_t ql[ZA_PS_Q];           // (17 bits) | (distance - 1) << 17;  length - 3
+};
+
+// returns the number of lanes whose sub-sequences were decoded (0: nothing done, position untouched)
+template <int MODE, typename SymT, int RING>
+__device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
+                            SymT *__restrict__ out, uint64_t out_cap, const ZaInfTabs &T, ZaParBuf *P, SymT *win,
+                            uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob)
+{
+    const int lane = za_lane();
+    const uint64_t in_bits = in_len * 8ull;
+    if (bitpos + 64ull * ZA_PS_MINBITS + 64ull > in_bits || out_cap - op < 256ull) return 0;
+    uint32_t S = (uint32_t)(((in_bits - bitpos - 64ull) >> 6) > (uint64_t)ZA_PS_BITS ? (uint64_t)ZA_PS_BITS : ((in_bits - bitpos - 64ull) >> 6));
+    const uint64_t sbyte = (bitpos >> 3) & ~3ull;
+    const uint32_t b0 = (uint32_t)(bitpos - sbyte * 8ull);                 // 0..31
+    const uint32_t ndw = ((b0 + 64u * S + 48u) >> 5) + 5u;                  // <= ZA_PS_DW: a lane reads up to 64 bits ahead
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < ndw; i += 64) {
+        const uint64_t o = sbyte + 4ull * i;
+        uint32_t v = 0;
+        if (o + 4 <= in_len + 8) v = za_ld32(in + o);                       // the buffer is padded by >= 8 bytes
+        else for (int k = 0; k < 4; k++) if (o + (unsigned)k < in_len + 8) v |= (uint32_t)in[o + (unsigned)k] << (8 * k);
+        P->stage[i] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // one lane, one sub-sequence: tokens from bit `from` up to the first boundary >= `lim`.  The lane keeps 33..64 bits of
+    // the stream in a register pair and takes one more dword from the staged bytes whenever 32 or fewer are left: a
+    // literal / length code with its extra bits needs 20 at most, a distance code with its extra bits 28.
+    uint32_t endp = 0, cnt = 0, nm = 0;
+    int st = 0;                                 // 0 ran to the limit, 1 end of block, 2 invalid code, 3 no start
+    int farrel = -(1 << 30);                    // (counting kernel) max over the lane's matches of distance - symbols before it
+    bool bad_dist = false;                      // (storing pass) a distance reaches before the history
+    uint32_t far_seen = 0;                      // (storing pass) furthest reach before this stream's first symbol
+    auto run = [&](const bool emit, uint32_t from, uint32_t lim, uint64_t obase, uint32_t rbase, uint32_t qb) {
+        uint32_t bp = from, c = 0, k = 0;
+        int s = 0, fr = -(1 << 30);
+        uint32_t w = from >> 5;
+        const uint32_t sh0 = from & 31u;
+        uint64_t bb = ((((uint64_t)P->stage[w + 1]) << 32) | (uint64_t)P->stage[w]) >> sh0;
+        uint32_t nb = 64u - sh0;
+        w += 2;
+        while (bp < lim) {
+            if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
+            uint32_t e = za_decode_sym(bb, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
+            if (!e) { s = 2; break; }
+            const int sym = (int)(e >> 4);
+            uint32_t used = e & 15u;
+            if (sym < 256) {
+                if (emit) out[obase + c] = (SymT)sym;
+                c++; bp += used; bb >>= used; nb -= used;
+                continue;
+            }
+            if (sym == 256) { s = 1; bp += used; break; }
+            const int ls = sym - 257;
+            if (ls > 28) { s = 2; break; }
+            int nx;
+            int len = za_len_base(ls, nx);
+            len += (int)((uint32_t)(bb >> used) & ((1u << nx) - 1u));
+            used += (uint32_t)nx;
+            bp += used; bb >>= used; nb -= used;
+            if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
+            e = za_decode_sym(bb, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
+            const int ds = (int)(e >> 4);
+            if (!e || ds >= 30) { s = 2; break; }
+            used = e & 15u;
+            int dist = za_dist_base(ds, nx);
+            dist += (int)((uint32_t)(bb >> used) & ((1u << nx) - 1u));
+            used += (uint32_t)nx;
+            bp += used; bb >>= used; nb -= used;
+            if (emit) {
+                P->qa[qb + k] = (rbase + c) | ((uint32_t)(dist - 1) << 17);
+                P->ql[qb + k] = (uint8_t)(len - 3);
+                const uint64_t at = obase + c;                               // symbols of this stream in front of the match
+                if ((uint64_t)dist > at) {
+                    if ((uint64_t)dist > at + (uint64_t)hist) bad_dist = true;
+                    const uint32_t f = (uint32_t)((uint64_t)dist - at);
+                    if (f > far_seen) far_seen = f;
+                }
+            }
+            else if (MODE == 1) { const int f = dist - (int)c; if (f > fr) fr = f; }     // nothing is stored later: validity is checked from this
+            c += (uint32_t)len; k++;
+        }
+        if (!emit) { endp = bp; cnt = c; nm = k; st = s; farrel = fr; }
+    };
+
+    uint32_t start = b0 + (uint32_t)lane * S;
+    const uint32_t lim = b0 + ((uint32_t)lane + 1u) * S;
+    bool dirty = true;
+    int nvalid = 64;
+    const unsigned long long t0 = ZA_STAT_T();
+    int its = 0;
+    for (int it = 1;; it++) {
+        its = it;
+        if (dirty) {
+            if (start == ZA_PS_NONE) { st = 3; endp = 0; cnt = 0; nm = 0; farrel = -(1 << 30); }
+            else run(false, start, lim, 0, 0, 0);
+        }
+        const uint32_t handed = (uint32_t)__shfl_up((int)(st == 0 ? endp : ZA_PS_NONE), 1, 64);
+        const bool ch = lane > 0 && handed != start;
+        if (lane > 0) start = handed;
+        dirty = ch;
+        const unsigned long long chm = __ballot(ch);
+        if (!chm) break;
+        if (it >= ZA_PS_MAXIT) { nvalid = __builtin_ctzll(chm); break; }
+    }
+    ZA_STAT_ADD(0, 1); ZA_STAT_ADD(2, its); ZA_STAT_ADD(3, ZA_STAT_T() - t0); ZA_STAT_ADD(13, nvalid);
+    // the chain ends at the first lane that did not run to its limit
+    bool eob_hit = false;
+    {
+        const unsigned long long stopm = __ballot(st != 0) & (nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull));
+        if (stopm) {
+            const int j = __builtin_ctzll(stopm);
+            if (__builtin_amdgcn_readlane(st, j) == 1) { nvalid = j + 1; eob_hit = true; }
+            else nvalid = j;
+        }
+    }
+    if (nvalid == 0) { ZA_STAT_ADD(6, 1); return 0; }
+    const bool act0 = lane < nvalid;
+    const uint32_t cinc = za_wave_incl_scan(act0 ? cnt : 0u), minc = za_wave_incl_scan(act0 ? nm : 0u);
+    const uint32_t base = cinc - (act0 ? cnt : 0u), qb = minc - (act0 ? nm : 0u);
+    {
+        // a lane is kept if its output fits the buffer, the 17-bit positions and the queue (the counting kernel has no
+        // queue, but checks here that no distance reaches before the history); the sweep ends in front of the first
+        // lane that does not
+        const bool fits = (uint64_t)cinc <= out_cap - op && cinc <= (1u << 17) && (MODE == 1 || minc <= (uint32_t)ZA_PS_Q) &&
+                          (MODE != 1 || (long long)farrel - (long long)(op + (uint64_t)base) <= (long long)hist);
+        const unsigned long long badm = __ballot(act0 && !fits);
+        if (badm) {
+            const int j = __builtin_ctzll(badm);
+            if (j < nvalid) { nvalid = j; eob_hit = false; }
+        }
+    }
+    if (nvalid == 0) { ZA_STAT_ADD(6, 1); return 0; }
+    ZA_STAT_ADD(1, nvalid);
+    const bool act = lane < nvalid;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)cinc, nvalid - 1);
+    const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)minc, nvalid - 1);
+    const uint32_t last_end = (uint32_t)__builtin_amdgcn_readlane((int)endp, nvalid - 1);
+    if (MODE != 1) {
+        const unsigned long long t1 = ZA_STAT_T();
+        if (act) run(true, start, lim, op + (uint64_t)base, base, qb);
+        // a distance before the history is an error of the stream: nothing is committed, the sequential rounds find and
+        // report it (what the storing pass wrote lies behind `op` and is overwritten)
+        if (__ballot(bad_dist)) { ZA_STAT_ADD(6, 1); return 0; }
+        if (far_io) {
+            uint32_t fv = far_seen;
+            for (int sft = 32; sft; sft >>= 1) { const uint32_t ov = (uint32_t)__shfl_xor((int)fv, sft, 64); fv = ov > fv ? ov : fv; }
+            if (fv > *far_io) *far_io = fv;
+        }
+        __threadfence_block();                  // literals (global) and the queue (LDS) are visible to the whole wave
+        __builtin_amdgcn_wave_barrier();
+        ZA_STAT_ADD(4, ZA_STAT_T() - t1);
+        const unsigned long long t2 = ZA_STAT_T();
+        // symbol at stream position q; q < 0 lies before the start: a marker (MODE 2) or a dictionary byte
+        auto sym_at = [&](long long q) -> SymT {
+            if (q >= 0) return out[q];
+            return MODE == 2 ? (SymT)(256u + (uint32_t)(ZA_WIN + q)) : (SymT)dict[(long long)dict_len + q];
+        };
+        for (uint32_t g = 0; g < M; g += 64) {
+            const bool has = g + (uint32_t)lane < M;
+            uint32_t qa = 0, mlen = 0;
+            if (has) { qa = P->qa[g + lane]; mlen = (uint32_t)P->ql[g + lane] + 3u; }
+            const uint32_t mdst = qa & 0x1FFFFu, mdist = (qa >> 17) + 1u;
+            bool done = !has;
+            unsigned long long pending = __ballot(!done);
+            // the matches of this group whose bytes mine reads are the lanes [jlo, jhi) (destinations ascend with the lane)
+            const uint32_t sdst = has ? mdst : 0xFFFFFFFFu, send = has ? mdst + mlen : 0xFFFFFFFFu;
+            const int src_a = (int)mdst - (int)mdist, src_b = src_a + (int)(mlen < mdist ? mlen : mdist);
+            uint32_t jhi = 0, jlo = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t vd = (uint32_t)__shfl((int)sdst, (int)(jhi + step - 1u), 64);
+                const uint32_t ve = (uint32_t)__shfl((int)send, (int)(jlo + step - 1u), 64);
+                if ((long long)vd < (long long)src_b) jhi += step;
+                if ((long long)ve <= (long long)src_a) jlo += step;
+            }
+            const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+            const uint64_t adst = op + (uint64_t)mdst;
+            // short non-overlapping matches whose source is real output are copied by their own lane, 16 bytes per batch
+            const uint32_t nbytes = mlen * (uint32_t)sizeof(SymT);
+            const bool simple = has && mdist >= mlen && nbytes <= 64u && adst >= (uint64_t)mdist;
+            while (pending) {
+                const bool ready = !done && (pending & deps) == 0ull;
+                if (ready && simple) {
+                    uint8_t *o = (uint8_t *)(out + adst);
+                    const uint8_t *sp = (const uint8_t *)(out + (adst - (uint64_t)mdist));
+                    for (uint32_t i = 0; i < nbytes; i += 16) {
+                        const uint32_t rem = nbytes - i;
+                        uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                        v0 = za_ld32(sp + i);
+                        if (rem > 4) v1 = za_ld32(sp + i + 4);
+                        if (rem > 8) v2 = za_ld32(sp + i + 8);
+                        if (rem > 12) v3 = za_ld32(sp + i + 12);
+                        const uint32_t vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int left = (int)rem - 4 * k;
+                            if (left >= 4) *(za_u32u *)(o + i + 4 * k) = vv[k];
+                            else if (left > 0) {
+                                o[i + 4 * k] = (uint8_t)vv[k];
+                                if (left > 1) o[i + 4 * k + 1] = (uint8_t)(vv[k] >> 8);
+                                if (left > 2) o[i + 4 * k + 2] = (uint8_t)(vv[k] >> 16);
+                            }
+                        }
+                    }
+                }
+                unsigned long long coop = __ballot(ready && !simple);
+                while (coop) {
+                    const int j = __builtin_ctzll(coop);
+                    coop &= coop - 1ull;
+                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
+                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
+                    const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
+                    const long long dq = (long long)(op + (uint64_t)cd);
+                    const float rd = 1.0f / (float)cdist;
+                    for (uint32_t bs = 0; bs < cl; bs += 64) {
+                        const uint32_t i = bs + (uint32_t)lane;
+                        if (i < cl) {
+                            int k = (int)i;                 // byte i of a self-overlapping match is byte (i mod dist) of its period
+                            if (cdist < cl) {
+                                k = (int)i - (int)cdist * (int)((float)i * rd);
+                                if (k < 0) k += (int)cdist;
+                                if (k >= (int)cdist) k -= (int)cdist;
+                            }
+                            out[dq + i] = sym_at(dq - (long long)cdist + k);
+                        }
+                    }
+                }
+                __threadfence_block();
+                done = done || ready;
+                pending = __ballot(!done);
+                ZA_STAT_ADD(14, 1);
+            }
+        }
+        ZA_STAT_ADD(5, ZA_STAT_T() - t2);
+    }
+    ZA_STAT_ADD(11, total); ZA_STAT_ADD(12, eob_hit ? 1 : 0); ZA_STAT_ADD(15, M);
+    op += (uint64_t)total;
+    bitpos = sbyte * 8ull + (uint64_t)last_end;
+    if (eob_hit) eob = true;
+    return nvalid;
+}
+
 // stop_at_sync ends the decode right after an empty stored block (sync-flush point) with ZA_I_SYNC.
 #define ZA_I_SYNC 2
 // MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
@@ -233,7 +570,8 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                                       ZaInfTabs &T, SymT *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
                                       uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr,
                                       uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr,
-                                      const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0, uint64_t abs_bit0 = 0)
+                                      const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0, uint64_t abs_bit0 = 0,
+                                      ZaParBuf *P = nullptr)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
@@ -241,6 +579,8 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
     uint64_t cp_bits = start_bit, cp_out = 0;
     uint32_t far = 0;
     int status = ZA_I_OK;
+    bool ring_stale = false;       // a parallel sweep wrote `out` only: the LDS ring is refreshed before the next sequential round
+    int par_wait = 0;              // sequential rounds to go before the next parallel sweep is tried
     if (hist == 0xFFFFFFFFu) hist = dict_len;
     if (MODE == 0) for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) if (dict_len - i <= (uint32_t)RING) win[(ZA_WIN - dict_len + i) & (RING - 1)] = (SymT)dict[i];
     // MODE 2: the ring starts out holding the markers of the RING positions before the start
@@ -292,7 +632,9 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             if (short_in) { status = ZA_I_INPUT; break; }
             if (stop_at_sync && len == 0 && !last) { status = ZA_I_SYNC; break; }
         } else {
-            status = za_read_tables(in, in_bits, bitpos, type, T, scratch);
+            const unsigned long long tt = ZA_STAT_T();
+            status = za_read_tables(in, in_bits, bitpos, type, T, scratch, P ? ibuf : nullptr);     // with P, ibuf is the large staging area
+            ZA_STAT_ADD(9, ZA_STAT_T() - tt); ZA_STAT_ADD(8, 1);
             if (status != ZA_I_OK) break;
             // Symbol loop.  The bitstream is staged through LDS (512 bytes at a time).  Per round: one 64-bit
             // window W at bitpos; lane l decodes, in one LDS round trip, the literal/length code and the
@@ -302,6 +644,31 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             bool eob = false;
             uint64_t ibase = ~0ull;                 // byte offset of ibuf[0] (multiple of 4); ~0 = nothing staged
             while (!eob && status == ZA_I_OK) {
+                if (P != nullptr) {
+                    if (par_wait == 0) {
+                        const int got = za_par_sweep<MODE, SymT, RING>(in, in_len, dict, dict_len, out, out_cap, T, P, win, bitpos, op, hist,
+                                                                     max_back ? &far : nullptr, eob);
+                        ibase = ~0ull;                                   // the staging area was used by the sweep
+                        if (got > 0) { ring_stale = true; if (got < 16) par_wait = 32; continue; }
+                        par_wait = 32;
+                    } else par_wait--;
+                    if (MODE != 1 && ring_stale) {
+                        // the last RING symbols go back into the LDS ring (positions before the start: dictionary / markers)
+                        __threadfence_block();
+                        for (uint32_t i = (uint32_t)lane; i < (uint32_t)RING; i += 64) {
+                            const long long q = (long long)op - (long long)RING + (long long)i;
+                            SymT v;
+                            if (q >= 0) v = out[q];
+                            else if (MODE == 2) v = (SymT)(256u + (uint32_t)(ZA_WIN + q));
+                            else v = (-q <= (long long)dict_len) ? (SymT)dict[(long long)dict_len + q] : (SymT)0;
+                            win[(uint64_t)q & (uint64_t)(RING - 1)] = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        ring_stale = false;
+                        ZA_STAT_ADD(10, 1);
+                    }
+                }
+                ZA_STAT_ADD(7, 1);
                 const uint64_t byte = bitpos >> 3;
                 if (ibase == ~0ull || byte < ibase || byte + 24 > ibase + 4ull * ZA_IBUF_DW) {
                     ibase = byte & ~3ull;
@@ -550,9 +917,10 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     __shared__ ZaInfTabs T;
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
-    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
+    __shared__ ZaParBuf P;
     uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
-    const int status = za_inflate_serial_core<0, uint8_t>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, ibuf, bits, op, start_bit, &cpb, &cpo);
+    const int status = za_inflate_serial_core<0, uint8_t>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
+                                                         0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
 
@@ -885,7 +1253,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     __shared__ uint8_t win[ZA_MEMBER_RING];       // 4 KiB of history in LDS (16 members per CU); older sources come from the output
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
-    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
+    __shared__ ZaParBuf P;
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
@@ -897,7 +1265,8 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, ibuf, bits, op);
+    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
+                                                                       0, nullptr, nullptr, 0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
         if (((bits + 7) >> 3) != m.in_len) status = ZA_I_DATA;          // the member must end where its size says
@@ -975,15 +1344,15 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
 {
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
-    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
+    __shared__ ZaParStage PS;
     const uint64_t abit = cands[blockIdx.x];                 // absolute bit offset of a possible block header
     const uint64_t off = abit >> 3;
     uint64_t bits = 0, op = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, ibuf,
+        status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, PS.stage,
                                                     bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == first_bit ? first_hist : (uint32_t)ZA_WIN, true, nullptr,
-                                                    cands, ncands, off * 8ull);
+                                                    cands, ncands, off * 8ull, static_cast<ZaParBuf *>(&PS));
     // bits = position relative to byte `off`; report the absolute end
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
@@ -995,7 +1364,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     __shared__ ZaInfTabs T;
     __shared__ uint16_t win[ZA_CHUNK_RING];
     __shared__ int scratch[2];
-    __shared__ uint32_t ibuf[ZA_IBUF_DW + 4];
+    __shared__ ZaParBuf P;
     const ZaChunk ch = chunks[blockIdx.x];
     const uint64_t off = ch.in_bit >> 3;
     uint64_t bits = 0, op = 0;
@@ -1003,8 +1372,8 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     int status = ZA_I_DATA;
     if (off <= in_len)
         status = za_inflate_serial_core<2, uint16_t, ZA_CHUNK_RING>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
-                                                     scratch, ibuf, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
-                                                     ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull);
+                                                     scratch, P.stage, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
+                                                     ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull, &P);
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
 

@@ -183,6 +183,13 @@ def _new_bytes(n):
 new_buffer = _new_bytes          # for callers that keep an output buffer across calls (see Context.gunzip_stream)
 
 
+def new_fillable(n):
+    """(bytes object, writable byte view of it) for `readinto`: an input window that is not zero-filled first -- a
+    bytearray(n) costs a memset of the whole window however little the file then delivers."""
+    obj, addr = _new_bytes(n)
+    return obj, memoryview((C.c_ubyte * max(int(n), 1)).from_address(addr.value)).cast("B")
+
+
 # raw-pointer views of four C-API functions: the object below is owned through a bare pointer until it is handed over
 _raw_new = C.PYFUNCTYPE(C.c_void_p, C.c_void_p, C.c_ssize_t)(("PyBytes_FromStringAndSize", C.pythonapi))
 _raw_buf = C.PYFUNCTYPE(C.c_void_p, C.c_void_p)(("PyBytes_AsString", C.pythonapi))

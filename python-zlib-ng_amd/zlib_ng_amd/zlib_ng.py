@@ -768,13 +768,13 @@ class _GzipReader:
             self._in_eof = True
             return carry + bytes(_view(self._fp)) if self._first else carry
         keep = len(carry)
-        buf = bytearray(keep + self._window)
+        obj, buf = _lib.new_fillable(keep + self._window)      # not zero-filled: only what the file delivers is ever touched
         buf[:keep] = carry
         got = keep
         into = getattr(self._fp, "readinto", None)
         while got < len(buf):
             if into is not None:
-                n = into(memoryview(buf)[got:])
+                n = into(buf[got:])
                 if not n:
                     self._in_eof = True
                     break
@@ -786,9 +786,8 @@ class _GzipReader:
                 n = len(chunk)
                 buf[got:got + n] = chunk
             got += n
-        if got < len(buf):
-            del buf[got:]
-        return buf
+        buf.release()
+        return memoryview(obj)[:got]
 
     def _set_error(self, code, data, ctx):
         msg = ctx.err()
