@@ -296,11 +296,17 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 // Anything unusual (end of input near, output nearly full, invalid code on the true chain, a distance before
 // the history, more output / matches than the LDS queue addresses) shortens the sweep or leaves the position
 // untouched; the sequential rounds of the caller then deal with it and produce the status.
+#ifndef ZA_PS_BITS
 #define ZA_PS_BITS   1024          // longest sub-sequence (bits per lane)
+#endif
 #define ZA_PS_MINBITS 64
 #define ZA_PS_DW     (64 * ZA_PS_BITS / 32 + 8)
+#ifndef ZA_PS_Q
 #define ZA_PS_Q      3072          // matches of one sweep
+#endif
+#ifndef ZA_PS_MAXIT
 #define ZA_PS_MAXIT  6
+#endif
 #define ZA_PS_NONE   0xFFFFFFFFu
 #ifdef ZA_PS_STATS
 __device__ unsigned long long za_ps_stat[16];
