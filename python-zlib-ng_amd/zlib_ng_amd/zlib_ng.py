@@ -249,6 +249,8 @@ def decompress(data, /, wbits=MAX_WBITS, bufsize=DEF_BUF_SIZE):
         raise _zerr(_lib.DATA_ERROR, W, "incorrect header check")
     if buf[2] != 8:
         raise _zerr(_lib.DATA_ERROR, W, "unknown compression method")
+    if buf[3] & 0xE0:                        # inflate() refuses reserved FLG bits; the gzip reader (like CPython's) does not look
+        raise _zerr(_lib.DATA_ERROR, W, "unknown header flags set")
     try:
         start = _parse_gzip_header(buf)
     except EOFError:
@@ -523,12 +525,16 @@ class _InflateCore:
             del b[:need]
             self.check = 1
         elif self.kind == "gzip":
+            if len(b) >= 4 and b[:2] == b"\x1f\x8b" and b[2] == 8 and b[3] & 0xE0:
+                raise _zerr(_lib.DATA_ERROR, W, "unknown header flags set")
             try:
                 start = _parse_gzip_header(bytes(b))
             except EOFError:
                 return False
-            except BadGzipFile:
-                raise _zerr(_lib.DATA_ERROR, W, "incorrect header check") from None
+            except BadGzipFile as e:
+                msg = str(e)
+                raise _zerr(_lib.DATA_ERROR, W, "unknown compression method" if msg.startswith("Unknown compression") else
+                            "header crc mismatch" if msg.startswith("Corrupted gzip header") else "incorrect header check") from None
             del b[:start]
             self.check = 0
         else:
@@ -538,10 +544,14 @@ class _InflateCore:
 
     def _trailer(self):
         need = {"zlib": 4, "gzip": 8, "raw": 0}[self.kind]
+        W = "while decompressing data"
+        if self.kind == "gzip" and 4 <= len(self.buf) < 8:
+            # inflate() compares the CRC as soon as its four bytes are there, before ISIZE has arrived
+            if _struct.unpack("<I", bytes(self.buf[:4]))[0] != self.check:
+                raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
         if len(self.buf) < need:
             return
         t = bytes(self.buf[:need])
-        W = "while decompressing data"
         if self.kind == "zlib" and _struct.unpack(">I", t)[0] != self.check:
             raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
         if self.kind == "gzip":

@@ -667,3 +667,32 @@ def test_module_constants(Z):
     # VersionTestCase.test_library_version (reference :65-71)
     assert Z.ZLIB_RUNTIME_VERSION[0] == Z.ZLIB_VERSION[0]
     assert Z.ZLIBNG_VERSION == Z.ZLIBNG_RUNTIME_VERSION
+
+
+# ------------------------------------------------------------------------------- every single-bit corruption of a small stream
+
+@pytest.mark.parametrize("wbits", [15, -15, 31])
+def test_every_single_bit_flip_of_small_streams(Z, wbits):
+    """Headers, every deflate bit and trailers: what inflate() refuses must be refused (reserved gzip flag bits included),
+    what it still accepts must give the same bytes -- one-shot and through an object."""
+    for payload in (b"", b"a", b"hello hello hello, hello?", TEXT[:300]):
+        co = CZ.compressobj(6, CZ.DEFLATED, wbits)
+        z = co.compress(payload) + co.flush()
+        differ = []
+        for pos in range(len(z)):
+            for bit in range(8):
+                zz = bytearray(z)
+                zz[pos] ^= 1 << bit
+                zz = bytes(zz)
+                a, b = outcome(lambda m: m.decompress(zz, wbits), CZ), outcome(lambda m: m.decompress(zz, wbits), Z)
+                if a != b:
+                    differ.append(("one-shot", pos, bit, a, b))
+
+                def through_object(m):
+                    do = m.decompressobj(wbits)
+                    out = do.decompress(zz)
+                    return out + do.flush(), do.eof
+                a, b = outcome(through_object, CZ), outcome(through_object, Z)
+                if a != b:
+                    differ.append(("object", pos, bit, a, b))
+        assert not differ, (len(differ), differ[:6])
