@@ -13,7 +13,7 @@ def stats():
     return dict(zip(names, list(a)))
 fq = gzip.open(os.path.join(ROOT, "tests", "golden", "test.fastq.gz")).read()
 text = corpus.text(1 << 20, seed=5).tobytes()
-for label, d in (("fastq 128K", fq[:131072]), ("fastq 1M", fq[:1 << 20]), ("text 128K", text[:131072]), ("text 1M", text),
+for label, d in (("fastq 4K", fq[:4096]), ("fastq 16K", fq[:16384]), ("fastq 128K", fq[:131072]), ("fastq 1M", fq[:1 << 20]), ("text 128K", text[:131072]), ("text 1M", text),
                  ("random 128K", os.urandom(131072)), ("zeros 1M", bytes(1 << 20))):
     for lvl in (1, 6, 9):
         z = zlib.compress(d, lvl)
