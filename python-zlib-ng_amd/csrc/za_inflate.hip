@@ -4,8 +4,10 @@
 // src/zlib_ng/zlib_ngmodule.c:328 and :2539) and the member loop of GzipReader_read_into_buffer
 // (:2426-2637) for streams of many independent members.
 //
-//   za_k_inflate_serial   any RFC 1951 stream: one wavefront per stream, decode state kept uniform
-//                         across the wave, 32 KiB history ring in LDS, copies done by all 64 lanes
+//   za_k_inflate_serial   any RFC 1951 stream, one wavefront per stream: inside a Huffman block the 64 lanes
+//                         decode 64 self-synchronising sub-sequences at once (za_par_sweep); block headers,
+//                         stored blocks, the ends of the input / output and errors are handled by wave-uniform
+//                         sequential rounds (32 KiB history ring in LDS, copies done by all 64 lanes)
 //   za_k_scan_members     pass 1 of the two-pass scheme: coalesced sweep of the compressed stream
 //                         for this engine's indexed gzip members ('Z','A' FEXTRA subfield)
 //   za_k_inflate_members  pass 2: one wavefront per member, one lane per 2 KiB segment decodes its
@@ -271,25 +273,13 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 }
 
 // ------------------------------------------------------------------------------------------------
-// sequential decoder: one wave per stream
-// ------------------------------------------------------------------------------------------------
-// Wave-uniform sequential RFC 1951 decode of one stream (all 64 lanes call with identical arguments).
-// T / win / scratch / ibuf are the caller's LDS; returns a ZA_I_* status, bits consumed and bytes produced.
-//   MODE 0  normal: SymT = u8, history ring `win` (32768 entries) and `out` hold bytes
-//   MODE 1  count only: nothing is stored (win / out unused); sizes a chunk and validates it
-//   MODE 2  markers: SymT = u16; the ring starts as 256 + j (j = index into the unknown previous 32 KiB), copies
-//           move symbols, so every output symbol is a byte (< 256) or names the byte of the previous window it
-//           equals; *max_back = farthest distance before the chunk start that was referenced
-// hist = bytes of history that may be referenced before out[0] (dict_len, or 32768 for a chunk in mid-stream);
-
-// ------------------------------------------------------------------------------------------------
 // Parallel decode inside ONE Huffman block of a foreign stream (no index): self-synchronising sub-sequences.
 // The next 64 x S bits of the block are cut into 64 sub-sequences, one per lane.  Only lane 0 knows a real token
 // boundary; the others start at a guess.  Every lane decodes from its start up to the first token boundary at or
 // behind the next lane's nominal start and hands that boundary on as the next lane's start; lanes whose start
-// changed decode again.  Deflate's prefix codes re-synchronise after a few tokens, so nearly always the second
-// pass changes nothing and all starts are exact (lane 0 is exact, and a lane whose start and predecessors did not
-// change is exact by induction).  After ZA_PS_MAXIT passes the lanes below the first one that still changed are
+// changed decode again.  Deflate's prefix codes re-synchronise after a few tokens, so after about three passes
+// nothing changes any more and all starts are exact (lane 0 is exact, and a lane whose start and predecessors did
+// not change is exact by induction).  After ZA_PS_MAXIT passes the lanes below the first one that still changed are
 // exact and the sweep covers only those.  The counting passes give each lane's output length and number of
 // matches; a last pass stores literals at their final place and queues the matches in LDS, and the queue is
 // resolved in output order, 64 matches at a time, exactly like phase B of za_k_inflate_members.
@@ -325,9 +315,9 @@ struct ZaParBuf : ZaParStage {     // the match queue is only touched when somet
 };
 
 // returns the number of lanes whose sub-sequences were decoded (0: nothing done, position untouched)
-template <int MODE, typename SymT, int RING>
+template <int MODE, typename SymT>
 __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
-                            SymT *__restrict__ out, uint64_t out_cap, const ZaInfTabs &T, ZaParBuf *P, SymT *win,
+                            SymT *__restrict__ out, uint64_t out_cap, const ZaInfTabs &T, ZaParBuf *P,
                             uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob)
 {
     const int lane = za_lane();
@@ -565,6 +555,18 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
     return nvalid;
 }
 
+// ------------------------------------------------------------------------------------------------
+// sequential decoder: one wave per stream
+// ------------------------------------------------------------------------------------------------
+// Wave-uniform sequential RFC 1951 decode of one stream (all 64 lanes call with identical arguments).
+// T / win / scratch / ibuf are the caller's LDS; returns a ZA_I_* status, bits consumed and bytes produced.
+//   MODE 0  normal: SymT = u8, history ring `win` (32768 entries) and `out` hold bytes
+//   MODE 1  count only: nothing is stored (win / out unused); sizes a chunk and validates it
+//   MODE 2  markers: SymT = u16; the ring starts as 256 + j (j = index into the unknown previous 32 KiB), copies
+//           move symbols, so every output symbol is a byte (< 256) or names the byte of the previous window it
+//           equals; *max_back = farthest distance before the chunk start that was referenced
+// hist = bytes of history that may be referenced before out[0] (dict_len, or 32768 for a chunk in mid-stream);
+// P = LDS of the parallel sweeps (za_par_sweep), nullptr = sequential rounds only; with P, `ibuf` is P->stage;
 // stop_at_sync ends the decode right after an empty stored block (sync-flush point) with ZA_I_SYNC.
 #define ZA_I_SYNC 2
 // MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
@@ -652,7 +654,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             while (!eob && status == ZA_I_OK) {
                 if (P != nullptr) {
                     if (par_wait == 0) {
-                        const int got = za_par_sweep<MODE, SymT, RING>(in, in_len, dict, dict_len, out, out_cap, T, P, win, bitpos, op, hist,
+                        const int got = za_par_sweep<MODE, SymT>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
                                                                      max_back ? &far : nullptr, eob);
                         ibase = ~0ull;                                   // the staging area was used by the sweep
                         if (got > 0) { ring_stale = true; if (got < 16) par_wait = 32; continue; }
