@@ -850,17 +850,34 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     {   ProfScope ps(c, ZNGAMD_K_SCAN);
         const uint64_t threads = (avail + 15) / 16;
         hipLaunchKernelGGL(za_k_scan_sync, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->ccand.p, max_c, d_n);
-        hipLaunchKernelGGL(za_k_find_blocks_a, dim3((uint32_t)((avail + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->csurv.p, max_s, d_n + 1);
     }
     HIPCHK(c, hipGetLastError());
     uint32_t cnt[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(cnt, d_n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt, d_n, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (cnt[0] > max_c) return chunk_bail(2);
-    // sync-scan hits are byte positions: turn them into bit offsets on the host while phase B runs
+    // sync-scan hits are byte positions: turn them into bit offsets on the host
     std::vector<uint64_t> cand(cnt[0]);
     if (cnt[0]) HIPCHK(c, hipMemcpy(cand.data(), c->ccand.p, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
     for (auto &q : cand) q *= 8ull;
+    // A stream written block-parallel (the reference's threaded writer, pigz, this engine) has a sync point every block: when
+    // no stretch of more than 2 MiB is without one, those are boundaries enough and the bit-level header finder (a pass over
+    // every bit offset of the stream, about as dear as the decode itself) is not run.
+    bool dense = cnt[0] >= 8;
+    if (dense) {
+        std::sort(cand.begin(), cand.end());
+        uint64_t prev = o.start_bit, gap = 0;
+        for (const uint64_t q : cand) { if (q > prev && q - prev > gap) gap = q - prev; if (q > prev) prev = q; }
+        if (avail * 8ull > prev && avail * 8ull - prev > gap) gap = avail * 8ull - prev;
+        dense = gap <= (16ull << 20);                                   // bits: 2 MiB
+    }
+    if (!dense) {
+        { ProfScope ps(c, ZNGAMD_K_SCAN);
+          hipLaunchKernelGGL(za_k_find_blocks_a, dim3((uint32_t)((avail + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->csurv.p, max_s, d_n + 1); }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(cnt + 1, d_n + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (cnt[1] > 0 && cnt[1] <= max_s) {
         HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
         { ProfScope ps(c, ZNGAMD_K_SCAN);
