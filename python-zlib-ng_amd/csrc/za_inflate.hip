@@ -1391,26 +1391,30 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
 __global__ __launch_bounds__(256) void za_k_find_blocks_a(const uint8_t *__restrict__ in, uint64_t n,
                                                           uint64_t *__restrict__ surv, uint32_t max_surv, uint32_t *__restrict__ n_surv)
 {
+    // Kraft sum of three 3-bit code lengths at once (units of 2^-7; a length of 0 = unused symbol adds nothing): the up to
+    // nineteen lengths of a header are seven table reads instead of a data-dependent loop
+    __shared__ uint8_t k3[512];
+    for (uint32_t i = threadIdx.x; i < 512u; i += 256u) {
+        const uint32_t a = i & 7u, b = (i >> 3) & 7u, c = i >> 6;
+        k3[i] = (uint8_t)((a ? 128u >> a : 0u) + (b ? 128u >> b : 0u) + (c ? 128u >> c : 0u));
+    }
+    __syncthreads();
     const uint64_t byte = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (byte + 12 > n) return;                                   // a real header is followed by far more than 12 bytes
     const uint64_t lo = za_ld64(in + byte);
     const uint32_t hi = za_ld32(in + byte + 8);
-    auto field = [&](uint32_t bitoff, uint32_t nb) -> uint32_t {     // nb bits at bit `bitoff` of the 96-bit window
-        const uint32_t mask = (1u << nb) - 1u;
-        if (bitoff + nb <= 64u) return (uint32_t)(lo >> bitoff) & mask;
-        if (bitoff >= 64u) return (hi >> (bitoff - 64u)) & mask;
-        return (uint32_t)((lo >> bitoff) | ((uint64_t)hi << (64u - bitoff))) & mask;
-    };
-#pragma unroll 1
+#pragma unroll
     for (uint32_t b = 0; b < 8; b++) {
-        if (field(b, 3) != 4u) continue;                         // BFINAL = 0, BTYPE = 10b
-        if (field(b + 3, 5) > 29u || field(b + 8, 5) > 29u) continue;
-        const uint32_t hclen = field(b + 13, 4) + 4u;
-        uint32_t kraft = 0;                                      // in units of 2^-7
-        for (uint32_t k = 0; k < hclen; k++) {
-            const uint32_t v = field(b + 17u + 3u * k, 3);       // last one ends at bit 7+17+57 = 81 < 96
-            if (v) kraft += 128u >> v;
-        }
+        const uint32_t head = (uint32_t)(lo >> b);               // 17 bits: BFINAL, BTYPE, HLIT, HDIST, HCLEN
+        if ((head & 7u) != 4u) continue;                         // BFINAL = 0, BTYPE = 10b
+        if (((head >> 3) & 31u) > 29u || ((head >> 8) & 31u) > 29u) continue;
+        const uint32_t hclen = ((head >> 13) & 15u) + 4u;
+        // the 3 * hclen <= 57 bits behind the 17 (bit b + 17 .. b + 73 of the 96-bit window)
+        uint64_t w = (lo >> (b + 17u)) | ((uint64_t)hi << (47u - b));
+        w &= (1ull << (3u * hclen)) - 1ull;
+        uint32_t kraft = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) kraft += k3[(uint32_t)(w >> (9u * k)) & 511u];
         if (kraft != 128u) continue;
         const uint32_t idx = atomicAdd(n_surv, 1u);
         if (idx < max_surv) surv[idx] = byte * 8ull + (uint64_t)b;
