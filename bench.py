@@ -4,9 +4,10 @@
 One "step" = one pass of the hot path over this rank's shard of synthetic text already resident in HBM:
   (1) compress: every 128 KiB block, primed with the previous 32 KiB of input as dictionary
       (reference semantics: gzip_ng_threaded.py:299-322 + zlib_ngmodule.c:1696-1782), through the five
-      deflate kernels, gathered into one contiguous raw-deflate slice; with N > 1 ranks the slices are
-      exchanged with an RCCL all-gather (issued asynchronously, overlapping leg 2) and re-assembled into the
-      member stream on every rank;
+      deflate kernels, gathered into one contiguous raw-deflate slice; with N > 1 ranks the blocks stay where
+      they were compressed (they are independent: no data-path collective) and the ranks all-gather the slice sizes,
+      i.e. the layout of the one output stream (BENCH_EXCHANGE=stream also all-gathers the slices themselves,
+      overlapped with leg 2, for a process that needs the whole stream);
   (2) decompress: two-pass inflate (member scan, then one wavefront per member) of a pre-built stream
       of independent indexed gzip members of the same text (BASELINE.json configs[2]).
 value = uncompressed bytes of all ranks / (max over ranks of the step time): the rate at which data goes
@@ -75,8 +76,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # BENCH_FORCE_EXCHANGE=1 runs the all-gather leg even with one rank (rehearsal of the N > 1 path on one GPU)
+    # BENCH_FORCE_EXCHANGE=1 runs the exchange leg even with one rank (rehearsal of the N > 1 path on one GPU).
+    # The blocks are independent, so the ranks only agree on the layout of the output stream (sizes: three integers per
+    # rank, shard.exchange_layout); BENCH_EXCHANGE=stream additionally moves every slice to every rank (one padded RCCL
+    # all-gather, overlapped with the inflate leg) for the case that one process must hold the whole stream.
     exchange = world > 1 or os.environ.get("BENCH_FORCE_EXCHANGE") == "1"
+    exchange_stream = exchange and os.environ.get("BENCH_EXCHANGE", "layout") == "stream"
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -135,9 +140,11 @@ def main():
         chk(L.zngamd_gather_dev(h, ptr(d_slots), ptr(d_ulen), n_units, ptr(d_comp), 0, d_comp.numel(), None,
                                 C.byref(comp_total)), "gather_dev")
         pending = None
-        if exchange:      # the slices travel while this rank runs its inflate leg
+        if exchange_stream:      # the slices travel while this rank runs its inflate leg
             torch.cuda.synchronize()
             pending = shard.allgather_stream_start(d_comp, comp_total.value, scratch=gathered)
+        elif exchange:           # where this rank's slice lies in the one output stream
+            gathered["layout"] = shard.exchange_layout(comp_total.value, 0, size, device=dev)
         # (2) two-pass inflate of the pre-built member stream
         nm, tot = C.c_uint32(0), C.c_uint64(0)
         chk(L.zngamd_gzip_scan_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nblocks, C.byref(nm),
@@ -216,7 +223,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.size_mib} MiB/GPU seeded Zipf-word text ({uniq >> 20} MiB distinct, tiled), "
                                f"128 KiB blocks, level {args.level}: dict-chained deflate + gather"
-                               f"{' + RCCL all-gather' if exchange else ''}, then two-pass inflate of "
+                               f"{' + RCCL all-gather of the slices' if exchange_stream else ' + layout exchange (sizes)' if exchange else ''}, then two-pass inflate of "
                                f"{nblocks} independent gzip members",
                    "block": BLOCK, "level": args.level, "bytes_per_gpu": size},
         "compress_MBps": round(world * size / (deflate_ms * 1e-3) / 1e6, 1),
@@ -277,9 +284,12 @@ def main():
                                   "note": "independent blocks, no dictionary"}
         except Exception:
             out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
-    if exchange:
+    if exchange_stream:
         # the re-assembled stream must be the concatenation of the rank slices: check this rank's slice in place
         assert gathered["total"] >= comp_total.value
+    elif exchange:
+        off, total, sizes, _, usize = gathered["layout"]
+        assert sizes[rank] == comp_total.value and off == sum(sizes[:rank]) and total == sum(sizes) and usize == world * size
     if rank == 0:
         print(json.dumps(out))
     if exchange:

@@ -1,10 +1,13 @@
-"""Block sharding across ranks and re-assembly of the compressed stream (multi-GPU leg).
+"""Block sharding across ranks (multi-GPU leg).
 
 The reference's only parallel strategy is round-robin blocks over threads with an in-order writer
-(gzip_ng_threaded.py:316-321, :382-398).  Here every rank owns a contiguous range of blocks, compresses
-it on its own GPU and the variable-size slices are exchanged with one all-gather (RCCL over xGMI with
-backend "nccl"; the same code runs on "gloo" for CPU tests).  Only torch.distributed plumbing and
-integer arithmetic live here; no payload byte is computed on the host.
+(gzip_ng_threaded.py:316-321, :382-398).  Here every rank owns a contiguous range of blocks and compresses it on its
+own GPU.  Blocks are independent, so the data path needs no collective: what the ranks must agree on is the LAYOUT of
+the one output stream -- where each rank's slice starts, the total size, and the CRC-32 / length of the whole input for
+the trailer -- which is an all-gather of three integers per rank (`exchange_layout`); every rank then writes its slice at
+its own offset.  When one rank has to hold the complete stream, `allgather_stream` moves the variable-size slices with
+one padded all-gather (RCCL over xGMI with backend "nccl"; the same code runs on "gloo" for the CPU tests).  Only
+torch.distributed plumbing and integer arithmetic live here; no payload byte is computed on the host.
 """
 import torch
 import torch.distributed as dist
@@ -17,6 +20,22 @@ def shard_range(n_blocks, rank, world):
     lo = (n_blocks * rank) // world
     hi = (n_blocks * (rank + 1)) // world
     return lo, hi
+
+
+def exchange_layout(local_len, crc=0, ulen=0, group=None, device=None):
+    """All-gather of (compressed bytes, CRC-32 of the uncompressed shard, uncompressed bytes) of every rank.  Returns
+    (offset of this rank's slice in the stream, total compressed size, per-rank sizes, CRC-32 of the whole input,
+    total uncompressed size): everything the writer's header / trailer and a positional write of the slice need
+    (gzip_ng_threaded.py:382-398 folds the CRCs the same way, block by block)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([int(local_len), int(crc) & 0xFFFFFFFF, int(ulen)], dtype=torch.int64, device=device)
+    parts = [torch.zeros(3, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    rows = [[int(v) for v in p.tolist()] for p in parts]
+    sizes = [r[0] for r in rows]
+    whole_crc = combine_crcs([(r[1], r[2]) for r in rows])
+    return sum(sizes[:rank]), sum(sizes), sizes, whole_crc, sum(r[2] for r in rows)
 
 
 def allgather_stream_start(local, local_len, group=None, scratch=None):

@@ -80,7 +80,7 @@ def test_framing_helpers():
     assert cover[0][0] == 0 and cover[-1][1] == 32768 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, path):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, PKG_DIR)
@@ -113,19 +113,33 @@ def _gloo_worker(rank, world, port, q):
     blob = header + bytes(stream[:total].numpy()) + trailer
     import gzip
     ok = gzip.decompress(blob) == data and sizes[rank] == len(mine) and crc == zlib.crc32(data)
+    # the same file without moving any payload between ranks: the layout (three integers per rank) tells every rank where
+    # its slice goes, and it writes it there itself
+    off, total2, sizes2, crc2, usize = shard.exchange_layout(len(mine), my_crc, (hi - lo) * bs)
+    ok = ok and (total2, sizes2, crc2, usize) == (total, sizes, crc, len(data)) and off == sum(sizes[:rank])
+    header2, trailer2 = shard.gzip_frame(total2, crc2, usize, 6)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+    os.pwrite(fd, mine, len(header2) + off)
+    if rank == 0:
+        os.pwrite(fd, header2, 0)
+        os.pwrite(fd, trailer2, len(header2) + total2)
+    os.close(fd)
+    dist.barrier()
+    ok = ok and gzip.decompress(open(path, "rb").read()) == data
     q.put((rank, ok, total))
     dist.destroy_process_group()
 
 
-def test_two_rank_allgather_reassembly_gloo():
+def test_two_rank_allgather_reassembly_gloo(tmp_path):
     import torch.multiprocessing as mp
+    path = str(tmp_path / "written_by_two_ranks.gz")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, path)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
