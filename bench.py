@@ -4,10 +4,10 @@
 One "step" = one pass of the hot path over this rank's shard of synthetic text already resident in HBM:
   (1) compress: every 128 KiB block, primed with the previous 32 KiB of input as dictionary
       (reference semantics: gzip_ng_threaded.py:299-322 + zlib_ngmodule.c:1696-1782), through the five
-      deflate kernels, gathered into one contiguous raw-deflate slice; with N > 1 ranks the blocks stay where
-      they were compressed (they are independent: no data-path collective) and the ranks all-gather the slice sizes,
-      i.e. the layout of the one output stream (BENCH_EXCHANGE=stream also all-gathers the slices themselves,
-      overlapped with leg 2, for a process that needs the whole stream);
+      deflate kernels, gathered into one contiguous raw-deflate slice; with N > 1 ranks the slices are
+      exchanged with one RCCL all-gather (issued asynchronously, overlapping leg 2), which leaves the member
+      stream on every rank as N slices in block order (BENCH_EXCHANGE=layout: sizes only, for ranks that write
+      their slice by offset);
   (2) decompress: two-pass inflate (member scan, then one wavefront per member) of a pre-built stream
       of independent indexed gzip members of the same text (BASELINE.json configs[2]).
 value = uncompressed bytes of all ranks / (max over ranks of the step time): the rate at which data goes
@@ -77,11 +77,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # BENCH_FORCE_EXCHANGE=1 runs the exchange leg even with one rank (rehearsal of the N > 1 path on one GPU).
-    # The blocks are independent, so the ranks only agree on the layout of the output stream (sizes: three integers per
-    # rank, shard.exchange_layout); BENCH_EXCHANGE=stream additionally moves every slice to every rank (one padded RCCL
-    # all-gather, overlapped with the inflate leg) for the case that one process must hold the whole stream.
+    # Default exchange (north_star): the member stream is reassembled on every rank with one padded RCCL all-gather of the
+    # slices, issued asynchronously so that it overlaps the inflate leg.  BENCH_EXCHANGE=layout exchanges only the layout of
+    # the stream (three integers per rank, shard.exchange_layout): what ranks that write their slices by offset need.
     exchange = world > 1 or os.environ.get("BENCH_FORCE_EXCHANGE") == "1"
-    exchange_stream = exchange and os.environ.get("BENCH_EXCHANGE", "layout") == "stream"
+    exchange_stream = exchange and os.environ.get("BENCH_EXCHANGE", "stream") != "layout"
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -152,8 +152,9 @@ def main():
         chk(L.zngamd_gzip_inflate_members_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nm.value,
                                               ptr(d_out), size, ptr(d_mstat)), "gzip_inflate_members_dev")
         if pending is not None:
-            stream, total, _ = shard.allgather_stream_finish(pending)
+            slices, total, _ = shard.allgather_stream_finish(pending, compact=False)      # in rank order, ready for one vectored write
             gathered["total"] = total
+            gathered["slices"] = slices
             torch.cuda.synchronize()
 
     def barrier():
@@ -285,8 +286,9 @@ def main():
         except Exception:
             out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
     if exchange_stream:
-        # the re-assembled stream must be the concatenation of the rank slices: check this rank's slice in place
+        # the gathered slices must be the rank slices: check this rank's own in place
         assert gathered["total"] >= comp_total.value
+        assert torch.equal(gathered["slices"][rank], d_comp[:comp_total.value])
     elif exchange:
         off, total, sizes, _, usize = gathered["layout"]
         assert sizes[rank] == comp_total.value and off == sum(sizes[:rank]) and total == sum(sizes) and usize == world * size

@@ -2,12 +2,12 @@
 
 The reference's only parallel strategy is round-robin blocks over threads with an in-order writer
 (gzip_ng_threaded.py:316-321, :382-398).  Here every rank owns a contiguous range of blocks and compresses it on its
-own GPU.  Blocks are independent, so the data path needs no collective: what the ranks must agree on is the LAYOUT of
-the one output stream -- where each rank's slice starts, the total size, and the CRC-32 / length of the whole input for
-the trailer -- which is an all-gather of three integers per rank (`exchange_layout`); every rank then writes its slice at
-its own offset.  When one rank has to hold the complete stream, `allgather_stream` moves the variable-size slices with
-one padded all-gather (RCCL over xGMI with backend "nccl"; the same code runs on "gloo" for the CPU tests).  Only
-torch.distributed plumbing and integer arithmetic live here; no payload byte is computed on the host.
+own GPU.  The member stream is reassembled with one padded all-gather of the variable-size slices (`allgather_stream`: RCCL
+over xGMI with backend "nccl", every rank sends its slice over all its links at once; the same code runs on "gloo" for the
+CPU tests).  Where nobody needs the whole stream in one memory, the ranks only have to agree on its LAYOUT -- where each
+slice starts, the total size, CRC-32 / length of the whole input for the trailer: three integers per rank
+(`exchange_layout`) -- and every rank writes its slice at its own offset.  Only torch.distributed plumbing and integer
+arithmetic live here; no payload byte is computed on the host.
 """
 import torch
 import torch.distributed as dist
@@ -39,9 +39,9 @@ def exchange_layout(local_len, crc=0, ulen=0, group=None, device=None):
 
 
 def allgather_stream_start(local, local_len, group=None, scratch=None):
-    """Start the exchange: sizes are all-gathered synchronously (8 bytes per rank), the payload all-gather
-    is issued asynchronously so that independent work (the inflate leg) can overlap it.  Returns a handle for
-    allgather_stream_finish."""
+    """Start the exchange of the slices: sizes are all-gathered synchronously (8 bytes per rank), the payload all-gather
+    (one collective into a contiguous [world x largest slice] buffer: no per-rank staging copies) is issued asynchronously
+    so that independent work (the inflate leg) can overlap it.  Returns a handle for allgather_stream_finish."""
     world = dist.get_world_size(group)
     dev = local.device
     mine = torch.tensor([int(local_len)], dtype=torch.int64, device=dev)
@@ -56,20 +56,27 @@ def allgather_stream_start(local, local_len, group=None, scratch=None):
     if scratch.get("cap", 0) < need:
         scratch["buf"] = torch.empty(need + need // 8, dtype=torch.uint8, device=dev)
         scratch["cap"] = scratch["buf"].numel()
-    if scratch.get("scap", 0) < sum(hs):
-        scratch["stream"] = torch.empty(sum(hs) + sum(hs) // 8 + 64, dtype=torch.uint8, device=dev)
-        scratch["scap"] = scratch["stream"].numel()
-    parts = [scratch["buf"][r * mx:(r + 1) * mx] for r in range(world)]
-    work = dist.all_gather(parts, local[:mx].contiguous(), group=group, async_op=True)
+    flat = scratch["buf"][:need]
+    work = dist.all_gather_into_tensor(flat, local[:mx].contiguous(), group=group, async_op=True)
+    parts = [flat[r * mx:(r + 1) * mx] for r in range(world)]
     return {"work": work, "parts": parts, "sizes": hs, "scratch": scratch}
 
 
-def allgather_stream_finish(h):
-    """Wait for the payload and re-assemble the slices in rank order (rank order == block order: ranges are
-    contiguous).  Returns (stream tensor, total length, per-rank sizes)."""
+def allgather_stream_finish(h, compact=True):
+    """Wait for the payload.  The slices lie in rank order (= block order: ranges are contiguous) at a stride of the
+    largest slice; compact=True closes the gaps (one device copy per rank) and returns (stream tensor, total length,
+    per-rank sizes); compact=False returns (list of slice views, total length, per-rank sizes) -- a writer can hand
+    those to one positional / vectored write without touching the bytes again."""
     h["work"].wait()
+    total = sum(h["sizes"])
+    if not compact:
+        return [p[:s] for p, s in zip(h["parts"], h["sizes"])], total, h["sizes"]
+    scratch = h["scratch"]
+    if scratch.get("scap", 0) < total:
+        scratch["stream"] = torch.empty(total + total // 8 + 64, dtype=torch.uint8, device=h["parts"][0].device)
+        scratch["scap"] = scratch["stream"].numel()
     off = 0
-    stream = h["scratch"]["stream"]
+    stream = scratch["stream"]
     for r, s in enumerate(h["sizes"]):
         stream[off:off + s] = h["parts"][r][:s]
         off += s
