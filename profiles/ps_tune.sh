@@ -1,5 +1,7 @@
 #!/bin/bash
-# sub-sequence length / queue size / pass limit of the block decoder: rebuild with each setting and time foreign streams
+# sub-sequence length / queue size / pass limit of the block decoder: rebuild with each setting and time foreign streams.
+# (How r01j_foreign_ps_tune.txt was made, when one setting served all kernels.  Since then BITS and Q are template arguments
+# per kernel -- ZaParBufT<BITS, Q> in za_inflate.hip -- and only ZA_PS_MAXIT is still a macro.)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 SO=python-zlib-ng_amd/zlib_ng_amd/libzng_amd.so

@@ -286,14 +286,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 // Anything unusual (end of input near, output nearly full, invalid code on the true chain, a distance before
 // the history, more output / matches than the LDS queue addresses) shortens the sweep or leaves the position
 // untouched; the sequential rounds of the caller then deal with it and produce the status.
-#ifndef ZA_PS_BITS
-#define ZA_PS_BITS   1024          // longest sub-sequence (bits per lane)
-#endif
 #define ZA_PS_MINBITS 64
-#define ZA_PS_DW     (64 * ZA_PS_BITS / 32 + 8)
-#ifndef ZA_PS_Q
-#define ZA_PS_Q      3072          // matches of one sweep
-#endif
 #ifndef ZA_PS_MAXIT
 #define ZA_PS_MAXIT  6
 #endif
@@ -306,27 +299,31 @@ __device__ unsigned long long za_ps_stat[16];
 #define ZA_STAT_ADD(i, v) do { } while (0)
 #define ZA_STAT_T() 0ull
 #endif
-struct ZaParStage {
-    uint32_t stage[ZA_PS_DW];      // the sweep's compressed bytes (also the sequential decoder's 512-byte staging area)
-};
-struct ZaParBuf : ZaParStage {     // the match queue is only touched when something is stored (MODE != 1): a counting
-    uint32_t qa[ZA_PS_Q];          // kernel passes a ZaParStage.  position relative to the sweep's first output symbol
-    uint8_t ql[ZA_PS_Q];           // (17 bits) | (distance - 1) << 17;  length - 3
+// LDS of the sweeps, sized per kernel: BITS = longest sub-sequence (bits per lane), Q = matches of one sweep.  The single-
+// stream kernel (one wavefront on the whole GPU) takes long sub-sequences, 1024 bits, which re-synchronise in fewer passes;
+// the kernels that run thousands of wavefronts (members, chunks) take 256 bits and a queue of 1024, which leaves room for
+// 9-11 workgroups per CU instead of 4 (chunk decode of 128 MiB: 5-6.6 -> 3.5 ms, 256 MiB of BGZF members: 8.3 -> 5.1 ms).
+template <int BITS, int Q>
+struct ZaParBufT {
+    static constexpr int kBits = BITS, kQ = Q;
+    uint32_t stage[64 * BITS / 32 + 8];   // the sweep's compressed bytes (also the sequential decoder's staging area and the header copy)
+    uint32_t qa[Q];                       // position relative to the sweep's first output symbol (17 bits) | (distance - 1) << 17
+    uint8_t ql[Q];                        // length - 3          (a counting kernel, MODE 1, never touches the queue: Q = 1)
 };
 
 // returns the number of lanes whose sub-sequences were decoded (0: nothing done, position untouched)
-template <int MODE, typename SymT>
+template <int MODE, typename SymT, typename PB>
 __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
-                            SymT *__restrict__ out, uint64_t out_cap, const ZaInfTabs &T, ZaParBuf *P,
+                            SymT *__restrict__ out, uint64_t out_cap, const ZaInfTabs &T, PB *P,
                             uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
     if (bitpos + 64ull * ZA_PS_MINBITS + 64ull > in_bits || out_cap - op < 256ull) return 0;
-    uint32_t S = (uint32_t)(((in_bits - bitpos - 64ull) >> 6) > (uint64_t)ZA_PS_BITS ? (uint64_t)ZA_PS_BITS : ((in_bits - bitpos - 64ull) >> 6));
+    uint32_t S = (uint32_t)(((in_bits - bitpos - 64ull) >> 6) > (uint64_t)PB::kBits ? (uint64_t)PB::kBits : ((in_bits - bitpos - 64ull) >> 6));
     const uint64_t sbyte = (bitpos >> 3) & ~3ull;
     const uint32_t b0 = (uint32_t)(bitpos - sbyte * 8ull);                 // 0..31
-    const uint32_t ndw = ((b0 + 64u * S + 48u) >> 5) + 5u;                  // <= ZA_PS_DW: a lane reads up to 64 bits ahead
+    const uint32_t ndw = ((b0 + 64u * S + 48u) >> 5) + 5u;                  // fits the staging area: a lane reads up to 64 bits ahead
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = (uint32_t)lane; i < ndw; i += 64) {
         const uint64_t o = sbyte + 4ull * i;
@@ -436,7 +433,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         // a lane is kept if its output fits the buffer, the 17-bit positions and the queue (the counting kernel has no
         // queue, but checks here that no distance reaches before the history); the sweep ends in front of the first
         // lane that does not
-        const bool fits = (uint64_t)cinc <= out_cap - op && cinc <= (1u << 17) && (MODE == 1 || minc <= (uint32_t)ZA_PS_Q) &&
+        const bool fits = (uint64_t)cinc <= out_cap - op && cinc <= (1u << 17) && (MODE == 1 || minc <= (uint32_t)PB::kQ) &&
                           (MODE != 1 || (long long)farrel - (long long)(op + (uint64_t)base) <= (long long)hist);
         const unsigned long long badm = __ballot(act0 && !fits);
         if (badm) {
@@ -571,7 +568,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 #define ZA_I_SYNC 2
 // MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
 // start), RING symbols in LDS; older sources are read back from `out` (written many rounds ago) or are markers.
-template <int MODE, typename SymT, int RING = ZA_WIN>
+template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>>
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       SymT *__restrict__ out, uint64_t out_cap,
@@ -579,7 +576,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                                       uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr,
                                       uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr,
                                       const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0, uint64_t abs_bit0 = 0,
-                                      ZaParBuf *P = nullptr)
+                                      PB *P = nullptr)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
@@ -654,7 +651,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             while (!eob && status == ZA_I_OK) {
                 if (P != nullptr) {
                     if (par_wait == 0) {
-                        const int got = za_par_sweep<MODE, SymT>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
+                        const int got = za_par_sweep<MODE, SymT, PB>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
                                                                      max_back ? &far : nullptr, eob);
                         ibase = ~0ull;                                   // the staging area was used by the sweep
                         if (got > 0) { ring_stale = true; if (got < 16) par_wait = 32; continue; }
@@ -925,9 +922,9 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     __shared__ ZaInfTabs T;
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
-    __shared__ ZaParBuf P;
+    __shared__ ZaParBufT<1024, 3072> P;
     uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
-    const int status = za_inflate_serial_core<0, uint8_t>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
+    const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
                                                          0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
@@ -1261,7 +1258,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     __shared__ uint8_t win[ZA_MEMBER_RING];       // 4 KiB of history in LDS (16 members per CU); older sources come from the output
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
-    __shared__ ZaParBuf P;
+    __shared__ ZaParBufT<256, 1024> P;
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
@@ -1273,7 +1270,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
+    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING, ZaParBufT<256, 1024>>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
                                                                        0, nullptr, nullptr, 0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
@@ -1341,10 +1338,14 @@ __global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict_
 // false candidate can cause; a real block that large (none of the common encoders emits one) sends the member to the
 // sequential decoder
 #define ZA_COUNT_CAP (64ull << 20)
-#define ZA_CHUNK_RING 4096          // symbols of history the marker decode keeps in LDS (8 KiB: 12 waves per CU)
+// Both chunk kernels exist in two sizes (template argument BITS = sub-sequence length of the block decoder): with more
+// chunks than fit the GPU at the large size (4 workgroups per CU) the small one wins by occupancy (11 per CU); with fewer,
+// every wavefront is resident either way and the long sub-sequences, which re-synchronise in fewer passes, are faster.
+// The host picks by the number of chunks (ZNGAMD_CHUNKS_SMALL_FROM in zng_amd.hip).
 struct ZaChunkRes { int32_t status; uint32_t max_back; uint64_t bits; uint64_t out_len; };
 struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t end_bit; };   // absolute bit offsets in the deflate stream
 
+template <int BITS>
 __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict__ in, uint64_t in_len,
                                                        const uint64_t *__restrict__ cands, uint32_t ncands,
                                                        ZaChunkRes *__restrict__ res,
@@ -1352,34 +1353,35 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
 {
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
-    __shared__ ZaParStage PS;
+    __shared__ ZaParBufT<BITS, 1> PS;
     const uint64_t abit = cands[blockIdx.x];                 // absolute bit offset of a possible block header
     const uint64_t off = abit >> 3;
     uint64_t bits = 0, op = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<1, uint8_t>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, PS.stage,
+        status = za_inflate_serial_core<1, uint8_t, ZA_WIN, ZaParBufT<BITS, 1>>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, PS.stage,
                                                     bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == first_bit ? first_hist : (uint32_t)ZA_WIN, true, nullptr,
-                                                    cands, ncands, off * 8ull, static_cast<ZaParBuf *>(&PS));
+                                                    cands, ncands, off * 8ull, &PS);
     // bits = position relative to byte `off`; report the absolute end
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
 
+template <int BITS, int Q, int RINGSYMS>       // RINGSYMS symbols of history in LDS; older sources are re-read from the chunk's own output
 __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restrict__ in, uint64_t in_len,
                                                         const ZaChunk *__restrict__ chunks, uint16_t *__restrict__ out16,
                                                         ZaChunkRes *__restrict__ res, uint64_t first_bit, uint32_t first_hist)
 {
     __shared__ ZaInfTabs T;
-    __shared__ uint16_t win[ZA_CHUNK_RING];
+    __shared__ uint16_t win[RINGSYMS];
     __shared__ int scratch[2];
-    __shared__ ZaParBuf P;
+    __shared__ ZaParBufT<BITS, Q> P;
     const ZaChunk ch = chunks[blockIdx.x];
     const uint64_t off = ch.in_bit >> 3;
     uint64_t bits = 0, op = 0;
     uint32_t far = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<2, uint16_t, ZA_CHUNK_RING>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
+        status = za_inflate_serial_core<2, uint16_t, RINGSYMS, ZaParBufT<BITS, Q>>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
                                                      scratch, P.stage, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
                                                      ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull, &P);
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }

@@ -606,6 +606,9 @@ static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_le
 // a stream that is resumed at a block header (bit offset + history) and / or may run past the end of the buffer
 struct ChunkOpts { uint32_t start_bit = 0; const uint8_t *d_dict = nullptr; uint32_t dict_len = 0; bool allow_cut = false; };
 struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; };
+// from this many chunks (or block candidates) on, the chunk kernels run in their small-LDS size: more than the 1 024
+// wavefronts the large size keeps resident (256 CUs x 4 workgroups)
+#define ZNGAMD_CHUNKS_SMALL_FROM 1536u
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
                                uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o = ChunkOpts(), ChunkInfo *info = nullptr);
 
@@ -901,7 +904,10 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(n));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_chunk_count, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, n, c->cres.p, (uint64_t)o.start_bit, o.dict_len); }
+      if (n >= ZNGAMD_CHUNKS_SMALL_FROM)
+          hipLaunchKernelGGL(za_k_chunk_count<512>, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, n, c->cres.p, (uint64_t)o.start_bit, o.dict_len);
+      else
+          hipLaunchKernelGGL(za_k_chunk_count<1024>, dim3(n), dim3(64), 0, c->stream, d_def, avail, c->ccand.p, n, c->cres.p, (uint64_t)o.start_bit, o.dict_len); }
     HIPCHK(c, hipGetLastError());
     std::vector<ZaChunkRes> res(n);
     HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)n * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
@@ -952,7 +958,10 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(m));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_chunk_decode, dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len); }
+      if (m >= ZNGAMD_CHUNKS_SMALL_FROM)
+          hipLaunchKernelGGL((za_k_chunk_decode<512, 1536, 1024>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len);
+      else
+          hipLaunchKernelGGL((za_k_chunk_decode<1024, 3072, 4096>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len); }
     HIPCHK(c, hipGetLastError());
     res.resize(m);
     HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)m * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
