@@ -191,3 +191,26 @@ def test_distance_before_the_start_is_refused(Z):
         else:
             with pytest.raises(Z.error):
                 Z.decompress(raw, -15)
+
+
+def test_many_chunks_take_the_small_kernel_size(Z, fastq):
+    """From 1 536 chunks on the chunk kernels run with 512-bit sub-sequences and a small LDS footprint
+    (ZNGAMD_CHUNKS_SMALL_FROM in csrc/zng_amd.hip); below, with 1 024 bits.  Both sizes must give the same bytes.  zlib -1
+    closes a block about every 75 KB of this text, so 144 MiB make about 1 900 chunks."""
+    from zlib_ng_amd import _lib, corpus
+    ctx = _lib.default_context()
+    text = corpus.text(16 << 20, seed=77).tobytes()
+    mixed = corpus.mixed(8 << 20, seed=78).tobytes()
+    data = text * 4 + mixed + fastq + text * 4 + mixed[:4 << 20]            # 144 MiB
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    z = co.compress(data) + co.flush()
+    ctx.decode_paths()                                   # reading the counters clears them
+    out = Z.decompress(z, -15, len(data))
+    assert ctx.decode_paths()["chunked"] == 1
+    assert len(out) == len(data) and out == data
+    del out
+    for level in (1, 6):                                 # same stream family, fewer chunks: the large size
+        small = data[(60 << 20):(84 << 20)]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        z = co.compress(small) + co.flush()
+        assert Z.decompress(z, -15) == small
