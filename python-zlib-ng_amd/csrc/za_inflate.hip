@@ -1484,6 +1484,7 @@ __global__ __launch_bounds__(64) void za_k_find_blocks_b(const uint8_t *__restri
             }
         }
         prev = val;
+        if (kl > 32768u || kd > 32768u) { bad = true; break; }      // over-subscribed already: most false survivors end here, after a few symbols
     }
     if (bad || !eob || bp > in_bits) return;
     const bool lit_ok = kl == 32768u || (kl < 32768u && maxl == 1);
