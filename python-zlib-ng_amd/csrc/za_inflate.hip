@@ -1390,37 +1390,65 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
 // ---- block finder: where could a dynamic-Huffman block header start? ----------------------------------------
 // Phase A tests every bit offset cheaply: BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29 and a COMPLETE code-length
 // code (Kraft sum exactly 1 over the HCLEN+4 three-bit lengths).  Survivors (about 1 offset in 10^3) are compacted.
-__global__ __launch_bounds__(256) void za_k_find_blocks_a(const uint8_t *__restrict__ in, uint64_t n,
+#define ZA_FINDA_THREADS 1024
+#define ZA_FINDA_LOCAL   512          // survivors a workgroup collects in LDS before it reserves room for them with ONE global atomic
+__global__ __launch_bounds__(ZA_FINDA_THREADS) void za_k_find_blocks_a(const uint8_t *__restrict__ in, uint64_t n,
                                                           uint64_t *__restrict__ surv, uint32_t max_surv, uint32_t *__restrict__ n_surv)
 {
+    // (an atomic per survivor on the one global counter -- 2 * 10^5 of them -- was what this kernel's time consisted of)
+    __shared__ uint64_t found[ZA_FINDA_LOCAL];
+    __shared__ uint32_t nfound, gbase;
+    if (threadIdx.x == 0) nfound = 0;
     // Kraft sum of three 3-bit code lengths at once (units of 2^-7; a length of 0 = unused symbol adds nothing): the up to
     // nineteen lengths of a header are seven table reads instead of a data-dependent loop
     __shared__ uint8_t k3[512];
-    for (uint32_t i = threadIdx.x; i < 512u; i += 256u) {
+    for (uint32_t i = threadIdx.x; i < 512u; i += ZA_FINDA_THREADS) {
         const uint32_t a = i & 7u, b = (i >> 3) & 7u, c = i >> 6;
         k3[i] = (uint8_t)((a ? 128u >> a : 0u) + (b ? 128u >> b : 0u) + (c ? 128u >> c : 0u));
     }
     __syncthreads();
-    const uint64_t byte = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (byte + 12 > n) return;                                   // a real header is followed by far more than 12 bytes
-    const uint64_t lo = za_ld64(in + byte);
-    const uint32_t hi = za_ld32(in + byte + 8);
+    // one thread per aligned dword of the input = 32 bit offsets; its four dword loads are coalesced across the wave
+    // (a thread per byte with an unaligned 12-byte window made 64 separate accesses per wave instruction)
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+    const uint8_t *base = in - mis;                              // 4-byte aligned; bytes before `in` are never reported
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t first = 4ull * t;                             // offset from `base` of this thread's first byte
+    const bool live = first + 16 <= n + mis;                     // the last few bytes of the buffer have no room for a header anyway
+    const uint32_t *p32 = (const uint32_t *)(base + (live ? first : 0));
+    const uint32_t d0 = p32[0], d1 = p32[1], d2 = p32[2], d3 = p32[3];
+    const uint64_t q0 = ((uint64_t)d1 << 32) | d0, q2 = ((uint64_t)d3 << 32) | d2;       // the 16 bytes as two little-endian halves
 #pragma unroll
-    for (uint32_t b = 0; b < 8; b++) {
-        const uint32_t head = (uint32_t)(lo >> b);               // 17 bits: BFINAL, BTYPE, HLIT, HDIST, HCLEN
-        if ((head & 7u) != 4u) continue;                         // BFINAL = 0, BTYPE = 10b
-        if (((head >> 3) & 31u) > 29u || ((head >> 8) & 31u) > 29u) continue;
-        const uint32_t hclen = ((head >> 13) & 15u) + 4u;
-        // the 3 * hclen <= 57 bits behind the 17 (bit b + 17 .. b + 73 of the 96-bit window)
-        uint64_t w = (lo >> (b + 17u)) | ((uint64_t)hi << (47u - b));
-        w &= (1ull << (3u * hclen)) - 1ull;
-        uint32_t kraft = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+        if (!live || first + k < mis) continue;                  // in front of the stream
+        const uint64_t byte = first + k - mis;
+        if (byte + 12 > n) continue;                             // a real header is followed by far more than 12 bytes
+        // 96-bit window at byte k of the 16 loaded bytes: lo = bits 0..63, hi = bits 64..95
+        const uint32_t sh = 8u * k;
+        const uint64_t lo = sh ? ((q0 >> sh) | ((uint64_t)d2 << (64u - sh))) : q0;
+        const uint32_t hi = (uint32_t)(q2 >> sh);
 #pragma unroll
-        for (uint32_t k = 0; k < 7; k++) kraft += k3[(uint32_t)(w >> (9u * k)) & 511u];
-        if (kraft != 128u) continue;
-        const uint32_t idx = atomicAdd(n_surv, 1u);
-        if (idx < max_surv) surv[idx] = byte * 8ull + (uint64_t)b;
+        for (uint32_t b = 0; b < 8; b++) {
+            const uint32_t head = (uint32_t)(lo >> b);               // 17 bits: BFINAL, BTYPE, HLIT, HDIST, HCLEN
+            if ((head & 7u) != 4u) continue;                         // BFINAL = 0, BTYPE = 10b
+            if (((head >> 3) & 31u) > 29u || ((head >> 8) & 31u) > 29u) continue;
+            const uint32_t hclen = ((head >> 13) & 15u) + 4u;
+            // the 3 * hclen <= 57 bits behind the 17 (bit b + 17 .. b + 73 of the 96-bit window)
+            uint64_t w = (lo >> (b + 17u)) | ((uint64_t)hi << (47u - b));
+            w &= (1ull << (3u * hclen)) - 1ull;
+            uint32_t kraft = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 7; j++) kraft += k3[(uint32_t)(w >> (9u * j)) & 511u];
+            if (kraft != 128u) continue;
+            const uint32_t li = atomicAdd(&nfound, 1u);
+            if (li < (uint32_t)ZA_FINDA_LOCAL) found[li] = byte * 8ull + (uint64_t)b;
+            else { const uint32_t idx = atomicAdd(n_surv, 1u); if (idx < max_surv) surv[idx] = byte * 8ull + (uint64_t)b; }     // list full (rare)
+        }
     }
+    __syncthreads();
+    const uint32_t cntl = nfound < (uint32_t)ZA_FINDA_LOCAL ? nfound : (uint32_t)ZA_FINDA_LOCAL;
+    if (threadIdx.x == 0 && cntl) gbase = atomicAdd(n_surv, cntl);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cntl; i += ZA_FINDA_THREADS) if (gbase + i < max_surv) surv[gbase + i] = found[i];
 }
 
 // Phase B, one lane per survivor: decode the HLIT+HDIST code lengths with the code-length code and require what
@@ -1440,8 +1468,15 @@ __global__ __launch_bounds__(64) void za_k_find_blocks_b(const uint8_t *__restri
     // code-length code: canonical (count, first code, first index) per length from the 3-bit lengths
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     uint32_t cll = 0, clh = 0;                                    // 19 x 3 bits packed: symbol s at bits 3s
+    // a window of >= 57 bits is fetched once and used until fewer than 17 of them are left (a symbol with its repeat
+    // count needs 14): one dependent load per ~8 symbols instead of one per symbol
+    uint64_t wbase = bp, wcur = za_peek(in, bp);
+    auto bits_at = [&](uint64_t at) -> uint32_t {
+        if (at - wbase > 40ull) { wbase = at; wcur = za_peek(in, at); }
+        return (uint32_t)(wcur >> (at - wbase));
+    };
     for (int k = 0; k < ncode; k++) {
-        const uint32_t v = (uint32_t)(za_peek(in, bp) & 7u); bp += 3;
+        const uint32_t v = bits_at(bp) & 7u; bp += 3;
         const int sft = 3 * order[k];
         if (sft < 30) cll |= v << sft; else clh |= v << (sft - 30);
     }
@@ -1454,7 +1489,7 @@ __global__ __launch_bounds__(64) void za_k_find_blocks_b(const uint8_t *__restri
     int idx = 0, prev = 0;
     while (idx < nlen + ndist && !bad) {
         if (bp + 7 > in_bits) { bad = true; break; }
-        const uint32_t bitsv = (uint32_t)za_peek(in, bp);
+        const uint32_t bitsv = bits_at(bp);
         // canonical decode over the 19-symbol code, bit by bit
         int code = 0, first = 0, index = 0, sym = -1, l = 1;
         uint32_t v = bitsv;

@@ -876,7 +876,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     }
     if (!dense) {
         { ProfScope ps(c, ZNGAMD_K_SCAN);
-          hipLaunchKernelGGL(za_k_find_blocks_a, dim3((uint32_t)((avail + 255) / 256)), dim3(256), 0, c->stream, d_def, avail, c->csurv.p, max_s, d_n + 1); }
+          hipLaunchKernelGGL(za_k_find_blocks_a, dim3((uint32_t)((avail / 4 + 1 + ZA_FINDA_THREADS - 1) / ZA_FINDA_THREADS)), dim3(ZA_FINDA_THREADS), 0, c->stream, d_def, avail, c->csurv.p, max_s, d_n + 1); }      // a thread per aligned dword
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(cnt + 1, d_n + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
