@@ -29,6 +29,28 @@ for window in (64 << 20, 16 << 20):
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     print("window %3d MiB: %d MiB read in %.2f s = %.0f MB/s wall (PCIe + host copies included); max RSS %d -> %d MiB; paths %s" % (
         window >> 20, n >> 20, dt, n / dt / 1e6, rss0 >> 10, rss1 >> 10, ctx.decode_paths(True)))
+os.environ["ZNGAMD_READ_WINDOW"] = str(64 << 20)
+from zlib_ng_amd import gzip_ng_threaded
+for piece_size in (32 << 20, 1 << 20, 128 << 10):
+    t = time.perf_counter()
+    n = 0
+    with gzip_ng_threaded.open(path, "rb", threads=1) as f:
+        while True:
+            piece = f.read(piece_size)
+            if not piece:
+                break
+            n += len(piece)
+    dt = time.perf_counter() - t
+    t = time.perf_counter()
+    m = 0
+    with gzip_ng.open(path, "rb") as f:
+        while True:
+            piece = f.read(piece_size)
+            if not piece:
+                break
+            m += len(piece)
+    dp = time.perf_counter() - t
+    print("reads of %5d KiB: gzip_ng_threaded.open %.0f MB/s, gzip_ng.open %.0f MB/s" % (piece_size >> 10, n / dt / 1e6, m / dp / 1e6))
 t = time.perf_counter()
 n = 0
 with gzip.open(path, "rb") as f:

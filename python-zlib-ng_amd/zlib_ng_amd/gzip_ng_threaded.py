@@ -60,9 +60,13 @@ def open_as_binary_stream(filename, open_mode):
 
 
 class _ThreadedGzipReader(io.RawIOBase):
-    """Streamed reading with one pump thread: it pulls `block_size` pieces out of the windowed GPU reader
-    (`zlib_ng._GzipReader`) and parks at most `queue_size` of them; readinto() takes them in order.  Same role as the
-    reference's prefetching reader (gzip_ng_threaded.py:90-167); the decode itself is chunk-parallel on the GPU."""
+    """Streamed reading with one pump thread.  The windowed GPU reader (`zlib_ng._GzipReader`) decodes a whole window of the
+    compressed file per engine call; the pump takes each decoded window over as it is (no per-block objects, no copy) and
+    parks one while the next is being read, sent and decoded, so that the consumer's copying out of window n overlaps the
+    file I/O, PCIe and kernels of window n + 1 (the engine call and the file read release the GIL).  readinto() copies
+    straight from the parked window into the caller's buffer: one copy per byte in all.  Same role as the reference's
+    prefetching reader (gzip_ng_threaded.py:90-167), whose queue of `queue_size` blocks of `block_size` bytes this
+    replaces; both arguments are accepted and only size the inner reader's first request."""
 
     def __init__(self, filename, queue_size=2, block_size=1024 * 1024):
         source, owns = open_as_binary_stream(filename, "rb")
@@ -71,12 +75,13 @@ class _ThreadedGzipReader(io.RawIOBase):
         self.block_size = block_size
         self.pos = 0
         # (the reference's tests pass a mode string in this position; anything that is not a positive count means 2)
-        self._depth = queue_size if isinstance(queue_size, int) and queue_size > 0 else 2
+        self._depth = 1                              # decoded windows parked ahead of the one being consumed
         self._parked = collections.deque()           # decoded pieces waiting for the consumer
         self._cv = threading.Condition()
         self._finished = False                       # pump has ended (end of stream or failure)
         self._failure = None
         self._current = memoryview(b"")
+        self._token = None                           # buffer of the window being consumed (goes back to the inner reader)
         self._closed = False
         self._stop = False
         self._owner = threading.current_thread()
@@ -89,8 +94,8 @@ class _ThreadedGzipReader(io.RawIOBase):
     def _pump(self):
         try:
             while self._wanted():
-                piece = self.fileobj.read(self.block_size)
-                if not piece:
+                piece = self.fileobj._take_window()
+                if piece is None:
                     break
                 with self._cv:
                     while len(self._parked) >= self._depth and self._wanted():
@@ -121,10 +126,13 @@ class _ThreadedGzipReader(io.RawIOBase):
             raise ValueError("I/O operation on closed file")
         out = memoryview(b).cast("B")
         if not len(self._current):
+            self._current = memoryview(b"")
+            self.fileobj._give_back(self._token)         # the window just finished can be decoded into again
+            self._token = None
             piece = self._next_piece()
             if piece is None:
                 return 0
-            self._current = memoryview(piece)
+            self._current, self._token = piece
         n = min(len(out), len(self._current))
         out[:n] = self._current[:n]
         self._current = self._current[n:]

@@ -770,6 +770,7 @@ class _GzipReader:
         self._first = True
         self._state = _lib.GzState()      # where a member larger than the window is being continued
         self._out = None                  # decoded window (object, address); reused, so its pages are faulted in once
+        self._spare = []                  # buffers given back by a consumer that took whole windows (_take_window)
 
     # -- compressed input, one window at a time
     def _read_window(self, carry):
@@ -830,6 +831,8 @@ class _GzipReader:
             isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
             cap = max(1 << 16, 4 * len(data), isize + 64)
             while True:
+                if self._out is None and self._spare:
+                    self._out = self._spare.pop()        # a window buffer the threaded reader's consumer has finished with
                 if self._out is None or len(self._out[0]) < cap:
                     self._buf = b""                      # drop the view of the old buffer before replacing it
                     self._out = _lib.new_buffer(cap + cap // 4)   # head-room: windows differ a little in size
@@ -888,9 +891,42 @@ class _GzipReader:
         self._check()
         if size is None or size < 0:
             return self.readall()
-        b = bytearray(size)
-        n = self.readinto(b)
-        return bytes(b[:n])
+        with self._lock:
+            n = min(int(size), self._avail())
+            if n <= 0:
+                if self._error is not None and size > 0:
+                    raise self._error
+                if size > 0:
+                    self._size = self._pos
+                return b""
+            piece = bytes(memoryview(self._buf)[self._boff:self._boff + n])      # the one copy
+            self._boff += n
+            self._pos += n
+            return piece
+
+    def _take_window(self):
+        """(view, token): the unread rest of the decoded window as a memoryview whose buffer now belongs to the caller (the next
+        window is decoded into another one; hand the token to _give_back when done), None at the end of the stream; a pending
+        error is raised once the good bytes are gone.
+        For a consumer that overlaps its own work with the decode of the next window (gzip_ng_threaded's reader)."""
+        self._check()
+        with self._lock:
+            if self._avail() <= 0:
+                if self._error is not None:
+                    raise self._error
+                self._size = self._pos
+                return None
+            view = memoryview(self._buf)[self._boff:]
+            self._pos += len(view)
+            self._boff = len(self._buf)
+            token, self._out = self._out, None
+            return view, token
+
+    def _give_back(self, token):
+        """A window buffer handed out by _take_window is free again (its pages are faulted in and known to the driver:
+        decoding into it again is much cheaper than into a fresh one)."""
+        if token is not None and len(self._spare) < 3:
+            self._spare.append(token)
 
     def readall(self):
         self._check()

@@ -241,3 +241,32 @@ def test_program_exits_when_it_fails_with_an_open_file(T, tmp_path, mode, thread
         "raise Exception('Error')\n")
     done = subprocess.run([sys.executable, str(program)], capture_output=True, timeout=120)
     assert done.returncode == 1 and b"Exception: Error" in done.stderr
+
+
+def test_threaded_reader_overlaps_windows(T, monkeypatch):
+    """Many read windows: the pump hands whole decoded windows to the consumer and gets their buffers back (three are in
+    rotation); odd read sizes cross window borders; a truncated file still raises after the good bytes."""
+    from zlib_ng_amd import corpus
+    monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(1 << 20))
+    data = corpus.text(20 << 20, seed=5).tobytes() + corpus.mixed(6 << 20, seed=6).tobytes()
+    blob = gzip.compress(data, 1) + gzip.compress(data[:3 << 20], 6)
+    want = data + data[:3 << 20]
+    for piece in (1 << 20, 777_777, 5 << 20):
+        got = bytearray()
+        with T.open(io.BytesIO(blob), "rb") as f:
+            while True:
+                b = f.read(piece)
+                if not b:
+                    break
+                got += b
+        assert bytes(got) == want, piece
+    got = bytearray()
+    with pytest.raises(EOFError):
+        with T.open(io.BytesIO(blob[:-5]), "rb") as f:
+            while True:
+                b = f.read(1 << 20)
+                if not b:
+                    break
+                got += b
+    # (io.BufferedReader drops what a read() call had gathered when the raw reader raises inside it: up to one request)
+    assert len(got) >= len(data) - (1 << 20) and want.startswith(bytes(got))
