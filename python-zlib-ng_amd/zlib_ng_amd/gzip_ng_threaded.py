@@ -205,6 +205,8 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self._drain_index = 0
         self._crc = 0
         self._size = 0
+        self._write_thread = None                    # file write of the last bulk batch, still running
+        self._write_error = None
         self.running = False
         self.raw, self.closefd = open_as_binary_stream(filename, mode)
         self._closed = False
@@ -243,6 +245,7 @@ class _ThreadedGzipWriter(io.RawIOBase):
             for lo in range(0, nbytes, self.block_size):
                 done += self.write(view[lo:lo + self.block_size])
             return done
+        self._settle_write()                         # a bulk batch still being written comes first in the file
         data = bytes(b)
         zdict = memoryview(self.previous_block)[-DEFLATE_WINDOW_SIZE:]
         self.previous_block = data
@@ -270,7 +273,11 @@ class _ThreadedGzipWriter(io.RawIOBase):
                 raise OverflowError(f"Compressed output exceeds buffer size of {cap}")
             for (_, ln, _, _), crc in zip(blocks, crcs):
                 self._crc = zlib_ng.crc32_combine(self._crc, crc, ln)
-            self.raw.write(packed)
+            # the file write of this batch runs beside the compression of the next one (the engine call and the write
+            # both release the GIL); the previous batch's write has to be through first: the order is the stream
+            self._settle_write()
+            self._write_thread = threading.Thread(target=self._write_later, args=(packed,), name="zng-amd-writer-io")
+            self._write_thread.start()
 
         # the first block needs the tail of what was written before: a small buffer of its own; every later block is primed
         # by the bytes in front of it in the caller's buffer, which goes to the engine as it is (no copy of the payload)
@@ -292,8 +299,26 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self.previous_block = bytes(view[nbytes - last:nbytes])
         return nbytes
 
+    def _write_later(self, packed):
+        try:
+            self.raw.write(packed)
+        except Exception as exc:                     # raised by the next call that touches the file
+            self._write_error = exc
+
+    def _settle_write(self):
+        """Wait for a batch write that is still running (and raise what it ran into)."""
+        t, self._write_thread = self._write_thread, None
+        if t is not None:
+            t.join()
+        if self._write_error is not None:
+            exc, self._write_error = self._write_error, None
+            with self.lock:
+                self.exception = exc
+            raise exc
+
     def _end_gzip_stream(self):
         self._check_closed()
+        self._settle_write()
         for q in self.input_queues:
             q.join()
         # empty final block, then CRC32 and ISIZE (gzip_ng_threaded.py:332-338)
