@@ -172,7 +172,8 @@ int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t 
 /* Host-buffer gzip reader: any multi-member gzip stream (headers with FEXTRA/FNAME/FCOMMENT/FHCRC,
  * NUL padding between members).  Four decode paths, picked per stream / member:
  *   1. this engine's indexed members          -> two-pass, lane-parallel inside each member
- *   2. BGZF-style members ('B','C' subfield)  -> one wavefront per member, one launch
+ *   2. BGZF-style members ('B','C' subfield)  -> one wavefront per member, one launch; runs of small ordinary members
+ *      (no member is more than 1 MiB of input from the next) likewise, after a count launch that finds where each ends
  *   3. any other member of at least 64 KiB with enough block boundaries -> chunk-parallel: chunk starts are
  *      the positions after sync-flush markers (block-parallel writers: gzip_ng_threaded, pigz) and the bit
  *      offsets where a dynamic block header parses (ordinary gzip files); a count-only pass sizes and

@@ -1349,7 +1349,8 @@ template <int BITS>
 __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict__ in, uint64_t in_len,
                                                        const uint64_t *__restrict__ cands, uint32_t ncands,
                                                        ZaChunkRes *__restrict__ res,
-                                                       uint64_t first_bit, uint32_t first_hist)   // where the stream (re)starts, and how much history it has there
+                                                       uint64_t first_bit, uint32_t first_hist,   // where the stream (re)starts, and how much history it has there
+                                                       int whole_streams = 0)                     // candidates are starts of separate streams (gzip members): each runs to its own end, no history
 {
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
@@ -1360,8 +1361,9 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
     int status = ZA_I_DATA;
     if (off <= in_len)
         status = za_inflate_serial_core<1, uint8_t, ZA_WIN, ZaParBufT<BITS, 1>>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, PS.stage,
-                                                    bits, op, (uint32_t)(abit & 7u), nullptr, nullptr, abit == first_bit ? first_hist : (uint32_t)ZA_WIN, true, nullptr,
-                                                    cands, ncands, off * 8ull, &PS);
+                                                    bits, op, (uint32_t)(abit & 7u), nullptr, nullptr,
+                                                    whole_streams ? 0u : (abit == first_bit ? first_hist : (uint32_t)ZA_WIN), !whole_streams, nullptr,
+                                                    cands, whole_streams ? 0u : ncands, off * 8ull, &PS);
     // bits = position relative to byte `off`; report the absolute end
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }

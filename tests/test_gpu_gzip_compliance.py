@@ -766,3 +766,68 @@ def test_every_single_bit_flip_of_small_files(G):
                         if a != b and not (pos in fhcrc_at and bit == 1 and b == ("raise", "BadGzipFile")):
                             differ.append((name, pos, bit, a, b))
             assert not differ, (len(differ), differ[:6])
+
+
+# ------------------------------------------------------------------------------------- files of many small members
+
+def _verdict(fn, m, zerr):
+    try:
+        return ("ok", fn(m))
+    except Exception as e:   # noqa: BLE001
+        return ("raise", "zlib.error" if isinstance(e, zerr) else type(e).__name__)
+
+
+def test_many_small_members_in_one_launch(G, fastq):
+    """Concatenated small members (logs, `cat *.gz`, files grown by appending) are sized and decoded in two launches, not member
+    by member (csrc/zng_amd.hip: hop_plain_members).  Member starts are found by their magic bytes, so the payloads here
+    contain the magic themselves (stored blocks: verbatim), headers carry names, padding sits between members, and a large
+    member or a damaged one ends the run and is handled by the member loop -- always CPython gzip's verdict."""
+    from zlib_ng_amd import _lib, zlib_ng
+    ctx = _lib.default_context()
+    rnd = random.Random(17)
+    magic = b"\x1f\x8b\x08\x00" + bytes(6)
+    parts, want = [], []
+    for i in range(400):
+        n = rnd.choice([0, 1, 300, 5000, 40000])
+        o = rnd.randrange(0, len(fastq) - n)
+        payload = fastq[o:o + n] + (magic * rnd.randrange(1, 4) if i % 3 == 0 else b"")
+        level = rnd.choice([0, 1, 6, 9])
+        if i % 5 == 0:
+            buf = io.BytesIO()
+            with CG.GzipFile(filename="name-%d.txt" % i, mode="wb", fileobj=buf, compresslevel=level, mtime=i) as f:
+                f.write(payload)
+            parts.append(buf.getvalue())
+        else:
+            parts.append(CG.compress(payload, level, mtime=0))
+        if i % 7 == 0:
+            parts.append(bytes(rnd.randrange(1, 9)))              # zero padding between members
+        want.append(payload)
+    blob, plain = b"".join(parts), b"".join(want)
+    ctx.decode_paths()
+    assert G.decompress(blob) == plain
+    paths = ctx.decode_paths()
+    assert paths["bgzf"] == 400 and paths["sequential"] == 0, paths          # "bgzf" counts members decoded one wavefront each in one launch
+    with G.open(io.BytesIO(blob), "rb") as f:
+        assert f.read() == plain
+    # a large member in the middle, and small ones behind it
+    big = fastq * 3
+    mixed = b"".join(parts[:120]) + CG.compress(big, 6) + b"".join(parts[120:])
+    head = len(b"".join(parts[:120]))
+    expect = CG.decompress(mixed)
+    assert G.decompress(mixed) == expect
+    # damage: a flipped bit in member 57's payload, a cut in the last member, junk behind the last member
+    starts = [0]
+    for p in parts:
+        starts.append(starts[-1] + len(p))
+    for bad in (blob[:starts[57] + 14] + bytes([blob[starts[57] + 14] ^ 0x10]) + blob[starts[57] + 15:],
+                blob[:-3], blob[:-9], blob + b"junk behind the members", blob[:starts[300] + 5]):
+        a = _verdict(lambda m: m.decompress(bad), CG, CZ.error)
+        b = _verdict(lambda m: m.decompress(bad), G, zlib_ng.error)
+        assert a == b, (a[:1], b[:1], a[1] if a[0] == "raise" else len(a[1]), b[1] if b[0] == "raise" else len(b[1]))
+
+        def rd(m):
+            with m.open(io.BytesIO(bad), "rb") as f:
+                return f.read()
+        a, b = _verdict(rd, CG, CZ.error), _verdict(rd, G, zlib_ng.error)
+        assert a == b, (a[:1], b[:1])
+    assert head > 0
