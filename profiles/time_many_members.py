@@ -4,8 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
 from zlib_ng_amd import _lib, corpus, gzip_ng
 ctx = _lib.default_context()
-text = corpus.text(32 << 20, seed=3).tobytes()
-for msize, count in ((16 << 10, 2000), (256 << 10, 128), (2 << 20, 16)):
+text = corpus.text(32 << 20, seed=3).tobytes() * 6
+for msize, count in ((16 << 10, 2000), (256 << 10, 128), (2 << 20, 16), (8 << 20, 4), (16 << 20, 12)):
     blob = b"".join(gzip.compress(text[i * msize:(i + 1) * msize], 6) for i in range(count))
     want = text[:msize * count]
     gzip_ng.decompress(blob)

@@ -1095,7 +1095,7 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
     int r = stage_in(c, in, in_len);
     if (r) return r;
     HIPCHK(c, c->st_out.ensure(out_cap + 64));
-    uint64_t pos = 0, op = 0;
+    uint64_t pos = 0, op = 0, last_member_bytes = 0;
     uint32_t members = 0;
     int ret = ZNGAMD_OK;
     // fast path: the whole stream is indexed members -> two-pass scheme
@@ -1206,10 +1206,21 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
         }
         ZaInfResult res;
         bool chunked = false;
-        {   // chunk-parallel decode where the stream offers enough block boundaries, else one wavefront
+        {   // chunk-parallel decode where the stream offers enough block boundaries, else one wavefront.
+            // The finder and the count pass look at everything they are given: behind the first member they get a
+            // bounded piece (twice the previous member, at least 4 MiB; four times more whenever the member proves to be
+            // longer) instead of the whole rest of the file, which made a file of N large members cost N^2 / 2 passes.
             uint64_t clen = 0, cused = 0;
             ChunkInfo ci;
-            const int cr = inflate_chunked_dev(c, c->st_in.p + doff, in_len - doff, c->st_out.p + op, out_cap - op, &clen, &cused, ChunkOpts(), &ci);
+            const uint64_t rest = in_len - doff;
+            uint64_t piece = rest;
+            if (members > 0 && !partial) piece = std::min<uint64_t>(rest, std::max<uint64_t>(4ull << 20, 2 * last_member_bytes));
+            int cr;
+            for (;;) {
+                cr = inflate_chunked_dev(c, c->st_in.p + doff, piece, c->st_out.p + op, out_cap - op, &clen, &cused, ChunkOpts(), &ci);
+                if (piece < rest && ci.cut) { piece = std::min<uint64_t>(rest, piece * 4); continue; }      // the member is longer than the piece: more
+                break;
+            }
             const bool cut = ci.cut;
             if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
             if (cr == ZNGAMD_BUF_ERROR) { *out_len = op + clen; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
@@ -1241,6 +1252,7 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
         if (tc != crc) { ret = ZNGAMD_E_GZ_CRC; char b[96]; snprintf(b, sizeof b, "CRC check failed %u != %u", tc, crc); c->err = b; break; }
         if (tl != (uint32_t)(res.out_len & 0xFFFFFFFFull)) { ret = ZNGAMD_E_GZ_LENGTH; c->err = "Incorrect length of data produced"; break; }
         cur += 8; op += res.out_len; members++;
+        last_member_bytes = cur - pos;
         c->paths[chunked ? ZNGAMD_PATH_CHUNKED : ZNGAMD_PATH_SEQUENTIAL]++;
         while (cur < in_len && in[cur] == 0) cur++;
         pos = cur;

@@ -115,13 +115,14 @@ def decompress(data):
         mv = mv.cast("B") if (mv.format != "B" or mv.ndim != 1) else mv
         ctx = zlib_ng._ctx()
         isize = int.from_bytes(mv[mv.nbytes - 4:], "little")
-        cap = max(1 << 16, isize + 64, 2 * mv.nbytes)
-        for _ in range(3):
+        cap = max(1 << 16, isize + 64, 4 * mv.nbytes)
+        for _ in range(4):
             code, out, _n = ctx.gunzip(mv, cap)
             if code == 0:
                 return out
             if code == zlib_ng._lib.BUF_ERROR and ctx.last_needed > cap:
-                cap = ctx.last_needed + 64
+                # what is reported is what the members seen so far need: with more members behind them, at least double
+                cap = max(ctx.last_needed + 64, 2 * cap)
                 continue
             break
     return _GzipReader(data).readall()
