@@ -1214,7 +1214,7 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
             ChunkInfo ci;
             const uint64_t rest = in_len - doff;
             uint64_t piece = rest;
-            if (members > 0 && !partial) piece = std::min<uint64_t>(rest, std::max<uint64_t>(4ull << 20, 2 * last_member_bytes));
+            if (members > 0) piece = std::min<uint64_t>(rest, std::max<uint64_t>(4ull << 20, 2 * last_member_bytes));
             int cr;
             for (;;) {
                 cr = inflate_chunked_dev(c, c->st_in.p + doff, piece, c->st_out.p + op, out_cap - op, &clen, &cused, ChunkOpts(), &ci);
