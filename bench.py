@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--unique-mib", type=int, default=64, help="MiB of distinct text, tiled to --size-mib")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-foreign", action="store_true", help="skip the foreign-member inflate leg (outside the timed region)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="0 = sized for ~10-30 s")
     args = ap.parse_args()
 
@@ -183,13 +184,68 @@ def main():
     # ---- correctness of what was timed -------------------------------------------------------------
     assert int((d_mstat != 0).sum().item()) == 0, "inflate reported member errors"
     assert torch.equal(d_out[:size], d_in[:size]), "inflate output differs from the input"
-    nchk = min(nblocks, 256)                      # compressed stream: a prefix through the system zlib
+    comp_bytes = int(d_ulen.to(torch.int64).sum().item())
+    assert comp_bytes == comp_total.value
+    # the WHOLE dict-chained compressed stream, closed with an empty final block, is inflated on the device by the
+    # chunk-parallel decoder (sync-flush points) and compared with the input; a prefix also goes through the system zlib
+    d_comp[comp_bytes:comp_bytes + 66] = 0
+    d_comp[comp_bytes] = 3
+    vlen, vused = C.c_uint64(0), C.c_uint64(0)
+    d_out.zero_()
+    rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
+    assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
+    assert torch.equal(d_out[:size], d_in[:size]), "the compressed stream does not inflate to the input"
+    nchk = min(nblocks, 64)
     ul = d_ulen[:nchk].cpu().numpy().astype(np.int64)
     pref = bytes(d_comp[:int(ul.sum())].cpu().numpy())
-    dec = zlib.decompressobj(-15).decompress(pref)
-    assert dec == bytes(host[:nchk * BLOCK] if nchk * BLOCK <= uniq else d_in[:nchk * BLOCK].cpu().numpy()), \
-        "compressed stream does not inflate to the input"
-    comp_bytes = int(d_ulen.to(torch.int64).sum().item())
+    assert zlib.decompressobj(-15).decompress(pref) == bytes(d_in[:nchk * BLOCK].cpu().numpy()), \
+        "compressed stream does not inflate to the input (system zlib)"
+
+    # ---- foreign members: the same text as 128 KiB gzip members written by the SYSTEM zlib (no index, ordinary dynamic
+    # headers), decoded one wavefront per member; outside the timed region, reported beside the headline inflate leg ----
+    foreign = None
+    if rank == 0 and not args.no_foreign:
+        import struct
+        from concurrent.futures import ThreadPoolExecutor
+        hv = memoryview(host)
+
+        def zmember(b):
+            co = zlib.compressobj(args.level, zlib.DEFLATED, -15)
+            raw = co.compress(hv[b * BLOCK:(b + 1) * BLOCK]) + co.flush()
+            return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + raw + struct.pack("<II", zlib.crc32(hv[b * BLOCK:(b + 1) * BLOCK]), BLOCK)
+        with ThreadPoolExecutor(host_cores()) as ex:
+            mem = list(ex.map(zmember, range(uniq // BLOCK)))
+        tile = b"".join(mem)
+        tl = len(tile)
+        d_tile = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
+        d_for = torch.empty(reps * tl + 64, dtype=torch.uint8, device=dev)
+        d_for[:reps * tl].view(reps, tl)[:] = d_tile
+        d_for[reps * tl:] = 0
+        ft = (_lib.Member * nblocks)()
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in mem])])
+        per = uniq // BLOCK
+        for b in range(nblocks):
+            o = (b // per) * tl + int(offs[b % per])
+            ln = len(mem[b % per])
+            ft[b] = _lib.Member(o + 10, ln - 18, b * BLOCK, BLOCK, 0, 0, 0)
+        d_ft = torch.frombuffer(bytearray(bytes(ft)), dtype=torch.uint8).to(dev)
+        d_out.zero_()
+        f_ms = []
+        for it in range(2):
+            ctx.profiling(True); ctx.kernel_times(reset=True)
+            chk(L.zngamd_gzip_inflate_plain_members_dev(h, ptr(d_for), reps * tl, ptr(d_ft), nblocks, ptr(d_out), size, ptr(d_mstat)),
+                "gzip_inflate_plain_members_dev")
+            f_ms.append(ctx.kernel_times(reset=True)["inflate"][0])
+            ctx.profiling(False)
+        assert int((d_mstat != 0).sum().item()) == 0, "foreign members: errors"
+        assert torch.equal(d_out[:size], d_in[:size]), "foreign members: output differs"
+        fbytes = reps * tl + size
+        foreign = {"bound": "hbm", "kernel": "za_k_inflate_serial_members", "members": nblocks,
+                   "writer": "system zlib " + zlib.ZLIB_RUNTIME_VERSION + f" level {args.level}, plain gzip members of 128 KiB",
+                   "ms": round(min(f_ms), 3), "decompress_MBps": round(size / (min(f_ms) * 1e-3) / 1e6, 1),
+                   "achieved": round(fbytes / (min(f_ms) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(fbytes / (min(f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        del d_for, d_tile, d_ft
 
     # ---- per-leg numbers -----------------------------------------------------------------------------
     steps = args.steps
@@ -203,19 +259,22 @@ def main():
     launches_per_step = launches / steps
     alg_bytes = per_step_bytes / launches_per_step
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
+    roofline = {"bound": "hbm", "kernel": "za_k_" + ("inflate_indexed" if dom == "inflate" else dom),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            per_unit = json.load(open(pmc)).get(roofline["kernel"])          # HBM bytes per unit from the PMC passes
+            pj = json.load(open(pmc))
+            per_unit = pj.get(roofline["kernel"])          # HBM bytes per unit from the PMC passes (profiles/run_pmc.sh)
             if per_unit:
                 roofline["traffic"] = int(per_unit * nblocks / launches_per_step)
+                roofline["traffic_source"] = pj.get("build", "profiles/pmc_traffic.json")
         except Exception:
             pass
 
+    free_b, total_b = torch.cuda.mem_get_info(dev)
     out = {
         "metric": "MB/s compress+decompress, 128 KiB blocks level 6",
         "value": round(world * size / dt * steps / 1e6, 1), "unit": "MB/s",
@@ -225,14 +284,18 @@ def main():
         "config": {"workload": f"{args.size_mib} MiB/GPU seeded Zipf-word text ({uniq >> 20} MiB distinct, tiled), "
                                f"128 KiB blocks, level {args.level}: dict-chained deflate + gather"
                                f"{' + RCCL all-gather of the slices' if exchange_stream else ' + layout exchange (sizes)' if exchange else ''}, then two-pass inflate of "
-                               f"{nblocks} independent gzip members",
+                               f"{nblocks} independent gzip members written by this engine ('ZA' chunk index, flat dynamic headers)",
                    "block": BLOCK, "level": args.level, "bytes_per_gpu": size},
         "compress_MBps": round(world * size / (deflate_ms * 1e-3) / 1e6, 1),
         "decompress_MBps": round(world * size / (inflate_ms * 1e-3) / 1e6, 1),
         "ratio": round(size / comp_bytes, 4),
         "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kt.items() if v[1]},
         "roofline": roofline,
-        "roofline_inflate": {"bound": "hbm", "kernel": "za_k_inflate_members",
+        "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains+search+parse+plan+pack+gather",
+                                      "achieved": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
+        "device_memory_in_use_GB": round((total_b - free_b) / 1e9, 1),
+        "roofline_inflate": {"bound": "hbm", "kernel": "za_k_inflate_indexed",
                              "achieved": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6, 2),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
@@ -292,6 +355,8 @@ def main():
     elif exchange:
         off, total, sizes, _, usize = gathered["layout"]
         assert sizes[rank] == comp_total.value and off == sum(sizes[:rank]) and total == sum(sizes) and usize == world * size
+    if foreign is not None:
+        out["roofline_inflate_foreign"] = foreign
     if rank == 0:
         print(json.dumps(out))
     if exchange:

@@ -49,6 +49,9 @@ typedef struct zngamd_ctx zngamd_ctx;
 #define ZNGAMD_E_OVERFLOW    (-203)   /* a block's compressed output reached its buffer size */
 
 #define ZNGAMD_FLAG_FINAL      1u     /* block ends the deflate stream (BFINAL=1, no sync flush) */
+#define ZNGAMD_FLAG_FLATHDR    2u     /* dynamic block headers in their flat form: the code-length code is the fixed 4-bit
+                                         code of the symbols 0..15, so a decoder finds every code length at a known bit offset
+                                         (what zngamd_gzip_members* writes; any inflater reads it as an ordinary dynamic header) */
 /* window of the stream the blocks belong to: match distances stay within 2^bits (deflateInit2's windowBits 9..15).
  * Taken from the FIRST block of a call and applied to all of them; 0 = 15. */
 #define ZNGAMD_FLAG_WBITS(bits) (((uint32_t)(bits) & 15u) << 8)
@@ -152,22 +155,37 @@ typedef struct {
     uint64_t out_off;      /* offset of the member's first output byte                             */
     uint32_t out_len;      /* ISIZE                                                                 */
     uint32_t crc;          /* CRC-32 from the trailer                                               */
-    uint32_t index_off;    /* offset (from in_off's buffer start) of the segment bit-index, 0 none  */
-    uint32_t nseg;
+    uint32_t index_off;    /* bytes from the start of the chunk index to in_off, 0 = no index       */
+    uint32_t nseg;         /* index entries - 1 = ceil(out_len / 256)                              */
 } zngamd_member;
 
 /* Pass 1 on the device: find every member of a multi-member stream written by this engine
- * (FEXTRA subfield 'Z','A' carrying member size, ISIZE and the segment bit index).  d_members must
+ * (FEXTRA subfield 'Z','A' carrying member size, ISIZE and the chunk bit index).  d_members must
  * hold max_members entries; *n_members / *total_out on the host.  Returns ZNGAMD_E_ARG when the
  * stream is not fully made of indexed members (caller then uses the sequential reader). */
 int zngamd_gzip_scan_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
                          zngamd_member *d_members, uint32_t max_members,
                          uint32_t *n_members, uint64_t *total_out);
-/* Pass 2: decode all members (one wavefront per member, one lane per 2 KiB segment), verify CRC-32
- * and ISIZE.  d_status[m] receives a ZNGAMD_* code per member. */
+/* Pass 2: decode all members (one 512-thread workgroup per member, one thread per 256-byte chunk of the
+ * index, the member's output built in LDS), verify CRC-32 and ISIZE.  d_status[m] receives a ZNGAMD_* code
+ * per member. */
 int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
                                     const zngamd_member *d_members, uint32_t n_members,
                                     void *d_out, uint64_t out_cap, int32_t *d_status);
+
+/* Pass 2 for members WITHOUT this engine's index whose extent is known (BGZF 'B','C' members, members written by any
+ * gzip with their sizes recorded by the caller): d_members[i].index_off = 0, in_off / in_len = the member's deflate bytes
+ * (the 8-byte trailer follows them), out_off / out_len = where its ISIZE bytes go.  One wavefront per member (64
+ * self-synchronising sub-sequences inside every Huffman block), CRC-32 / ISIZE verified against the trailer. */
+int zngamd_gzip_inflate_plain_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
+                                          const zngamd_member *d_members, uint32_t n_members,
+                                          void *d_out, uint64_t out_cap, int32_t *d_status);
+
+/* One raw deflate stream that lies in device memory (d_in must be readable 64 bytes past in_len), decoded into device
+ * memory: chunk-parallel where the stream offers block boundaries (sync-flush points, dynamic block headers), else on one
+ * wavefront.  Returns ZNGAMD_STREAM_END when the final block ended; *out_len = bytes produced, *in_used = bytes consumed. */
+int zngamd_inflate_raw_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, void *d_out, uint64_t out_cap,
+                           uint64_t *out_len, uint64_t *in_used);
 
 /* Host-buffer gzip reader: any multi-member gzip stream (headers with FEXTRA/FNAME/FCOMMENT/FHCRC,
  * NUL padding between members).  Four decode paths, picked per stream / member:
@@ -221,6 +239,33 @@ int zngamd_gzip_members(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, uin
 int zngamd_gzip_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, uint32_t block_size,
                             int level, void *d_out, uint64_t out_cap, uint64_t *out_len,
                             uint32_t *n_members);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU (gzip_ng_threaded.py:233-246 gives every worker thread a
+ * compressor, :316-321 deals the blocks round-robin, :382-398 drains them in order; here every rank owns a contiguous block
+ * range and the ranks reassemble the member stream with ONE exchange step) -------------------------------------------------
+ * librccl is loaded on the first call (dlopen), so the library itself does not depend on it.  The 128-byte unique id is made
+ * on one rank and handed to the others by the launcher's own means (bench.py: a TCP socket on MASTER_ADDR). */
+typedef struct zngamd_comm zngamd_comm;
+#define ZNGAMD_COMM_ID_BYTES 128
+int zngamd_comm_unique_id(uint8_t id[ZNGAMD_COMM_ID_BYTES]);
+/* collective over all ranks: communicator bound to ctx's device, with a stream of its own (exchanges overlap ctx's kernels) */
+int zngamd_comm_create(zngamd_ctx *ctx, const uint8_t id[ZNGAMD_COMM_ID_BYTES], int rank, int world, zngamd_comm **out);
+void zngamd_comm_destroy(zngamd_comm *comm);
+const char *zngamd_comm_last_error(zngamd_comm *comm);
+/* layout of the one output stream: all-gather of {compressed bytes, CRC-32 of the rank's input, input bytes} (24 bytes per
+ * rank), then on every rank: sizes[world], the offset of the own slice, the total, the CRC-32 of the whole input folded with
+ * crc32_combine in rank order, and the whole input length -- what header / trailer and a positional write need */
+int zngamd_comm_layout(zngamd_comm *comm, uint64_t local_len, uint32_t local_crc, uint64_t local_ulen, uint64_t *sizes,
+                       uint64_t *my_off, uint64_t *total, uint32_t *whole_crc, uint64_t *whole_ulen);
+/* exact-size exchange of the slices (no padding): every rank sends d_local[0 .. sizes[rank]) to every other rank and
+ * receives their slices at their offsets, grouped ncclSend / ncclRecv over all links at once; afterwards d_stream holds the
+ * whole stream on every rank.  Starts behind the work queued on ctx's stream so far and returns at once;
+ * zngamd_comm_wait blocks until the exchange is done. */
+int zngamd_comm_allgather_stream(zngamd_comm *comm, const void *d_local, const uint64_t *sizes, void *d_stream, uint64_t stream_cap);
+int zngamd_comm_wait(zngamd_comm *comm);
+/* plumbing for a driver: barrier, and the maximum of one double over the ranks (step time of the slowest rank) */
+int zngamd_comm_barrier(zngamd_comm *comm);
+int zngamd_comm_max_f64(zngamd_comm *comm, double *value);
 
 /* ---- measurement ---- */
 /* With profiling on, every kernel launch is bracketed by HIP events on the context's stream. */

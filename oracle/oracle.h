@@ -49,6 +49,13 @@ extern "C" {
 #define ZA_TOO_FAR    4096      /* a minimum-length match farther than this is dropped */
 
 #define ZA_FLAG_FINAL 1         /* last block gets BFINAL=1, no sync-flush marker    */
+#define ZA_FLAG_FLATHDR 2       /* dynamic header in its flat form: the code-length code is the fixed 4-bit code of
+                                   the symbols 0..15 (no run-length symbols), so every code length sits at a known bit
+                                   offset and a decoder can read the header in parallel (indexed gzip members)        */
+#define ZA_LIMIT_L    11        /* longest literal/length code: a 2^11-entry table decodes every symbol in one step */
+#define ZA_LIMIT_D    9         /* longest distance code                                                            */
+#define ZA_CHUNK_SHIFT 8        /* index granularity of indexed members: one entry per 256 bytes of output           */
+#define ZA_MAX_CHUNKS (ZA_MAX_UNIT >> ZA_CHUNK_SHIFT)
 
 /* return codes, zlib numbering (zlib_ngmodule.c:68-95 maps them to messages) */
 #define ZA_OK            0
@@ -79,6 +86,9 @@ typedef struct {
     uint32_t *seg_bits;   /* [ZA_MAX_SEGS+1] bit offset of each segment's first token
                              from the unit's first byte; [nseg] = offset of EOB      */
     int      *btype;      /* 0 stored, 1 fixed, 2 dynamic                            */
+    uint32_t *chunk_idx;  /* [ZA_MAX_CHUNKS+1] entry c: bit offset (23 bits) of the first token that starts at
+                             or behind output byte c*256, | (that token's start - c*256) << 23;
+                             entry nchunk = offset of EOB (stage 5; Huffman blocks only)  */
 } za_o_debug;
 
 long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int flags,

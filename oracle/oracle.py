@@ -18,6 +18,9 @@ MAX_UNIT = 131072
 MAX_SEGS = 64
 WIN = 32768
 FLAG_FINAL = 1
+FLAG_FLATHDR = 2
+CHUNK_SHIFT = 8
+MAX_CHUNKS = MAX_UNIT >> CHUNK_SHIFT
 
 OK, STREAM_END, NEED_DICT = 0, 1, 2
 STREAM_ERROR, DATA_ERROR, MEM_ERROR, BUF_ERROR = -2, -3, -4, -5
@@ -37,7 +40,7 @@ def build(force=False):
 class _Debug(C.Structure):
     _fields_ = [("prevdist", C.c_void_p), ("best", C.c_void_p), ("tokens", C.c_void_p),
                 ("seg_ntok", C.c_void_p), ("hist", C.c_void_p), ("lens", C.c_void_p),
-                ("seg_bits", C.c_void_p), ("btype", C.c_void_p)]
+                ("seg_bits", C.c_void_p), ("btype", C.c_void_p), ("chunk_idx", C.c_void_p)]
 
 
 _lib = None
@@ -109,9 +112,9 @@ def deflate_unit(data, zdict=b"", level=6, flags=0, debug=False, cap=None):
                     tokens=np.zeros(max(nseg * SEG, 1), np.uint32),
                     seg_ntok=np.zeros(MAX_SEGS, np.uint32), hist=np.zeros(320, np.uint32),
                     lens=np.zeros(320, np.uint8), seg_bits=np.zeros(MAX_SEGS + 1, np.uint32),
-                    btype=np.zeros(1, np.int32))
+                    btype=np.zeros(1, np.int32), chunk_idx=np.zeros(MAX_CHUNKS + 1, np.uint32))
         dbg = _Debug(*[arrs[k].ctypes.data for k in
-                       ("prevdist", "best", "tokens", "seg_ntok", "hist", "lens", "seg_bits", "btype")])
+                       ("prevdist", "best", "tokens", "seg_ntok", "hist", "lens", "seg_bits", "btype", "chunk_idx")])
     r = lib().za_o_deflate_unit(buf.ctypes.data + dl, dl, n, level, flags, out.ctypes.data, cap,
                                 C.byref(crc), C.byref(dbg) if dbg is not None else None)
     if r < 0:

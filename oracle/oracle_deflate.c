@@ -261,6 +261,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         return ZA_STREAM_ERROR;
     const za_level *L = (g_override.chain > 0 && level > 0) ? &g_override : &LEVELS[level];
     int final = (flags & ZA_FLAG_FINAL) != 0;
+    int flat = (flags & ZA_FLAG_FLATHDR) != 0;
     bitwr w = { out, cap, 0, 0, 0, 0 };
     if (crc) *crc = za_o_crc32(0, data, (size_t)n);
     int nseg = (n + ZA_SEG - 1) / ZA_SEG;
@@ -280,6 +281,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
     uint16_t *prevdist = NULL;
     uint32_t seg_ntok[ZA_MAX_SEGS];
     uint32_t seg_bits[ZA_MAX_SEGS + 1];
+    uint32_t chunk_idx[ZA_MAX_CHUNKS + 1];
     int btype = 0;
     uint8_t cl_lens[19]; uint16_t cl_codes[19];
     uint16_t cltok[320]; int ncltok = 0, hlit = 257, hdist = 1, hclen = 4;
@@ -287,6 +289,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
     memset(lens, 0, sizeof lens);
     memset(seg_ntok, 0, sizeof seg_ntok);
     memset(seg_bits, 0, sizeof seg_bits);
+    memset(chunk_idx, 0, sizeof chunk_idx);
 
     if (!use_stored) {
         prevdist = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(dict_len + n));
@@ -342,8 +345,8 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
             if (cntd < 2 && fd[0] == 0) { fd[0] = 1; cntd++; }
             if (cntd < 2) fd[1] = 1;
         }
-        huff_lengths(fl, 286, 15, lens);
-        huff_lengths(fd, 30, 15, lens + 288);
+        huff_lengths(fl, 286, ZA_LIMIT_L, lens);
+        huff_lengths(fd, 30, ZA_LIMIT_D, lens + 288);
         canon_codes(lens, 286, codes);
         canon_codes(lens + 288, 30, codes + 288);
         hlit = 286; while (hlit > 257 && lens[hlit - 1] == 0) hlit--;
@@ -378,6 +381,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
             int s = cltok[i] & 0xFF;
             hdr_dyn += cl_lens[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0);
         }
+        if (flat) hdr_dyn = 3 + 5 + 5 + 4 + 3 * 19 + 4 * (uint64_t)(hlit + hdist);
         uint64_t cost_dyn = hdr_dyn + data_dyn, cost_fix = 3 + data_fix;
         uint64_t nchunks = ((uint64_t)n + 65534) / 65535;
         uint64_t cost_sto = 8 * ((uint64_t)n + 5 * nchunks);
@@ -411,7 +415,18 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         }
     } else {
         putbits(&w, (uint32_t)final | ((uint32_t)btype << 1), 3);
-        if (btype == 2) {
+        if (btype == 2 && flat) {
+            /* flat header: code-length code = symbols 0..15 at 4 bits each (16, 17, 18 unused), so code(s) = s;
+             * every code length is one 4-bit field at a fixed offset */
+            putbits(&w, (uint32_t)(hlit - 257), 5);
+            putbits(&w, (uint32_t)(hdist - 1), 5);
+            putbits(&w, 15, 4);
+            for (int i = 0; i < 19; i++) putbits(&w, cl_order[i] < 16 ? 4u : 0u, 3);
+            for (int i = 0; i < hlit + hdist; i++) {
+                uint32_t v = i < hlit ? lens[i] : lens[288 + i - hlit];
+                putbits(&w, ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3), 4);
+            }
+        } else if (btype == 2) {
             putbits(&w, (uint32_t)(hlit - 257), 5);
             putbits(&w, (uint32_t)(hdist - 1), 5);
             putbits(&w, (uint32_t)(hclen - 4), 4);
@@ -427,23 +442,32 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         for (int s = 0; s < nseg; s++) {
             const uint32_t *t = tokens + (size_t)s * ZA_SEG;
             seg_bits[s] = (uint32_t)bitpos(&w);
+            int op = s * ZA_SEG, oend = op + ZA_SEG, nextb = op;       /* output position, next 256-byte boundary to index */
+            if (oend > n) oend = n;
             for (uint32_t k = 0; k < seg_ntok[s]; k++) {
                 uint32_t tk = t[k];
+                for (; nextb <= op; nextb += 1 << ZA_CHUNK_SHIFT)
+                    chunk_idx[nextb >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w) | ((uint32_t)(op - nextb) << 23);
                 if (tk & 0x80000000u) {
                     int lc = (int)((tk >> 26) & 31), dc = (int)((tk >> 16) & 31);
                     putbits(&w, codes[257 + lc], lens[257 + lc]);
                     putbits(&w, (tk >> 21) & 31u, len_extra[lc]);
                     putbits(&w, codes[288 + dc], lens[288 + dc]);
                     putbits(&w, tk & 0x1FFFu, dist_extra[dc]);
-                } else putbits(&w, codes[tk], lens[tk]);
+                    op += len_base[lc] + (int)((tk >> 21) & 31u);
+                } else { putbits(&w, codes[tk], lens[tk]); op++; }
             }
+            for (; nextb < oend; nextb += 1 << ZA_CHUNK_SHIFT)          /* boundaries behind the last token start */
+                chunk_idx[nextb >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w) | ((uint32_t)(oend - nextb) << 23);
         }
         seg_bits[nseg] = (uint32_t)bitpos(&w);
+        chunk_idx[(n + (1 << ZA_CHUNK_SHIFT) - 1) >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w);
         putbits(&w, codes[256], lens[256]);
     }
     if (final) flushbyte(&w);
     else { putbits(&w, 0, 3); flushbyte(&w); putbits(&w, 0, 16); putbits(&w, 0xFFFF, 16); }
     if (dbg && dbg->seg_bits) memcpy(dbg->seg_bits, seg_bits, sizeof seg_bits);
+    if (dbg && dbg->chunk_idx) memcpy(dbg->chunk_idx, chunk_idx, sizeof chunk_idx);
     free(prevdist); free(best); free(tokens);
     return w.overflow ? ZA_BUF_ERROR : (long)w.pos;
 }

@@ -1,25 +1,32 @@
-"""Kernel time of the two-pass member inflate on 1 GiB of level-6 members (ablation builds: see abl_inflate.sh)."""
+"""Per-phase time of za_k_inflate_indexed (measurement build with -DZA_IDX_STATS, see idx_stats.sh): 1 GiB of level-6 members."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
 import torch
 from zlib_ng_amd import _lib, corpus
 ctx = _lib.Context(0); L, h = ctx.L, ctx.h
-n = 1 << 30; B = 131072; nb = n // B
+n = int(os.environ.get("MIB", "1024")) << 20; B = 131072; nb = n // B
 host = corpus.text(64 << 20, seed=1)
 d = torch.cat([torch.from_numpy(host).cuda().repeat(n // host.size), torch.zeros(64, dtype=torch.uint8, device="cuda")])
 p = lambda t: C.c_void_p(t.data_ptr())
-ms = torch.empty(n // 2 + nb * 400 + (64 << 20), dtype=torch.uint8, device="cuda")
+ms = torch.empty(n // 2 + nb * 2800 + (64 << 20), dtype=torch.uint8, device="cuda")
 ml, mn = C.c_uint64(0), C.c_uint32(0)
 assert L.zngamd_gzip_members_dev(h, p(d), n, B, 6, p(ms), ms.numel() - 64, C.byref(ml), C.byref(mn)) == 0
 mtab = torch.empty(nb * C.sizeof(_lib.Member), dtype=torch.uint8, device="cuda")
 mstat = torch.empty(nb, dtype=torch.int32, device="cuda")
 out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 nm, tot = C.c_uint32(0), C.c_uint64(0)
+st = (C.c_ulonglong * 8)()
 for it in range(3):
     ctx.profiling(True); ctx.kernel_times(True)
+    if hasattr(L, "zngamd_debug_idx_stats"):
+        L.zngamd_debug_idx_stats(st)
     assert L.zngamd_gzip_scan_dev(h, p(ms), ml.value, p(mtab), nb, C.byref(nm), C.byref(tot)) == 0
     r = L.zngamd_gzip_inflate_members_dev(h, p(ms), ml.value, p(mtab), nm.value, p(out), n, p(mstat))
     kt = ctx.kernel_times(True)
-ok = bool((out[:n] == d[:n]).all().item())
-print(os.environ.get("ABL", "full"), "rc", r, "output ok", ok, {k: round(v[0], 2) for k, v in kt.items() if v[1]})
+ok = bool((out[:n] == d[:n]).all().item()) and int((mstat != 0).sum().item()) == 0
+print("rc", r, "output ok", ok, {k: round(v[0], 3) for k, v in kt.items() if v[1]}, "member stream bytes", ml.value)
+if hasattr(L, "zngamd_debug_idx_stats"):
+    L.zngamd_debug_idx_stats(st)
+    names = ["setup+tables", "phase A decode", "phase B matches", "phase C crc+store", "whole"]
+    print("per member, microseconds:", {k: round(st[i] / 100.0 / nb, 2) for i, k in enumerate(names)})

@@ -19,6 +19,11 @@
 #define ZA_TOO_FAR    4096
 
 #define ZA_FLAG_FINAL 1u
+#define ZA_FLAG_FLATHDR 2u      // dynamic header in its flat form (4-bit code lengths at fixed offsets): indexed members
+#define ZA_LIMIT_L     11       // longest literal/length code the encoder emits: one 2^11-entry table decodes every symbol
+#define ZA_LIMIT_D     9        // longest distance code
+#define ZA_CHUNK_SHIFT 8        // index granularity of indexed members: one entry per 256 bytes of output
+#define ZA_MAX_CHUNKS  (ZA_MAX_UNIT >> ZA_CHUNK_SHIFT)
 
 // per-unit workspace strides (elements)
 #define ZA_PREV_STRIDE   (ZA_WIN + ZA_MAX_UNIT)   // u16 chain links, index = p + dict_len
@@ -27,6 +32,7 @@
 #define ZA_HIST_STRIDE   320                      // u32: 0..285 lit/len, 288..317 dist
 #define ZA_CODE_STRIDE   320                      // u32: code | len<<16, same layout
 #define ZA_SEGB_STRIDE   (ZA_MAX_SEGS + 1)        // u32 bit offsets
+#define ZA_CIDX_STRIDE   (ZA_MAX_CHUNKS + 4)      // u32 chunk index entries: bit offset | overshoot << 23; [nchunk] = EOB
 
 // unit status bits
 #define ZA_ST_OVERFLOW   1u     // compressed output did not fit the slot

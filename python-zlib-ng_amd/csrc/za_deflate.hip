@@ -306,22 +306,15 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
                     uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2;
                     uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
-                    // keep all four compares unconditional: hipcc otherwise sinks the loads into nested
-                    // branches, one LDS round trip per level
-                    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-                    // first differing bit of the 128: v_ffbl gives 0xFFFFFFFF for "none", which the saturating adds
-                    // keep as "none"; 4 ffbl + 3 add + min3 + min + shift + min
-                    // (written out: the compiler otherwise turns each "none" into a compare + select)
-                    uint32_t f0, f1, f2, f3, fbit;
-                    asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(x0));
-                    asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(x1));
-                    asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(x2));
-                    asm("v_ffbl_b32 %0, %1" : "=v"(f3) : "v"(x3));
-                    asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(f1) : "v"(f1));
-                    asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(f2) : "v"(f2));
-                    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(f3) : "v"(f3), "s"(96u));     // 96 is not an inline constant
-                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(fbit) : "v"(f0), "v"(f1), "v"(f2));
-                    fbit = min(fbit, f3);
+                    // first differing bit of the 128: v_ffbl gives 0xFFFFFFFF for "none", which the saturating adds keep as
+                    // "none"; 4 ffbl + 3 add + min3 + min.  ONE asm statement: hipcc pads every statement with an s_nop, and the
+                    // statement also keeps all four compares unconditional (the compiler otherwise sinks the loads into nested
+                    // branches, one LDS round trip per level, and turns each "none" into a compare + select)
+                    uint32_t fbit, f1, f2, f3;
+                    asm("v_ffbl_b32 %0, %4\n\tv_ffbl_b32 %1, %5\n\tv_ffbl_b32 %2, %6\n\tv_ffbl_b32 %3, %7\n\t"
+                        "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
+                        "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
+                        : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));     // 96 is not an inline constant
                     int len = (int)min(fbit >> 3, 16u);
                     if (FULL && len == 16 && cap > 16 && best_len < cap) {
                         // levels that compare in full: at least 16 equal bytes -- finish the compare the long way
@@ -345,10 +338,9 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                         const uint32_t a0 = za_lds_ld32(win32, qb + o) ^ za_lds_ld32(win32, P + o);
                         const uint32_t a1 = za_lds_ld32(win32, qb + o + 4u) ^ za_lds_ld32(win32, P + o + 4u);
                         uint32_t g0, g1;
-                        asm("v_ffbl_b32 %0, %1" : "=v"(g0) : "v"(a0));
-                        asm("v_ffbl_b32 %0, %1" : "=v"(g1) : "v"(a1));
-                        asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(g1) : "v"(g1));
-                        const int nb = (int)min(min(g0, g1) >> 3, 8u);
+                        asm("v_ffbl_b32 %0, %2\n\tv_ffbl_b32 %1, %3\n\tv_add_u32_e64 %1, %1, 32 clamp\n\tv_min_u32_e32 %0, %0, %1"
+                            : "=&v"(g0), "=&v"(g1) : "v"(a0), "v"(a1));
+                        const int nb = (int)min(g0 >> 3, 8u);
                         best_len += nb;
                         if (nb < 8 || best_len >= maxlen) break;
                     }
@@ -384,9 +376,16 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 // input bytes; a dependent global load per token would cost microseconds, so both streams are staged
 // through LDS in chunks of 32 positions per lane (rows with an odd dword stride: conflict free), with
 // the next chunk's global loads in flight while the current one is parsed.
+// The loads are TRANSPOSED: a lane does not fetch its own row (64 lanes x 16 bytes in 64 different cache lines per
+// instruction = 64 memory requests, and the kernel was bound by the request rate of L2, not by bytes or instructions) --
+// eight lanes fetch the eight 16-byte pieces of one segment's 128-byte row, so an instruction touches eight whole lines,
+// and the pieces are written to the owning lane's LDS row.  A row keeps the previous chunk's last entry in front of the
+// chunk (slot 0): the token at a chunk's last position needs best[p + 1] (lazy rule) and is decided one chunk later.
 #define ZA_PCH 32
-#define ZA_PROW (ZA_PCH + 1)          // best entries per row: chunk + one look-ahead (lazy rule)
-#define ZA_DROW (ZA_PCH / 4 + 1)      // data dwords per row (+1 keeps the stride odd)
+#define ZA_PROW (ZA_PCH + 1)          // carried entry + chunk (odd stride)
+#define ZA_DROW (ZA_PCH / 4 + 1)      // carried dword + chunk dwords (odd stride)
+
+struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };
 
 __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in, uint64_t in_total,
                                                  const ZaUnit *__restrict__ units,
@@ -399,7 +398,7 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
 {
     __shared__ uint32_t hist[ZA_HIST_STRIDE];
     __shared__ uint32_t crct[256];
-    __shared__ uint32_t rowb[64 * ZA_PROW];
+    __shared__ uint32_t rowb[64 * ZA_PROW + 1];      // (+1: the look-ahead read of a segment's very last position)
     __shared__ uint32_t rowd[64 * ZA_DROW];
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
@@ -421,32 +420,26 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     uint32_t *myb = rowb + lane * ZA_PROW;
     uint32_t *myd = rowd + lane * ZA_DROW;
 
-    uint4 pb[ZA_PCH / 4];          // prefetched best entries of the next chunk
-    uint32_t pla = 0;              // its look-ahead entry
-    uint32_t pd[ZA_PCH / 4];       // prefetched data dwords
-    auto prefetch = [&](int cb) {
+    uint4 pb[8];                   // piece lane & 7 of the `best` rows of segments 8 j + (lane >> 3)
+    uint4 pd[2];                   // piece lane & 1 of the data rows of segments 32 j + (lane >> 1)
+    auto prefetch = [&](int c) {
+        const int rel = c * ZA_PCH;
 #pragma unroll
-        for (int j = 0; j < ZA_PCH / 4; j++) {
+        for (int j = 0; j < 8; j++) {
+            const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + rel;
             pb[j] = make_uint4(0, 0, 0, 0);
-            pd[j] = 0;
+            if (do_parse && c < ZA_SEG / ZA_PCH && sg < nseg && off < n) pb[j] = *(const uint4 *)(best + off + 4 * (lane & 7));   // rows are 128-byte aligned
         }
-        pla = 0;
-        if (active && cb < s1) {
-            if (do_parse) {
 #pragma unroll
-                for (int j = 0; j < ZA_PCH / 4; j++) pb[j] = *(const uint4 *)(best + cb + 4 * j);   // workspace rows are 16 B aligned
-                if (cb + ZA_PCH < n) pla = best[cb + ZA_PCH];
-            }
-            if ((long long)cb + ZA_PCH <= readable) {          // everywhere but at the very end of the caller's buffer
-#pragma unroll
-                for (int j = 0; j < ZA_PCH / 4; j++) pd[j] = za_ld32(data + cb + 4 * j);
-            } else {
-#pragma unroll 1
-                for (int j = 0; j < ZA_PCH / 4; j++) {
-                    const int o = cb + 4 * j;
-                    uint32_t v = 0;
-                    for (int k = 0; k < 4; k++) if ((long long)(o + k) < readable) v |= (uint32_t)data[o + k] << (8 * k);
-                    pd[j] = v;
+        for (int j = 0; j < 2; j++) {
+            const int sg = 32 * j + (lane >> 1), off = (sg << ZA_SEG_SHIFT) + rel + 16 * (lane & 1);
+            pd[j] = make_uint4(0, 0, 0, 0);
+            if (c < ZA_SEG / ZA_PCH && sg < nseg && off < n) {
+                if ((long long)off + 16 <= readable) { const ZaU4u v = *(const ZaU4u *)(data + off); pd[j] = make_uint4(v.x, v.y, v.z, v.w); }
+                else {                                           // the very end of the caller's buffer
+                    uint32_t t[4] = {0, 0, 0, 0};
+                    for (int k = 0; k < 16; k++) if ((long long)(off + k) < readable) t[k >> 2] |= (uint32_t)data[off + k] << (8 * (k & 3));
+                    pd[j] = make_uint4(t[0], t[1], t[2], t[3]);
                 }
             }
         }
@@ -455,10 +448,11 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     uint32_t ntok = 0;
     uint32_t crc_r = 0xFFFFFFFFu;
     int p = s0;
+    uint32_t carry_b = 0, carry_d = 0;
     // tokens leave in groups of four (one 16-byte store): single dword stores from 64 lanes to 64 different
     // lines cost 3-4x their bytes in HBM write traffic
     uint32_t tb0 = 0, tb1 = 0, tb2 = 0;
-    prefetch(s0);
+    prefetch(0);
 #pragma unroll 1
     for (int c = 0; c < ZA_SEG / ZA_PCH; c++) {
         const int cb = s0 + c * ZA_PCH;
@@ -466,37 +460,44 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
         if (__ballot(active && cb < s1) == 0ull) break;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < ZA_PCH / 4; j++) {
-            myb[4 * j + 0] = pb[j].x; myb[4 * j + 1] = pb[j].y; myb[4 * j + 2] = pb[j].z; myb[4 * j + 3] = pb[j].w;
-            myd[j] = pd[j];
+        for (int j = 0; j < 8; j++) {
+            uint32_t *r = rowb + (8 * j + (lane >> 3)) * ZA_PROW + 1 + 4 * (lane & 7);
+            r[0] = pb[j].x; r[1] = pb[j].y; r[2] = pb[j].z; r[3] = pb[j].w;
         }
-        myb[ZA_PCH] = pla;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            uint32_t *r = rowd + (32 * j + (lane >> 1)) * ZA_DROW + 1 + 4 * (lane & 1);
+            r[0] = pd[j].x; r[1] = pd[j].y; r[2] = pd[j].z; r[3] = pd[j].w;
+        }
+        myb[0] = carry_b; myd[0] = carry_d;
         __builtin_amdgcn_wave_barrier();
-        prefetch(cb + ZA_PCH);
+        prefetch(c + 1);
         int ce = cb + ZA_PCH;
         if (ce > s1) ce = s1;
-        if (active) {
+        if (active && cb < s1) {
             // CRC-32 over this chunk's bytes (zng_crc32_z at zlib_ngmodule.c:1741)
-            const uint8_t *bytes = (const uint8_t *)myd;
+            const uint8_t *bytes = (const uint8_t *)myd;          // byte of position q at bytes[q - cb + 4]
             {
                 int k = cb;
                 for (; k + 4 <= ce; k += 4) {                     // one row dword, four table steps
-                    const uint32_t w4 = myd[(k - cb) >> 2];
+                    const uint32_t w4 = myd[1 + ((k - cb) >> 2)];
                     crc_r = crct[(crc_r ^ w4) & 0xFF] ^ (crc_r >> 8);
                     crc_r = crct[(crc_r ^ (w4 >> 8)) & 0xFF] ^ (crc_r >> 8);
                     crc_r = crct[(crc_r ^ (w4 >> 16)) & 0xFF] ^ (crc_r >> 8);
                     crc_r = crct[(crc_r ^ (w4 >> 24)) & 0xFF] ^ (crc_r >> 8);
                 }
-                for (; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb]) & 0xFF] ^ (crc_r >> 8);
+                for (; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb + 4]) & 0xFF] ^ (crc_r >> 8);
             }
             if (do_parse) {
-                // one token per lane and round, literal and match on one predicated path (no divergent if/else)
-                while (p < ce) {
-                    const uint32_t b = myb[p - cb], bn = myb[p + 1 - cb];      // row has one look-ahead entry
+                // one token per lane and round, literal and match on one predicated path (no divergent if/else); the chunk's
+                // last position waits for the next chunk (its successor's entry is not here yet) unless the segment ends
+                const int lim = ce == s1 ? ce : ce - 1;
+                while (p < lim) {
+                    const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2];
                     const int len = (int)(b >> 16), nlen = (int)(bn >> 16);
                     const bool deferred = L.lazy && len < L.lazy && p + 1 < s1 && nlen > len;
                     const bool is_match = len >= ZA_MIN_MATCH && !deferred;
-                    const uint32_t lit = bytes[p - cb];
+                    const uint32_t lit = bytes[p - cb + 4];
                     const int dist = is_match ? (int)(b & 0xFFFFu) : 1;
                     int lc, ln, le, dc, dn, de;
                     za_len_sym(is_match ? len : 3, lc, ln, le);
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                     p += is_match ? len : 1;
                 }
             }
+            carry_b = myb[ZA_PCH]; carry_d = myd[ZA_PCH / 4];
         }
     }
     {   // the last, partial group of tokens
@@ -675,6 +677,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
     const int n = (int)u.in_len;
     const int lane = za_lane();
     const bool final = (u.flags & ZA_FLAG_FINAL) != 0;
+    const bool flat = (u.flags & ZA_FLAG_FLATHDR) != 0;      // header form of indexed members
     ZaPlan plan; plan.btype = 0; plan.header_bits = 0; plan.pad0 = plan.pad1 = 0;
     uint32_t *code_out = code_ws + (size_t)blockIdx.x * ZA_CODE_STRIDE;
     if (n == 0 || level == 0) {
@@ -693,12 +696,12 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
     __syncthreads();
     // lit/len tree
     za_sort_syms(S, S.freq, 286);
-    if (lane == 0) za_lengths_serial(S, 286, 15, S.lens);
+    if (lane == 0) za_lengths_serial(S, 286, ZA_LIMIT_L, S.lens);
     __syncthreads();
     if (lane < 2) S.lens[286 + lane] = 0;
     // distance tree
     za_sort_syms(S, S.freq + 288, 30);
-    if (lane == 0) { za_lengths_serial(S, 30, 15, S.lens + 288); S.lens[318] = S.lens[319] = 0; }
+    if (lane == 0) { za_lengths_serial(S, 30, ZA_LIMIT_D, S.lens + 288); S.lens[318] = S.lens[319] = 0; }
     __syncthreads();
 
     if (lane == 0) {
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
             const int s = S.cltok[k] & 0xFF;
             hdr_dyn += S.cl_lens[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0);
         }
+        if (flat) hdr_dyn = 3 + 5 + 5 + 4 + 3 * 19 + 4ull * (unsigned)(hlit + hdist);
         const unsigned long long cost_dyn = hdr_dyn + data_dyn, cost_fix = 3 + data_fix;
         const unsigned long long nchunks = ((unsigned long long)n + 65534ull) / 65535ull;
         const unsigned long long cost_sto = 8ull * ((unsigned long long)n + 5ull * nchunks);
@@ -785,7 +789,17 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
             w.out = (uint32_t *)(out + (size_t)blockIdx.x * out_stride);
             w.cap_words = out_stride / 4; w.w = 0; w.acc = 0; w.nb = 0; w.ovf = false;
             w.put((uint32_t)final | ((uint32_t)btype << 1), 3);
-            if (btype == 2) {
+            if (btype == 2 && flat) {
+                // flat form: the code-length code is the 4-bit code of the symbols 0..15 (code(s) = s), no run lengths
+                w.put((uint32_t)(hlit - 257), 5);
+                w.put((uint32_t)(hdist - 1), 5);
+                w.put(15u, 4);
+                for (int k = 0; k < 19; k++) w.put(za_cl_order[k] < 16 ? 4u : 0u, 3);
+                for (int k = 0; k < hlit + hdist; k++) {
+                    const uint32_t v = k < hlit ? S.lens[k] : S.lens[288 + k - hlit];
+                    w.put(((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3), 4);
+                }
+            } else if (btype == 2) {
                 w.put((uint32_t)(hlit - 257), 5);
                 w.put((uint32_t)(hdist - 1), 5);
                 w.put((uint32_t)(hclen - 4), 4);
@@ -815,23 +829,40 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
 // owned by the lane alone and stored directly.
 #define ZA_TCH 32      // tokens staged per lane and chunk in k_pack
 
+struct __attribute__((aligned(4))) ZaW4 { uint32_t x, y, z, w; };
+
+// Per-lane LSB-first bit writer.  The first word a lane touches and its trailing partial word may be shared with a
+// neighbour (or with the header): they are merged with atomic OR into words that hold zero.  The words in between are
+// the lane's alone and leave four at a time as one 16-byte store (single dword stores from 64 lanes were 64 memory
+// requests per instruction, and the request rate of L2 bounded the kernel).
 struct ZaLaneW {
     uint32_t *out; uint32_t cap_words; uint32_t w; uint64_t acc; int nb; bool first; bool ovf;
+    uint32_t b0, b1, b2; uint32_t nbuf;
     __device__ void init(uint32_t *o, uint32_t cap, uint32_t bitpos)
     {
         out = o; cap_words = cap; w = bitpos >> 5; nb = (int)(bitpos & 31u); acc = 0; first = true; ovf = false;
+        b0 = b1 = b2 = 0; nbuf = 0;
+    }
+    __device__ void word(uint32_t v)
+    {
+        if (w >= cap_words) { ovf = true; w++; return; }
+        if (first) { atomicOr(&out[w], v); first = false; w++; return; }
+        if (nbuf == 3u) { ZaW4 q; q.x = b0; q.y = b1; q.z = b2; q.w = v; *(ZaW4 *)(out + (w - 3u)) = q; nbuf = 0; }
+        else { b0 = nbuf == 0u ? v : b0; b1 = nbuf == 1u ? v : b1; b2 = nbuf == 2u ? v : b2; nbuf++; }
+        w++;
     }
     __device__ void put(uint32_t v, int n)
     {
         acc |= (uint64_t)v << nb; nb += n;
-        if (nb >= 32) {
-            if (w < cap_words) { if (first) atomicOr(&out[w], (uint32_t)acc); else out[w] = (uint32_t)acc; }
-            else ovf = true;
-            first = false; w++; acc >>= 32; nb -= 32;
-        }
+        if (nb >= 32) { word((uint32_t)acc); acc >>= 32; nb -= 32; }
     }
     __device__ void finish()
     {
+        // buffered whole words (all below cap_words: word() checked them), then the trailing partial word
+        if (nbuf > 0u) out[w - nbuf] = b0;
+        if (nbuf > 1u) out[w - nbuf + 1u] = b1;
+        if (nbuf > 2u) out[w - nbuf + 2u] = b2;
+        nbuf = 0;
         if (nb > 0 && (uint32_t)acc != 0u) { if (w < cap_words) atomicOr(&out[w], (uint32_t)acc); else ovf = true; }
     }
 };
@@ -839,7 +870,8 @@ struct ZaLaneW {
 __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
                                                 const uint32_t *__restrict__ tok_ws, const uint32_t *__restrict__ segtok_ws,
                                                 const uint32_t *__restrict__ code_ws, const ZaPlan *__restrict__ plan_ws,
-                                                uint32_t *__restrict__ segbits_ws, uint8_t *__restrict__ out,
+                                                uint32_t *__restrict__ segbits_ws, uint32_t *__restrict__ cidx_ws,
+                                                uint8_t *__restrict__ out,
                                                 uint32_t out_stride, uint32_t *__restrict__ out_len,
                                                 uint32_t *__restrict__ status)
 {
@@ -855,6 +887,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     uint32_t *slot32 = (uint32_t *)slot;
     const uint32_t cap_words = out_stride / 4;
     uint32_t *segbits = segbits_ws + (size_t)blockIdx.x * ZA_SEGB_STRIDE;
+    uint32_t *cidx = cidx_ws + (size_t)blockIdx.x * ZA_CIDX_STRIDE;       // chunk index of indexed members (oracle: chunk_idx)
     const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
     bool ovf = false;
     uint32_t total_bytes = 0;
@@ -866,6 +899,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             out_len[blockIdx.x] = total_bytes; status[blockIdx.x] = 0;
         }
         for (int i = lane; i < ZA_SEGB_STRIDE; i += 64) segbits[i] = 0;
+        for (int i = lane; i < ZA_CIDX_STRIDE; i += 64) cidx[i] = 0;
         return;
     }
     if (plan.btype == 0) {
@@ -893,6 +927,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             if (!final) total_bytes += 5;
         }
         for (int i = lane; i < ZA_SEGB_STRIDE; i += 64) segbits[i] = 0;
+        for (int i = lane; i < ZA_CIDX_STRIDE; i += 64) cidx[i] = 0;
         if (lane == 0) { out_len[blockIdx.x] = ovf ? 0u : total_bytes; status[blockIdx.x] = ovf ? ZA_ST_OVERFLOW : 0u; }
         return;
     }
@@ -905,13 +940,20 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(maxtok, d, 64); maxtok = o > maxtok ? o : maxtok; }
     uint32_t *myt = rowt + lane * (ZA_TCH + 1);
 
-    // Walk my tokens in chunks of ZA_TCH staged through LDS (next chunk's loads in flight meanwhile).
+    // Walk my tokens in chunks of ZA_TCH staged through LDS (next chunk's loads in flight meanwhile).  The loads are
+    // transposed as in k_parse: eight lanes fetch the eight 16-byte pieces of one segment's 128-byte token row.
+    __shared__ uint32_t sntok[64];
+    sntok[lane] = ntok;
+    __syncthreads();
+    const uint32_t *tok_unit = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE;
     auto for_each_token = [&](auto &&fn) {
         uint4 pt[ZA_TCH / 4];
         auto prefetch = [&](uint32_t k0) {
-            if (k0 < ntok) {
 #pragma unroll
-                for (int j = 0; j < ZA_TCH / 4; j++) pt[j] = *(const uint4 *)(tok + k0 + 4 * j);
+            for (int j = 0; j < ZA_TCH / 4; j++) {
+                const int sg = 8 * j + (lane >> 3);
+                pt[j] = make_uint4(0, 0, 0, 0);
+                if (k0 < sntok[sg]) pt[j] = *(const uint4 *)(tok_unit + ((size_t)sg << ZA_SEG_SHIFT) + k0 + 4 * (lane & 7));
             }
         };
         prefetch(0);
@@ -920,7 +962,8 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < ZA_TCH / 4; j++) {
-                myt[4 * j + 0] = pt[j].x; myt[4 * j + 1] = pt[j].y; myt[4 * j + 2] = pt[j].z; myt[4 * j + 3] = pt[j].w;
+                uint32_t *r = rowt + (8 * j + (lane >> 3)) * (ZA_TCH + 1) + 4 * (lane & 7);
+                r[0] = pt[j].x; r[1] = pt[j].y; r[2] = pt[j].z; r[3] = pt[j].w;
             }
             __builtin_amdgcn_wave_barrier();
             prefetch(k0 + ZA_TCH);
@@ -946,19 +989,47 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     else segbits[lane] = end_all;
     if (lane == 0) segbits[ZA_MAX_SEGS] = end_all;
 
+    // The words that are merged with atomic OR must hold zero: every lane's first word (shared with its predecessor's
+    // tail) unless it is the header's last word, which the plan kernel wrote, and the words from the end of the last
+    // segment on (end-of-block code, padding, sync marker).  Everything else is written whole, so the slots need no memset.
+    {
+        const uint32_t first_free = (plan.header_bits + 31u) >> 5;       // words below hold header bits written by the plan kernel
+        if (lane < nseg && (start >> 5) >= first_free && (start >> 5) < cap_words) slot32[start >> 5] = 0;
+        if (lane == 0) {
+            for (uint32_t k = end_all >> 5; k < (end_all >> 5) + 4u; k++)
+                if (k >= first_free && k < cap_words) slot32[k] = 0;
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
     // pass B: emit
     ZaLaneW w;
     w.init(slot32, cap_words, start);
+    // chunk index: for every 256-byte boundary of my segment the first token that starts at or behind it
+    uint32_t op = (uint32_t)lane << ZA_SEG_SHIFT, nextb = op;
+    uint32_t oend = op + ZA_SEG; if (oend > (uint32_t)n) oend = (uint32_t)n;
     for_each_token([&](uint32_t t) {
         const bool m = (t & 0x80000000u) != 0u;
         const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
         const int ln = m ? za_len_extra_bits(lc) : 0, dn = za_dist_extra_bits(dc);
         const uint32_t le = m ? (t >> 21) & 31u : 0u, de = t & 0x1FFFu;
+        while (nextb <= op) {
+            cidx[nextb >> ZA_CHUNK_SHIFT] = (w.w * 32u + (uint32_t)w.nb) | ((op - nextb) << 23);
+            nextb += 1u << ZA_CHUNK_SHIFT;
+        }
+        {   // length of the token from its symbols (literal: 1)
+            const uint32_t l8 = (uint32_t)lc;
+            const uint32_t mlen = l8 < 8u ? 3u + l8 : l8 == 28u ? 258u : ((4u + (l8 & 3u)) << ((l8 >> 2) - 1u)) + 3u + le;
+            op += m ? mlen : 1u;
+        }
         const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
         // literal / length code + extra fit in 20 bits, distance code + extra in 28 (0 bits for a literal)
         w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
         w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : 0u, m ? (int)(cd >> 16) + dn : 0);
     });
+    for (; nextb < oend && lane < nseg; nextb += 1u << ZA_CHUNK_SHIFT)       // boundaries behind my last token start
+        cidx[nextb >> ZA_CHUNK_SHIFT] = (w.w * 32u + (uint32_t)w.nb) | ((oend - nextb) << 23);
+    if (lane == 0) cidx[((uint32_t)n + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT] = end_all;
     w.finish();
     ovf = w.ovf;
     // tail: EOB, then final padding or the sync-flush marker (empty stored block)
@@ -1014,16 +1085,20 @@ __global__ __launch_bounds__(256) void za_k_gather(const uint8_t *__restrict__ s
 }
 
 // exclusive prefix sum of unit sizes -> byte offsets (single workgroup; batches are <= a few 10^5)
+// units != nullptr: indexed members -- every unit also takes 4 bytes of index per 256 bytes of its input
 __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict__ out_len, uint32_t n, uint32_t extra,
                                                      uint64_t base, uint64_t *__restrict__ dst_off,
-                                                     uint64_t *__restrict__ total)
+                                                     uint64_t *__restrict__ total, const ZaUnit *__restrict__ units)
 {
+    auto ext = [&](uint32_t i) -> unsigned long long {
+        return (unsigned long long)extra + (units ? 4ull * ((units[i].in_len + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT) : 0ull);
+    };
     __shared__ unsigned long long part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t b = tid * per, e = (b + per < n) ? b + per : n;
     unsigned long long s = 0;
-    for (uint32_t i = b; i < e; i++) s += (unsigned long long)out_len[i] + extra;
+    for (uint32_t i = b; i < e; i++) s += (unsigned long long)out_len[i] + ext(i);
     part[tid] = s;
     __syncthreads();
     if (tid == 0) {
@@ -1033,5 +1108,5 @@ __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict_
     }
     __syncthreads();
     unsigned long long run = part[tid];
-    for (uint32_t i = b; i < e; i++) { dst_off[i] = run; run += (unsigned long long)out_len[i] + extra; }
+    for (uint32_t i = b; i < e; i++) { dst_off[i] = run; run += (unsigned long long)out_len[i] + ext(i); }
 }

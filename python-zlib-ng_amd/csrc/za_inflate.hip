@@ -10,10 +10,7 @@
 //                         sequential rounds (32 KiB history ring in LDS, copies done by all 64 lanes)
 //   za_k_scan_members     pass 1 of the two-pass scheme: coalesced sweep of the compressed stream
 //                         for this engine's indexed gzip members ('Z','A' FEXTRA subfield)
-//   za_k_inflate_members  pass 2: one wavefront per member, one lane per 2 KiB segment decodes its
-//                         tokens from the indexed bit offset (literals stored directly, matches
-//                         queued), then the wave resolves the queued matches in output order,
-//                         64 at a time, byte-parallel; CRC-32 / ISIZE verified in the same kernel
+//   za_k_inflate_indexed  pass 2 (za_inflate_idx.hip): one 512-thread workgroup per member, output built in LDS
 //   za_k_assemble_members writes header + index + deflate bytes + trailer of each member
 #include "za_common.h"
 #include "za_crc.h"
@@ -934,12 +931,13 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
 // ------------------------------------------------------------------------------------------------
 // Member layout written by za_k_assemble_members (all little endian):
 //   0  1f 8b 08 04 | 4 mtime=0 | 8 xfl | 9 os=ff | 10 XLEN(u16) | 12 'Z' 'A' | 14 SLEN(u16)
-//   16 member_size(u32) | 20 isize(u32) | 24 nseg(u16) | 26 version(u16)=1
-//   28 (ZA_MAX_SEGS+1) x u32 bit offsets from the first deflate byte (entry nseg = offset of EOB)
-//   28+260 = 288 deflate bytes ... | crc32(u32) | isize(u32)
-#define ZA_MEMBER_HDR   288
-#define ZA_MEMBER_XLEN  (ZA_MEMBER_HDR - 12)
-#define ZA_MEMBER_SLEN  (ZA_MEMBER_HDR - 16)
+//   16 member_size(u32) | 20 isize(u32) | 24 nchunk(u16) = ceil(isize / 256) | 26 version(u8) = 2 | 27 chunk shift(u8) = 8
+//   28 (nchunk + 1) x u32 index entries: bits 0..22 = bit offset (from the first deflate byte) of the first token that
+//      starts at or behind output byte 256 c, bits 23..31 = how many bytes behind (0..257: a match may run across the
+//      boundary -- token boundaries are NOT forced here); entry nchunk = bit offset of the end-of-block code
+//   32 + 4 nchunk: deflate bytes (one final block; a dynamic header in its flat form) ... | crc32(u32) | isize(u32)
+#define ZA_MEMBER_FIXED 32                                     // header bytes besides the 4 per chunk
+#define ZA_MEMBER_HDR(nchunk) (ZA_MEMBER_FIXED + 4u * (nchunk))
 
 struct ZaMember {          // mirrors zngamd_member
     uint64_t in_off, in_len, out_off;
@@ -968,279 +966,16 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
         const uint32_t v = sh ? ((w[wi] >> sh) | (w[wi + 1] << (32 - sh))) : w[wi];
         if (v != 0x04088b1fu) continue;
         const uint64_t o = base + (uint64_t)k;
-        if (o + ZA_MEMBER_HDR + 8 > in_len) continue;
+        if (o + ZA_MEMBER_FIXED + 8 > in_len) continue;
         const uint8_t *h = in + o;
-        if (h[9] != 0xFF || h[10] != (ZA_MEMBER_XLEN & 0xFF) || h[11] != (ZA_MEMBER_XLEN >> 8) || h[12] != 'Z' || h[13] != 'A' ||
-            h[14] != (ZA_MEMBER_SLEN & 0xFF) || h[15] != (ZA_MEMBER_SLEN >> 8) || h[26] != 1 || h[27] != 0) continue;
-        const uint32_t size = za_ld32(h + 16), isize = za_ld32(h + 20);
-        if (size < ZA_MEMBER_HDR + 8 || o + size > in_len) continue;
+        if (h[9] != 0xFF || h[12] != 'Z' || h[13] != 'A' || h[26] != 2 || h[27] != ZA_CHUNK_SHIFT) continue;
+        const uint32_t size = za_ld32(h + 16), isize = za_ld32(h + 20), nchunk = za_ld16(h + 24), xlen = za_ld16(h + 10), slen = za_ld16(h + 14);
+        const uint32_t hdr = ZA_MEMBER_HDR(nchunk);
+        if (isize > ZA_MAX_UNIT || nchunk != ((isize + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT) || xlen != hdr - 12u || slen != hdr - 16u) continue;
+        if (size < hdr + 8u || o + size > in_len) continue;
         const uint32_t idx = atomicAdd(n_cands, 1u);
         if (idx < max_cands) { ZaCand c; c.off = o; c.size = size; c.isize = isize; cands[idx] = c; }
     }
-}
-
-#define ZA_MATCHQ_PER_SEG 688      // >= 2048/3 matches per segment
-#define ZA_IROW 19                 // dwords per lane row of staged input: 72 bytes + 1 (odd stride)
-
-__global__ __launch_bounds__(64) void za_k_inflate_members(const uint8_t *__restrict__ in, uint64_t in_total,
-                                                           const ZaMember *__restrict__ members,
-                                                           uint8_t *__restrict__ out, uint64_t out_cap,
-                                                           uint2 *__restrict__ matchq,          // [grid][64][ZA_MATCHQ_PER_SEG]
-                                                           const uint32_t *__restrict__ crc_table,
-                                                           const uint32_t *__restrict__ x8k_table,
-                                                           int32_t *__restrict__ status_out)
-{
-    __shared__ ZaInfTabs T;
-    __shared__ int scratch[2];
-    __shared__ uint32_t crct[256];
-    __shared__ uint32_t rows[64 * ZA_IROW];
-    const int lane = za_lane();
-    const ZaMember m = members[blockIdx.x];
-    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
-    __syncthreads();
-    int status = ZA_I_OK;
-    const uint8_t *src = in + m.in_off;
-    const uint64_t in_bits = m.in_len * 8ull;
-    uint8_t *dst = out + m.out_off;
-    const int n = (int)m.out_len;
-    const int nseg = (int)m.nseg;
-    if (m.in_off + m.in_len + 8 > in_total || m.out_off + m.out_len > out_cap || n > ZA_MAX_UNIT ||
-        nseg != ((n + ZA_SEG - 1) >> ZA_SEG_SHIFT) || m.index_off == 0 || m.index_off > m.in_off || n == 0) {
-        if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX;
-        return;
-    }
-    const uint32_t *index = (const uint32_t *)(src - m.index_off);      // member starts are byte aligned only: unaligned loads
-    uint32_t my_start = za_ld32((const uint8_t *)(index + (lane < nseg ? lane : nseg)));
-    uint32_t my_stop = za_ld32((const uint8_t *)(index + (lane < nseg ? lane + 1 : nseg)));
-    // block header (uniform)
-    uint64_t bitpos = 0;
-    if (in_bits < 3) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
-    uint64_t bits = za_peek(src, 0);
-    const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
-    bitpos = 3;
-    if (!last || type == 0 || type == 3) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
-    status = za_read_tables(src, in_bits, bitpos, type, T, scratch);
-    if (status != ZA_I_OK) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
-    const uint32_t first_start = __shfl(my_start, 0, 64);
-    if ((uint64_t)first_start != bitpos) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
-
-    // ---- phase A: every lane decodes its own segment.
-    // A dependent 8-byte global load per token would cost microseconds, so each lane's compressed bytes
-    // are staged through an LDS row: round r holds bytes [56 r, 56 r + 72) counted from the lane's first
-    // byte; a lane decodes while its read position is inside the first 56 bytes of the row, and the next
-    // row is already in flight in registers meanwhile.
-    uint2 *myq = matchq + ((size_t)blockIdx.x * 64 + (size_t)lane) * ZA_MATCHQ_PER_SEG;
-    uint32_t nmatch = 0;
-    int lane_err = 0;      // 0 ok, 1 index mismatch, 2 data error
-    {
-        uint32_t *myrow = rows + lane * ZA_IROW;
-        const bool act = lane < nseg;
-        int pos = lane << ZA_SEG_SHIFT;
-        int end = pos + ZA_SEG; if (end > n) end = n;
-        uint64_t bp = my_start;
-        if (act && (bp > in_bits || my_stop > in_bits || my_stop < my_start)) lane_err = 1;
-        const uint64_t byte0 = my_start >> 3;                       // lane origin inside src
-        const uint64_t readable = in_total - m.in_off;              // bytes that may be read from src
-        bool done = !act || lane_err != 0 || pos >= end;
-        // Output of this lane is collected in a 16-byte block (two 64-bit halves) and stored once per block:
-        // literal bytes land in it, match bytes are left zero -- phase B overwrites them later, and no other
-        // lane owns bytes of this block (segment starts are multiples of 16 inside the member).  The block
-        // that holds the member's last bytes is stored bytewise so that nothing past `n` is touched.
-        uint64_t blk_lo = 0, blk_hi = 0;
-        bool blk_dirty = false;                                 // a literal was put into the block
-        int blk_base = pos;                                     // multiple of 16
-        auto flush_block = [&](int upto) {                      // store [blk_base, min(blk_base+16, upto))
-            if (blk_base + 16 <= n) {
-                za_u64u *d64 = (za_u64u *)(dst + blk_base);
-                d64[0] = blk_lo; d64[1] = blk_hi;
-            } else {
-                for (int k = blk_base; k < upto && k < n; k++) {
-                    const int o = k - blk_base;
-                    dst[k] = (uint8_t)(o < 8 ? blk_lo >> (8 * o) : blk_hi >> (8 * (o - 8)));
-                }
-            }
-            blk_lo = 0; blk_hi = 0; blk_dirty = false;
-        };
-        uint32_t pre[ZA_IROW - 1];
-        auto prefetch = [&](uint32_t r) {
-#pragma unroll
-            for (int j = 0; j < ZA_IROW - 1; j++) {
-                const uint64_t o = byte0 + 56ull * r + 4ull * (unsigned)j;
-                pre[j] = (!done && o + 4 <= readable) ? za_ld32(src + o) : 0u;
-            }
-        };
-        prefetch(0);
-#pragma unroll 1
-        for (uint32_t r = 0;; r++) {
-            if (__ballot(!done) == 0ull) break;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < ZA_IROW - 1; j++) myrow[j] = pre[j];
-            __builtin_amdgcn_wave_barrier();
-            prefetch(r + 1);
-            const uint64_t row_bit0 = (byte0 + 56ull * r) * 8ull;
-            const uint64_t row_lim = row_bit0 + 56ull * 8ull;       // decode while bp < row_lim
-            while (!done && bp < row_lim) {
-                if (bp > in_bits) { lane_err = 1; break; }
-                const uint32_t rel = (uint32_t)(bp - row_bit0);     // < 448
-                const uint32_t w = rel >> 5, sh = rel & 31u;
-                // 64 bits starting at bit `rel` of the row (3 dwords)
-                const uint32_t d0 = myrow[w], d1 = myrow[w + 1], d2 = myrow[w + 2];
-                const uint64_t lo = ((uint64_t)d1 << 32) | d0;
-                const uint64_t b = sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
-                uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
-                if (!e) { lane_err = 2; break; }
-                int sym = (int)(e >> 4);
-                uint32_t used = e & 15u;
-                if (sym < 256) {
-                    const int o = pos - blk_base;
-                    if (o < 8) blk_lo |= (uint64_t)(uint32_t)sym << (8 * o); else blk_hi |= (uint64_t)(uint32_t)sym << (8 * (o - 8));
-                    blk_dirty = true;
-                    pos++; bp += used;
-                    if (pos - blk_base == 16) { flush_block(pos); blk_base = pos; }
-                    if (pos >= end) done = true;
-                    continue;
-                }
-                // match: every validity test of the token is collected and branched on once (the fields of an invalid
-                // token are computed from clamped symbols, never used)
-                const int ls = sym - 257;                               // 256 (end of block inside a segment) gives -1
-                int nx;
-                int len = za_len_base(ls < 0 ? 0 : (ls > 28 ? 28 : ls), nx);
-                len += (int)((b >> used) & ((1u << nx) - 1u));
-                used += (uint32_t)nx;
-                e = za_decode_sym(b >> used, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
-                const int ds = (int)(e >> 4);
-                used += e & 15u;
-                int dist = za_dist_base(ds > 29 ? 29 : ds, nx);
-                dist += (int)((b >> used) & ((1u << nx) - 1u));
-                used += (uint32_t)nx;
-                const bool bad_data = ls > 28 || e == 0u || ds >= 30 || dist > pos;
-                const bool bad_index = ls < 0 || pos + len > end || nmatch >= ZA_MATCHQ_PER_SEG;
-                if (bad_data || bad_index) { lane_err = (ls < 0 || !bad_data) ? 1 : 2; break; }    // same verdict order as a test at a time
-                myq[nmatch++] = make_uint2((uint32_t)pos | ((uint32_t)len << 17), (uint32_t)dist);
-                pos += len; bp += used;
-                if (pos - blk_base >= 16) {
-                    // the block being filled holds literals only if something was put in it
-                    if (blk_dirty) flush_block(pos);
-                    blk_base = pos & ~15;
-                }
-                if (pos >= end) done = true;
-            }
-            if (lane_err) done = true;
-        }
-        if (act && blk_dirty) flush_block(pos);
-        if (act && !lane_err && bp != my_stop) lane_err = 1;
-        if (act && !lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
-            const uint64_t b = za_peek(src, bp);         // bp == my_stop <= in_bits
-            const uint32_t e = za_decode_sym(b, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
-            if (!e || (e >> 4) != 256u) lane_err = 1;
-            else if (((bp + (e & 15u) + 7ull) >> 3) != m.in_len) lane_err = 1;
-        }
-    }
-    const unsigned long long e1 = __ballot(lane_err == 1), e2 = __ballot(lane_err == 2);
-    if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
-    __threadfence_block();       // literals and the match queues are visible to the whole wave
-
-    // ---- phase B: resolve matches in output order, 64 at a time.  A match is ready when its source lies
-    // below the first unresolved match of the group (the lowest pending one always is).  Each ready lane
-    // copies its own match: 16 bytes per batch as four unaligned dword loads followed by the stores (the
-    // loads of a batch are independent, so they overlap); a self-overlapping match (dist < len) reads its
-    // period byte-wise, which lies entirely below its destination.
-    const uint64_t out_room = out_cap - m.out_off;     // bytes of dst that may be touched
-#ifndef ZA_ABL_NO_B
-    for (int s = 0; s < nseg; s++) {
-        const uint32_t cnt = __shfl(nmatch, s, 64);
-        const uint2 *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
-        for (uint32_t g = 0; g < cnt; g += 64) {
-            const bool has = g + (uint32_t)lane < cnt;
-            uint2 mm = make_uint2(0, 1);
-            if (has) mm = q[g + lane];
-            const uint32_t mdst = mm.x & 0x1FFFFu, mlen = mm.x >> 17, mdist = mm.y;
-            bool done = !has;
-            unsigned long long pending = __ballot(!done);
-            // Which matches of this group write bytes that mine reads?  Destinations are disjoint and ascending with
-            // the lane, so they are the lanes [jlo, jhi): jhi = matches that start below the end of my source,
-            // jlo = matches that end at or below its start (two 6-step binary searches with shuffles; both counts
-            // are at most my own lane).  A match is ready as soon as none of those is pending -- the lowest
-            // pending one always is.
-            const uint32_t sdst = has ? mdst : 0xFFFFFFFFu, send = has ? mdst + mlen : 0xFFFFFFFFu;
-            const uint32_t src_a = mdst - mdist, src_b = src_a + (mlen < mdist ? mlen : mdist);
-            uint32_t jhi = 0, jlo = 0;
-#pragma unroll
-            for (uint32_t step = 32; step; step >>= 1) {
-                const uint32_t vd = (uint32_t)__shfl((int)sdst, (int)(jhi + step - 1u), 64);
-                const uint32_t ve = (uint32_t)__shfl((int)send, (int)(jlo + step - 1u), 64);
-                if (vd < src_b) jhi += step;
-                if (ve <= src_a) jlo += step;
-            }
-            const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
-            // short non-overlapping matches (nearly all) are copied by their own lane, at most two 16-byte batches;
-            // long or self-overlapping ones would keep the other 63 lanes waiting, so the whole wave copies those
-            const bool simple = mdist >= mlen && mlen <= 32u && (uint64_t)mdst + mlen + 4 <= out_room;
-            while (pending) {
-                const bool ready = !done && (pending & deps) == 0ull;
-                if (ready && simple) {
-                    uint8_t *o = dst + mdst;
-                    const uint8_t *sp = o - mdist;
-                    for (uint32_t i = 0; i < mlen; i += 16) {
-                        const uint32_t rem = mlen - i;
-                        uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                        v0 = za_ld32(sp + i);
-                        if (rem > 4) v1 = za_ld32(sp + i + 4);
-                        if (rem > 8) v2 = za_ld32(sp + i + 8);
-                        if (rem > 12) v3 = za_ld32(sp + i + 12);
-                        const uint32_t vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int left = (int)rem - 4 * k;
-                            if (left >= 4) *(za_u32u *)(o + i + 4 * k) = vv[k];
-                            else if (left > 0) {
-                                o[i + 4 * k] = (uint8_t)vv[k];
-                                if (left > 1) o[i + 4 * k + 1] = (uint8_t)(vv[k] >> 8);
-                                if (left > 2) o[i + 4 * k + 2] = (uint8_t)(vv[k] >> 16);
-                            }
-                        }
-                    }
-                }
-                unsigned long long coop = __ballot(ready && !simple);
-                while (coop) {
-                    const int j = __builtin_ctzll(coop);
-                    coop &= coop - 1ull;
-                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
-                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
-                    const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
-                    uint8_t *o = dst + cd;
-                    const uint8_t *sp = o - cdist;
-                    const float rd = 1.0f / (float)cdist;
-                    for (uint32_t base = 0; base < cl; base += 64) {
-                        const uint32_t i = base + (uint32_t)lane;
-                        if (i < cl) {
-                            // byte i of a self-overlapping match is byte (i mod dist) of its period, which lies below it
-                            int k = (int)i;
-                            if (cdist < cl) {
-                                k = (int)i - (int)cdist * (int)((float)i * rd);
-                                if (k < 0) k += (int)cdist;
-                                if (k >= (int)cdist) k -= (int)cdist;
-                            }
-                            o[i] = sp[k];
-                        }
-                    }
-                }
-                __threadfence_block();
-                done = done || ready;
-                pending = __ballot(!done);
-            }
-        }
-    }
-#endif
-    // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
-#ifdef ZA_ABL_NO_CRC
-    const uint32_t c = za_ld32(src + m.in_len);
-#else
-    const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
-#endif
-    const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
-    if (lane == 0) status_out[blockIdx.x] = (c != want_crc) ? ZA_I_CRC : (want_len != (uint32_t)n) ? ZA_I_LENGTH : ZA_I_OK;
 }
 
 // Members whose extent is known up front without this engine's index (BGZF: 'B','C' subfield with the
@@ -1624,46 +1359,43 @@ __global__ __launch_bounds__(256) void za_k_chunk_resolve(const uint16_t *__rest
     }
 }
 
-// One workgroup per member: header with the segment index, deflate bytes from the unit slot, trailer.
+// One workgroup per member: header with the chunk index, deflate bytes from the unit slot, trailer.
 __global__ __launch_bounds__(256) void za_k_assemble_members(const uint8_t *__restrict__ slots, uint32_t slot_stride,
                                                              const uint32_t *__restrict__ unit_len,
                                                              const uint32_t *__restrict__ unit_crc,
-                                                             const uint32_t *__restrict__ segbits_ws,
+                                                             const uint32_t *__restrict__ cidx_ws,
                                                              const ZaUnit *__restrict__ units,
-                                                             const uint64_t *__restrict__ member_off,   // offsets with +296 per member
+                                                             const uint64_t *__restrict__ member_off,   // offsets with header + trailer per member
                                                              uint8_t *__restrict__ dst, uint8_t xfl)
 {
     const uint32_t u = blockIdx.x;
     const uint32_t dlen = unit_len[u];
     const uint32_t n = units[u].in_len;
-    const uint32_t nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    const uint32_t nchunk = (n + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT;
+    const uint32_t hdr = ZA_MEMBER_HDR(nchunk);
     uint8_t *d = dst + member_off[u];
-    const uint32_t size = ZA_MEMBER_HDR + dlen + 8;
-    const uint32_t *sb = segbits_ws + (size_t)u * ZA_SEGB_STRIDE;
+    const uint32_t size = hdr + dlen + 8;
+    const uint32_t *ci = cidx_ws + (size_t)u * ZA_CIDX_STRIDE;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < ZA_MEMBER_HDR; i += blockDim.x) {
+    for (uint32_t i = tid; i < hdr; i += blockDim.x) {
         uint8_t b = 0;
         switch (i) {
         case 0: b = 0x1f; break; case 1: b = 0x8b; break; case 2: b = 8; break; case 3: b = 4; break;
         case 8: b = xfl; break; case 9: b = 0xff; break;
-        case 10: b = ZA_MEMBER_XLEN & 0xFF; break; case 11: b = ZA_MEMBER_XLEN >> 8; break;
+        case 10: b = (uint8_t)((hdr - 12u) & 0xFF); break; case 11: b = (uint8_t)((hdr - 12u) >> 8); break;
         case 12: b = 'Z'; break; case 13: b = 'A'; break;
-        case 14: b = ZA_MEMBER_SLEN & 0xFF; break; case 15: b = ZA_MEMBER_SLEN >> 8; break;
-        case 24: b = (uint8_t)(nseg & 0xFF); break; case 25: b = (uint8_t)(nseg >> 8); break;
-        case 26: b = 1; break;
+        case 14: b = (uint8_t)((hdr - 16u) & 0xFF); break; case 15: b = (uint8_t)((hdr - 16u) >> 8); break;
+        case 24: b = (uint8_t)(nchunk & 0xFF); break; case 25: b = (uint8_t)(nchunk >> 8); break;
+        case 26: b = 2; break; case 27: b = ZA_CHUNK_SHIFT; break;
         default:
             if (i >= 16 && i < 20) b = (uint8_t)(size >> (8 * (i - 16)));
             else if (i >= 20 && i < 24) b = (uint8_t)(n >> (8 * (i - 20)));
-            else if (i >= 28) {
-                const uint32_t k = (i - 28) >> 2;                       // 0..64
-                const uint32_t v = sb[k < nseg ? k : ZA_MAX_SEGS];      // entries >= nseg hold the EOB offset
-                b = (uint8_t)(v >> (8 * ((i - 28) & 3)));
-            }
+            else if (i >= 28) b = (uint8_t)(ci[(i - 28) >> 2] >> (8 * ((i - 28) & 3)));
         }
         d[i] = b;
     }
     const uint8_t *src = slots + (size_t)u * slot_stride;
-    uint8_t *p = d + ZA_MEMBER_HDR;
+    uint8_t *p = d + hdr;
     for (uint32_t i = tid; i < dlen; i += blockDim.x) p[i] = src[i];
     if (tid < 8) {
         const uint32_t v = tid < 4 ? unit_crc[u] : n;

@@ -6,6 +6,7 @@
 // kernels and assembles container framing bytes (gzip / zlib headers and trailers).
 #include "za_deflate.hip"
 #include "za_inflate.hip"
+#include "za_inflate_idx.hip"
 #include "za_checksum.hip"
 #include "../../include/zng_amd.h"
 
@@ -51,16 +52,17 @@ struct zngamd_ctx {
     std::mutex mu;
     // constant tables
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
+    uint32_t *d_crc_slice4 = nullptr, *d_x256 = nullptr, *d_x8 = nullptr;     // tables of za_k_inflate_indexed
     // deflate workspaces (per chunk of units)
     uint32_t chunk_units = 16384;                // units per launch: 1.4 MiB of workspace each (23 GB); fewer, fuller launches
     DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     // per call
-    DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, status;
+    DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status;
     uint32_t last_units = 0; bool last_single_chunk = false;
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
     DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
-    DevBuf<ZaCkPart> ck; DevBuf<uint2> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
+    DevBuf<ZaCkPart> ck; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
     uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
@@ -132,6 +134,23 @@ int zngamd_ctx_create(int device, zngamd_ctx **out)
         hipMemcpy(c->d_x8k, x8k, sizeof x8k, hipMemcpyHostToDevice) != hipSuccess) {
         zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
     }
+    {   // tables of the indexed-member decoder: CRC slice-by-4, x^(8*256*k) for k < 512, x^(8*k) for k <= 256
+        std::vector<uint32_t> s4(1024), x256(512), x8(257);
+        for (int i = 0; i < 256; i++) s4[i] = tab[i];
+        for (int t = 1; t < 4; t++) for (int i = 0; i < 256; i++) s4[256 * t + i] = (s4[256 * (t - 1) + i] >> 8) ^ tab[s4[256 * (t - 1) + i] & 0xFF];
+        uint32_t xs = 0x80000000u;
+        for (int k = 0; k <= 256; k++) { x8[k] = xs; xs = za_multmodp(xs, 0x00800000u); }
+        const uint32_t step = x8[256];
+        xs = 0x80000000u;
+        for (int k = 0; k < 512; k++) { x256[k] = xs; xs = za_multmodp(xs, step); }
+        if (hipMalloc((void **)&c->d_crc_slice4, 4096) != hipSuccess || hipMalloc((void **)&c->d_x256, 2048) != hipSuccess ||
+            hipMalloc((void **)&c->d_x8, 257 * 4) != hipSuccess ||
+            hipMemcpy(c->d_crc_slice4, s4.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_x256, x256.data(), 2048, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_x8, x8.data(), 257 * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
+        }
+    }
     *out = c;
     return ZNGAMD_OK;
 }
@@ -144,13 +163,16 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     c->prev.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
-    c->plan.release(); c->units.release(); c->segbits.release(); c->status.release();
+    c->plan.release(); c->units.release(); c->segbits.release(); c->cidx.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
-    c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
+    c->st_off.release(); c->ck.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
+    if (c->d_crc_slice4) (void)hipFree(c->d_crc_slice4);
+    if (c->d_x256) (void)hipFree(c->d_x256);
+    if (c->d_x8) (void)hipFree(c->d_x8);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -324,7 +346,7 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
             u.in_off = B.off + rel;
             u.in_len = (uint32_t)std::min<uint64_t>(ZA_MAX_UNIT, B.len - rel);
             u.dict_len = (uint32_t)std::min<uint64_t>(ZA_WIN, (uint64_t)B.dict_len + rel);
-            u.flags = (k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u;
+            u.flags = (B.flags & ZNGAMD_FLAG_FLATHDR) | ((k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u);
             u.block = b;
             hu.push_back(u);
         }
@@ -342,7 +364,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     if (n == 0) return ZNGAMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t ch = std::min(n, c->chunk_units);
-    HIPCHK(c, c->units.ensure(n)); HIPCHK(c, c->segbits.ensure((size_t)n * ZA_SEGB_STRIDE)); HIPCHK(c, c->status.ensure(n));
+    HIPCHK(c, c->units.ensure(n)); HIPCHK(c, c->segbits.ensure((size_t)n * ZA_SEGB_STRIDE)); HIPCHK(c, c->cidx.ensure((size_t)n * ZA_CIDX_STRIDE)); HIPCHK(c, c->status.ensure(n));
     if (level > 0) {
         HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
         HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
@@ -350,7 +372,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
     HIPCHK(c, c->codes.ensure((size_t)ch * ZA_CODE_STRIDE)); HIPCHK(c, c->plan.ensure(ch));
     HIPCHK(c, hipMemcpyAsync(c->units.p, hu.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(d_slots, 0, (size_t)n * ZNGAMD_SLOT_STRIDE, c->stream));
+    // (no memset of the slots: the pack kernel zeroes the few words it merges with atomic OR and writes the rest whole)
     ZaLevel L = ZA_LEVELS[level];
     L.max_dist = (max_dist < 1 || max_dist > ZA_WIN) ? ZA_WIN : max_dist;
     for (uint32_t c0 = 0; c0 < n; c0 += ch) {
@@ -371,7 +393,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
                              d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE, (uint32_t)ZNGAMD_SLOT_STRIDE, level); }
         { ProfScope ps(c, ZNGAMD_K_PACK);
           hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok.p, c->segtok.p, c->codes.p, c->plan.p,
-                             c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE,
+                             c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, c->cidx.p + (size_t)c0 * ZA_CIDX_STRIDE, d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE,
                              (uint32_t)ZNGAMD_SLOT_STRIDE, d_unit_len + c0, c->status.p + c0); }
         HIPCHK(c, hipGetLastError());
     }
@@ -396,14 +418,15 @@ int zngamd_deflate_blocks_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, 
 }
 
 static int gather_dev(zngamd_ctx *c, const uint8_t *d_slots, const uint32_t *d_unit_len, uint32_t n, uint32_t extra,
-                      uint8_t *d_dst, uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off, uint64_t *total, bool do_copy)
+                      uint8_t *d_dst, uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off, uint64_t *total, bool do_copy,
+                      const ZaUnit *d_units_for_index = nullptr)
 {
     if (n == 0) { *total = 0; return ZNGAMD_OK; }
     uint64_t *offs = d_unit_off;
     if (!offs) { HIPCHK(c, c->st_off.ensure(n)); offs = c->st_off.p; }
     uint64_t *d_total = (uint64_t *)c->d_small;
     { ProfScope ps(c, ZNGAMD_K_GATHER);
-      hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(1024), 0, c->stream, d_unit_len, n, extra, dst_base, offs, d_total); }
+      hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(1024), 0, c->stream, d_unit_len, n, extra, dst_base, offs, d_total, d_units_for_index); }
     HIPCHK(c, hipMemcpyAsync(total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (dst_base + *total > dst_cap) return fail(c, ZNGAMD_BUF_ERROR, "destination too small");
@@ -566,6 +589,7 @@ int zngamd_debug_fetch(zngamd_ctx *c, int what, uint32_t unit, void *dst, size_t
     case 5: src = c->codes.p + (size_t)unit * ZA_CODE_STRIDE; lim = ZA_CODE_STRIDE * 4ull; break;
     case 6: src = c->segbits.p + (size_t)unit * ZA_SEGB_STRIDE; lim = ZA_SEGB_STRIDE * 4ull; break;
     case 7: src = c->plan.p + unit; lim = sizeof(ZaPlan); break;
+    case 8: src = c->cidx.p + (size_t)unit * ZA_CIDX_STRIDE; lim = ZA_CIDX_STRIDE * 4ull; break;
     default: return fail(c, ZNGAMD_E_ARG, "unknown stage");
     }
     if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
@@ -701,8 +725,8 @@ static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
                             bool allow_tail = false, uint64_t *covered = nullptr)
 {
     hm.clear(); *total_out = 0;
-    if (in_len < ZA_MEMBER_HDR + 8) return ZNGAMD_E_ARG;
-    const uint32_t max_c = (uint32_t)std::min<uint64_t>(in_len / (ZA_MEMBER_HDR + 8) + 1, 1u << 26);
+    if (in_len < ZA_MEMBER_FIXED + 8) return ZNGAMD_E_ARG;
+    const uint32_t max_c = (uint32_t)std::min<uint64_t>(in_len / (ZA_MEMBER_FIXED + 8) + 1, 1u << 26);
     HIPCHK(c, c->cands.ensure(max_c));
     uint32_t *d_n = (uint32_t *)((uint8_t *)c->d_small + 128);
     HIPCHK(c, hipMemsetAsync(d_n, 0, 4, c->stream));
@@ -725,8 +749,9 @@ static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
         while (i < hc.size() && hc[i].off < pos) i++;
         if (i == hc.size() || hc[i].off != pos) { if (allow_tail && !hm.empty()) break; return ZNGAMD_E_ARG; }
         ZaMember m;
-        m.in_off = pos + ZA_MEMBER_HDR; m.in_len = hc[i].size - ZA_MEMBER_HDR - 8; m.out_off = outp;
-        m.out_len = hc[i].isize; m.crc = 0; m.index_off = ZA_MEMBER_HDR - 28; m.nseg = (hc[i].isize + ZA_SEG - 1) / ZA_SEG;
+        const uint32_t nchunk = (hc[i].isize + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT, hdr = ZA_MEMBER_HDR(nchunk);
+        m.in_off = pos + hdr; m.in_len = hc[i].size - hdr - 8; m.out_off = outp;
+        m.out_len = hc[i].isize; m.crc = 0; m.index_off = hdr - 28; m.nseg = nchunk;
         hm.push_back(m);
         pos += hc[i].size; outp += hc[i].isize;
     }
@@ -755,13 +780,10 @@ int zngamd_gzip_scan_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, zngam
 static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const ZaMember *d_members, uint32_t n,
                                uint8_t *d_out, uint64_t out_cap, int32_t *d_status)
 {
-    const uint32_t ch = std::min<uint32_t>(n, 32768);          // members per launch: 352 KiB of match queue each (11.5 GB)
-    HIPCHK(c, c->matchq.ensure((size_t)ch * 64 * ZA_MATCHQ_PER_SEG));
-    for (uint32_t c0 = 0; c0 < n; c0 += ch) {
-        const uint32_t m = std::min(ch, n - c0);
+    if (n) {          // one workgroup per member; no workspace: a member's output is built in LDS
         ProfScope ps(c, ZNGAMD_K_INFLATE);
-        hipLaunchKernelGGL(za_k_inflate_members, dim3(m), dim3(64), 0, c->stream, d_in, in_len, d_members + c0, d_out, out_cap,
-                           c->matchq.p, c->d_crc_table, c->d_x8k, d_status + c0);
+        hipLaunchKernelGGL(za_k_inflate_indexed, dim3(n), dim3(ZA_IDX_THREADS), 0, c->stream, d_in, in_len, d_members, d_out, out_cap,
+                           c->d_crc_slice4, c->d_x256, c->d_x8, d_status);
     }
     HIPCHK(c, hipGetLastError());
     return ZNGAMD_OK;
@@ -778,6 +800,44 @@ int zngamd_gzip_inflate_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return ZNGAMD_OK;
+}
+
+int zngamd_gzip_inflate_plain_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_member *d_members,
+                                          uint32_t n_members, void *d_out, uint64_t out_cap, int32_t *d_status)
+{
+    if (!c || !d_in || !d_members || !d_out || !d_status) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_members) {
+        ProfScope ps(c, ZNGAMD_K_INFLATE);
+        hipLaunchKernelGGL(za_k_inflate_serial_members, dim3(n_members), dim3(64), 0, c->stream, (const uint8_t *)d_in, in_len,
+                           (const ZaMember *)d_members, (uint8_t *)d_out, out_cap, c->d_crc_table, c->d_x8k, d_status);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ZNGAMD_OK;
+}
+
+int zngamd_inflate_raw_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, void *d_out, uint64_t out_cap, uint64_t *out_len,
+                           uint64_t *in_used)
+{
+    if (!c || !d_in || !d_out || !out_len) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t clen = 0, cused = 0;
+    const int cr = inflate_chunked_dev(c, (const uint8_t *)d_in, in_len, (uint8_t *)d_out, out_cap, &clen, &cused);
+    if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
+    if (cr == ZNGAMD_BUF_ERROR) { *out_len = clen; if (in_used) *in_used = 0; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+    if (cr == 0) { *out_len = clen; if (in_used) *in_used = cused; c->paths[ZNGAMD_PATH_CHUNKED]++; return ZNGAMD_STREAM_END; }
+    ZaInfResult res;
+    int r = inflate_serial_dev(c, (const uint8_t *)d_in, in_len, nullptr, 0, (uint8_t *)d_out, out_cap, &res);
+    if (r) return r;
+    c->paths[ZNGAMD_PATH_SEQUENTIAL]++;
+    *out_len = res.out_len;
+    if (in_used) *in_used = (res.in_bits + 7) >> 3;
+    if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
+    return map_status(res.status);
 }
 
 // ---- general gzip reader (host buffer) --------------------------------------------------------
@@ -797,7 +857,7 @@ static int parse_gzip_header(const uint8_t *in, uint64_t in_len, uint64_t pos, u
         const uint64_t fl = in[cur] | (in[cur + 1] << 8);
         cur += 2;
         if (cur + fl >= in_len) return ZNGAMD_E_GZ_TRUNC;
-        if (fl == ZA_MEMBER_XLEN && in[cur] == 'Z' && in[cur + 1] == 'A' && flags == 4) *za_indexed = true;
+        if (fl >= ZA_MEMBER_FIXED - 12 && in[cur] == 'Z' && in[cur + 1] == 'A' && flags == 4 && in[pos + 26] == 2) *za_indexed = true;
         cur += fl;
     }
     if (flags & 8) {
@@ -1101,7 +1161,7 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
     // fast path: the whole stream is indexed members -> two-pass scheme
     {
         uint64_t doff; bool za; uint32_t hl;
-        if (in_len >= ZA_MEMBER_HDR + 8 && parse_gzip_header(in, in_len, 0, &doff, &za, &hl) == ZNGAMD_OK && za) {
+        if (in_len >= ZA_MEMBER_FIXED + 8 && parse_gzip_header(in, in_len, 0, &doff, &za, &hl) == ZNGAMD_OK && za) {
             std::vector<ZaMember> hm; uint64_t total = 0;
             uint64_t covered = 0;
             if (scan_members_dev(c, c->st_in.p, in_len, hm, &total, partial, &covered) == ZNGAMD_OK) {
@@ -1401,20 +1461,20 @@ static int gzip_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
     std::vector<ZaUnit> hu(nb);
     for (uint32_t b = 0; b < nb; b++) {
         ZaUnit u; u.in_off = (uint64_t)b * block_size; u.in_len = (uint32_t)std::min<uint64_t>(block_size, in_len - u.in_off);
-        u.dict_len = 0; u.flags = ZA_FLAG_FINAL; u.block = b; hu[b] = u;
+        u.dict_len = 0; u.flags = ZA_FLAG_FINAL | ZA_FLAG_FLATHDR; u.block = b; hu[b] = u;
     }
     HIPCHK(c, c->st_slots.ensure((size_t)nb * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(nb)); HIPCHK(c, c->st_crc.ensure(nb));
     int r = deflate_units_dev(c, d_in, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p);
     if (r) return r;
     HIPCHK(c, c->st_off.ensure(nb));
     uint64_t total = 0;
-    r = gather_dev(c, c->st_slots.p, c->st_len.p, nb, ZA_MEMBER_HDR + 8, d_out, 0, out_cap, c->st_off.p, &total, false);
+    r = gather_dev(c, c->st_slots.p, c->st_len.p, nb, ZA_MEMBER_FIXED + 8, d_out, 0, out_cap, c->st_off.p, &total, false, c->units.p);
     if (r) return r;
     const int lv = level == -1 ? 6 : level;
     const uint8_t xfl = lv == 9 ? 2 : lv == 1 ? 4 : 0;
     { ProfScope ps(c, ZNGAMD_K_GATHER);
       hipLaunchKernelGGL(za_k_assemble_members, dim3(nb), dim3(256), 0, c->stream, c->st_slots.p, (uint32_t)ZNGAMD_SLOT_STRIDE, c->st_len.p,
-                         c->st_crc.p, c->segbits.p, c->units.p, c->st_off.p, d_out, xfl); }
+                         c->st_crc.p, c->cidx.p, c->units.p, c->st_off.p, d_out, xfl); }
     HIPCHK(c, hipGetLastError());
     std::vector<uint32_t> st(nb);
     HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, nb * 4ull, hipMemcpyDeviceToHost, c->stream));
@@ -1443,7 +1503,7 @@ int zngamd_gzip_members(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint3
     int r = stage_in(c, in, in_len);
     if (r) return r;
     const uint64_t nb = in_len == 0 ? 1 : (in_len + (block_size ? block_size : 1) - 1) / (block_size ? block_size : 1);
-    const uint64_t bound = in_len + nb * (ZA_MEMBER_HDR + 8 + 64);
+    const uint64_t bound = in_len + in_len / 32 + nb * (ZA_MEMBER_FIXED + 8 + 600);      // worst case stored + index + flat header
     HIPCHK(c, c->st_aux.ensure(bound));
     uint64_t total = 0;
     r = gzip_members_dev(c, c->st_in.p, in_len, block_size, level, c->st_aux.p, bound, &total, nullptr);
@@ -1455,6 +1515,199 @@ int zngamd_gzip_members(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint3
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU exchange over RCCL (one process per GPU).  librccl is loaded with dlopen on first use.
+// ---------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi *rccl_api(std::string *why)
+{
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (api.lib) return &api;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { if (why) *why = std::string("librccl not found: ") + dlerror(); return nullptr; }
+#define ZA_SYM(field, name) do { api.field = (decltype(api.field))dlsym(h, name); if (!api.field) { if (why) *why = std::string("librccl lacks ") + name; return nullptr; } } while (0)
+    ZA_SYM(GetUniqueId, "ncclGetUniqueId"); ZA_SYM(CommInitRank, "ncclCommInitRank"); ZA_SYM(CommDestroy, "ncclCommDestroy");
+    ZA_SYM(AllGather, "ncclAllGather"); ZA_SYM(AllReduce, "ncclAllReduce"); ZA_SYM(Send, "ncclSend"); ZA_SYM(Recv, "ncclRecv");
+    ZA_SYM(GroupStart, "ncclGroupStart"); ZA_SYM(GroupEnd, "ncclGroupEnd"); ZA_SYM(GetErrorString, "ncclGetErrorString");
+#undef ZA_SYM
+    api.lib = h;
+    return &api;
+}
+
+struct zngamd_comm {
+    zngamd_ctx *ctx = nullptr; RcclApi *api = nullptr; ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
+    uint64_t *d_rec = nullptr;           // [3 * world] gathered layout records, [3] own record behind them
+    double *d_val = nullptr;
+    std::string err;
+};
+#define NCCLCHK(cm, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    (cm)->err = std::string(#call) + ": " + (cm)->api->GetErrorString(r_); return ZNGAMD_E_HIP; } } while (0)
+#define HIPCHKM(cm, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (cm)->err = std::string(#call) + ": " + hipGetErrorString(e_); return ZNGAMD_E_HIP; } } while (0)
+
+extern "C" {
+
+int zngamd_comm_unique_id(uint8_t id[ZNGAMD_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == ZNGAMD_COMM_ID_BYTES, "unique id size");
+    if (!id) return ZNGAMD_E_ARG;
+    RcclApi *a = rccl_api(nullptr);
+    if (!a) return ZNGAMD_E_HIP;
+    ncclUniqueId u;
+    if (a->GetUniqueId(&u) != ncclSuccess) return ZNGAMD_E_HIP;
+    memcpy(id, &u, sizeof u);
+    return ZNGAMD_OK;
+}
+
+int zngamd_comm_create(zngamd_ctx *c, const uint8_t id[ZNGAMD_COMM_ID_BYTES], int rank, int world, zngamd_comm **out)
+{
+    if (!c || !id || !out || world < 1 || rank < 0 || rank >= world) return ZNGAMD_E_ARG;
+    *out = nullptr;
+    std::string why;
+    RcclApi *a = rccl_api(&why);
+    if (!a) { c->err = why; return ZNGAMD_E_HIP; }
+    zngamd_comm *m = new zngamd_comm();
+    m->ctx = c; m->api = a; m->rank = rank; m->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&m->d_rec, (size_t)(3 * world + 3) * 8) != hipSuccess || hipMalloc((void **)&m->d_val, 16) != hipSuccess) {
+        c->err = "comm: HIP resources"; zngamd_comm_destroy(m); return ZNGAMD_E_HIP;
+    }
+    const ncclResult_t r = a->CommInitRank(&m->comm, world, u, rank);
+    if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + a->GetErrorString(r); m->comm = nullptr; zngamd_comm_destroy(m); return ZNGAMD_E_HIP; }
+    *out = m;
+    return ZNGAMD_OK;
+}
+
+void zngamd_comm_destroy(zngamd_comm *m)
+{
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm) (void)m->api->CommDestroy(m->comm);
+    if (m->d_rec) (void)hipFree(m->d_rec);
+    if (m->d_val) (void)hipFree(m->d_val);
+    if (m->ev) (void)hipEventDestroy(m->ev);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+const char *zngamd_comm_last_error(zngamd_comm *m) { return m ? m->err.c_str() : "no communicator"; }
+
+int zngamd_comm_layout(zngamd_comm *m, uint64_t local_len, uint32_t local_crc, uint64_t local_ulen, uint64_t *sizes,
+                       uint64_t *my_off, uint64_t *total, uint32_t *whole_crc, uint64_t *whole_ulen)
+{
+    if (!m || !sizes || !my_off || !total) return ZNGAMD_E_ARG;
+    HIPCHKM(m, hipSetDevice(m->ctx->device));
+    const uint64_t mine[3] = {local_len, (uint64_t)local_crc, local_ulen};
+    uint64_t *d_mine = m->d_rec + 3 * (size_t)m->world;
+    HIPCHKM(m, hipMemcpyAsync(d_mine, mine, sizeof mine, hipMemcpyHostToDevice, m->stream));
+    NCCLCHK(m, m->api->AllGather(d_mine, m->d_rec, 3, ncclUint64, m->comm, m->stream));
+    std::vector<uint64_t> rec(3 * (size_t)m->world);
+    HIPCHKM(m, hipMemcpyAsync(rec.data(), m->d_rec, rec.size() * 8, hipMemcpyDeviceToHost, m->stream));
+    HIPCHKM(m, hipStreamSynchronize(m->stream));
+    uint64_t off = 0, tot = 0, ul = 0;
+    uint32_t crc = 0;
+    for (int r = 0; r < m->world; r++) {
+        sizes[r] = rec[3 * r];
+        if (r < m->rank) off += rec[3 * r];
+        tot += rec[3 * r];
+        crc = r ? zngamd_crc32_combine(crc, (uint32_t)rec[3 * r + 1], rec[3 * r + 2]) : (uint32_t)rec[1];
+        ul += rec[3 * r + 2];
+    }
+    *my_off = off; *total = tot;
+    if (whole_crc) *whole_crc = crc;
+    if (whole_ulen) *whole_ulen = ul;
+    return ZNGAMD_OK;
+}
+
+int zngamd_comm_allgather_stream(zngamd_comm *m, const void *d_local, const uint64_t *sizes, void *d_stream, uint64_t stream_cap)
+{
+    if (!m || !d_local || !sizes || !d_stream) return ZNGAMD_E_ARG;
+    HIPCHKM(m, hipSetDevice(m->ctx->device));
+    uint64_t total = 0, my_off = 0;
+    for (int r = 0; r < m->world; r++) { if (r < m->rank) my_off += sizes[r]; total += sizes[r]; }
+    if (total > stream_cap) { m->err = "stream buffer too small"; return ZNGAMD_BUF_ERROR; }
+    // the slices are final once the work queued on the context's stream so far is done
+    HIPCHKM(m, hipEventRecord(m->ev, m->ctx->stream));
+    HIPCHKM(m, hipStreamWaitEvent(m->stream, m->ev, 0));
+    uint8_t *dst = (uint8_t *)d_stream;
+    if (sizes[m->rank] && dst + my_off != (const uint8_t *)d_local)
+        HIPCHKM(m, hipMemcpyAsync(dst + my_off, d_local, sizes[m->rank], hipMemcpyDeviceToDevice, m->stream));
+    if (m->world > 1) {
+        NCCLCHK(m, m->api->GroupStart());
+        uint64_t off = 0;
+        for (int r = 0; r < m->world; r++) {
+            if (r != m->rank) {
+                if (sizes[m->rank]) NCCLCHK(m, m->api->Send(d_local, sizes[m->rank], ncclUint8, r, m->comm, m->stream));
+                if (sizes[r]) NCCLCHK(m, m->api->Recv(dst + off, sizes[r], ncclUint8, r, m->comm, m->stream));
+            }
+            off += sizes[r];
+        }
+        NCCLCHK(m, m->api->GroupEnd());
+    }
+    return ZNGAMD_OK;
+}
+
+int zngamd_comm_wait(zngamd_comm *m)
+{
+    if (!m) return ZNGAMD_E_ARG;
+    HIPCHKM(m, hipStreamSynchronize(m->stream));
+    return ZNGAMD_OK;
+}
+
+int zngamd_comm_max_f64(zngamd_comm *m, double *value)
+{
+    if (!m || !value) return ZNGAMD_E_ARG;
+    HIPCHKM(m, hipSetDevice(m->ctx->device));
+    HIPCHKM(m, hipMemcpyAsync(m->d_val, value, 8, hipMemcpyHostToDevice, m->stream));
+    NCCLCHK(m, m->api->AllReduce(m->d_val, m->d_val + 1, 1, ncclFloat64, ncclMax, m->comm, m->stream));
+    HIPCHKM(m, hipMemcpyAsync(value, m->d_val + 1, 8, hipMemcpyDeviceToHost, m->stream));
+    HIPCHKM(m, hipStreamSynchronize(m->stream));
+    return ZNGAMD_OK;
+}
+
+int zngamd_comm_barrier(zngamd_comm *m)
+{
+    double v = 0;
+    return zngamd_comm_max_f64(m, &v);
+}
+
+}  // extern "C"
+
+#ifdef ZA_IDX_STATS
+// measurement build only (profiles/idx_stats.sh): per-phase times of za_k_inflate_indexed, read and cleared
+extern "C" int zngamd_debug_idx_stats(unsigned long long *out8)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(za_idx_stat), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(za_idx_stat), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef ZA_PS_STATS
 // profiling build only (profiles/ps_stats.sh): counters of the parallel sweep, read and cleared

@@ -8,7 +8,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzng_amd.so")
+# ZNGAMD_LIB: measurement builds of the same library kept elsewhere (profiles/*.sh compile their variants to a scratch path and
+# point this at them -- the product library in the tree is never overwritten)
+LIB_PATH = os.environ.get("ZNGAMD_LIB") or os.path.join(_HERE, "libzng_amd.so")
 
 OK, STREAM_END, NEED_DICT = 0, 1, 2
 STREAM_ERROR, DATA_ERROR, MEM_ERROR, BUF_ERROR = -2, -3, -4, -5
@@ -16,6 +18,8 @@ E_GZ_MAGIC, E_GZ_METHOD, E_GZ_HCRC, E_GZ_CRC, E_GZ_LENGTH, E_GZ_TRUNC = -101, -1
 E_HIP, E_ARG, E_OVERFLOW = -201, -202, -203
 
 FLAG_FINAL = 1
+FLAG_FLATHDR = 2
+CHUNK_SHIFT = 8
 UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
@@ -28,6 +32,9 @@ SYMBOLS = [
     "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
     "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
+    "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev",
+    "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_layout",
+    "zngamd_comm_allgather_stream", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
     "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch",
 ]
@@ -102,6 +109,8 @@ def load():
         L.zngamd_gzip_scan_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint64)]
         L.zngamd_gzip_inflate_members_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp]
+        L.zngamd_gzip_inflate_plain_members_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp]
+        L.zngamd_inflate_raw_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.zngamd_gunzip.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_uint32)]
         L.zngamd_gunzip_partial.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64),
@@ -302,6 +311,8 @@ class Context:
         n = len(blocks)
         arr = (Block * max(n, 1))()
         for i, (off, ln, dl, fl) in enumerate(blocks):
+            if ln > 0xFFFFFFFF or dl > 0xFFFFFFFF:            # ctypes would cut the u32 fields silently
+                raise OverflowError("a block is limited to 4 GiB - 1 bytes: split it")
             arr[i] = Block(off, ln, dl, fl, 0)
         p, keep = _addr(buf)
         lens = (C.c_uint32 * max(n, 1))()
@@ -432,7 +443,7 @@ class Context:
         p, keep = _addr(data)
         n = memoryview(data).nbytes
         nb = max(1, (n + block_size - 1) // max(block_size, 1))
-        cap = n + nb * 400 + 64
+        cap = n + n // 16 + nb * 2800 + 64          # index: 4 bytes per 256 bytes of input; flat headers; stored worst case
         out = _Out(cap)
         ol = C.c_uint64(0)
         self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, out.addr(), cap, C.byref(ol)))

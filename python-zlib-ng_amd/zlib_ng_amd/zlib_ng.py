@@ -399,12 +399,16 @@ class _Compress:
         outs, crcs, _ = ctx.deflate_blocks(head, [(len(self._tail), first, len(self._tail), wflag)], self._level, first + first // 8 + 256)
         out.append(outs[0])
         self._crc = crc32_combine(self._crc, crcs[0], first)
-        if n > first:
-            rest = n - first
-            packed, crcs, _, _ = ctx.deflate_blocks(view, [(first, rest, 32768, wflag)], self._level,
-                                                    rest + rest // 8 + (rest // 131072 + 2) * 64, joined=True)
+        # the engine's block length is a u32: the rest goes in pieces of at most 1 GiB (whole units), each primed by the 32 KiB
+        # in front of it in the caller's buffer (the reference loops in UINT32_MAX pieces, zlib_ngmodule.c:142-147)
+        pos = first
+        while pos < n:
+            ln = min(n - pos, 1 << 30)
+            packed, crcs, _, _ = ctx.deflate_blocks(view, [(pos, ln, 32768, wflag)], self._level,
+                                                    ln + ln // 8 + (ln // 131072 + 2) * 64, joined=True)
             out.append(packed)
-            self._crc = crc32_combine(self._crc, crcs[0], rest)
+            self._crc = crc32_combine(self._crc, crcs[0], ln)
+            pos += ln
         if self._kind == "zlib":
             self._adler = ctx.adler32(view, self._adler)
         self._size += n
@@ -600,10 +604,14 @@ class _InflateCore:
             self.skip = 0
             self._trailer()
         elif code == _lib.E_OVERFLOW:
-            # output limit reached in the middle of a block: remember what was delivered, report the input
-            # beyond the stop position as unconsumed (it stays buffered here as well)
-            self.skip = len(out)
+            # output limit reached in the middle of a block: report the input beyond the stop position as unconsumed (it
+            # stays buffered here as well) and move the resume point to the header of the block the decoder stopped in,
+            # so that the next call re-decodes at most that one block's delivered part instead of the whole buffer
             left = max(0, len(self.buf) - (in_bits + 7) // 8)
+            self.window = (self.window + out[:bo])[-32768:]
+            del self.buf[:bb // 8]
+            self.start_bit = bb & 7
+            self.skip = len(out) - bo
         else:                                   # input ran out: move the resume point to the last block header
             self.window = (self.window + out[:bo])[-32768:]
             del self.buf[:bb // 8]
@@ -686,29 +694,33 @@ class _ZlibDecompressor:
     def __init__(self, wbits=MAX_WBITS, zdict=b""):
         self._core = _InflateCore(wbits, zdict)
         self._lock = _threading.Lock()
-        self._held = b""
+        self._more = False       # the last call stopped at max_length: output may be waiting behind buffered input
         self.needs_input = True
 
     @property
     def eof(self):
-        return self._core.eof and not self._held
+        return self._core.eof
 
     @property
     def unused_data(self):
         return self._core.unused
 
     def decompress(self, data, max_length=-1):
+        """max_length bounds what is DECODED, not only what is returned: input that is not needed yet stays buffered as
+        compressed bytes (zlib_ngmodule.c:1198-1308), so a small input cannot make the object hold a large output."""
         max_length = _ssize(max_length)
         with self._lock:
-            if self._core.eof and not self._held:
+            if self._core.eof:
                 raise EOFError("End of stream already reached")
-            out, _ = self._core.feed(bytes(_view(data)), None)
-            out = self._held + out
-            if 0 <= max_length < len(out):
-                out, self._held = out[:max_length], out[max_length:]
-            else:
-                self._held = b""
-            self.needs_input = not self._held and not self._core.eof
+            data = bytes(_view(data))
+            if max_length == 0:
+                self._core.buf += data
+                self._more = True
+                self.needs_input = False
+                return b""
+            out, _ = self._core.feed(data, max_length if max_length > 0 else None)
+            self._more = max_length > 0 and len(out) >= max_length and not self._core.eof
+            self.needs_input = not self._more and not self._core.eof
             return out
 
 

@@ -53,6 +53,10 @@ def _stage_compare(ctx, O, data, zdict, level, flags):
             sb = np.frombuffer(ctx.debug_fetch(6, 0, 4 * 65), np.uint32)
             assert np.array_equal(sb[:nseg], dbg["seg_bits"][:nseg]), "stage5 segment bit offsets differ"
             assert sb[64] == dbg["seg_bits"][nseg]
+            nchunk = (n + 255) // 256
+            ci = np.frombuffer(ctx.debug_fetch(8, 0, 4 * (nchunk + 1)), np.uint32)
+            assert np.array_equal(ci, dbg["chunk_idx"][:nchunk + 1]), \
+                f"stage5 chunk index differs at {np.flatnonzero(ci != dbg['chunk_idx'][:nchunk + 1])[:5]}"
     assert crcs[0] == exp_crc == zlib.crc32(data)
     assert not ovf and got[0] == exp, "final bytes differ"
     return got[0]
@@ -67,6 +71,20 @@ def test_stagewise_parity(ctx, fastq, level):
         c = _stage_compare(ctx, O, data, b"", level, 0)
         d = zlib.decompressobj(-15)
         assert d.decompress(c) == data, name
+
+
+def test_flat_header_form(ctx, fastq):
+    """Units of indexed members carry the dynamic header in its flat form (flag 2): same stages, any inflater reads it."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    for name, data in _inputs(fastq).items():
+        for flags in (2, 3):
+            c = _stage_compare(ctx, O, data, b"", 6, flags)
+            d = zlib.decompressobj(-15)
+            assert d.decompress(c) == data and d.eof == bool(flags & 1), name
+    blk0, blk1 = fastq[:131072], fastq[131072:262144]
+    c = _stage_compare(ctx, O, blk1, blk0[-32768:], 1, 2)
+    assert zlib.decompressobj(-15, zdict=blk0[-32768:]).decompress(c) == blk1
 
 
 def test_dictionary_and_final(ctx, fastq):
