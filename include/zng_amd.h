@@ -187,6 +187,9 @@ int zngamd_gzip_inflate_plain_members_dev(zngamd_ctx *ctx, const void *d_in, uin
 int zngamd_inflate_raw_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, void *d_out, uint64_t out_cap,
                            uint64_t *out_len, uint64_t *in_used);
 
+/* Number of differing 4-byte words (bytes in the tail) of two device buffers: the round-trip check of device-resident callers. */
+int zngamd_compare_dev(zngamd_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, uint64_t *mismatches);
+
 /* Host-buffer gzip reader: any multi-member gzip stream (headers with FEXTRA/FNAME/FCOMMENT/FHCRC,
  * NUL padding between members).  Four decode paths, picked per stream / member:
  *   1. this engine's indexed members          -> two-pass, lane-parallel inside each member

@@ -52,9 +52,9 @@ extern "C" {
 #define ZA_FLAG_FLATHDR 2       /* dynamic header in its flat form: the code-length code is the fixed 4-bit code of
                                    the symbols 0..15 (no run-length symbols), so every code length sits at a known bit
                                    offset and a decoder can read the header in parallel (indexed gzip members)        */
-#define ZA_LIMIT_L    11        /* longest literal/length code: a 2^11-entry table decodes every symbol in one step */
+#define ZA_LIMIT_L    10        /* longest literal/length code: a 2^11-entry table decodes every symbol in one step */
 #define ZA_LIMIT_D    9         /* longest distance code                                                            */
-#define ZA_CHUNK_SHIFT 8        /* index granularity of indexed members: one entry per 256 bytes of output           */
+#define ZA_CHUNK_SHIFT 11       /* index granularity of indexed members: one entry per 2 KiB segment */
 #define ZA_MAX_CHUNKS (ZA_MAX_UNIT >> ZA_CHUNK_SHIFT)
 
 /* return codes, zlib numbering (zlib_ngmodule.c:68-95 maps them to messages) */

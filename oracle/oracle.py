@@ -19,7 +19,7 @@ MAX_SEGS = 64
 WIN = 32768
 FLAG_FINAL = 1
 FLAG_FLATHDR = 2
-CHUNK_SHIFT = 8
+CHUNK_SHIFT = 11
 MAX_CHUNKS = MAX_UNIT >> CHUNK_SHIFT
 
 OK, STREAM_END, NEED_DICT = 0, 1, 2

@@ -1,4 +1,5 @@
-"""Per-phase time of za_k_inflate_indexed (measurement build with -DZA_IDX_STATS, see idx_stats.sh): 1 GiB of level-6 members."""
+"""Kernel time of the two-pass member inflate on MIB (default 1024) MiB of level-6 members; with ZNGAMD_LIB pointing at an
+ablation build (profiles/abl_inflate.sh) the output check is only reported, not required."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
@@ -16,17 +17,13 @@ mtab = torch.empty(nb * C.sizeof(_lib.Member), dtype=torch.uint8, device="cuda")
 mstat = torch.empty(nb, dtype=torch.int32, device="cuda")
 out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 nm, tot = C.c_uint32(0), C.c_uint64(0)
-st = (C.c_ulonglong * 8)()
-for it in range(3):
+best = None
+for it in range(4):
     ctx.profiling(True); ctx.kernel_times(True)
-    if hasattr(L, "zngamd_debug_idx_stats"):
-        L.zngamd_debug_idx_stats(st)
     assert L.zngamd_gzip_scan_dev(h, p(ms), ml.value, p(mtab), nb, C.byref(nm), C.byref(tot)) == 0
     r = L.zngamd_gzip_inflate_members_dev(h, p(ms), ml.value, p(mtab), nm.value, p(out), n, p(mstat))
     kt = ctx.kernel_times(True)
+    best = kt["inflate"][0] if best is None else min(best, kt["inflate"][0])
 ok = bool((out[:n] == d[:n]).all().item()) and int((mstat != 0).sum().item()) == 0
-print("rc", r, "output ok", ok, {k: round(v[0], 3) for k, v in kt.items() if v[1]}, "member stream bytes", ml.value)
-if hasattr(L, "zngamd_debug_idx_stats"):
-    L.zngamd_debug_idx_stats(st)
-    names = ["setup+tables", "phase A decode", "phase B matches", "phase C crc+store", "whole"]
-    print("per member, microseconds:", {k: round(st[i] / 100.0 / nb, 2) for i, k in enumerate(names)})
+print("%-40s rc %d output ok %-5s inflate %.3f ms scan %.3f ms (member stream %d bytes)" %
+      (os.environ.get("ABL", "product build"), r, ok, best, kt["scan"][0], ml.value))

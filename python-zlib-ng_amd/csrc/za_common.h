@@ -20,9 +20,9 @@
 
 #define ZA_FLAG_FINAL 1u
 #define ZA_FLAG_FLATHDR 2u      // dynamic header in its flat form (4-bit code lengths at fixed offsets): indexed members
-#define ZA_LIMIT_L     11       // longest literal/length code the encoder emits: one 2^11-entry table decodes every symbol
+#define ZA_LIMIT_L     10       // longest literal/length code the encoder emits: one 2^10-entry table decodes every symbol
 #define ZA_LIMIT_D     9        // longest distance code
-#define ZA_CHUNK_SHIFT 8        // index granularity of indexed members: one entry per 256 bytes of output
+#define ZA_CHUNK_SHIFT 11       // index granularity of indexed members: one entry per 2 KiB segment
 #define ZA_MAX_CHUNKS  (ZA_MAX_UNIT >> ZA_CHUNK_SHIFT)
 
 // per-unit workspace strides (elements)

@@ -10,7 +10,10 @@
 //                         sequential rounds (32 KiB history ring in LDS, copies done by all 64 lanes)
 //   za_k_scan_members     pass 1 of the two-pass scheme: coalesced sweep of the compressed stream
 //                         for this engine's indexed gzip members ('Z','A' FEXTRA subfield)
-//   za_k_inflate_indexed  pass 2 (za_inflate_idx.hip): one 512-thread workgroup per member, output built in LDS
+//   za_k_inflate_members  pass 2: one wavefront per member, one lane per 2 KiB segment decodes its
+//                         tokens from the indexed bit offset (literals stored directly, matches
+//                         queued), then the wave resolves the queued matches in output order,
+//                         64 at a time, byte-parallel; CRC-32 / ISIZE verified in the same kernel
 //   za_k_assemble_members writes header + index + deflate bytes + trailer of each member
 #include "za_common.h"
 #include "za_crc.h"
@@ -976,6 +979,381 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
         const uint32_t idx = atomicAdd(n_cands, 1u);
         if (idx < max_cands) { ZaCand c; c.off = o; c.size = size; c.isize = isize; cands[idx] = c; }
     }
+}
+
+#define ZA_MATCHQ_PER_SEG 688      // queue entries per segment: >= 2048/4 matches + skip entries, a multiple of 4
+#define ZA_IROW 17                 // dwords per lane row of staged input: 4 x 16 bytes + 1 (odd stride); 48 bytes are consumed per row
+#define ZA_IROW_BYTES 48
+#define ZA_ML_BITS 10              // literal/length table: every code of an indexed member is at most 10 bits long (ZA_LIMIT_L)
+#define ZA_MD_BITS 9               // distance table (ZA_LIMIT_D)
+
+// Tables of the member decoder.  One table read decodes any symbol (the encoder limits the code lengths, and a member with
+// longer codes is left to the sequential decoder); the entries carry what the token needs:
+//   lut_l  bit 15 = 0: literal, bits 4..11 the byte;  bit 15 = 1: length, bits 4..11 = base - 3, bits 12..14 = extra bits
+//          (7 = end of block);  bits 0..3 = code length, 0 = invalid code
+//   lut_d  bits 8..23 = base, bits 4..7 = extra bits, bits 0..3 = code length, 0 = invalid code
+struct ZaMemTabs {
+    uint16_t lut_l[1 << ZA_ML_BITS];
+    uint32_t lut_d[1 << ZA_MD_BITS];
+};
+struct ZaMemBuild {                 // only while the tables are built: lives in the row area
+    uint16_t tmp_d[1 << ZA_MD_BITS];
+    uint16_t cnt_l[16], cnt_d[16];
+    uint16_t sym_l[288], sym_d[32];
+    uint8_t lens[320];
+};
+
+__global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__restrict__ in, uint64_t in_total,
+                                                              const ZaMember *__restrict__ members,
+                                                              uint8_t *__restrict__ out, uint64_t out_cap,
+                                                              uint32_t *__restrict__ matchq,       // [grid][64][ZA_MATCHQ_PER_SEG]
+                                                           const uint32_t *__restrict__ crc_table,
+                                                           const uint32_t *__restrict__ x8k_table,
+                                                           int32_t *__restrict__ status_out)
+{
+    __shared__ ZaMemTabs T;
+    __shared__ int scratch[2];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[64 * ZA_IROW];      // table build: ZaMemBuild; phase A: staged input; then the CRC table
+    static_assert(sizeof(ZaMemBuild) <= sizeof(uint32_t) * 64 * ZA_IROW, "build area");
+    ZaMemBuild &B = *(ZaMemBuild *)rows;
+    const int lane = za_lane();
+    const ZaMember m = members[blockIdx.x];
+    const uint8_t *src = in + m.in_off;
+    const uint64_t in_bits = m.in_len * 8ull;
+    uint8_t *dst = out + m.out_off;
+    const int n = (int)m.out_len;
+    const int nseg = (int)m.nseg;
+    if (m.in_off + m.in_len + 8 > in_total || m.out_off + m.out_len > out_cap || n > ZA_MAX_UNIT || m.in_len > (1u << 20) ||
+        nseg != ((n + ZA_SEG - 1) >> ZA_SEG_SHIFT) || m.index_off != 4u * ((uint32_t)nseg + 1u) || m.index_off > m.in_off || n == 0) {
+        if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX;
+        return;
+    }
+    const uint32_t *index = (const uint32_t *)(src - m.index_off);      // member starts are byte aligned only: unaligned loads
+    // index entries: bit offset | overshoot << 23; at this granularity (one entry per 2 KiB segment, where the codec forces a
+    // token boundary) the overshoot is zero
+    const uint32_t my_start = za_ld32((const uint8_t *)(index + (lane < nseg ? lane : nseg)));
+    const uint32_t my_stop = za_ld32((const uint8_t *)(index + (lane < nseg ? lane + 1 : nseg)));
+    if (__ballot((my_start >> 23) != 0u || (my_stop >> 23) != 0u) != 0ull || in_bits < 3) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+    // ---- block header (uniform).  Members written by this engine are one final block, fixed or dynamic with the header in its
+    // flat form: HCLEN = 19, the code-length code is the fixed 4-bit code of the symbols 0..15, so code length k sits in the
+    // 4 bits at 74 + 4 k (bit-reversed) and all lanes read the header at once.  Anything else: sequential decoder.
+    const uint64_t bits = za_peek(src, 0);
+    const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
+    uint32_t nlen = 288, ndist = 30, hdr_end = 3;
+    bool hdr_ok = last && (type == 1 || type == 2);
+    if (hdr_ok && type == 2) {
+        nlen = (uint32_t)((bits >> 3) & 31u) + 257u; ndist = (uint32_t)((bits >> 8) & 31u) + 1u;
+        uint64_t want = 0;
+        for (int i = 3; i < 19; i++) want |= 4ull << (3 * i);
+        hdr_end = 74u + 4u * (nlen + ndist);
+        hdr_ok = in_bits >= 74 && ((bits >> 13) & 15u) == 15u && (za_peek(src, 17) & ((1ull << 57) - 1ull)) == want && nlen <= 286 && ndist <= 30 &&
+                 hdr_end <= in_bits;
+    }
+    if (!hdr_ok || __shfl(my_start, 0, 64) != hdr_end) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+    {
+        bool toolong = false;
+        for (int i = lane; i < 320; i += 64) {
+            uint32_t v = 0;
+            if (type == 1) v = i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : i < 288 ? 8u : i < 318 ? 5u : 0u;
+            else {
+                const bool isl = (uint32_t)i < nlen, isd = i >= 288 && (uint32_t)(i - 288) < ndist;
+                if (isl || isd) {
+                    const uint32_t k = isl ? (uint32_t)i : nlen + (uint32_t)(i - 288);
+                    const uint32_t f = (uint32_t)(za_peek(src, 74u + 4u * k) & 15u);
+                    v = ((f & 1u) << 3) | ((f & 2u) << 1) | ((f & 4u) >> 1) | ((f & 8u) >> 3);
+                }
+            }
+            toolong = toolong || v > (i < 288 ? (uint32_t)ZA_ML_BITS : (uint32_t)ZA_MD_BITS);
+            B.lens[i] = (uint8_t)v;
+        }
+        if (__ballot(toolong) != 0ull) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+        __syncthreads();
+        // plain tables ((symbol << 4) | length) first -- the distance one in the row area -- then the entries are rewritten
+        uint16_t *tmp_d = B.tmp_d;
+        int ok = B.lens[256] != 0;
+        int st = za_build_table(B.lens, (int)nlen, B.cnt_l, B.sym_l, T.lut_l, ZA_ML_BITS, &scratch[0], &scratch[1]);
+        if (st < 0 || (st > 0 && scratch[1] != 1)) ok = 0;
+        st = za_build_table(B.lens + 288, (int)(type == 1 ? 32u : ndist), B.cnt_d, B.sym_d, tmp_d, ZA_MD_BITS, &scratch[0], &scratch[1]);
+        if (st < 0 || (st > 0 && scratch[1] != 1 && type != 1)) ok = 0;       // (the fixed block's 30 five-bit distance codes are incomplete by design)
+        if (!ok) { if (lane == 0) status_out[blockIdx.x] = ZA_I_INDEX; return; }
+        for (int e = lane; e < (1 << ZA_ML_BITS); e += 64) {
+            const uint32_t v = T.lut_l[e], s = v >> 4, l = v & 15u;
+            uint32_t r = 0;
+            if (l) {
+                if (s < 256) r = (s << 4) | l;
+                else if (s == 256) r = 0xF000u | l;
+                else if (s < 286) { int nx; const int base = za_len_base((int)s - 257, nx); r = 0x8000u | ((uint32_t)nx << 12) | ((uint32_t)(base - 3) << 4) | l; }
+            }
+            T.lut_l[e] = (uint16_t)r;
+        }
+        for (int e = lane; e < (1 << ZA_MD_BITS); e += 64) {
+            const uint32_t v = tmp_d[e], s = v >> 4, l = v & 15u;
+            uint32_t r = 0;
+            if (l && s < 30) { int nx; const int base = za_dist_base((int)s, nx); r = ((uint32_t)base << 8) | ((uint32_t)nx << 4) | l; }
+            T.lut_d[e] = r;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase A: every lane decodes its own segment.
+    // A dependent 8-byte global load per token would cost microseconds, so each lane's compressed bytes are staged through an
+    // LDS row: row r holds the 64 bytes at the lane's (16-byte aligned) origin + 48 r; a lane decodes while its read position is
+    // inside the first 48 bytes of the row, and the next row (four aligned 16-byte loads) is already in flight in registers.
+    uint32_t *myq = matchq + ((size_t)blockIdx.x * 64 + (size_t)lane) * ZA_MATCHQ_PER_SEG;
+    uint32_t nmatch = 0;       // queue entries of my segment
+    int lane_err = 0;          // 0 ok, 1 index mismatch, 2 data error
+    {
+        uint32_t *myrow = rows + lane * ZA_IROW;
+        const bool act = lane < nseg;
+        int pos = lane << ZA_SEG_SHIFT;
+        int end = pos + ZA_SEG; if (end > n) end = n;
+        uint32_t bp = my_start;
+        if (act && (my_stop > in_bits || my_stop < my_start)) lane_err = 1;
+        // my stream starts in the byte at src + (my_start >> 3); rows start at the 16-byte aligned address below it
+        const uint8_t *a0 = src + (my_start >> 3);
+        const uint8_t *org = (const uint8_t *)((uintptr_t)a0 & ~(uintptr_t)15);
+        const uint32_t org_bit = my_start - ((uint32_t)(a0 - org) * 8u + (my_start & 7u));      // bit offset (from src bit 0) of the origin; may be "negative" (wraps): only differences are used
+        const uint8_t *lim = in + in_total;
+        bool done = !act || lane_err != 0 || pos >= end;
+        // Output of this lane is collected in a 16-byte block and stored once per block: literal bytes land in it, match bytes
+        // are left zero -- phase B overwrites them later, and no other lane owns bytes of this block (segment starts are
+        // multiples of 16 inside the member).  Inside the loop only whole blocks are stored; the block that is open when the
+        // segment ends is stored behind the loop (bytewise where it holds the member's last bytes).
+        uint64_t blk_lo = 0, blk_hi = 0;
+        bool blk_dirty = false;                                 // a literal was put into the block
+        int blk_base = pos;                                     // multiple of 16
+        // queue entries: distance - 1 | (length - 3) << 15 | (literals since the previous match) << 23; runs of 511 literals and
+        // more go into an entry of their own (length field 0 -- a real match of an indexed member is at least 4 long).
+        // Entries leave four at a time as one 16-byte store.
+        uint32_t qb0 = 0, qb1 = 0, qb2 = 0;
+        int prev_end = pos;
+        auto push = [&](uint32_t ent) {
+            const uint32_t k = nmatch & 3u;
+#ifndef ZA_ABL_NO_ASTORE
+            if (k == 3u) *(uint4 *)(myq + (nmatch & ~3u)) = make_uint4(qb0, qb1, qb2, ent);
+#endif
+            qb0 = k == 0u ? ent : qb0; qb1 = k == 1u ? ent : qb1; qb2 = k == 2u ? ent : qb2;
+            nmatch++;
+        };
+        uint4 pre[4];
+        auto prefetch = [&](uint32_t r) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint8_t *p = org + (size_t)ZA_IROW_BYTES * r + 16u * (unsigned)j;
+                pre[j] = make_uint4(0, 0, 0, 0);
+                if (!done && p >= in && p + 16 <= lim) pre[j] = *(const uint4 *)p;
+            }
+            if (!done && (org + (size_t)ZA_IROW_BYTES * r < in || org + (size_t)ZA_IROW_BYTES * r + 64 > lim)) {
+                // a row that reaches over an end of the caller's buffer (first / last member only): byte by byte
+                uint32_t t[16];
+#pragma unroll 1
+                for (int k = 0; k < 16; k++) {
+                    uint32_t v = 0;
+                    for (int q = 0; q < 4; q++) { const uint8_t *p = org + (size_t)ZA_IROW_BYTES * r + 4u * (unsigned)k + (unsigned)q; if (p >= in && p < lim) v |= (uint32_t)*p << (8 * q); }
+                    t[k] = v;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) pre[j] = make_uint4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+            }
+        };
+        prefetch(0);
+#pragma unroll 1
+        for (uint32_t r = 0;; r++) {
+            if (__ballot(!done) == 0ull) break;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; j++) { myrow[4 * j] = pre[j].x; myrow[4 * j + 1] = pre[j].y; myrow[4 * j + 2] = pre[j].z; myrow[4 * j + 3] = pre[j].w; }
+            __builtin_amdgcn_wave_barrier();
+            prefetch(r + 1);
+            const uint32_t row_bit0 = org_bit + (uint32_t)ZA_IROW_BYTES * 8u * r;
+            // one token per lane and round, on one path: no break / continue inside (the compiler otherwise copies the whole lane
+            // state at every edge)
+#pragma unroll 1
+            for (;;) {
+                const uint32_t rel = bp - row_bit0;                 // < 384 while inside the row's first 48 bytes
+                const bool go = !done && rel < (uint32_t)ZA_IROW_BYTES * 8u;
+                if (__ballot(go) == 0ull) break;
+                if (go) {
+                    const uint32_t w = rel >> 5, sh = rel & 31u;
+                    // 64 bits starting at bit `rel` of the row (3 dwords; a token takes at most 10 + 5 + 9 + 13 = 37)
+                    const uint32_t d0 = myrow[w], d1 = myrow[w + 1], d2 = myrow[w + 2];
+                    const uint64_t lo = ((uint64_t)d1 << 32) | d0;
+                    const uint64_t b = sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
+                    const uint32_t e = T.lut_l[(uint32_t)b & ((1u << ZA_ML_BITS) - 1u)];
+                    const uint32_t l = e & 15u;
+                    int adv = 1;
+                    uint32_t used = l;
+                    int err = (e == 0u) ? 2 : (bp > in_bits ? 1 : 0);
+                    if (!(e & 0x8000u)) {
+                        const int o = pos - blk_base;
+                        const uint64_t by = (uint64_t)((e >> 4) & 0xFFu);
+                        if (o < 8) blk_lo |= by << (8 * o); else blk_hi |= by << (8 * (o - 8));
+                        blk_dirty = true;
+                    } else {
+                        // match: every validity test of the token is collected and branched on once
+                        const uint32_t nxb = (e >> 12) & 7u;
+                        const int len = (int)(((e >> 4) & 0xFFu) + 3u + ((uint32_t)(b >> l) & ((1u << nxb) - 1u)));
+                        used = l + nxb;
+                        const uint32_t d = T.lut_d[(uint32_t)(b >> used) & ((1u << ZA_MD_BITS) - 1u)];
+                        const uint32_t dl = d & 15u, dnx = (d >> 4) & 15u;
+                        const int dist = (int)((d >> 8) + ((uint32_t)(b >> (used + dl)) & ((1u << dnx) - 1u)));
+                        used += dl + dnx;
+                        const bool bad_data = d == 0u || dist > pos;
+                        // end of block inside a segment, a length this queue cannot hold, a match across the segment end, queue full
+                        const bool bad_index = nxb == 7u || len < 4 || pos + len > end || nmatch + 2u > ZA_MATCHQ_PER_SEG;
+                        if (bad_data || bad_index) err = (nxb == 7u || !bad_data) ? 1 : 2;
+                        else {
+                            uint32_t gap = (uint32_t)(pos - prev_end);
+                            if (gap >= 511u) { push(gap); gap = 0; }
+                            push((uint32_t)(dist - 1) | ((uint32_t)(len - 3) << 15) | (gap << 23));
+                            adv = len;
+                        }
+                    }
+                    if (err) { lane_err = err; done = true; adv = 0; used = 0; }
+                    pos += adv; bp += used;
+                    if (!(e & 0x8000u)) { } else prev_end = pos;
+                    if (pos - blk_base >= 16) {
+                        // a whole block lies behind me: it goes out if a literal was put into it
+#ifndef ZA_ABL_NO_ASTORE
+                        if (blk_dirty) { ZaU4u v; v.x = (uint32_t)blk_lo; v.y = (uint32_t)(blk_lo >> 32); v.z = (uint32_t)blk_hi; v.w = (uint32_t)(blk_hi >> 32); *(ZaU4u *)(dst + blk_base) = v; }
+#endif
+                        blk_lo = 0; blk_hi = 0; blk_dirty = false;
+                        blk_base = pos & ~15;
+                    }
+                    if (pos >= end) done = true;
+                }
+            }
+        }
+        if (act && blk_dirty && !lane_err) {                    // the block that was open when the segment ended
+            if (blk_base + 16 <= n) { ZaU4u v; v.x = (uint32_t)blk_lo; v.y = (uint32_t)(blk_lo >> 32); v.z = (uint32_t)blk_hi; v.w = (uint32_t)(blk_hi >> 32); *(ZaU4u *)(dst + blk_base) = v; }
+            else for (int k = blk_base; k < n; k++) { const int o = k - blk_base; dst[k] = (uint8_t)(o < 8 ? blk_lo >> (8 * o) : blk_hi >> (8 * (o - 8))); }
+        }
+#ifndef ZA_ABL_NO_ASTORE
+        {   // the last, partial group of queue entries
+            const uint32_t k = nmatch & 3u, b4 = nmatch & ~3u;
+            if (k > 0) myq[b4] = qb0;
+            if (k > 1) myq[b4 + 1] = qb1;
+            if (k > 2) myq[b4 + 2] = qb2;
+        }
+#endif
+        if (act && !lane_err && bp != my_stop) lane_err = 1;
+        if (act && !lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
+            const uint32_t e = T.lut_l[(uint32_t)za_peek(src, bp) & ((1u << ZA_ML_BITS) - 1u)];         // bp == my_stop <= in_bits
+            if ((e & 0xF000u) != 0xF000u) lane_err = 1;
+            else if (((bp + (e & 15u) + 7u) >> 3) != (uint32_t)m.in_len) lane_err = 1;
+        }
+    }
+    const unsigned long long e1 = __ballot(lane_err == 1), e2 = __ballot(lane_err == 2);
+    if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
+    __threadfence_block();       // literals and the match queues are visible to the whole wave
+    // the CRC table takes the place of the input rows
+    uint32_t *crct = rows;
+    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
+
+    // ---- phase B: resolve matches in output order, 64 at a time.  A match is ready when its source lies
+    // below the first unresolved match of the group (the lowest pending one always is).  Each ready lane
+    // copies its own match: 16 bytes per batch as four unaligned dword loads followed by the stores (the
+    // loads of a batch are independent, so they overlap); a self-overlapping match (dist < len) reads its
+    // period byte-wise, which lies entirely below its destination.
+    const uint64_t out_room = out_cap - m.out_off;     // bytes of dst that may be touched
+#ifndef ZA_ABL_NO_B
+    for (int s = 0; s < nseg; s++) {
+        const uint32_t cnt = __shfl(nmatch, s, 64);
+        const uint32_t *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
+        uint32_t segpos = (uint32_t)s << ZA_SEG_SHIFT;             // output position behind the entries handled so far
+        for (uint32_t g = 0; g < cnt; g += 64) {
+            const bool hasq = g + (uint32_t)lane < cnt;
+            const uint32_t ent = hasq ? q[g + lane] : 0u;
+            const uint32_t l3 = (ent >> 15) & 0xFFu;
+            const bool has = hasq && l3 != 0u;                      // a real match (length field 0: a run of literals)
+            const uint32_t mlen = has ? l3 + 3u : 0u, mdist = (ent & 0x7FFFu) + 1u;
+            const uint32_t adv = !hasq ? 0u : has ? (ent >> 23) + mlen : ent;      // literals in front of the match + the match
+            const uint32_t incl = za_wave_incl_scan(adv);
+            const uint32_t mdst = segpos + incl - mlen;
+            segpos += (uint32_t)__shfl((int)incl, 63, 64);
+            bool done = !has;
+            unsigned long long pending = __ballot(!done);
+            // Which matches of this group write bytes that mine reads?  Destinations are disjoint and ascending with
+            // the lane, so they are the lanes [jlo, jhi): jhi = matches that start below the end of my source,
+            // jlo = matches that end at or below its start (two 6-step binary searches with shuffles; both counts
+            // are at most my own lane).  A match is ready as soon as none of those is pending -- the lowest
+            // pending one always is.  (Lanes without a match sit at their position with length 0: they order correctly.)
+            const uint32_t sdst = hasq ? mdst : 0xFFFFFFFFu, send = hasq ? mdst + mlen : 0xFFFFFFFFu;
+            const uint32_t src_a = mdst - mdist, src_b = src_a + (mlen < mdist ? mlen : mdist);
+            uint32_t jhi = 0, jlo = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t vd = (uint32_t)__shfl((int)sdst, (int)(jhi + step - 1u), 64);
+                const uint32_t ve = (uint32_t)__shfl((int)send, (int)(jlo + step - 1u), 64);
+                if (vd < src_b) jhi += step;
+                if (ve <= src_a) jlo += step;
+            }
+            const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+            // short non-overlapping matches (nearly all) are copied by their own lane, at most two 16-byte batches;
+            // long or self-overlapping ones would keep the other 63 lanes waiting, so the whole wave copies those
+            const bool simple = mdist >= mlen && mlen <= 32u && (uint64_t)mdst + 32u <= out_room;
+            while (pending) {
+                const bool ready = !done && (pending & deps) == 0ull;
+                if (ready && simple) {
+                    // one or two unaligned 16-byte loads (what they read past the source's end is not used), then the bytes leave
+                    // as 16 / 8 / 4 / 2 / 1-byte stores: one load and about two stores for the typical match of 10 bytes
+                    uint8_t *o = dst + mdst;
+                    const uint8_t *sp = o - mdist;
+                    ZaU4u v = *(const ZaU4u *)sp;
+                    uint32_t rem = mlen;
+                    if (mlen > 16u) {
+                        const ZaU4u v2 = *(const ZaU4u *)(sp + 16);
+                        *(ZaU4u *)o = v;
+                        o += 16; v = v2; rem = mlen - 16u;
+                    }
+                    if (rem == 16u) *(ZaU4u *)o = v;
+                    else {
+                        if (rem & 8u) { *(za_u64u *)o = ((uint64_t)v.y << 32) | v.x; o += 8; v.x = v.z; v.y = v.w; }
+                        if (rem & 4u) { *(za_u32u *)o = v.x; o += 4; v.x = v.y; }
+                        if (rem & 2u) { *(za_u16u *)o = (uint16_t)v.x; o += 2; v.x >>= 16; }
+                        if (rem & 1u) *o = (uint8_t)v.x;
+                    }
+                }
+                unsigned long long coop = __ballot(ready && !simple);
+                while (coop) {
+                    const int j = __builtin_ctzll(coop);
+                    coop &= coop - 1ull;
+                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
+                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
+                    const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
+                    uint8_t *o = dst + cd;
+                    const uint8_t *sp = o - cdist;
+                    const float rd = 1.0f / (float)cdist;
+                    for (uint32_t base = 0; base < cl; base += 64) {
+                        const uint32_t i = base + (uint32_t)lane;
+                        if (i < cl) {
+                            // byte i of a self-overlapping match is byte (i mod dist) of its period, which lies below it
+                            int k = (int)i;
+                            if (cdist < cl) {
+                                k = (int)i - (int)cdist * (int)((float)i * rd);
+                                if (k < 0) k += (int)cdist;
+                                if (k >= (int)cdist) k -= (int)cdist;
+                            }
+                            o[i] = sp[k];
+                        }
+                    }
+                }
+                __threadfence_block();
+                done = done || ready;
+                pending = __ballot(!done);
+            }
+        }
+    }
+#endif
+    // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
+#ifdef ZA_ABL_NO_CRC
+    const uint32_t c = za_ld32(src + m.in_len);
+#else
+    __syncthreads();
+    const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
+#endif
+    const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
+    if (lane == 0) status_out[blockIdx.x] = (c != want_crc) ? ZA_I_CRC : (want_len != (uint32_t)n) ? ZA_I_LENGTH : ZA_I_OK;
 }
 
 // Members whose extent is known up front without this engine's index (BGZF: 'B','C' subfield with the

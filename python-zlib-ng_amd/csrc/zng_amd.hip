@@ -6,7 +6,6 @@
 // kernels and assembles container framing bytes (gzip / zlib headers and trailers).
 #include "za_deflate.hip"
 #include "za_inflate.hip"
-#include "za_inflate_idx.hip"
 #include "za_checksum.hip"
 #include "../../include/zng_amd.h"
 
@@ -62,7 +61,7 @@ struct zngamd_ctx {
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
     DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
-    DevBuf<ZaCkPart> ck; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
+    DevBuf<ZaCkPart> ck; DevBuf<uint32_t> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
     uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
@@ -166,7 +165,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->plan.release(); c->units.release(); c->segbits.release(); c->cidx.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
-    c->st_off.release(); c->ck.release(); c->cands.release(); c->members.release(); c->mstatus.release();
+    c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
@@ -780,10 +779,13 @@ int zngamd_gzip_scan_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, zngam
 static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const ZaMember *d_members, uint32_t n,
                                uint8_t *d_out, uint64_t out_cap, int32_t *d_status)
 {
-    if (n) {          // one workgroup per member; no workspace: a member's output is built in LDS
+    const uint32_t ch = std::min<uint32_t>(n, 32768);          // members per launch: 176 KiB of match queue each (5.8 GB)
+    HIPCHK(c, c->matchq.ensure((size_t)ch * 64 * ZA_MATCHQ_PER_SEG));
+    for (uint32_t c0 = 0; c0 < n; c0 += ch) {
+        const uint32_t m = std::min(ch, n - c0);
         ProfScope ps(c, ZNGAMD_K_INFLATE);
-        hipLaunchKernelGGL(za_k_inflate_indexed, dim3(n), dim3(ZA_IDX_THREADS), 0, c->stream, d_in, in_len, d_members, d_out, out_cap,
-                           c->d_crc_slice4, c->d_x256, c->d_x8, d_status);
+        hipLaunchKernelGGL(za_k_inflate_members, dim3(m), dim3(64), 0, c->stream, d_in, in_len, d_members + c0, d_out, out_cap,
+                           c->matchq.p, c->d_crc_table, c->d_x8k, d_status + c0);
     }
     HIPCHK(c, hipGetLastError());
     return ZNGAMD_OK;
@@ -838,6 +840,26 @@ int zngamd_inflate_raw_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, voi
     if (in_used) *in_used = (res.in_bits + 7) >> 3;
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
+}
+
+int zngamd_compare_dev(zngamd_ctx *c, const void *d_a, const void *d_b, uint64_t n, uint64_t *mismatches)
+{
+    if (!c || (!d_a && n) || (!d_b && n) || !mismatches) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long *d_bad = (unsigned long long *)((uint8_t *)c->d_small + 192);
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, 8, c->stream));
+    if (n) {
+        const uint64_t threads = (n + 15) / 16;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((threads + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(za_k_compare, dim3(blocks), dim3(256), 0, c->stream, (const uint8_t *)d_a, (const uint8_t *)d_b, n, d_bad);
+    }
+    HIPCHK(c, hipGetLastError());
+    unsigned long long bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mismatches = bad;
+    return ZNGAMD_OK;
 }
 
 // ---- general gzip reader (host buffer) --------------------------------------------------------
@@ -1698,16 +1720,6 @@ int zngamd_comm_barrier(zngamd_comm *m)
 }
 
 }  // extern "C"
-
-#ifdef ZA_IDX_STATS
-// measurement build only (profiles/idx_stats.sh): per-phase times of za_k_inflate_indexed, read and cleared
-extern "C" int zngamd_debug_idx_stats(unsigned long long *out8)
-{
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(za_idx_stat), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    unsigned long long z[8] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(za_idx_stat), z, sizeof z) == hipSuccess ? 0 : -1;
-}
-#endif
 
 #ifdef ZA_PS_STATS
 // profiling build only (profiles/ps_stats.sh): counters of the parallel sweep, read and cleared

@@ -19,7 +19,7 @@ E_HIP, E_ARG, E_OVERFLOW = -201, -202, -203
 
 FLAG_FINAL = 1
 FLAG_FLATHDR = 2
-CHUNK_SHIFT = 8
+CHUNK_SHIFT = 11
 UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
@@ -32,7 +32,7 @@ SYMBOLS = [
     "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
     "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
-    "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev",
+    "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev", "zngamd_compare_dev",
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
@@ -111,6 +111,7 @@ def load():
         L.zngamd_gzip_inflate_members_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp]
         L.zngamd_gzip_inflate_plain_members_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp]
         L.zngamd_inflate_raw_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.zngamd_compare_dev.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
         L.zngamd_gunzip.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_uint32)]
         L.zngamd_gunzip_partial.argtypes = [vp, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64),
@@ -468,6 +469,94 @@ class Context:
 
 _default = None
 _default_lock = threading.Lock()
+_pool = {}
+
+
+def writer_devices(limit=None):
+    """Devices a block-parallel writer of THIS process spreads its batches over: ZNGAMD_DEVICES ("0,1,2,3"; a device may be
+    named twice, which gives two contexts on it) or every visible GPU, cut to `limit` entries.  A process that was given
+    one GPU by its launcher (LOCAL_RANK / ZNGAMD_DEVICE set) stays on it."""
+    spec = os.environ.get("ZNGAMD_DEVICES")
+    if spec:
+        devs = [int(x) for x in spec.replace(";", ",").split(",") if x.strip() != ""]
+    elif "ZNGAMD_DEVICE" in os.environ or "LOCAL_RANK" in os.environ:
+        devs = [default_context().device]
+    else:
+        devs = list(range(max(1, load().zngamd_device_count())))
+    if limit is not None:
+        devs = devs[:max(1, limit)]
+    return devs
+
+
+def contexts(limit=None):
+    """One context per entry of writer_devices(limit); entry 0 is the process-wide default context when it names its device.
+    Contexts live as long as the process (their device workspaces are grow-only)."""
+    out = []
+    with _default_lock:
+        pass
+    seen = {}
+    for d in writer_devices(limit):
+        k = (d, seen.get(d, 0))
+        seen[d] = seen.get(d, 0) + 1
+        with _default_lock:
+            c = _pool.get(k)
+        if c is None:
+            if k[1] == 0 and default_context().device == d:
+                c = default_context()
+            else:
+                c = Context(device=d)
+            with _default_lock:
+                c = _pool.setdefault(k, c)
+        out.append(c)
+    return out
+
+
+def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap):
+    """deflate_blocks(joined=True) over several contexts: the blocks are cut into contiguous ranges of about equal input,
+    one per context; every range goes to its GPU as the slice of `buf` it needs (its blocks and the dictionary in front of
+    its first block -- the previous range's input tail), the ranges run side by side (the engine calls release the GIL) and
+    the results come back in block order.  This is the reference's worker fan-out (gzip_ng_threaded.py:233-246, :316-321)
+    with contiguous ranges in place of round-robin, and its in-order drain (:382-398).
+    -> (packed bytes, crcs, overflowed, lens) like Context.deflate_blocks(joined=True)."""
+    n = len(blocks)
+    total = sum(b[1] for b in blocks)
+    g = min(len(ctxs), n)
+    if g <= 1 or total < (8 << 20):
+        return ctxs[0].deflate_blocks(buf, blocks, level, out_cap, joined=True)
+    mv = memoryview(buf)
+    if mv.format != "B" or mv.ndim != 1:
+        mv = mv.cast("B")
+    # contiguous ranges by cumulative input bytes
+    cuts, acc, k = [0], 0, 1
+    for i, b in enumerate(blocks):
+        acc += b[1]
+        if k < g and acc * g >= total * k and i + 1 < n:
+            cuts.append(i + 1)
+            k += 1
+    cuts.append(n)
+    parts = [None] * (len(cuts) - 1)
+    errs = []
+
+    def run(j):
+        try:
+            sub = blocks[cuts[j]:cuts[j + 1]]
+            lo = min(o - d for o, _, d, _ in sub)
+            hi = max(o + ln for o, ln, _, _ in sub)
+            parts[j] = ctxs[j].deflate_blocks(mv[lo:hi], [(o - lo, ln, d, f) for o, ln, d, f in sub], level, out_cap, joined=True)
+        except BaseException as exc:                      # raised in the caller's thread below
+            errs.append(exc)
+    ths = [threading.Thread(target=run, args=(j,), name=f"zng-amd-gpu{j}") for j in range(1, len(parts))]
+    for t in ths:
+        t.start()
+    run(0)
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    packed = b"".join(p[0] for p in parts)
+    crcs = [c for p in parts for c in p[1]]
+    lens = [x for p in parts for x in p[3]]
+    return packed, crcs, any(p[2] for p in parts), lens
 
 
 def default_context():

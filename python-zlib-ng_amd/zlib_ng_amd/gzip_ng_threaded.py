@@ -5,7 +5,10 @@ Reference design: N worker threads each own a `_ParallelCompress`; `write()` cut
 of at most `block_size`, primes block i with the last 32 KiB of block i-1 and deals blocks round-robin to
 the workers; a writer thread drains results in order and folds CRCs with crc32_combine.
 
-Here the data-parallel axis is the GPU, not threads: `threads` is the number of blocks kept in flight.
+Here the data-parallel axis is the GPU, not threads: `threads` is the number of blocks kept in flight and the upper bound
+of GPUs one writer uses -- with threads > 1 every batch is cut into contiguous block ranges, one per visible GPU (or per
+entry of ZNGAMD_DEVICES), each range primed by the input in front of it, compressed side by side and written in order
+(`_lib.deflate_blocks_multi`; a process that its launcher bound to one GPU stays on it).
 `write()` cuts and primes blocks exactly as the reference does and puts them on `threads` bounded
 queues in round-robin order; ONE worker thread drains whatever is queued (in the same order), submits
 those blocks to the engine as a single batch (`_ParallelCompress.compress_and_crc_batch`), and writes
@@ -22,7 +25,7 @@ import queue
 import struct
 import threading
 
-from . import gzip_ng, zlib_ng
+from . import _lib, gzip_ng, zlib_ng
 
 DEFLATE_WINDOW_SIZE = 2 ** 15
 
@@ -192,6 +195,7 @@ class _ThreadedGzipWriter(io.RawIOBase):
         # incompressible data grows a little; 10 % head-room as in gzip_ng_threaded.py:229-231
         self.compressors = [zlib_ng._ParallelCompress(buffersize=block_size + max(block_size // 10, 500), level=level)]
         self.threads = threads
+        self._ctxs = None                            # contexts of the GPUs this writer spreads its batches over (made on first use)
         # The reference keeps queue_size blocks per worker thread in flight.  One engine batch replaces the N worker
         # threads, and a batch of 8 blocks is all launch overhead: the queues are made deep enough for about 32 MiB
         # of pending input per batch (a memory bound of the same kind as the reference's threads * queue_size blocks).
@@ -265,10 +269,10 @@ class _ThreadedGzipWriter(io.RawIOBase):
         tail = bytes(memoryview(self.previous_block)[-DEFLATE_WINDOW_SIZE:])
         bs = self.block_size
         cap = bs + max(bs // 10, 500)
-        ctx = zlib_ng._ctx()
+        ctxs = self._contexts()
 
         def emit(buf, blocks):
-            packed, crcs, overflowed, _ = ctx.deflate_blocks(buf, blocks, self.level, cap, joined=True)
+            packed, crcs, overflowed, _ = _lib.deflate_blocks_multi(ctxs, buf, blocks, self.level, cap)
             if overflowed:
                 raise OverflowError(f"Compressed output exceeds buffer size of {cap}")
             for (_, ln, _, _), crc in zip(blocks, crcs):
@@ -298,6 +302,11 @@ class _ThreadedGzipWriter(io.RawIOBase):
         last = nbytes - ((nbytes - 1) // bs) * bs                    # the next block is primed with the last block, as always
         self.previous_block = bytes(view[nbytes - last:nbytes])
         return nbytes
+
+    def _contexts(self):
+        if self._ctxs is None:
+            self._ctxs = _lib.contexts(self.threads)
+        return self._ctxs
 
     def _write_later(self, packed):
         try:

@@ -1,16 +1,22 @@
-"""Block sharding across ranks (multi-GPU leg).
+"""Block sharding across ranks (multi-GPU leg, one process per GPU).  No torch: RCCL is driven through the C ABI.
 
 The reference's only parallel strategy is round-robin blocks over threads with an in-order writer
-(gzip_ng_threaded.py:316-321, :382-398).  Here every rank owns a contiguous range of blocks and compresses it on its
-own GPU.  The member stream is reassembled with one padded all-gather of the variable-size slices (`allgather_stream`: RCCL
-over xGMI with backend "nccl", every rank sends its slice over all its links at once; the same code runs on "gloo" for the
-CPU tests).  Where nobody needs the whole stream in one memory, the ranks only have to agree on its LAYOUT -- where each
-slice starts, the total size, CRC-32 / length of the whole input for the trailer: three integers per rank
-(`exchange_layout`) -- and every rank writes its slice at its own offset.  Only torch.distributed plumbing and integer
-arithmetic live here; no payload byte is computed on the host.
+(gzip_ng_threaded.py:316-321, :382-398).  Here every rank owns a contiguous range of blocks (`shard_range`), primes the
+first block of its range with the 32 KiB of input in front of it (the previous rank's tail, gzip_ng_threaded.py:317) and
+compresses the range on its own GPU into one contiguous slice.  One exchange step reassembles the member stream:
+  * `Comm.layout`           all-gather of {slice bytes, CRC-32 of the rank's input, input bytes} -- 24 bytes per rank; gives
+                            every rank the offset of its slice, the total size and the CRC-32 / length of the whole input
+                            for the trailer (crc32_combine is associative: the folds of the ranks fold again);
+  * `Comm.allgather_stream` exact-size exchange of the slices: grouped ncclSend / ncclRecv over all xGMI links at once,
+                            every slice lands at its offset; runs on a stream of its own so that it overlaps later kernels.
+Where nobody needs the whole stream in one memory the layout alone is enough: every rank writes its slice at its own offset.
+`exchange_layout` takes any all-gather of three integers per rank (`Comm.layout` on GPUs; the CPU tests hand in a gloo one).
+Only integer arithmetic and framing bytes live here; no payload byte is computed on the host.
 """
-import torch
-import torch.distributed as dist
+import ctypes as C
+import socket
+import struct
+import time
 
 from . import _lib
 
@@ -22,73 +28,6 @@ def shard_range(n_blocks, rank, world):
     return lo, hi
 
 
-def exchange_layout(local_len, crc=0, ulen=0, group=None, device=None):
-    """All-gather of (compressed bytes, CRC-32 of the uncompressed shard, uncompressed bytes) of every rank.  Returns
-    (offset of this rank's slice in the stream, total compressed size, per-rank sizes, CRC-32 of the whole input,
-    total uncompressed size): everything the writer's header / trailer and a positional write of the slice need
-    (gzip_ng_threaded.py:382-398 folds the CRCs the same way, block by block)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    mine = torch.tensor([int(local_len), int(crc) & 0xFFFFFFFF, int(ulen)], dtype=torch.int64, device=device)
-    parts = [torch.zeros(3, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    rows = [[int(v) for v in p.tolist()] for p in parts]
-    sizes = [r[0] for r in rows]
-    whole_crc = combine_crcs([(r[1], r[2]) for r in rows])
-    return sum(sizes[:rank]), sum(sizes), sizes, whole_crc, sum(r[2] for r in rows)
-
-
-def allgather_stream_start(local, local_len, group=None, scratch=None):
-    """Start the exchange of the slices: sizes are all-gathered synchronously (8 bytes per rank), the payload all-gather
-    (one collective into a contiguous [world x largest slice] buffer: no per-rank staging copies) is issued asynchronously
-    so that independent work (the inflate leg) can overlap it.  Returns a handle for allgather_stream_finish."""
-    world = dist.get_world_size(group)
-    dev = local.device
-    mine = torch.tensor([int(local_len)], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, mine, group=group)
-    hs = [int(s.item()) for s in sizes]
-    mx = max(max(hs), 1)
-    if local.numel() < mx:
-        raise ValueError("local buffer shorter than the largest slice")
-    scratch = scratch if scratch is not None else {}
-    need = world * mx
-    if scratch.get("cap", 0) < need:
-        scratch["buf"] = torch.empty(need + need // 8, dtype=torch.uint8, device=dev)
-        scratch["cap"] = scratch["buf"].numel()
-    flat = scratch["buf"][:need]
-    work = dist.all_gather_into_tensor(flat, local[:mx].contiguous(), group=group, async_op=True)
-    parts = [flat[r * mx:(r + 1) * mx] for r in range(world)]
-    return {"work": work, "parts": parts, "sizes": hs, "scratch": scratch}
-
-
-def allgather_stream_finish(h, compact=True):
-    """Wait for the payload.  The slices lie in rank order (= block order: ranges are contiguous) at a stride of the
-    largest slice; compact=True closes the gaps (one device copy per rank) and returns (stream tensor, total length,
-    per-rank sizes); compact=False returns (list of slice views, total length, per-rank sizes) -- a writer can hand
-    those to one positional / vectored write without touching the bytes again."""
-    h["work"].wait()
-    total = sum(h["sizes"])
-    if not compact:
-        return [p[:s] for p, s in zip(h["parts"], h["sizes"])], total, h["sizes"]
-    scratch = h["scratch"]
-    if scratch.get("scap", 0) < total:
-        scratch["stream"] = torch.empty(total + total // 8 + 64, dtype=torch.uint8, device=h["parts"][0].device)
-        scratch["scap"] = scratch["stream"].numel()
-    off = 0
-    stream = scratch["stream"]
-    for r, s in enumerate(h["sizes"]):
-        stream[off:off + s] = h["parts"][r][:s]
-        off += s
-    return stream, off, h["sizes"]
-
-
-def allgather_stream(local, local_len, group=None, scratch=None):
-    """All ranks contribute local[:local_len] (uint8, 1-D); every rank gets the slices concatenated in
-    rank order.  Returns (stream tensor, total length, per-rank sizes).  `scratch` caches buffers."""
-    return allgather_stream_finish(allgather_stream_start(local, local_len, group, scratch))
-
-
 def combine_crcs(crcs_and_lens):
     """Fold (crc32, uncompressed_len) pairs in order, as _write does (gzip_ng_threaded.py:394)."""
     L = _lib.load()
@@ -98,10 +37,136 @@ def combine_crcs(crcs_and_lens):
     return crc
 
 
+def layout_from_records(records, rank):
+    """records[r] = (slice bytes, crc32 of rank r's input, input bytes of rank r), in rank order ->
+    (offset of `rank`'s slice, total bytes, per-rank sizes, CRC-32 of the whole input, whole input length)."""
+    sizes = [int(r[0]) for r in records]
+    return (sum(sizes[:rank]), sum(sizes), sizes, combine_crcs([(int(r[1]), int(r[2])) for r in records]),
+            sum(int(r[2]) for r in records))
+
+
+def exchange_layout(local_len, crc, ulen, rank, allgather):
+    """`allgather((len, crc, ulen))` -> the records of all ranks in rank order; see layout_from_records."""
+    return layout_from_records(allgather((int(local_len), int(crc) & 0xFFFFFFFF, int(ulen))), rank)
+
+
 def gzip_frame(body_len_total, crc, size, level):
     """Header / trailer bytes of the reference's threaded writer (gzip_ng_threaded.py:269-284, :324-338)."""
-    import struct
     xfl = 2 if level == 9 else 4 if level == 1 else 0
     header = struct.pack("BBBBIBB", 0x1f, 0x8b, 8, 0, 0, 0xff, xfl)
     trailer = b"\x03\x00" + struct.pack("<II", crc & 0xFFFFFFFF, size & 0xFFFFFFFF)
     return header, trailer
+
+
+def rendezvous_bytes(rank, world, addr, port, payload=None, timeout=120.0):
+    """Rank 0 hands `payload` (bytes) to the other ranks over TCP (one short connection each); every rank returns it.
+    What a launcher without a key-value store needs to pass the 128-byte RCCL unique id around."""
+    if world == 1:
+        return payload
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            conn, _ = srv.accept()
+            conn.sendall(struct.pack("<I", len(payload)) + payload)
+            conn.close()
+        srv.close()
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < 4:
+        buf += s.recv(4 - len(buf))
+    n = struct.unpack("<I", buf)[0]
+    out = b""
+    while len(out) < n:
+        chunk = s.recv(n - len(out))
+        if not chunk:
+            raise ConnectionError("rendezvous: connection closed early")
+        out += chunk
+    s.close()
+    return out
+
+
+class Comm:
+    """RCCL communicator of the engine (zngamd_comm_*): one per process, bound to a context's GPU."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        L = _lib.load()
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        r = L.zngamd_comm_unique_id(buf)
+        if r != _lib.OK:
+            raise RuntimeError(f"zng_amd: RCCL is not usable here (zngamd_comm_unique_id -> {r})")
+        return bytes(buf)
+
+    def __init__(self, ctx, uid, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.L = ctx.L
+        L = self.L
+        L.zngamd_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.zngamd_comm_destroy.argtypes = [C.c_void_p]
+        L.zngamd_comm_last_error.argtypes = [C.c_void_p]
+        L.zngamd_comm_last_error.restype = C.c_char_p
+        L.zngamd_comm_layout.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.zngamd_comm_allgather_stream.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64]
+        L.zngamd_comm_wait.argtypes = [C.c_void_p]
+        L.zngamd_comm_barrier.argtypes = [C.c_void_p]
+        L.zngamd_comm_max_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self.h = C.c_void_p()
+        r = L.zngamd_comm_create(ctx.h, bytes(uid), rank, world, C.byref(self.h))
+        if r != _lib.OK:
+            raise RuntimeError(f"zng_amd: zngamd_comm_create -> {r}: {ctx.err()}")
+
+    def _chk(self, r):
+        if r != _lib.OK:
+            raise RuntimeError(f"zng_amd comm: {r}: {self.L.zngamd_comm_last_error(self.h).decode('utf-8', 'replace')}")
+
+    def layout(self, local_len, crc, ulen):
+        """-> (offset of this rank's slice, total bytes, per-rank sizes, CRC-32 of the whole input, whole input length)"""
+        sizes = (C.c_uint64 * self.world)()
+        off, total, wl = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        wc = C.c_uint32(0)
+        self._chk(self.L.zngamd_comm_layout(self.h, int(local_len), int(crc) & 0xFFFFFFFF, int(ulen), sizes, C.byref(off), C.byref(total),
+                                            C.byref(wc), C.byref(wl)))
+        return off.value, total.value, [int(x) for x in sizes], wc.value, wl.value
+
+    def allgather_stream(self, d_local, sizes, d_stream, stream_cap):
+        """Start the exchange of the slices (device pointers as integers); wait() blocks until it is done."""
+        arr = (C.c_uint64 * self.world)(*sizes)
+        self._chk(self.L.zngamd_comm_allgather_stream(self.h, C.c_void_p(d_local), arr, C.c_void_p(d_stream), int(stream_cap)))
+
+    def wait(self):
+        self._chk(self.L.zngamd_comm_wait(self.h))
+
+    def barrier(self):
+        self._chk(self.L.zngamd_comm_barrier(self.h))
+
+    def max(self, value):
+        v = C.c_double(float(value))
+        self._chk(self.L.zngamd_comm_max_f64(self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h:
+            self.L.zngamd_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -270,3 +270,37 @@ def test_threaded_reader_overlaps_windows(T, monkeypatch):
                 got += b
     # (io.BufferedReader drops what a read() call had gathered when the raw reader raises inside it: up to one request)
     assert len(got) >= len(data) - (1 << 20) and want.startswith(bytes(got))
+
+
+def test_writer_spreads_batches_over_contexts(monkeypatch):
+    """threads > 1: every batch is cut into contiguous block ranges, one per GPU context (here two contexts on the one GPU of the
+    test box), each range primed by the input in front of it -- the file is byte for byte what one context writes, and the
+    stdlib reads it (reference fan-out / in-order drain: gzip_ng_threaded.py:233-246, :316-321, :382-398)."""
+    import gzip
+    import io
+    from zlib_ng_amd import _lib, corpus, gzip_ng_threaded
+    data = corpus.text(40 << 20, seed=9).tobytes() + b"tail" * 1000
+    one = io.BytesIO()
+    with gzip_ng_threaded.open(one, "wb", compresslevel=6, threads=1, block_size=128 * 1024) as f:
+        f.write(data)
+    monkeypatch.setenv("ZNGAMD_DEVICES", "0,0,0")
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    monkeypatch.delenv("ZNGAMD_DEVICE", raising=False)
+    assert len(_lib.contexts(8)) == 3 and len({id(c) for c in _lib.contexts(8)}) == 3 and len(_lib.contexts(2)) == 2
+    many = io.BytesIO()
+    with gzip_ng_threaded.open(many, "wb", compresslevel=6, threads=3, block_size=128 * 1024) as f:
+        f.write(data)
+        f.write(data[:3 << 20])
+    ref = io.BytesIO()
+    with gzip_ng_threaded.open(ref, "wb", compresslevel=6, threads=1, block_size=128 * 1024) as f:
+        f.write(data)
+        f.write(data[:3 << 20])
+    assert many.getvalue() == ref.getvalue()
+    assert gzip.decompress(many.getvalue()) == data + data[:3 << 20]
+    assert gzip.decompress(one.getvalue()) == data
+    # the ranges of one batch: contiguous, in order, each with its dictionary in front
+    ctxs = _lib.contexts(3)
+    blocks = [(o, min(131072, len(data) - o), min(32768, o), 0) for o in range(0, len(data), 131072)]
+    a = _lib.deflate_blocks_multi(ctxs, data, blocks, 6, 131072 + 13107 + 500)
+    b = ctxs[0].deflate_blocks(data, blocks, 6, 131072 + 13107 + 500, joined=True)
+    assert a[0] == b[0] and list(a[1]) == list(b[1]) and a[2] == b[2] and list(a[3]) == list(b[3])

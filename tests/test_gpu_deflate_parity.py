@@ -53,7 +53,7 @@ def _stage_compare(ctx, O, data, zdict, level, flags):
             sb = np.frombuffer(ctx.debug_fetch(6, 0, 4 * 65), np.uint32)
             assert np.array_equal(sb[:nseg], dbg["seg_bits"][:nseg]), "stage5 segment bit offsets differ"
             assert sb[64] == dbg["seg_bits"][nseg]
-            nchunk = (n + 255) // 256
+            nchunk = (n + 2047) // 2048
             ci = np.frombuffer(ctx.debug_fetch(8, 0, 4 * (nchunk + 1)), np.uint32)
             assert np.array_equal(ci, dbg["chunk_idx"][:nchunk + 1]), \
                 f"stage5 chunk index differs at {np.flatnonzero(ci != dbg['chunk_idx'][:nchunk + 1])[:5]}"

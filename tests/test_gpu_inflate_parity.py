@@ -183,7 +183,7 @@ def test_indexed_stream_fuzz(ctx, fastq):
     rng = np.random.default_rng(99)
     for trial in range(120):
         bad = bytearray(stream)
-        pos = int(rng.integers(0, len(bad))) if trial % 3 else int(rng.integers(0, 2080))
+        pos = int(rng.integers(0, len(bad))) if trial % 3 else int(rng.integers(0, 288))
         bad[pos] ^= 1 << int(rng.integers(0, 8))
         code, out, nm = ctx.gunzip(bytes(bad), len(data) + 4096)
         ocode, oout, onm = O.gunzip(bytes(bad), len(data) + 4096)
