@@ -187,6 +187,11 @@ int zngamd_gzip_inflate_plain_members_dev(zngamd_ctx *ctx, const void *d_in, uin
 int zngamd_inflate_raw_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, void *d_out, uint64_t out_cap,
                            uint64_t *out_len, uint64_t *in_used);
 
+/* CRC-32 of the concatenation of n pieces from their CRC-32s (a device array, e.g. the d_unit_crc of
+ * zngamd_deflate_blocks_dev): pieces 0 .. n-2 are each_len bytes long, the last one last_len -- the in-order fold of the
+ * reference's writer thread (gzip_ng_threaded.py:394), GF(2) arithmetic on the host. */
+int zngamd_crc32_fold_dev(zngamd_ctx *ctx, const uint32_t *d_crcs, uint32_t n, uint64_t each_len, uint64_t last_len, uint32_t *crc);
+
 /* Number of differing 4-byte words (bytes in the tail) of two device buffers: the round-trip check of device-resident callers. */
 int zngamd_compare_dev(zngamd_ctx *ctx, const void *d_a, const void *d_b, uint64_t n, uint64_t *mismatches);
 

@@ -316,8 +316,10 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                         "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
                         : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));     // 96 is not an inline constant
                     int len = (int)min(fbit >> 3, 16u);
-                    if (FULL && len == 16 && cap > 16 && best_len < cap) {
-                        // levels that compare in full: at least 16 equal bytes -- finish the compare the long way
+                    if (FULL && len == 16 && cap > 16 && best_len < cap &&
+                        (best_len < 16 || (uint8_t)za_lds_ld32(win32, q + (uint32_t)best_len) == (uint8_t)za_lds_ld32(win32, P + (uint32_t)best_len))) {
+                        // levels that compare in full: at least 16 equal bytes -- finish the compare the long way (a candidate that
+                        // differs at the byte behind the best length so far cannot beat it: zlib's quick reject, one LDS read)
                         while (len < maxlen) {
                             const uint32_t x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
                             if (x) { len += (int)(__builtin_ctz(x) >> 3); break; }

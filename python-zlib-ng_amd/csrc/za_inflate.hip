@@ -1007,9 +1007,9 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                                                               const ZaMember *__restrict__ members,
                                                               uint8_t *__restrict__ out, uint64_t out_cap,
                                                               uint32_t *__restrict__ matchq,       // [grid][64][ZA_MATCHQ_PER_SEG]
-                                                           const uint32_t *__restrict__ crc_table,
-                                                           const uint32_t *__restrict__ x8k_table,
-                                                           int32_t *__restrict__ status_out)
+                                                              const uint32_t *__restrict__ crc_slice4,   // [4][256]: slice-by-4 tables
+                                                              const uint32_t *__restrict__ x8k_table,
+                                                              int32_t *__restrict__ status_out)
 {
     __shared__ ZaMemTabs T;
     __shared__ int scratch[2];
@@ -1177,13 +1177,12 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                     const uint32_t w = rel >> 5, sh = rel & 31u;
                     // 64 bits starting at bit `rel` of the row (3 dwords; a token takes at most 10 + 5 + 9 + 13 = 37)
                     const uint32_t d0 = myrow[w], d1 = myrow[w + 1], d2 = myrow[w + 2];
-                    const uint64_t lo = ((uint64_t)d1 << 32) | d0;
-                    const uint64_t b = sh ? ((lo >> sh) | ((uint64_t)d2 << (64 - sh))) : lo;
+                    const uint64_t b = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);   // two funnel shifts, no branch on sh == 0
                     const uint32_t e = T.lut_l[(uint32_t)b & ((1u << ZA_ML_BITS) - 1u)];
                     const uint32_t l = e & 15u;
                     int adv = 1;
                     uint32_t used = l;
-                    int err = (e == 0u) ? 2 : (bp > in_bits ? 1 : 0);
+                    int err = (e == 0u) ? 2 : 0;        // (a lane that runs past its stop offset is caught behind the loop; rows never read outside the buffer)
                     if (!(e & 0x8000u)) {
                         const int o = pos - blk_base;
                         const uint64_t by = (uint64_t)((e >> 4) & 0xFFu);
@@ -1246,9 +1245,10 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
     const unsigned long long e1 = __ballot(lane_err == 1), e2 = __ballot(lane_err == 2);
     if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
     __threadfence_block();       // literals and the match queues are visible to the whole wave
-    // the CRC table takes the place of the input rows
+    // the CRC slice tables take the place of the input rows
     uint32_t *crct = rows;
-    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
+    static_assert(sizeof(uint32_t) * 64 * ZA_IROW >= 4096, "slice tables");
+    for (int i = lane; i < 1024; i += 64) crct[i] = crc_slice4[i];
 
     // ---- phase B: resolve matches in output order, 64 at a time.  A match is ready when its source lies
     // below the first unresolved match of the group (the lowest pending one always is).  Each ready lane
@@ -1261,9 +1261,11 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
         const uint32_t cnt = __shfl(nmatch, s, 64);
         const uint32_t *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
         uint32_t segpos = (uint32_t)s << ZA_SEG_SHIFT;             // output position behind the entries handled so far
+        uint32_t ent_next = (uint32_t)lane < cnt ? q[lane] : 0u;
         for (uint32_t g = 0; g < cnt; g += 64) {
             const bool hasq = g + (uint32_t)lane < cnt;
-            const uint32_t ent = hasq ? q[g + lane] : 0u;
+            const uint32_t ent = ent_next;
+            ent_next = g + 64u + (uint32_t)lane < cnt ? q[g + 64u + lane] : 0u;      // the next group's entries travel while this group is resolved
             const uint32_t l3 = (ent >> 15) & 0xFFu;
             const bool has = hasq && l3 != 0u;                      // a real match (length field 0: a run of literals)
             const uint32_t mlen = has ? l3 + 3u : 0u, mdist = (ent & 0x7FFFu) + 1u;
@@ -1350,7 +1352,40 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
     const uint32_t c = za_ld32(src + m.in_len);
 #else
     __syncthreads();
-    const uint32_t c = za_wave_crc32(dst, n, crct, x8k_table);
+    uint32_t c = 0;
+    {
+        // lane per 2 KiB segment, 16 bytes per load with the next load in flight, slice-by-4 (four independent table reads per
+        // dword instead of a chain of four); the per-segment values are folded as in za_wave_crc32
+        const int s0 = lane << ZA_SEG_SHIFT;
+        int s1 = s0 + ZA_SEG; if (s1 > n) s1 = n;
+        if (lane < nseg) {
+            uint32_t r = 0xFFFFFFFFu;
+            int p = s0;
+            ZaU4u cur = {0, 0, 0, 0};
+            if (p + 16 <= s1) cur = *(const ZaU4u *)(dst + p);
+            for (; p + 16 <= s1; p += 16) {
+                ZaU4u nx = {0, 0, 0, 0};
+                if (p + 32 <= s1) nx = *(const ZaU4u *)(dst + p + 16);
+                const uint32_t wv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    r ^= wv[k];
+                    r = crct[768 + (r & 0xFFu)] ^ crct[512 + ((r >> 8) & 0xFFu)] ^ crct[256 + ((r >> 16) & 0xFFu)] ^ crct[r >> 24];
+                }
+                cur = nx;
+            }
+            for (; p < s1; p++) r = crct[(r ^ dst[p]) & 0xFFu] ^ (r >> 8);
+            c = r ^ 0xFFFFFFFFu;
+            if (lane < nseg - 1) {
+                // crc(A||B) = crc(A) * x^(8|B|) ^ crc(B);  |B| = (nseg-2-lane) full segments + the tail
+                const int tail = n - ((nseg - 1) << ZA_SEG_SHIFT);
+                uint32_t xt = 0x80000000u, sq = 0x00800000u;       // x^0, x^8
+                for (int mm = tail; mm; mm >>= 1) { if (mm & 1) xt = za_multmodp(sq, xt); sq = za_multmodp(sq, sq); }
+                c = za_multmodp(za_multmodp(x8k_table[nseg - 2 - lane], xt), c);
+            }
+        }
+        c = za_wave_xor_reduce(c);
+    }
 #endif
     const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);
     if (lane == 0) status_out[blockIdx.x] = (c != want_crc) ? ZA_I_CRC : (want_len != (uint32_t)n) ? ZA_I_LENGTH : ZA_I_OK;

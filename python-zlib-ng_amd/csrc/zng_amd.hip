@@ -25,7 +25,7 @@ static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants
 // level is >= zlib 1.2.11's at the same level on the text / FASTQ / mixed corpora
 static const ZaLevel ZA_LEVELS[10] = {
     {0, 0, 0, ZA_WIN, 0}, {1, 8, 0, ZA_WIN, 16}, {2, 8, 0, ZA_WIN, 16}, {3, 16, 0, ZA_WIN, 16}, {2, 16, 8, ZA_WIN, 16}, {3, 32, 16, ZA_WIN, 16},
-    {4, 32, 16, ZA_WIN, 16}, {8, 32, 16, ZA_WIN, 258}, {16, 64, 16, ZA_WIN, 258}, {128, 258, 128, ZA_WIN, 258}};
+    {4, 32, 16, ZA_WIN, 16}, {8, 32, 16, ZA_WIN, 258}, {16, 64, 16, ZA_WIN, 258}, {32, 258, 128, ZA_WIN, 258}};
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;
@@ -785,7 +785,7 @@ static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_l
         const uint32_t m = std::min(ch, n - c0);
         ProfScope ps(c, ZNGAMD_K_INFLATE);
         hipLaunchKernelGGL(za_k_inflate_members, dim3(m), dim3(64), 0, c->stream, d_in, in_len, d_members + c0, d_out, out_cap,
-                           c->matchq.p, c->d_crc_table, c->d_x8k, d_status + c0);
+                           c->matchq.p, c->d_crc_slice4, c->d_x8k, d_status + c0);
     }
     HIPCHK(c, hipGetLastError());
     return ZNGAMD_OK;
@@ -840,6 +840,27 @@ int zngamd_inflate_raw_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, voi
     if (in_used) *in_used = (res.in_bits + 7) >> 3;
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
+}
+
+int zngamd_crc32_fold_dev(zngamd_ctx *c, const uint32_t *d_crcs, uint32_t n, uint64_t each_len, uint64_t last_len, uint32_t *crc)
+{
+    if (!c || (!d_crcs && n) || !crc) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint32_t> v(n);
+    if (n) HIPCHK(c, hipMemcpyAsync(v.data(), d_crcs, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // x^(8 each_len) once; then Horner: crc = crc * x^(8 len_i) ^ crc_i
+    uint32_t xe = 0x80000000u, sq = 0x00800000u;
+    for (uint64_t k = each_len; k; k >>= 1) { if (k & 1) xe = za_multmodp(sq, xe); sq = za_multmodp(sq, sq); }
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (i == 0) r = v[0];
+        else if (i + 1 < n || last_len == each_len) r = za_multmodp(xe, r) ^ v[i];
+        else r = zngamd_crc32_combine(r, v[i], last_len);
+    }
+    *crc = r;
+    return ZNGAMD_OK;
 }
 
 int zngamd_compare_dev(zngamd_ctx *c, const void *d_a, const void *d_b, uint64_t n, uint64_t *mismatches)

@@ -89,7 +89,8 @@ def _gloo_worker(rank, world, port, q, path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     # each rank "compresses" its contiguous block range (stand-in codec: the system zlib; the exchange logic
-    # under test is independent of who produced the bytes) with the reference's dictionary chaining
+    # under test is independent of who produced the bytes) with the reference's dictionary chaining: the first block of
+    # rank 1's range is primed with the tail of rank 0's input
     data = bytes((i * 7 + (i >> 9)) & 0xFF for i in range(40 * 1024))
     bs = 4096
     nb = len(data) // bs
@@ -101,31 +102,40 @@ def _gloo_worker(rank, world, port, q, path):
         parts.append(co.compress(data[b * bs:(b + 1) * bs]) + co.flush(zlib.Z_SYNC_FLUSH))
         crcs.append((zlib.crc32(data[b * bs:(b + 1) * bs]), bs))
     mine = b"".join(parts)
-    local = torch.zeros(len(mine) + 5000, dtype=torch.uint8)
-    local[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
-    stream, total, sizes = shard.allgather_stream(local, len(mine))
-    # CRC of the whole stream from the per-rank folds (associative)
     my_crc = shard.combine_crcs(crcs)
-    pairs = [None] * world
-    dist.all_gather_object(pairs, (my_crc, (hi - lo) * bs))
-    crc = shard.combine_crcs(pairs)
-    header, trailer = shard.gzip_frame(total, crc, len(data), 6)
-    blob = header + bytes(stream[:total].numpy()) + trailer
+
+    def allgather(rec):                       # the transport under the layout exchange: gloo here, RCCL (Comm.layout) on GPUs
+        out = [None] * world
+        dist.all_gather_object(out, rec)
+        return out
+    off, total, sizes, crc, usize = shard.exchange_layout(len(mine), my_crc, (hi - lo) * bs, rank, allgather)
+    ok = sizes[rank] == len(mine) and off == sum(sizes[:rank]) and total == sum(sizes) and crc == zlib.crc32(data) and usize == len(data)
+    # (1) the whole stream on every rank: slices land at their offsets (what Comm.allgather_stream does with ncclSend/ncclRecv)
+    stream = torch.zeros(total, dtype=torch.uint8)
+    mx = max(sizes)
+    padded = torch.zeros(mx, dtype=torch.uint8)
+    padded[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+    got = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(got, padded)
+    o = 0
+    for r in range(world):
+        stream[o:o + sizes[r]] = got[r][:sizes[r]]
+        o += sizes[r]
+    header, trailer = shard.gzip_frame(total, crc, usize, 6)
     import gzip
-    ok = gzip.decompress(blob) == data and sizes[rank] == len(mine) and crc == zlib.crc32(data)
-    # the same file without moving any payload between ranks: the layout (three integers per rank) tells every rank where
-    # its slice goes, and it writes it there itself
-    off, total2, sizes2, crc2, usize = shard.exchange_layout(len(mine), my_crc, (hi - lo) * bs)
-    ok = ok and (total2, sizes2, crc2, usize) == (total, sizes, crc, len(data)) and off == sum(sizes[:rank])
-    header2, trailer2 = shard.gzip_frame(total2, crc2, usize, 6)
+    ok = ok and gzip.decompress(header + bytes(stream.numpy()) + trailer) == data
+    # (2) the same file without moving any payload between ranks: every rank writes its slice at its own offset
     fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
-    os.pwrite(fd, mine, len(header2) + off)
+    os.pwrite(fd, mine, len(header) + off)
     if rank == 0:
-        os.pwrite(fd, header2, 0)
-        os.pwrite(fd, trailer2, len(header2) + total2)
+        os.pwrite(fd, header, 0)
+        os.pwrite(fd, trailer, len(header) + total)
     os.close(fd)
     dist.barrier()
     ok = ok and gzip.decompress(open(path, "rb").read()) == data
+    # (3) the launcher-free hand-over of the communicator id: rank 0 serves 128 bytes over TCP
+    uid = bytes(range(128)) if rank == 0 else None
+    ok = ok and shard.rendezvous_bytes(rank, world, "127.0.0.1", port + 1, uid) == bytes(range(128))
     q.put((rank, ok, total))
     dist.destroy_process_group()
 
