@@ -831,40 +831,27 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
 // owned by the lane alone and stored directly.
 #define ZA_TCH 32      // tokens staged per lane and chunk in k_pack
 
-struct __attribute__((aligned(4))) ZaW4 { uint32_t x, y, z, w; };
-
 // Per-lane LSB-first bit writer.  The first word a lane touches and its trailing partial word may be shared with a
-// neighbour (or with the header): they are merged with atomic OR into words that hold zero.  The words in between are
-// the lane's alone and leave four at a time as one 16-byte store (single dword stores from 64 lanes were 64 memory
-// requests per instruction, and the request rate of L2 bounded the kernel).
+// neighbour (or with the header): they are merged with atomic OR into words that hold zero (the pack kernel zeroes exactly
+// those words itself).  The words in between are the lane's alone and stored directly.  (Collecting four words for one
+// 16-byte store was measured: 5.8 -> 6.9 ms per 4 GiB -- the kernel is bound by its instruction count, not by its stores.)
 struct ZaLaneW {
     uint32_t *out; uint32_t cap_words; uint32_t w; uint64_t acc; int nb; bool first; bool ovf;
-    uint32_t b0, b1, b2; uint32_t nbuf;
     __device__ void init(uint32_t *o, uint32_t cap, uint32_t bitpos)
     {
         out = o; cap_words = cap; w = bitpos >> 5; nb = (int)(bitpos & 31u); acc = 0; first = true; ovf = false;
-        b0 = b1 = b2 = 0; nbuf = 0;
-    }
-    __device__ void word(uint32_t v)
-    {
-        if (w >= cap_words) { ovf = true; w++; return; }
-        if (first) { atomicOr(&out[w], v); first = false; w++; return; }
-        if (nbuf == 3u) { ZaW4 q; q.x = b0; q.y = b1; q.z = b2; q.w = v; *(ZaW4 *)(out + (w - 3u)) = q; nbuf = 0; }
-        else { b0 = nbuf == 0u ? v : b0; b1 = nbuf == 1u ? v : b1; b2 = nbuf == 2u ? v : b2; nbuf++; }
-        w++;
     }
     __device__ void put(uint32_t v, int n)
     {
         acc |= (uint64_t)v << nb; nb += n;
-        if (nb >= 32) { word((uint32_t)acc); acc >>= 32; nb -= 32; }
+        if (nb >= 32) {
+            if (w < cap_words) { if (first) atomicOr(&out[w], (uint32_t)acc); else out[w] = (uint32_t)acc; }
+            else ovf = true;
+            first = false; w++; acc >>= 32; nb -= 32;
+        }
     }
     __device__ void finish()
     {
-        // buffered whole words (all below cap_words: word() checked them), then the trailing partial word
-        if (nbuf > 0u) out[w - nbuf] = b0;
-        if (nbuf > 1u) out[w - nbuf + 1u] = b1;
-        if (nbuf > 2u) out[w - nbuf + 2u] = b2;
-        nbuf = 0;
         if (nb > 0 && (uint32_t)acc != 0u) { if (w < cap_words) atomicOr(&out[w], (uint32_t)acc); else ovf = true; }
     }
 };

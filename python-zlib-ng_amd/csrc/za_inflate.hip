@@ -1245,108 +1245,160 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
     const unsigned long long e1 = __ballot(lane_err == 1), e2 = __ballot(lane_err == 2);
     if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
     __threadfence_block();       // literals and the match queues are visible to the whole wave
-    // the CRC slice tables take the place of the input rows
+
+    // ---- phase B: resolve matches in output order, segment by segment, 64 at a time, inside an LDS image of the segment.
+    // The image (in the row area) holds the segment's 2 KiB as phase A left them (literals in place) behind the last 272 bytes
+    // of the output in front of the segment.  A match whose source starts inside the image is copied LDS to LDS; the others
+    // (their source ends below the segment: final bytes in memory) with one or two 16-byte global loads into the image.
+    // Inside a group a match waits for the lanes that write what it reads (exact masks from two shuffle binary searches);
+    // those rounds cost LDS round trips instead of the store-fence-load round trips through L2 they cost when the matches
+    // were copied in memory.  The finished segment leaves as 64 x 32 bytes, coalesced.
+#ifndef ZA_ABL_NO_B
+    {
+        uint8_t *img = (uint8_t *)rows;                            // [0, 272): output in front of the segment, [272, 272 + 2048): the segment
+        const uint32_t TAIL = 272u;
+        static_assert(sizeof(uint32_t) * 64 * ZA_IROW >= 272 + ZA_SEG + 32, "segment image");
+        for (int s = 0; s < nseg; s++) {
+            const uint32_t cnt = __shfl(nmatch, s, 64);
+            const uint32_t *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
+            const uint32_t seg_start = (uint32_t)s << ZA_SEG_SHIFT;
+            const uint32_t seg_len = (uint32_t)n - seg_start < (uint32_t)ZA_SEG ? (uint32_t)n - seg_start : (uint32_t)ZA_SEG;
+            uint32_t ent_next = (uint32_t)lane < cnt ? q[lane] : 0u;
+            // image: the tail of the previous segment moves to the front (it is final), the segment comes from memory
+            __builtin_amdgcn_wave_barrier();
+            uint32_t t0 = 0, t1 = 0;
+            if (s > 0) { t0 = ((const uint32_t *)(img + ZA_SEG))[lane]; if (lane < 4) t1 = ((const uint32_t *)(img + ZA_SEG))[64 + lane]; }
+            {
+                const uint32_t o = (uint32_t)lane * 32u;
+                ZaU4u a = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
+                if (o + 32u <= seg_len) { a = *(const ZaU4u *)(dst + seg_start + o); b2 = *(const ZaU4u *)(dst + seg_start + o + 16); }
+                else if (o < seg_len) {
+                    uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t k = 0; k < 32u && o + k < seg_len; k++) t[k >> 2] |= (uint32_t)dst[seg_start + o + k] << (8 * (k & 3));
+                    a.x = t[0]; a.y = t[1]; a.z = t[2]; a.w = t[3]; b2.x = t[4]; b2.y = t[5]; b2.z = t[6]; b2.w = t[7];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (s > 0) { ((uint32_t *)img)[lane] = t0; if (lane < 4) ((uint32_t *)img)[64 + lane] = t1; }
+                *(uint4 *)(img + TAIL + o) = make_uint4(a.x, a.y, a.z, a.w);
+                *(uint4 *)(img + TAIL + o + 16) = make_uint4(b2.x, b2.y, b2.z, b2.w);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t segpos = seg_start;                               // output position behind the entries handled so far
+            for (uint32_t g = 0; g < cnt; g += 64) {
+                const bool hasq = g + (uint32_t)lane < cnt;
+                const uint32_t ent = ent_next;
+                ent_next = g + 64u + (uint32_t)lane < cnt ? q[g + 64u + lane] : 0u;      // the next group's entries travel while this group is resolved
+                const uint32_t l3 = (ent >> 15) & 0xFFu;
+                const bool has = hasq && l3 != 0u;                      // a real match (length field 0: a run of literals)
+                const uint32_t mlen = has ? l3 + 3u : 0u, mdist = (ent & 0x7FFFu) + 1u;
+                const uint32_t adv = !hasq ? 0u : has ? (ent >> 23) + mlen : ent;      // literals in front of the match + the match
+                const uint32_t incl = za_wave_incl_scan(adv);
+                const uint32_t mdst = segpos + incl - mlen;
+                segpos += (uint32_t)__shfl((int)incl, 63, 64);
+                bool done = !has;
+                unsigned long long pending = __ballot(!done);
+                // Which matches of this group write bytes that mine reads?  Destinations are disjoint and ascending with
+                // the lane, so they are the lanes [jlo, jhi): jhi = matches that start below the end of my source,
+                // jlo = matches that end at or below its start (two 6-step binary searches with shuffles; both counts
+                // are at most my own lane).  A match is ready as soon as none of those is pending -- the lowest
+                // pending one always is.  (Lanes without a match sit at their position with length 0: they order correctly.)
+                const uint32_t sdst = hasq ? mdst : 0xFFFFFFFFu, send = hasq ? mdst + mlen : 0xFFFFFFFFu;
+                const uint32_t src_a = mdst - mdist, src_b = src_a + (mlen < mdist ? mlen : mdist);
+                uint32_t jhi = 0, jlo = 0;
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1) {
+                    const uint32_t vd = (uint32_t)__shfl((int)sdst, (int)(jhi + step - 1u), 64);
+                    const uint32_t ve = (uint32_t)__shfl((int)send, (int)(jlo + step - 1u), 64);
+                    if (vd < src_b) jhi += step;
+                    if (ve <= src_a) jlo += step;
+                }
+                const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+                // far: the source ends below the segment (it starts more than 272 bytes in front of it): final bytes in memory
+                const bool far = src_a + TAIL < seg_start;
+                const bool simple = mdist >= mlen && mlen <= 32u;      // copied by its own lane, at most two 16-byte batches
+                uint8_t *od = img + TAIL + (mdst - seg_start);          // my destination inside the image
+                // the far sources of the whole group are fetched at once (nothing in this group can change them)
+                ZaU4u fv = {0, 0, 0, 0}, fv2 = {0, 0, 0, 0};
+                if (has && far && simple) {
+                    fv = *(const ZaU4u *)(dst + src_a);
+                    if (mlen > 16u) fv2 = *(const ZaU4u *)(dst + src_a + 16);
+                }
+                while (pending) {
+                    const bool ready = !done && (pending & deps) == 0ull;
+                    if (ready && simple) {
+                        ZaU4u v = fv, v2 = fv2;
+                        if (!far) {
+                            const uint8_t *sp = od - mdist;                 // inside the image: src_a >= seg_start - 272
+                            v.x = *(const za_u32u *)sp; v.y = *(const za_u32u *)(sp + 4); v.z = *(const za_u32u *)(sp + 8); v.w = *(const za_u32u *)(sp + 12);
+                            if (mlen > 16u) { v2.x = *(const za_u32u *)(sp + 16); v2.y = *(const za_u32u *)(sp + 20); v2.z = *(const za_u32u *)(sp + 24); v2.w = *(const za_u32u *)(sp + 28); }
+                        }
+                        uint8_t *o = od;
+                        uint32_t rem = mlen;
+                        if (mlen > 16u) {
+                            *(za_u32u *)o = v.x; *(za_u32u *)(o + 4) = v.y; *(za_u32u *)(o + 8) = v.z; *(za_u32u *)(o + 12) = v.w;
+                            o += 16; v = v2; rem = mlen - 16u;
+                        }
+                        if (rem & 16u) { *(za_u32u *)o = v.x; *(za_u32u *)(o + 4) = v.y; *(za_u32u *)(o + 8) = v.z; *(za_u32u *)(o + 12) = v.w; }
+                        else {
+                            if (rem & 8u) { *(za_u32u *)o = v.x; *(za_u32u *)(o + 4) = v.y; o += 8; v.x = v.z; v.y = v.w; }
+                            if (rem & 4u) { *(za_u32u *)o = v.x; o += 4; v.x = v.y; }
+                            if (rem & 2u) { *(za_u16u *)o = (uint16_t)v.x; o += 2; v.x >>= 16; }
+                            if (rem & 1u) *o = (uint8_t)v.x;
+                        }
+                    }
+                    // long or self-overlapping matches: the whole wave copies them, one at a time
+                    unsigned long long coop = __ballot(ready && !simple);
+                    while (coop) {
+                        const int j = __builtin_ctzll(coop);
+                        coop &= coop - 1ull;
+                        const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
+                        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
+                        const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
+                        const bool cfar = cd - cdist + TAIL < seg_start;      // (then cdist > cl: no overlap)
+                        uint8_t *o = img + TAIL + (cd - seg_start);
+                        const float rd = 1.0f / (float)cdist;
+                        for (uint32_t base = 0; base < cl; base += 64) {
+                            const uint32_t i = base + (uint32_t)lane;
+                            if (i < cl) {
+                                // byte i of a self-overlapping match is byte (i mod dist) of its period, which lies below it
+                                int k = (int)i;
+                                if (cdist < cl) {
+                                    k = (int)i - (int)cdist * (int)((float)i * rd);
+                                    if (k < 0) k += (int)cdist;
+                                    if (k >= (int)cdist) k -= (int)cdist;
+                                }
+                                o[i] = cfar ? dst[cd - cdist + (uint32_t)k] : (o - cdist)[k];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the image is LDS and one wave's LDS accesses execute in order: only the compiler must keep the order (no wait, no trip to L2)
+                    __builtin_amdgcn_wave_barrier();
+                    done = done || ready;
+                    pending = __ballot(!done);
+                }
+            }
+            // the finished segment: 32 bytes per lane, coalesced (its last, partial piece bytewise)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint32_t o = (uint32_t)lane * 32u;
+                if (o + 32u <= seg_len) {
+                    const uint4 a = *(const uint4 *)(img + TAIL + o), b2 = *(const uint4 *)(img + TAIL + o + 16);
+                    ZaU4u va = {a.x, a.y, a.z, a.w}, vb = {b2.x, b2.y, b2.z, b2.w};
+                    *(ZaU4u *)(dst + seg_start + o) = va; *(ZaU4u *)(dst + seg_start + o + 16) = vb;
+                } else for (uint32_t k = 0; k < 32u && o + k < seg_len; k++) dst[seg_start + o + k] = img[TAIL + o + k];
+            }
+            __threadfence_block();       // later segments read these bytes from memory
+        }
+    }
+#endif
+    // the CRC slice tables take the place of the segment image
+    __builtin_amdgcn_wave_barrier();
     uint32_t *crct = rows;
     static_assert(sizeof(uint32_t) * 64 * ZA_IROW >= 4096, "slice tables");
     for (int i = lane; i < 1024; i += 64) crct[i] = crc_slice4[i];
 
-    // ---- phase B: resolve matches in output order, 64 at a time.  A match is ready when its source lies
-    // below the first unresolved match of the group (the lowest pending one always is).  Each ready lane
-    // copies its own match: 16 bytes per batch as four unaligned dword loads followed by the stores (the
-    // loads of a batch are independent, so they overlap); a self-overlapping match (dist < len) reads its
-    // period byte-wise, which lies entirely below its destination.
-    const uint64_t out_room = out_cap - m.out_off;     // bytes of dst that may be touched
-#ifndef ZA_ABL_NO_B
-    for (int s = 0; s < nseg; s++) {
-        const uint32_t cnt = __shfl(nmatch, s, 64);
-        const uint32_t *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
-        uint32_t segpos = (uint32_t)s << ZA_SEG_SHIFT;             // output position behind the entries handled so far
-        uint32_t ent_next = (uint32_t)lane < cnt ? q[lane] : 0u;
-        for (uint32_t g = 0; g < cnt; g += 64) {
-            const bool hasq = g + (uint32_t)lane < cnt;
-            const uint32_t ent = ent_next;
-            ent_next = g + 64u + (uint32_t)lane < cnt ? q[g + 64u + lane] : 0u;      // the next group's entries travel while this group is resolved
-            const uint32_t l3 = (ent >> 15) & 0xFFu;
-            const bool has = hasq && l3 != 0u;                      // a real match (length field 0: a run of literals)
-            const uint32_t mlen = has ? l3 + 3u : 0u, mdist = (ent & 0x7FFFu) + 1u;
-            const uint32_t adv = !hasq ? 0u : has ? (ent >> 23) + mlen : ent;      // literals in front of the match + the match
-            const uint32_t incl = za_wave_incl_scan(adv);
-            const uint32_t mdst = segpos + incl - mlen;
-            segpos += (uint32_t)__shfl((int)incl, 63, 64);
-            bool done = !has;
-            unsigned long long pending = __ballot(!done);
-            // Which matches of this group write bytes that mine reads?  Destinations are disjoint and ascending with
-            // the lane, so they are the lanes [jlo, jhi): jhi = matches that start below the end of my source,
-            // jlo = matches that end at or below its start (two 6-step binary searches with shuffles; both counts
-            // are at most my own lane).  A match is ready as soon as none of those is pending -- the lowest
-            // pending one always is.  (Lanes without a match sit at their position with length 0: they order correctly.)
-            const uint32_t sdst = hasq ? mdst : 0xFFFFFFFFu, send = hasq ? mdst + mlen : 0xFFFFFFFFu;
-            const uint32_t src_a = mdst - mdist, src_b = src_a + (mlen < mdist ? mlen : mdist);
-            uint32_t jhi = 0, jlo = 0;
-#pragma unroll
-            for (uint32_t step = 32; step; step >>= 1) {
-                const uint32_t vd = (uint32_t)__shfl((int)sdst, (int)(jhi + step - 1u), 64);
-                const uint32_t ve = (uint32_t)__shfl((int)send, (int)(jlo + step - 1u), 64);
-                if (vd < src_b) jhi += step;
-                if (ve <= src_a) jlo += step;
-            }
-            const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
-            // short non-overlapping matches (nearly all) are copied by their own lane, at most two 16-byte batches;
-            // long or self-overlapping ones would keep the other 63 lanes waiting, so the whole wave copies those
-            const bool simple = mdist >= mlen && mlen <= 32u && (uint64_t)mdst + 32u <= out_room;
-            while (pending) {
-                const bool ready = !done && (pending & deps) == 0ull;
-                if (ready && simple) {
-                    // one or two unaligned 16-byte loads (what they read past the source's end is not used), then the bytes leave
-                    // as 16 / 8 / 4 / 2 / 1-byte stores: one load and about two stores for the typical match of 10 bytes
-                    uint8_t *o = dst + mdst;
-                    const uint8_t *sp = o - mdist;
-                    ZaU4u v = *(const ZaU4u *)sp;
-                    uint32_t rem = mlen;
-                    if (mlen > 16u) {
-                        const ZaU4u v2 = *(const ZaU4u *)(sp + 16);
-                        *(ZaU4u *)o = v;
-                        o += 16; v = v2; rem = mlen - 16u;
-                    }
-                    if (rem == 16u) *(ZaU4u *)o = v;
-                    else {
-                        if (rem & 8u) { *(za_u64u *)o = ((uint64_t)v.y << 32) | v.x; o += 8; v.x = v.z; v.y = v.w; }
-                        if (rem & 4u) { *(za_u32u *)o = v.x; o += 4; v.x = v.y; }
-                        if (rem & 2u) { *(za_u16u *)o = (uint16_t)v.x; o += 2; v.x >>= 16; }
-                        if (rem & 1u) *o = (uint8_t)v.x;
-                    }
-                }
-                unsigned long long coop = __ballot(ready && !simple);
-                while (coop) {
-                    const int j = __builtin_ctzll(coop);
-                    coop &= coop - 1ull;
-                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
-                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
-                    const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
-                    uint8_t *o = dst + cd;
-                    const uint8_t *sp = o - cdist;
-                    const float rd = 1.0f / (float)cdist;
-                    for (uint32_t base = 0; base < cl; base += 64) {
-                        const uint32_t i = base + (uint32_t)lane;
-                        if (i < cl) {
-                            // byte i of a self-overlapping match is byte (i mod dist) of its period, which lies below it
-                            int k = (int)i;
-                            if (cdist < cl) {
-                                k = (int)i - (int)cdist * (int)((float)i * rd);
-                                if (k < 0) k += (int)cdist;
-                                if (k >= (int)cdist) k -= (int)cdist;
-                            }
-                            o[i] = sp[k];
-                        }
-                    }
-                }
-                __threadfence_block();
-                done = done || ready;
-                pending = __ballot(!done);
-            }
-        }
-    }
-#endif
     // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
 #ifdef ZA_ABL_NO_CRC
     const uint32_t c = za_ld32(src + m.in_len);
