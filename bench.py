@@ -297,18 +297,23 @@ def main():
     launches_per_step = launches / steps
     alg_bytes = per_step_bytes / launches_per_step
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "za_k_" + ("inflate_indexed" if dom == "inflate" else dom),
+    roofline = {"bound": "hbm", "kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic_step, traffic_src = {}, None
     if os.path.exists(pmc):
         try:
-            pj = json.load(open(pmc))
-            per_unit = pj.get(roofline["kernel"])          # HBM bytes per unit from the PMC passes (profiles/run_pmc.sh)
+            pj = json.load(open(pmc))                      # HBM bytes per unit from the PMC passes (profiles/run_pmc.sh)
+            traffic_src = "PMC passes of build '%s' (profiles/pmc_traffic.json)" % pj.get("build", "?")
+            for k in ("chains", "search", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
+                if pj.get("za_k_" + k):
+                    traffic_step[k] = int(pj["za_k_" + k] * nblocks)
+            per_unit = pj.get(roofline["kernel"])
             if per_unit:
                 roofline["traffic"] = int(per_unit * nblocks / launches_per_step)
-                roofline["traffic_source"] = pj.get("build", "profiles/pmc_traffic.json")
+                roofline["traffic_source"] = traffic_src
         except Exception:
             pass
 
@@ -333,10 +338,13 @@ def main():
                                       "achieved": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
         "device_memory_in_use_GB": round((total_b - free_b) / 1e9, 1),
-        "roofline_inflate": {"bound": "hbm", "kernel": "za_k_inflate_indexed",
+        "roofline_inflate": {"bound": "hbm", "kernel": "za_k_inflate_members",
                              "achieved": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6, 2),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
+                             "frac": round((ms_len.value + size) / max(kt["inflate"][0] / steps, 1e-9) / 1e6 / HBM_PEAK_GBS, 5),
+                             "alg_bytes_per_launch": int(ms_len.value + size), "traffic": traffic_step.get("inflate_members"),
+                             "traffic_source": traffic_src},
+        "hbm_traffic_bytes_per_step": traffic_step or None,
     }
 
     # ---- CPU baseline on this box's host cores (rank 0, N = 1 only) ------------------------------------

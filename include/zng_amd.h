@@ -166,9 +166,9 @@ typedef struct {
 int zngamd_gzip_scan_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
                          zngamd_member *d_members, uint32_t max_members,
                          uint32_t *n_members, uint64_t *total_out);
-/* Pass 2: decode all members (one 512-thread workgroup per member, one thread per 256-byte chunk of the
- * index, the member's output built in LDS), verify CRC-32 and ISIZE.  d_status[m] receives a ZNGAMD_* code
- * per member. */
+/* Pass 2: decode all members (one wavefront per member, one lane per 2 KiB segment of the chunk index:
+ * symbols decoded through LDS tables, matches resolved in an LDS image of the segment), verify CRC-32 and
+ * ISIZE.  d_status[m] receives a ZNGAMD_* code per member. */
 int zngamd_gzip_inflate_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
                                     const zngamd_member *d_members, uint32_t n_members,
                                     void *d_out, uint64_t out_cap, int32_t *d_status);
@@ -247,6 +247,46 @@ int zngamd_gzip_members(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, uin
 int zngamd_gzip_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, uint32_t block_size,
                             int level, void *d_out, uint64_t out_cap, uint64_t *out_len,
                             uint32_t *n_members);
+
+/* ---- streaming: the zng_stream calling convention ------------------------------------------------
+ * What a binding of the reference swaps in for zng_deflateInit2 / zng_deflate / zng_deflateSetDictionary / zng_deflateCopy /
+ * zng_deflateEnd (zlib_ngmodule.c:394, :552, :743, :401, :811) and zng_inflateInit2 / zng_inflate / zng_inflateSetDictionary /
+ * zng_inflateCopy / zng_inflateEnd (:477, :667, :995, :1150, :446, :893): same fields, same flush values, same return codes
+ * (ZNGAMD_OK 0, ZNGAMD_STREAM_END 1, ZNGAMD_NEED_DICT 2, ZNGAMD_STREAM_ERROR -2, ZNGAMD_DATA_ERROR -3, ZNGAMD_MEM_ERROR -4,
+ * ZNGAMD_BUF_ERROR -5), `msg` set where zng_inflate sets it ("incorrect header check", "invalid window size", "incorrect data
+ * check", ...).  deflate collects input until a flush or 8 MiB and compresses it as one dictionary-chained engine batch
+ * (a piece of 8 MiB or more handed in at once is compressed where it lies); inflate keeps the compressed bytes from the last
+ * block header on, decodes from there (bit offset + 32 KiB of history) and hands out what is new; input the stream does not
+ * need yet comes back through avail_in, as with zng_inflate. */
+typedef struct zngamd_stream_state zngamd_stream_state;
+typedef struct zngamd_stream {
+    const uint8_t *next_in;   /* next input byte */
+    uint32_t avail_in;        /* bytes available at next_in */
+    uint64_t total_in;
+    uint8_t *next_out;        /* next output byte goes here */
+    uint32_t avail_out;       /* room at next_out */
+    uint64_t total_out;
+    const char *msg;          /* last error message, NULL if none */
+    zngamd_stream_state *state;
+    uint32_t adler;           /* Adler-32 (zlib) or CRC-32 (gzip) of the uncompressed data so far; DICTID after ZNGAMD_NEED_DICT */
+    uint32_t reserved;
+} zngamd_stream;
+#define ZNGAMD_NO_FLUSH 0
+#define ZNGAMD_PARTIAL_FLUSH 1
+#define ZNGAMD_SYNC_FLUSH 2
+#define ZNGAMD_FULL_FLUSH 3
+#define ZNGAMD_FINISH 4
+#define ZNGAMD_BLOCK 5
+int zngamd_stream_deflate_init(zngamd_ctx *ctx, zngamd_stream *strm, int level, int method, int wbits, int mem_level, int strategy);
+int zngamd_stream_deflate(zngamd_stream *strm, int flush);
+int zngamd_stream_deflate_set_dictionary(zngamd_stream *strm, const uint8_t *dict, uint32_t len);
+int zngamd_stream_deflate_copy(zngamd_stream *dst, const zngamd_stream *src);
+int zngamd_stream_deflate_end(zngamd_stream *strm);
+int zngamd_stream_inflate_init(zngamd_ctx *ctx, zngamd_stream *strm, int wbits);
+int zngamd_stream_inflate(zngamd_stream *strm, int flush);
+int zngamd_stream_inflate_set_dictionary(zngamd_stream *strm, const uint8_t *dict, uint32_t len);
+int zngamd_stream_inflate_copy(zngamd_stream *dst, const zngamd_stream *src);
+int zngamd_stream_inflate_end(zngamd_stream *strm);
 
 /* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU (gzip_ng_threaded.py:233-246 gives every worker thread a
  * compressor, :316-321 deals the blocks round-robin, :382-398 drains them in order; here every rank owns a contiguous block

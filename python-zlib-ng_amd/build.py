@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "zlib_ng_amd", "libzng_amd.so")
 SOURCES = ["zng_amd.hip"]
-DEPS = ["zng_amd.hip", "za_common.h", "za_crc.h", "za_deflate.hip", "za_inflate.hip", "za_checksum.hip",
+DEPS = ["zng_amd.hip", "zng_stream.hip", "za_common.h", "za_crc.h", "za_deflate.hip", "za_inflate.hip", "za_checksum.hip",
         os.path.join("..", "..", "include", "zng_amd.h")]
 
 

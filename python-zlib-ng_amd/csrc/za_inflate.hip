@@ -982,8 +982,11 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
 }
 
 #define ZA_MATCHQ_PER_SEG 688      // queue entries per segment: >= 2048/4 matches + skip entries, a multiple of 4
-#define ZA_IROW 17                 // dwords per lane row of staged input: 4 x 16 bytes + 1 (odd stride); 48 bytes are consumed per row
-#define ZA_IROW_BYTES 48
+#ifndef ZA_IROW_LOADS
+#define ZA_IROW_LOADS 4            // 16-byte loads per row of staged input
+#endif
+#define ZA_IROW (4 * ZA_IROW_LOADS + 1)            // dwords per lane row (+ 1: odd stride)
+#define ZA_IROW_BYTES (16 * ZA_IROW_LOADS - 16)    // bytes consumed per row; the last 16 are look-ahead (a token takes up to 37 bits)
 #define ZA_ML_BITS 10              // literal/length table: every code of an indexed member is at most 10 bits long (ZA_LIMIT_L)
 #define ZA_MD_BITS 9               // distance table (ZA_LIMIT_D)
 
@@ -1135,25 +1138,25 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
             qb0 = k == 0u ? ent : qb0; qb1 = k == 1u ? ent : qb1; qb2 = k == 2u ? ent : qb2;
             nmatch++;
         };
-        uint4 pre[4];
+        uint4 pre[ZA_IROW_LOADS];
         auto prefetch = [&](uint32_t r) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < ZA_IROW_LOADS; j++) {
                 const uint8_t *p = org + (size_t)ZA_IROW_BYTES * r + 16u * (unsigned)j;
                 pre[j] = make_uint4(0, 0, 0, 0);
                 if (!done && p >= in && p + 16 <= lim) pre[j] = *(const uint4 *)p;
             }
-            if (!done && (org + (size_t)ZA_IROW_BYTES * r < in || org + (size_t)ZA_IROW_BYTES * r + 64 > lim)) {
+            if (!done && (org + (size_t)ZA_IROW_BYTES * r < in || org + (size_t)ZA_IROW_BYTES * r + 16 * ZA_IROW_LOADS > lim)) {
                 // a row that reaches over an end of the caller's buffer (first / last member only): byte by byte
-                uint32_t t[16];
+                uint32_t t[4 * ZA_IROW_LOADS];
 #pragma unroll 1
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < 4 * ZA_IROW_LOADS; k++) {
                     uint32_t v = 0;
                     for (int q = 0; q < 4; q++) { const uint8_t *p = org + (size_t)ZA_IROW_BYTES * r + 4u * (unsigned)k + (unsigned)q; if (p >= in && p < lim) v |= (uint32_t)*p << (8 * q); }
                     t[k] = v;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) pre[j] = make_uint4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+                for (int j = 0; j < ZA_IROW_LOADS; j++) pre[j] = make_uint4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
             }
         };
         prefetch(0);
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
             if (__ballot(!done) == 0ull) break;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; j++) { myrow[4 * j] = pre[j].x; myrow[4 * j + 1] = pre[j].y; myrow[4 * j + 2] = pre[j].z; myrow[4 * j + 3] = pre[j].w; }
+            for (int j = 0; j < ZA_IROW_LOADS; j++) { myrow[4 * j] = pre[j].x; myrow[4 * j + 1] = pre[j].y; myrow[4 * j + 2] = pre[j].z; myrow[4 * j + 3] = pre[j].w; }
             __builtin_amdgcn_wave_barrier();
             prefetch(r + 1);
             const uint32_t row_bit0 = org_bit + (uint32_t)ZA_IROW_BYTES * 8u * r;

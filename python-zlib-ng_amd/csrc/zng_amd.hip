@@ -51,7 +51,7 @@ struct zngamd_ctx {
     std::mutex mu;
     // constant tables
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
-    uint32_t *d_crc_slice4 = nullptr, *d_x256 = nullptr, *d_x8 = nullptr;     // tables of za_k_inflate_indexed
+    uint32_t *d_crc_slice4 = nullptr;                                         // CRC slice-by-4 table of za_k_inflate_members
     // deflate workspaces (per chunk of units)
     uint32_t chunk_units = 16384;                // units per launch: 1.4 MiB of workspace each (23 GB); fewer, fuller launches
     DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
@@ -133,20 +133,12 @@ int zngamd_ctx_create(int device, zngamd_ctx **out)
         hipMemcpy(c->d_x8k, x8k, sizeof x8k, hipMemcpyHostToDevice) != hipSuccess) {
         zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
     }
-    {   // tables of the indexed-member decoder: CRC slice-by-4, x^(8*256*k) for k < 512, x^(8*k) for k <= 256
-        std::vector<uint32_t> s4(1024), x256(512), x8(257);
+    {   // CRC slice-by-4 table of the indexed-member decoder
+        std::vector<uint32_t> s4(1024);
         for (int i = 0; i < 256; i++) s4[i] = tab[i];
         for (int t = 1; t < 4; t++) for (int i = 0; i < 256; i++) s4[256 * t + i] = (s4[256 * (t - 1) + i] >> 8) ^ tab[s4[256 * (t - 1) + i] & 0xFF];
-        uint32_t xs = 0x80000000u;
-        for (int k = 0; k <= 256; k++) { x8[k] = xs; xs = za_multmodp(xs, 0x00800000u); }
-        const uint32_t step = x8[256];
-        xs = 0x80000000u;
-        for (int k = 0; k < 512; k++) { x256[k] = xs; xs = za_multmodp(xs, step); }
-        if (hipMalloc((void **)&c->d_crc_slice4, 4096) != hipSuccess || hipMalloc((void **)&c->d_x256, 2048) != hipSuccess ||
-            hipMalloc((void **)&c->d_x8, 257 * 4) != hipSuccess ||
-            hipMemcpy(c->d_crc_slice4, s4.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(c->d_x256, x256.data(), 2048, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(c->d_x8, x8.data(), 257 * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMalloc((void **)&c->d_crc_slice4, 4096) != hipSuccess ||
+            hipMemcpy(c->d_crc_slice4, s4.data(), 4096, hipMemcpyHostToDevice) != hipSuccess) {
             zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
         }
     }
@@ -170,8 +162,6 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
     if (c->d_crc_slice4) (void)hipFree(c->d_crc_slice4);
-    if (c->d_x256) (void)hipFree(c->d_x256);
-    if (c->d_x8) (void)hipFree(c->d_x8);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1741,6 +1731,8 @@ int zngamd_comm_barrier(zngamd_comm *m)
 }
 
 }  // extern "C"
+
+#include "zng_stream.hip"
 
 #ifdef ZA_PS_STATS
 // profiling build only (profiles/ps_stats.sh): counters of the parallel sweep, read and cleared

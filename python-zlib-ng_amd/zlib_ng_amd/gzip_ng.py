@@ -115,7 +115,8 @@ def decompress(data):
         mv = mv.cast("B") if (mv.format != "B" or mv.ndim != 1) else mv
         ctx = zlib_ng._ctx()
         isize = int.from_bytes(mv[mv.nbytes - 4:], "little")
-        cap = max(1 << 16, isize + 64, 4 * mv.nbytes)
+        # (ISIZE is untrusted input: never more than what deflate can expand this many bytes to)
+        cap = max(1 << 16, min(isize, 1032 * mv.nbytes) + 64, 4 * mv.nbytes)
         for _ in range(4):
             code, out, _n = ctx.gunzip(mv, cap)
             if code == 0:

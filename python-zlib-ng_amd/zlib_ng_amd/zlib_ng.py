@@ -326,106 +326,159 @@ class _ParallelCompress:
 _ParallelCompress.__module__ = "zlib_ng"
 
 
-# ---- compressobj: buffering writer ------------------------------------------------------------------------
-class _Compress:
-    """Incremental compressor with zlib.compressobj's surface (compress / flush).  Input is collected
-    and handed to the engine in large dictionary-chained batches; every batch ends on a sync-flush
-    boundary, so the concatenation is one valid deflate stream."""
+# ---- streaming objects: thin bindings of zngamd_stream_* (include/zng_amd.h), laid out like the reference's C methods ----------
+import ctypes as _C
 
-    _BATCH = 8 << 20
+
+class _ZStream(_C.Structure):                # zngamd_stream
+    _fields_ = [("next_in", _C.c_void_p), ("avail_in", _C.c_uint32), ("total_in", _C.c_uint64),
+                ("next_out", _C.c_void_p), ("avail_out", _C.c_uint32), ("total_out", _C.c_uint64),
+                ("msg", _C.c_char_p), ("state", _C.c_void_p), ("adler", _C.c_uint32), ("reserved", _C.c_uint32)]
+
+
+def _slib():
+    L = _lib.load()
+    if not getattr(L, "_zs_ready", False):
+        P, vp = _C.POINTER(_ZStream), _C.c_void_p
+        L.zngamd_stream_deflate_init.argtypes = [vp, P, _C.c_int, _C.c_int, _C.c_int, _C.c_int, _C.c_int]
+        L.zngamd_stream_deflate.argtypes = [P, _C.c_int]
+        L.zngamd_stream_deflate_set_dictionary.argtypes = [P, vp, _C.c_uint32]
+        L.zngamd_stream_deflate_copy.argtypes = [P, P]
+        L.zngamd_stream_deflate_end.argtypes = [P]
+        L.zngamd_stream_inflate_init.argtypes = [vp, P, _C.c_int]
+        L.zngamd_stream_inflate.argtypes = [P, _C.c_int]
+        L.zngamd_stream_inflate_set_dictionary.argtypes = [P, vp, _C.c_uint32]
+        L.zngamd_stream_inflate_copy.argtypes = [P, P]
+        L.zngamd_stream_inflate_end.argtypes = [P]
+        L._zs_ready = True
+    return L
+
+
+def _stream_error(zst, err, while_):
+    # zlib_error(), zlib_ngmodule.c:68-95: the stream's own message first, then the fallbacks per code
+    if err == _lib.MEM_ERROR:
+        return MemoryError("Can't allocate memory for (de)compression object" if not zst.msg else zst.msg.decode("utf-8", "replace"))
+    return _zerr(err, while_, zst.msg.decode("utf-8", "replace") if zst.msg else None)
+
+
+class _OutBuf:
+    """Growing output buffer of a streaming call (arrange_output_buffer, zlib_ngmodule.c:142-197): starts at `length`,
+    doubles, never beyond `limit`."""
+
+    def __init__(self, zst, length, limit=None):
+        self.zst, self.limit = zst, limit
+        self.buf = bytearray(max(1, length if limit is None else min(length, max(limit, 1))))
+        self.used = 0
+        self._point()
+
+    def _point(self):
+        room = len(self.buf) - self.used
+        self.hold = (_C.c_char * len(self.buf)).from_buffer(self.buf)
+        self.zst.next_out = _C.addressof(self.hold) + self.used
+        self.zst.avail_out = min(room, 0xFFFFFFFF)
+
+    def sync(self):
+        self.used = (self.zst.next_out or _C.addressof(self.hold)) - _C.addressof(self.hold)
+
+    def grow(self):
+        """Room for more output; False when the limit is reached."""
+        self.sync()
+        if self.used < len(self.buf):
+            self._point()
+            return True
+        if self.limit is not None and len(self.buf) >= self.limit:
+            return False
+        new = len(self.buf) * 2
+        if self.limit is not None:
+            new = min(new, self.limit)
+        del self.hold
+        self.buf.extend(bytes(new - len(self.buf)))
+        self._point()
+        return True
+
+    def result(self):
+        self.sync()
+        del self.hold
+        self.zst.next_out = None
+        self.zst.avail_out = 0
+        return bytes(self.buf[:self.used])
+
+
+_CHUNK = 1 << 30          # input pieces per engine call (arrange_input_buffer cuts at UINT32_MAX, :142-147)
+
+
+class _Compress:
+    """zlib.compressobj look-alike (zlib_ngmodule.c:376-430, :530-575, :718-850) on zngamd_stream_deflate*."""
 
     def __init__(self, level, method, wbits, memLevel, strategy, zdict):
-        try:
-            _check_level(level)
-        except error:
-            raise ValueError("Invalid initialization option") from None
-        if method != DEFLATED or not (1 <= memLevel <= 9) or strategy not in (0, 1, 2, 3, 4):
-            raise ValueError("Invalid initialization option")
-        try:
-            self._kind, self._wb = _container(wbits)
-        except error:
-            raise ValueError("Invalid initialization option") from None
-        self._level = level
-        self._pending = bytearray()
-        self._tail = bytes(_view(zdict))[-32768:] if zdict is not None else b""
-        self._started = False
-        self._finished = False
-        self._crc, self._adler, self._size = 0, 1, 0
+        L = _slib()
+        self._zst = _ZStream()
         self._lock = _threading.Lock()
-        # zlib container with a preset dictionary: FDICT + DICTID in the header (deflateSetDictionary, zlib_ngmodule.c:401)
-        self._dictid = adler32(_view(zdict)) if (zdict is not None and self._kind == "zlib") else None
+        self._init = False
+        if not isinstance(level, int):
+            raise TypeError(f"an integer is required (got type {type(level).__name__})")
+        err = L.zngamd_stream_deflate_init(_ctx().h, _C.byref(self._zst), level, method, wbits, memLevel, strategy)
+        if err == _lib.MEM_ERROR:
+            raise MemoryError("Can't allocate memory for compression object")
+        if err != _lib.OK:
+            raise ValueError("Invalid initialization option")
+        self._init = True
+        self._finished = False
+        if zdict is not None:
+            z = _view(zdict)
+            p, keep = _lib._addr(z)
+            err = L.zngamd_stream_deflate_set_dictionary(_C.byref(self._zst), p, z.nbytes)
+            if err == _lib.STREAM_ERROR:
+                raise ValueError("Invalid dictionary")
+            if err != _lib.OK:
+                raise ValueError("deflateSetDictionary()")
 
-    def _emit(self, final):
-        out = []
-        if not self._started:
-            self._started = True
-            if self._kind == "zlib":
-                out.append(_zlib_header(self._level, self._wb, self._dictid))
-            elif self._kind == "gzip":
-                out.append(_gzip_header(self._level))
-        data = bytes(self._pending)
-        self._pending.clear()
-        if data or final:
-            ctx = _ctx()
-            buf = self._tail + data
-            flags = (_lib.FLAG_FINAL if final else 0) | ((self._wb & 15) << 8)      # ZNGAMD_FLAG_WBITS: stay inside the declared window
-            outs, crcs, _ = ctx.deflate_blocks(buf, [(len(self._tail), len(data), len(self._tail), flags)],
-                                               self._level, len(data) + len(data) // 8 + (len(data) // 131072 + 2) * 64)
-            out.append(outs[0])
-            self._crc = crc32_combine(self._crc, crcs[0], len(data))
-            if self._kind == "zlib" and data:
-                self._adler = ctx.adler32(data, self._adler)
-            self._size += len(data)
-            self._tail = buf[-32768:]
-        if final:
-            self._finished = True
-            if self._kind == "zlib":
-                out.append(_struct.pack(">I", self._adler))
-            elif self._kind == "gzip":
-                out.append(_struct.pack("<II", self._crc, self._size & 0xFFFFFFFF))
-        return b"".join(out)
+    def __del__(self):
+        try:
+            if self._init:
+                _slib().zngamd_stream_deflate_end(_C.byref(self._zst))
+                self._init = False
+        except Exception:
+            pass
 
-    def _emit_direct(self, view):
-        """A large piece with nothing pending: its first 128 KiB go through a small buffer behind the dictionary tail, the
-        rest is compressed where it lies in the caller's buffer (each unit primed by the bytes in front of it)."""
-        out = []
-        if not self._started:
-            out.append(self._emit(False))                   # header only (nothing pending)
-        ctx = _ctx()
-        n = view.nbytes
-        first = min(131072, n)
-        wflag = (self._wb & 15) << 8
-        head = self._tail + bytes(view[:first])
-        outs, crcs, _ = ctx.deflate_blocks(head, [(len(self._tail), first, len(self._tail), wflag)], self._level, first + first // 8 + 256)
-        out.append(outs[0])
-        self._crc = crc32_combine(self._crc, crcs[0], first)
-        # the engine's block length is a u32: the rest goes in pieces of at most 1 GiB (whole units), each primed by the 32 KiB
-        # in front of it in the caller's buffer (the reference loops in UINT32_MAX pieces, zlib_ngmodule.c:142-147)
-        pos = first
-        while pos < n:
-            ln = min(n - pos, 1 << 30)
-            packed, crcs, _, _ = ctx.deflate_blocks(view, [(pos, ln, 32768, wflag)], self._level,
-                                                    ln + ln // 8 + (ln // 131072 + 2) * 64, joined=True)
-            out.append(packed)
-            self._crc = crc32_combine(self._crc, crcs[0], ln)
+    @property
+    def _crc(self):
+        """CRC-32 of everything compressed so far (complete once the object has been flushed): gzip_ng.GzipNGFile takes its
+        trailer value from here instead of sending every write() to the GPU a second time."""
+        return self._zst.adler
+
+    def _run(self, view, flush, while_):
+        """Feed `view` (may be None) and collect what deflate hands out; with Z_FINISH until the stream has ended."""
+        L, zst = _slib(), self._zst
+        out = _OutBuf(zst, DEF_BUF_SIZE)
+        n = view.nbytes if view is not None else 0
+        base, keep = _lib._addr(view) if n else (None, None)
+        pos = 0
+        while True:
+            ln = min(n - pos, _CHUNK)
+            last = pos + ln >= n
+            zst.next_in = (base.value + pos) if ln else None
+            zst.avail_in = ln
+            mode = flush if last else Z_NO_FLUSH
+            while True:
+                err = L.zngamd_stream_deflate(_C.byref(zst), mode)
+                if err not in (_lib.OK, _lib.STREAM_END, _lib.BUF_ERROR):
+                    out.result()
+                    raise _stream_error(zst, err, while_)
+                if zst.avail_out != 0 and zst.avail_in == 0:
+                    break
+                out.grow()
             pos += ln
-        if self._kind == "zlib":
-            self._adler = ctx.adler32(view, self._adler)
-        self._size += n
-        self._tail = bytes(view[-32768:]) if n >= 32768 else (self._tail + bytes(view))[-32768:]
-        return b"".join(out)
+            if last:
+                break
+        return out.result()
 
     def compress(self, data, /):
         with self._lock:
+            view = _view(data)
             if self._finished:
                 raise _zerr(_lib.STREAM_ERROR, "while compressing data")
-            view = _view(data)
-            if not self._pending and view.nbytes >= self._BATCH and view.contiguous:
-                return self._emit_direct(view)
-            self._pending += view
-            if len(self._pending) >= self._BATCH:
-                return self._emit(False)
-            return b""
+            return self._run(view, Z_NO_FLUSH, "while compressing data")
 
     def flush(self, mode=Z_FINISH, /):
         mode = _operator.index(mode)
@@ -434,21 +487,27 @@ class _Compress:
                 return b""
             if self._finished or not (0 <= mode <= Z_BLOCK):       # deflate() answers Z_STREAM_ERROR to both
                 raise _zerr(_lib.STREAM_ERROR, "while flushing")
-            return self._emit(mode == Z_FINISH)
+            res = self._run(None, mode, "while flushing")
+            if mode == Z_FINISH:
+                self._finished = True
+            return res
 
     def copy(self):
-        """zlib_Compress_copy_impl (zlib_ngmodule.c:790-850): an independent compressor in the same state.  All stream
-        state lives here (pending input, 32 KiB dictionary tail, running checksums), so the copy is exact."""
+        """zlib_Compress_copy_impl (zlib_ngmodule.c:795-850): an independent compressor in the same state."""
         with self._lock:
             if self._finished:
                 raise ValueError("Inconsistent stream state")
             o = _Compress.__new__(_Compress)
-            o._kind, o._wb, o._level, o._dictid = self._kind, self._wb, self._level, self._dictid
-            o._pending = bytearray(self._pending)
-            o._tail = self._tail
-            o._started, o._finished = self._started, self._finished
-            o._crc, o._adler, o._size = self._crc, self._adler, self._size
+            o._zst = _ZStream()
             o._lock = _threading.Lock()
+            o._init = False
+            err = _slib().zngamd_stream_deflate_copy(_C.byref(o._zst), _C.byref(self._zst))
+            if err == _lib.MEM_ERROR:
+                raise MemoryError("Can't allocate memory for compression object")
+            if err != _lib.OK:
+                raise ValueError("Inconsistent stream state")
+            o._init = True
+            o._finished = False
             return o
 
     __copy__ = copy
@@ -465,212 +524,150 @@ def compressobj(level=Z_DEFAULT_COMPRESSION, method=DEFLATED, wbits=MAX_WBITS, m
     return _Compress(level, method, wbits, memLevel, strategy, zdict)
 
 
-# ---- incremental inflate: decompressobj / _ZlibDecompressor (zlib_ngmodule.c:456-502, :622-716, :1040-1438) ----------
-class _InflateCore:
-    """Block-resumable inflate on the GPU engine.  Input is kept from the last deflate-block header onward;
-    every call decodes from there (start bit + up to 32 KiB of history) with the sequential wavefront decoder
-    (`zngamd_inflate_resume`) and hands out only what is new.  Container header / trailer bytes are handled
-    here; payload checksums are computed by the engine."""
+class _InflateStream:
+    """Shared part of the two decompressor objects: the zngamd_stream, its dictionary, the inflate loop."""
 
-    def __init__(self, wbits, zdict):
-        if wbits == 0 or 8 <= wbits <= 15:
-            self.kind = "zlib"
-        elif -15 <= wbits <= -8:
-            self.kind = "raw"
-        elif 24 <= wbits <= 31 or wbits == 16:
-            self.kind = "gzip"
-        elif 40 <= wbits <= 47 or wbits == 32:
-            self.kind = "auto"
-        else:
+    def _open(self, wbits, zdict):
+        L = _slib()
+        if not isinstance(wbits, int):
+            raise TypeError(f"'{type(wbits).__name__}' object cannot be interpreted as an integer")
+        self._zst = _ZStream()
+        self._init = False
+        self._zdict = bytes(_view(zdict)) if zdict is not None else b""
+        err = L.zngamd_stream_inflate_init(_ctx().h, _C.byref(self._zst), wbits)
+        if err == _lib.MEM_ERROR:
+            raise MemoryError("Can't allocate memory for decompression object")
+        if err != _lib.OK:
             raise ValueError("Invalid initialization option")
-        self.wbits = wbits
-        self.zdict = bytes(_view(zdict)) if zdict is not None else b""
-        self.window = self.zdict[-32768:] if self.kind == "raw" else b""
-        self.buf = bytearray()
-        self.start_bit = 0
-        self.skip = 0
-        self.header_done = self.kind == "raw"
-        self.deflate_done = False
-        self.eof = False
-        self.unused = b""
-        self.check = 1                    # running Adler-32 (zlib) or CRC-32 (gzip)
-        self.total = 0
+        self._init = True
+        if self._zdict and wbits < 0:              # raw stream: the dictionary is its history from the start (:490-500)
+            self._set_zdict()
 
-    def clone(self):
-        import copy as _copy
-        o = _copy.copy(self)
-        o.buf = bytearray(self.buf)
-        return o
+    def _set_zdict(self):
+        err = _slib().zngamd_stream_inflate_set_dictionary(_C.byref(self._zst), _C.cast(_C.c_char_p(self._zdict), _C.c_void_p), len(self._zdict))
+        if err != _lib.OK:
+            raise _stream_error(self._zst, err, "while setting zdict")
 
-    def _header(self):
-        W = "while decompressing data"
-        b = self.buf
-        if self.kind == "auto" and len(b) >= 2:
-            self.kind = "gzip" if b[:2] == b"\x1f\x8b" else "zlib"
-            self.wbits -= 32                 # 0: take the window from the zlib header
-        if self.kind == "zlib":
-            if len(b) < 2:
-                return False
-            cmf, flg = b[0], b[1]
-            if (cmf & 15) != 8 or ((cmf << 8) | flg) % 31:
-                raise _zerr(_lib.DATA_ERROR, W, "incorrect header check")
-            if (cmf >> 4) + 8 > (self.wbits if self.wbits else 15):
-                raise _zerr(_lib.DATA_ERROR, W, "invalid window size")
-            need = 2
-            if flg & 0x20:
-                if len(b) < 6:
-                    return False
-                if not self.zdict:
-                    raise _zerr(_lib.NEED_DICT, W)
-                if _struct.unpack(">I", bytes(b[2:6]))[0] != adler32(self.zdict):
-                    raise _zerr(_lib.DATA_ERROR, "while setting zdict")
-                self.window = self.zdict[-32768:]
-                need = 6
-            del b[:need]
-            self.check = 1
-        elif self.kind == "gzip":
-            if len(b) >= 4 and b[:2] == b"\x1f\x8b" and b[2] == 8 and b[3] & 0xE0:
-                raise _zerr(_lib.DATA_ERROR, W, "unknown header flags set")
-            try:
-                start = _parse_gzip_header(bytes(b))
-            except EOFError:
-                return False
-            except BadGzipFile as e:
-                msg = str(e)
-                raise _zerr(_lib.DATA_ERROR, W, "unknown compression method" if msg.startswith("Unknown compression") else
-                            "header crc mismatch" if msg.startswith("Corrupted gzip header") else "incorrect header check") from None
-            del b[:start]
-            self.check = 0
-        else:
-            return False
-        self.header_done = True
-        return True
+    def _close(self):
+        if getattr(self, "_init", False):
+            _slib().zngamd_stream_inflate_end(_C.byref(self._zst))
+            self._init = False
 
-    def _trailer(self):
-        need = {"zlib": 4, "gzip": 8, "raw": 0}[self.kind]
-        W = "while decompressing data"
-        if self.kind == "gzip" and 4 <= len(self.buf) < 8:
-            # inflate() compares the CRC as soon as its four bytes are there, before ISIZE has arrived
-            if _struct.unpack("<I", bytes(self.buf[:4]))[0] != self.check:
-                raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
-        if len(self.buf) < need:
-            return
-        t = bytes(self.buf[:need])
-        if self.kind == "zlib" and _struct.unpack(">I", t)[0] != self.check:
-            raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
-        if self.kind == "gzip":
-            crc, isize = _struct.unpack("<II", t)
-            if crc != self.check:
-                raise _zerr(_lib.DATA_ERROR, W, "incorrect data check")
-            if isize != self.total & 0xFFFFFFFF:
-                raise _zerr(_lib.DATA_ERROR, W, "incorrect length check")
-        self.unused = bytes(self.buf[need:])
-        self.buf.clear()
-        self.eof = True
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
 
-    def feed(self, data, limit=None):
-        """Append `data`, decode, return the new output (at most `limit` bytes when given) and the number of
-        input bytes of this call that zlib would report as still unconsumed."""
-        if self.eof:
-            self.unused += bytes(data)
-            return b"", 0
-        self.buf += data
-        if not self.header_done and not self._header():
-            return b"", 0
-        if self.deflate_done:
-            self._trailer()
-            return b"", 0
-        ctx = _ctx()
-        want = None if limit is None else self.skip + limit
-        cap = max(1 << 16, 8 * len(self.buf) + self.skip)
-        if want is not None and want < cap:
-            cap = want
+    def _inflate(self, view, start_len, limit):
+        """The double loop of zlib_Decompress_decompress_impl / decompress_buf (:622-716, :1102-1195): feed `view` in pieces,
+        grow the output up to `limit` (None: no limit).  -> (output bytes, last return code, bytes of `view` not consumed)."""
+        L, zst = _slib(), self._zst
+        out = _OutBuf(zst, start_len, limit)
+        n = view.nbytes
+        base, keep = _lib._addr(view) if n else (None, None)
+        pos, err = 0, _lib.OK
+        full = False
         while True:
-            code, out, in_bits, bb, bo = ctx.inflate_resume(bytes(self.buf), self.start_bit, self.window, max(cap, 1))
-            if code == _lib.E_OVERFLOW and (want is None or cap < want):      # our guess was short, not the caller's limit
-                cap = cap * 4 if want is None else min(cap * 4, want)
-                continue
-            break
-        new = out[self.skip:]
-        if code == _lib.DATA_ERROR:
-            raise _zerr(_lib.DATA_ERROR, "while decompressing data")
-        if new:
-            self.check = crc32(new, self.check) if self.kind == "gzip" else adler32(new, self.check) if self.kind == "zlib" else 0
-            self.total += len(new)
-        left = 0
-        if code == _lib.STREAM_END:
-            del self.buf[:(in_bits + 7) // 8]
-            self.deflate_done = True
-            self.skip = 0
-            self._trailer()
-        elif code == _lib.E_OVERFLOW:
-            # output limit reached in the middle of a block: report the input beyond the stop position as unconsumed (it
-            # stays buffered here as well) and move the resume point to the header of the block the decoder stopped in,
-            # so that the next call re-decodes at most that one block's delivered part instead of the whole buffer
-            left = max(0, len(self.buf) - (in_bits + 7) // 8)
-            self.window = (self.window + out[:bo])[-32768:]
-            del self.buf[:bb // 8]
-            self.start_bit = bb & 7
-            self.skip = len(out) - bo
-        else:                                   # input ran out: move the resume point to the last block header
-            self.window = (self.window + out[:bo])[-32768:]
-            del self.buf[:bb // 8]
-            self.start_bit = bb & 7
-            self.skip = len(out) - bo
-        return new, left
+            ln = min(n - pos, _CHUNK)
+            zst.next_in = (base.value + pos) if ln else None
+            zst.avail_in = ln
+            while True:
+                if not out.grow():
+                    full = True
+                    break
+                err = L.zngamd_stream_inflate(_C.byref(zst), Z_SYNC_FLUSH)
+                if err == _lib.NEED_DICT:
+                    if self._zdict:
+                        self._set_zdict()
+                        continue                   # "repeat the call to inflate"
+                    out.result()
+                    raise _zerr(_lib.NEED_DICT, "while decompressing data")
+                if err not in (_lib.OK, _lib.BUF_ERROR, _lib.STREAM_END):
+                    out.result()
+                    raise _stream_error(zst, err, "while decompressing data")
+                if zst.avail_out != 0 or err == _lib.STREAM_END:
+                    break
+            pos += ln - zst.avail_in
+            if full or err == _lib.STREAM_END or pos >= n or zst.avail_in:
+                break
+        return out.result(), err, n - pos
 
 
-class _Decompress:
+class _Decompress(_InflateStream):
     """zlib.decompressobj look-alike (zlib_ngmodule.c:622-1037): decompress(data, max_length), flush, copy,
     unused_data, unconsumed_tail, eof."""
 
     def __init__(self, wbits=MAX_WBITS, zdict=b""):
-        self._core = _InflateCore(wbits, zdict)
         self._lock = _threading.Lock()
         self.unused_data = b""
         self.unconsumed_tail = b""
         self.eof = False
-        self._ahead = 0          # bytes at the end of the core buffer that were handed back as unconsumed_tail
         self._ended = False      # flush() after the end of the stream releases it (inflateEnd): no copy() afterwards
+        self._open(wbits, zdict)
 
-    def _sync(self):
-        self.eof = self._core.eof
-        self.unused_data = self._core.unused
+    def _save_unconsumed(self, view, left, err):
+        # save_unconsumed_input, zlib_ngmodule.c:579-620
+        tail = bytes(view[view.nbytes - left:]) if left else b""
+        if err == _lib.STREAM_END:
+            if tail:
+                self.unused_data += tail
+            self.unconsumed_tail = b""
+        else:
+            self.unconsumed_tail = tail
 
     def decompress(self, data, /, max_length=0):
-        data = bytes(_view(data))
+        view = _view(data)
         max_length = _ssize(max_length)
         if max_length < 0:
             raise ValueError("max_length must be non-negative")
         with self._lock:
-            if self._ahead:                     # the caller feeds unconsumed_tail back: already buffered
-                data = data[min(self._ahead, len(data)):]
-                self._ahead = 0
-            out, left = self._core.feed(data, max_length or None)
-            self.unconsumed_tail = bytes(self._core.buf[len(self._core.buf) - left:]) if left else b""
-            self._ahead = left
-            self._sync()
+            if self.eof:                        # inflate() after the end: nothing is consumed, nothing comes out
+                if view.nbytes:
+                    self.unused_data += bytes(view)
+                self.unconsumed_tail = b""
+                return b""
+            limit = max_length or None
+            out, err, left = self._inflate(view, min(DEF_BUF_SIZE, max_length) if max_length else DEF_BUF_SIZE, limit)
+            self._save_unconsumed(view, left, err)
+            if err == _lib.STREAM_END:
+                self.eof = True
             return out
 
     def flush(self, length=DEF_BUF_SIZE, /):
-        if _ssize(length) <= 0:
+        length = _ssize(length)
+        if length <= 0:
             raise ValueError("length must be greater than zero")
         with self._lock:
-            self._ahead = 0
-            out, _ = self._core.feed(b"", None)
-            self.unconsumed_tail = b""
-            self._sync()
-            self._ended = self._ended or self.eof
+            view = _view(self.unconsumed_tail)
+            if self.eof:                        # inflateEnd on a finished stream: no copy() afterwards
+                self._ended = True
+                self._close()
+                return b""
+            out, err, left = self._inflate(view, length, None)
+            self._save_unconsumed(view, left, err)
+            if err == _lib.STREAM_END:
+                self.eof = True
+                self._ended = True
+                self._close()
             return out
 
     def copy(self):
         with self._lock:
-            if self._ended:
+            if self._ended or not self._init:
                 raise ValueError("Inconsistent stream state")
             o = _Decompress.__new__(_Decompress)
-            o._core = self._core.clone()
             o._lock = _threading.Lock()
-            o.unused_data, o.unconsumed_tail, o.eof, o._ahead = self.unused_data, self.unconsumed_tail, self.eof, self._ahead
+            o._zst = _ZStream()
+            o._init = False
+            o._zdict = self._zdict
+            err = _slib().zngamd_stream_inflate_copy(_C.byref(o._zst), _C.byref(self._zst))
+            if err == _lib.MEM_ERROR:
+                raise MemoryError("Can't allocate memory for decompression object")
+            if err != _lib.OK:
+                raise ValueError("Inconsistent stream state")
+            o._init = True
+            o.unused_data, o.unconsumed_tail, o.eof = self.unused_data, self.unconsumed_tail, self.eof
             o._ended = False
             return o
 
@@ -687,40 +684,48 @@ def decompressobj(wbits=MAX_WBITS, zdict=b""):
     return _Decompress(wbits, zdict)
 
 
-class _ZlibDecompressor:
+class _ZlibDecompressor(_InflateStream):
     """bz2/lzma-style decompressor (zlib_ngmodule.c:1040-1438): decompress(data, max_length=-1), eof,
-    unused_data, needs_input."""
+    unused_data, needs_input.  Input that is not needed yet stays here as compressed bytes (:1198-1308)."""
 
     def __init__(self, wbits=MAX_WBITS, zdict=b""):
-        self._core = _InflateCore(wbits, zdict)
         self._lock = _threading.Lock()
-        self._more = False       # the last call stopped at max_length: output may be waiting behind buffered input
+        self._pending = b""          # unconsumed input of earlier calls
+        self.eof = False
+        self.unused_data = b""
         self.needs_input = True
-
-    @property
-    def eof(self):
-        return self._core.eof
-
-    @property
-    def unused_data(self):
-        return self._core.unused
+        self._open(wbits, zdict)
 
     def decompress(self, data, max_length=-1):
-        """max_length bounds what is DECODED, not only what is returned: input that is not needed yet stays buffered as
-        compressed bytes (zlib_ngmodule.c:1198-1308), so a small input cannot make the object hold a large output."""
         max_length = _ssize(max_length)
         with self._lock:
-            if self._core.eof:
+            if self.eof:
                 raise EOFError("End of stream already reached")
             data = bytes(_view(data))
-            if max_length == 0:
-                self._core.buf += data
-                self._more = True
-                self.needs_input = False
+            view = _view(self._pending + data if self._pending else data)
+            if max_length < 0:
+                limit, start = None, DEF_BUF_SIZE
+            else:
+                limit, start = max_length, min(max_length, 4 << 20)
+            if limit == 0:
+                self._pending = bytes(view)
+                self.needs_input = False if view.nbytes else True
                 return b""
-            out, _ = self._core.feed(data, max_length if max_length > 0 else None)
-            self._more = max_length > 0 and len(out) >= max_length and not self._core.eof
-            self.needs_input = not self._more and not self._core.eof
+            out, err, left = self._inflate(view, max(start, 1), limit)
+            tail = bytes(view[view.nbytes - left:]) if left else b""
+            if err == _lib.STREAM_END:
+                self.eof = True
+                self.needs_input = False
+                self._pending = b""
+                if tail:
+                    self.unused_data = tail
+                self._close()
+            elif not tail:
+                self._pending = b""
+                self.needs_input = True
+            else:
+                self._pending = tail
+                self.needs_input = False
             return out
 
 
@@ -841,7 +846,7 @@ class _GzipReader:
                 return
             final = self._in_eof
             isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
-            cap = max(1 << 16, 4 * len(data), isize + 64)
+            cap = max(1 << 16, 4 * len(data), min(isize, 1032 * len(data)) + 64)      # (ISIZE is untrusted: bounded by what deflate can expand)
             while True:
                 if self._out is None and self._spare:
                     self._out = self._spare.pop()        # a window buffer the threaded reader's consumer has finished with
