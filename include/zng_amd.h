@@ -64,7 +64,7 @@ typedef struct zngamd_ctx zngamd_ctx;
 int         zngamd_device_count(void);
 int         zngamd_ctx_create(int device, zngamd_ctx **out);
 void        zngamd_ctx_destroy(zngamd_ctx *ctx);
-const char *zngamd_last_error(zngamd_ctx *ctx);
+const char *zngamd_last_error(zngamd_ctx *ctx);     /* message of the calling thread's last failing call (thread-local) */
 const char *zngamd_version(void);
 /* run all work of this context on a caller-owned hipStream_t (pass NULL to go back to the own stream) */
 int         zngamd_set_stream(zngamd_ctx *ctx, void *hip_stream);
@@ -281,6 +281,8 @@ int zngamd_stream_deflate_init(zngamd_ctx *ctx, zngamd_stream *strm, int level, 
 int zngamd_stream_deflate(zngamd_stream *strm, int flush);
 int zngamd_stream_deflate_set_dictionary(zngamd_stream *strm, const uint8_t *dict, uint32_t len);
 int zngamd_stream_deflate_copy(zngamd_stream *dst, const zngamd_stream *src);
+/* output produced and not yet handed out (zng_deflatePending; also valid for an inflate stream): lets the caller size its buffer once */
+int zngamd_stream_pending(const zngamd_stream *strm, uint64_t *pending);
 int zngamd_stream_deflate_end(zngamd_stream *strm);
 int zngamd_stream_inflate_init(zngamd_ctx *ctx, zngamd_stream *strm, int wbits);
 int zngamd_stream_inflate(zngamd_stream *strm, int flush);

@@ -44,10 +44,19 @@ template <typename T> struct DevBuf {
 
 struct EvPair { hipEvent_t a, b; int cls; };
 
+// Message of the last failing call, kept per calling thread: a context is shared by many threads (readers, writers, the
+// pump of the threaded reader), and the message is read after the call has left the context's mutex.
+static thread_local std::string za_tl_err;
+struct ZaErrSlot {
+    ZaErrSlot &operator=(const char *m) { za_tl_err = m; return *this; }
+    ZaErrSlot &operator=(const std::string &m) { za_tl_err = m; return *this; }
+    const char *c_str() const { return za_tl_err.c_str(); }
+};
+
 struct zngamd_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    std::string err;
+    ZaErrSlot err;
     std::mutex mu;
     // constant tables
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;

@@ -9,7 +9,7 @@
 //   zngamd_stream_inflate*   replace zng_inflateInit2 / zng_inflate / zng_inflateSetDictionary / zng_inflateCopy / zng_inflateEnd
 //                            as called by Decompress.decompress (:622-716), Decompress.flush (:959-1037), ZlibDecompressor (:1102-1195)
 //
-// A GPU wants large batches, a zng_stream caller feeds whatever it has: deflate collects input until a flush or 8 MiB and
+// A GPU wants large batches, a zng_stream caller feeds whatever it has: deflate collects input until a flush or 32 MiB and
 // then runs one dictionary-chained engine batch that ends on a sync-flush boundary (so the pieces concatenate into one valid
 // stream); inflate keeps the compressed bytes from the last block header on and decodes from there each call (bit offset +
 // up to 32 KiB of history), handing out only what is new -- exactly what the Python objects did before, now behind the C ABI.
@@ -18,11 +18,22 @@
 #define ZS_NO_FLUSH 0
 #define ZS_FINISH   4
 #define ZS_BLOCK    5
-#define ZS_BATCH    (8u << 20)
+#define ZS_BATCH    (32u << 20)
+
+// byte vector whose resize() does not zero-fill (the engine writes into the new room straight away)
+template <class T> struct ZsNoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = ZsNoInit<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+typedef std::vector<uint8_t, ZsNoInit<uint8_t>> ZsBytes;
 
 struct ZsDeflate {
     int level = 6, kind = 1 /* 0 raw, 1 zlib, 2 gzip */, wb = 15;
-    std::vector<uint8_t> pending, tail;
+    std::vector<uint8_t> pending, tail;      // pending = [pend_tail bytes of tail][collected input] (empty: nothing collected)
+    size_t pend_tail = 0;
     bool started = false, finished = false, has_dict = false;
     uint32_t crc = 0, adler = 1, dictid = 0;
     uint64_t size = 0;
@@ -40,7 +51,7 @@ struct zngamd_stream_state {
     bool is_deflate = false;
     ZsDeflate d;
     ZsInflate i;
-    std::vector<uint8_t> outq;       // produced, not yet handed out
+    ZsBytes outq;                    // produced, not yet handed out
     size_t outpos = 0;
     std::string msg;
 };
@@ -141,6 +152,36 @@ static int zs_deflate_batch(zngamd_stream *s, const uint8_t *data, size_t n, boo
     }
     return ZNGAMD_OK;
 }
+// the collected input in ONE engine call: `pending` = [the 32 KiB tail][collected input], the block is primed from the tail
+static int zs_deflate_pending(zngamd_stream *s, bool final)
+{
+    zngamd_stream_state *st = s->state;
+    ZsDeflate &d = st->d;
+    zngamd_ctx *c = st->ctx;
+    if (d.pending.empty()) { d.pending = d.tail; d.pend_tail = d.tail.size(); }        // (final with nothing collected)
+    const size_t tl = d.pend_tail, n = d.pending.size() - tl;
+    zngamd_block B; B.off = tl; B.len = (uint32_t)n; B.dict_len = (uint32_t)tl; B.flags = ZNGAMD_FLAG_WBITS(d.wb) | (final ? ZNGAMD_FLAG_FINAL : 0u); B.reserved = 0;
+    const uint64_t cap = n + n / 8 + (n / ZA_MAX_UNIT + 2) * 64 + 64;
+    const size_t at = st->outq.size();
+    st->outq.resize(at + cap);
+    uint32_t olen = 0, crc = 0;
+    int r = zngamd_deflate_blocks(c, d.pending.data(), d.pending.size(), &B, 1, d.level, st->outq.data() + at, cap, &olen, &crc);
+    if (r != ZNGAMD_OK) { st->outq.resize(at); return r; }
+    st->outq.resize(at + olen);
+    d.crc = zngamd_crc32_combine(d.crc, crc, n);
+    d.size += n;
+    if (d.kind == 1 && n) {
+        uint32_t a = d.adler;
+        r = zngamd_adler32(c, a, d.pending.data() + tl, n, &a);
+        if (r) return r;
+        d.adler = a;
+    }
+    const size_t keep = std::min<size_t>(d.pending.size(), ZA_WIN);
+    d.tail.assign(d.pending.end() - keep, d.pending.end());
+    if (d.pending.capacity() > (4u << 20) && n < (1u << 20)) std::vector<uint8_t>().swap(d.pending);   // a small flush does not pin a large buffer
+    d.pending.clear(); d.pend_tail = 0;
+    return ZNGAMD_OK;
+}
 static int zs_deflate_emit(zngamd_stream *s, const uint8_t *direct, size_t direct_len, bool final)
 {
     zngamd_stream_state *st = s->state;
@@ -151,11 +192,7 @@ static int zs_deflate_emit(zngamd_stream *s, const uint8_t *direct, size_t direc
     }
     int r = ZNGAMD_OK;
     if (direct) { if (direct_len || final) r = zs_deflate_batch(s, direct, direct_len, final); }
-    else if (!d.pending.empty() || final) {
-        std::vector<uint8_t> data;
-        data.swap(d.pending);
-        r = zs_deflate_batch(s, data.data(), data.size(), final);
-    }
+    else if (!d.pending.empty() || final) r = zs_deflate_pending(s, final);
     if (r) return r;
     if (final) {
         d.finished = true;
@@ -224,10 +261,11 @@ int zngamd_stream_deflate(zngamd_stream *s, int flush)
             if (r == ZNGAMD_OK) { s->next_in += s->avail_in; s->total_in += s->avail_in; s->avail_in = 0; }
         } else {
             if (s->avail_in) {
+                if (d.pending.empty()) { d.pending = d.tail; d.pend_tail = d.tail.size(); }
                 d.pending.insert(d.pending.end(), s->next_in, s->next_in + s->avail_in);
                 s->next_in += s->avail_in; s->total_in += s->avail_in; s->avail_in = 0;
             }
-            if (flush != ZS_NO_FLUSH || d.pending.size() >= ZS_BATCH) r = zs_deflate_emit(s, nullptr, 0, flush == ZS_FINISH);
+            if (flush != ZS_NO_FLUSH || d.pending.size() - d.pend_tail >= ZS_BATCH) r = zs_deflate_emit(s, nullptr, 0, flush == ZS_FINISH);
         }
         if (r != ZNGAMD_OK) return zs_msg(s, r == ZNGAMD_E_HIP ? ZNGAMD_MEM_ERROR : r > 0 || r < -6 ? ZNGAMD_STREAM_ERROR : r, zngamd_last_error(st->ctx));
     }
@@ -235,6 +273,13 @@ int zngamd_stream_deflate(zngamd_stream *s, int flush)
     s->adler = d.kind == 1 ? d.adler : d.crc;        // zlib: Adler-32; gzip and raw: CRC-32 of what has been compressed so far
     if (d.finished && st->outq.empty()) return ZNGAMD_STREAM_END;
     if (in0 == s->avail_in && out0 == s->avail_out && in0 == 0 && flush == ZS_NO_FLUSH) return ZNGAMD_BUF_ERROR;     // no progress possible
+    return ZNGAMD_OK;
+}
+
+int zngamd_stream_pending(const zngamd_stream *s, uint64_t *pending)
+{
+    if (!s || !s->state || !pending) return ZNGAMD_STREAM_ERROR;
+    *pending = s->state->outq.size() - s->state->outpos;
     return ZNGAMD_OK;
 }
 

@@ -5,6 +5,7 @@ works but the first call that needs the engine raises ``RuntimeError``.
 """
 import ctypes as C
 import os
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,7 +34,7 @@ SYMBOLS = [
     "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev", "zngamd_compare_dev", "zngamd_crc32_fold_dev",
-    "zngamd_stream_deflate_init", "zngamd_stream_deflate", "zngamd_stream_deflate_set_dictionary", "zngamd_stream_deflate_copy",
+    "zngamd_stream_deflate_init", "zngamd_stream_deflate", "zngamd_stream_deflate_set_dictionary", "zngamd_stream_deflate_copy", "zngamd_stream_pending",
     "zngamd_stream_deflate_end", "zngamd_stream_inflate_init", "zngamd_stream_inflate", "zngamd_stream_inflate_set_dictionary",
     "zngamd_stream_inflate_copy", "zngamd_stream_inflate_end",
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_layout",
@@ -226,6 +227,14 @@ class _Out:
     def addr(self):
         return C.c_void_p(_raw_buf(self.ptr))
 
+    def resize(self, n):
+        """Grow (or cut) the buffer in place; its address may change."""
+        n = max(int(n), 1)
+        if _raw_resize(C.byref(self.ptr), n) != 0:
+            self.ptr = C.c_void_p(None)          # _PyBytes_Resize released the object on failure
+            raise MemoryError("cannot resize the result")
+        self.cap = n
+
     def take(self, n):
         n = min(int(n), self.cap)
         if n == 0:
@@ -271,7 +280,16 @@ class Context:
                 f"zng_amd: no usable GPU (zngamd_ctx_create({device}) -> {r}); this engine has no CPU path")
         self.L, self.h, self.device = L, h, device
         self._scratch, self._scratch_lock = None, threading.Lock()
-        self.last_needed = 0
+        self._tls = threading.local()
+
+    @property
+    def last_needed(self):
+        """Room the calling thread's last inflate call asked for (0 = it fitted); per thread, like the engine's message."""
+        return getattr(self._tls, "needed", 0)
+
+    @last_needed.setter
+    def last_needed(self, v):
+        self._tls.needed = v
 
     def close(self):
         if self.h:
@@ -525,7 +543,7 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap):
     n = len(blocks)
     total = sum(b[1] for b in blocks)
     g = min(len(ctxs), n)
-    if g <= 1 or total < (8 << 20):
+    if g <= 1 or total < (8 << 20) or sys.is_finalizing():      # (no new threads while the interpreter shuts down)
         return ctxs[0].deflate_blocks(buf, blocks, level, out_cap, joined=True)
     mv = memoryview(buf)
     if mv.format != "B" or mv.ndim != 1:

@@ -89,7 +89,9 @@ class GzipNGFile(gzip.GzipFile):
         view = data if isinstance(data, bytes) else memoryview(data)
         nbytes = len(data) if isinstance(data, bytes) else view.nbytes
         if nbytes:
-            self.fileobj.write(self.compress.compress(view))
+            out = self.compress.compress(view)
+            if out:                                  # (most calls only add to the engine's batch)
+                self.fileobj.write(out)
             self.size += nbytes
             self.offset += nbytes
         return nbytes

@@ -58,43 +58,73 @@ def gzip_frame(body_len_total, crc, size, level):
     return header, trailer
 
 
-def rendezvous_bytes(rank, world, addr, port, payload=None, timeout=120.0):
+_RDV_MAGIC = b"ZNGA"
+
+
+def rendezvous_bytes(rank, world, addr, port, payload=None, timeout=120.0, tries=8):
     """Rank 0 hands `payload` (bytes) to the other ranks over TCP (one short connection each); every rank returns it.
-    What a launcher without a key-value store needs to pass the 128-byte RCCL unique id around."""
+    What a launcher without a key-value store needs to pass the 128-byte RCCL unique id around.  Rank 0 listens on the first
+    free port of port .. port+tries-1; the others go round those ports until one answers with the magic word."""
     if world == 1:
         return payload
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
+        srv, err = None, None
+        for k in range(tries):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, port + k))
+                srv = s
+                break
+            except OSError as e:
+                err = e
+                s.close()
+        if srv is None:
+            raise err
         srv.listen(world)
         srv.settimeout(timeout)
-        for _ in range(world - 1):
+        served = 0
+        while served < world - 1:
             conn, _ = srv.accept()
-            conn.sendall(struct.pack("<I", len(payload)) + payload)
-            conn.close()
+            try:
+                conn.settimeout(5.0)
+                if _recv_exact(conn, 4) != _RDV_MAGIC:              # not one of ours
+                    continue
+                conn.sendall(_RDV_MAGIC + struct.pack("<I", len(payload)) + payload)
+                served += 1
+            except OSError:
+                pass
+            finally:
+                conn.close()
         srv.close()
         return payload
     deadline = time.time() + timeout
+    k = 0
     while True:
         try:
-            s = socket.create_connection((addr, port), timeout=5.0)
-            break
+            s = socket.create_connection((addr, port + k % tries), timeout=5.0)
+            try:
+                s.sendall(_RDV_MAGIC)
+                if _recv_exact(s, 4) == _RDV_MAGIC:
+                    n = struct.unpack("<I", _recv_exact(s, 4))[0]
+                    return _recv_exact(s, n)
+            finally:
+                s.close()
         except OSError:
-            if time.time() > deadline:
-                raise
-            time.sleep(0.05)
-    buf = b""
-    while len(buf) < 4:
-        buf += s.recv(4 - len(buf))
-    n = struct.unpack("<I", buf)[0]
+            pass
+        if time.time() > deadline:
+            raise TimeoutError(f"rendezvous: nobody answered on {addr}:{port}..{port + tries - 1}")
+        k += 1
+        time.sleep(0.05)
+
+
+def _recv_exact(sock, n):
     out = b""
     while len(out) < n:
-        chunk = s.recv(n - len(out))
+        chunk = sock.recv(n - len(out))
         if not chunk:
             raise ConnectionError("rendezvous: connection closed early")
         out += chunk
-    s.close()
     return out
 
 

@@ -350,6 +350,7 @@ def _slib():
         L.zngamd_stream_inflate_set_dictionary.argtypes = [P, vp, _C.c_uint32]
         L.zngamd_stream_inflate_copy.argtypes = [P, P]
         L.zngamd_stream_inflate_end.argtypes = [P]
+        L.zngamd_stream_pending.argtypes = [P, _C.POINTER(_C.c_uint64)]
         L._zs_ready = True
     return L
 
@@ -363,45 +364,47 @@ def _stream_error(zst, err, while_):
 
 class _OutBuf:
     """Growing output buffer of a streaming call (arrange_output_buffer, zlib_ngmodule.c:142-197): starts at `length`,
-    doubles, never beyond `limit`."""
+    doubles, never beyond `limit`.  It is the result object itself (an uninitialised bytes object held through a bare
+    pointer, grown and finally cut to size in place like CPython's own _PyBytes_Resize use): no zero fill, no final copy."""
 
     def __init__(self, zst, length, limit=None):
         self.zst, self.limit = zst, limit
-        self.buf = bytearray(max(1, length if limit is None else min(length, max(limit, 1))))
+        self.out = _lib._Out(max(1, length if limit is None else min(length, max(limit, 1))))
         self.used = 0
         self._point()
 
     def _point(self):
-        room = len(self.buf) - self.used
-        self.hold = (_C.c_char * len(self.buf)).from_buffer(self.buf)
-        self.zst.next_out = _C.addressof(self.hold) + self.used
-        self.zst.avail_out = min(room, 0xFFFFFFFF)
+        self.base = self.out.addr().value
+        self.zst.next_out = self.base + self.used
+        self.zst.avail_out = min(self.out.cap - self.used, 0xFFFFFFFF)
 
     def sync(self):
-        self.used = (self.zst.next_out or _C.addressof(self.hold)) - _C.addressof(self.hold)
+        self.used = (self.zst.next_out or self.base) - self.base
 
     def grow(self):
         """Room for more output; False when the limit is reached."""
         self.sync()
-        if self.used < len(self.buf):
+        if self.used < self.out.cap:
             self._point()
             return True
-        if self.limit is not None and len(self.buf) >= self.limit:
+        if self.limit is not None and self.out.cap >= self.limit:
             return False
-        new = len(self.buf) * 2
+        # doubled as the reference does -- or straight to what the stream holds ready (zngamd_stream_pending), so that a
+        # batch of output is copied once instead of through a ladder of doubled buffers
+        queued = _C.c_uint64(0)
+        _slib().zngamd_stream_pending(_C.byref(self.zst), _C.byref(queued))
+        new = max(self.out.cap * 2, self.used + queued.value)
         if self.limit is not None:
             new = min(new, self.limit)
-        del self.hold
-        self.buf.extend(bytes(new - len(self.buf)))
+        self.out.resize(new)
         self._point()
         return True
 
     def result(self):
         self.sync()
-        del self.hold
         self.zst.next_out = None
         self.zst.avail_out = 0
-        return bytes(self.buf[:self.used])
+        return self.out.take(self.used)
 
 
 _CHUNK = 1 << 30          # input pieces per engine call (arrange_input_buffer cuts at UINT32_MAX, :142-147)

@@ -156,3 +156,41 @@ def test_two_rank_allgather_reassembly_gloo(tmp_path):
     for p in procs:
         p.join(30)
     assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]
+
+
+def test_rendezvous_skips_a_busy_port():
+    """shard.rendezvous_bytes: rank 0 takes the first free port of the range, the other ranks find it; a foreign listener on
+    the first port (accepts, says nothing useful) does not confuse them."""
+    import threading
+    from zlib_ng_amd import shard
+    squat = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    squat.bind(("127.0.0.1", 0))
+    squat.listen(8)
+    port = squat.getsockname()[1]
+    stop = threading.Event()
+
+    def foreign():
+        squat.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = squat.accept()
+                c.sendall(b"HTTP/1.0 400\r\n\r\n")
+                c.close()
+            except OSError:
+                pass
+    ft = threading.Thread(target=foreign, daemon=True)
+    ft.start()
+    payload = os.urandom(128)
+    got = {}
+
+    def run(rank):
+        got[rank] = shard.rendezvous_bytes(rank, 3, "127.0.0.1", port, payload if rank == 0 else None, timeout=30.0)
+    ts = [threading.Thread(target=run, args=(r,)) for r in (1, 2, 0)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(40)
+    stop.set()
+    ft.join(2)
+    squat.close()
+    assert got == {0: payload, 1: payload, 2: payload}
