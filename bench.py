@@ -205,25 +205,60 @@ def main():
     # The WHOLE dict-chained compressed stream -- with N > 1 the stream assembled from the slices of all ranks, on rank 0 -- is
     # closed with an empty final block, inflated on the device by the chunk-parallel decoder (sync-flush points) and compared
     # with the input; its CRC-32 must be the one the layout exchange folded; a prefix also goes through the system zlib.
-    if exchange_stream and rank == 0:
+    if exchange:
         off, total, sizes, whole_crc, whole_len = gathered["layout"]
-        assert whole_len == total_size and sizes[rank] == comp_bytes and off == 0 and total == sum(sizes)
-        assert torch.equal(d_stream[:comp_bytes], d_comp[:comp_bytes]), "rank 0's slice is not at the head of the assembled stream"
-        if total_size <= (40 << 30) and total_size % uniq == 0:
+        assert sizes[rank] == comp_bytes and off == sum(sizes[:rank]) and total == sum(sizes) and whole_len == total_size
+        # the trailer CRC-32 folded from the ranks against the CRC-32 of the whole input, folded on the host from the tile's
+        if total_size % uniq == 0:
+            tile_crc, want = zlib.crc32(host), 0
+            for _ in range(total_size // uniq):
+                want = ctx.crc32_combine(want, tile_crc, uniq)
+            assert want == whole_crc, "trailer CRC-32 folded from the ranks differs from the CRC-32 of the whole input"
+    if exchange_stream:
+        # (a) my slice lies at its offset in my copy of the assembled stream
+        assert torch.equal(d_stream[off:off + comp_bytes], d_comp[:comp_bytes]), "my slice is not at its offset in the assembled stream"
+        # (b) every rank decodes the head of a slice ANOTHER rank compressed (rank r: slice r + 1), taken from its own copy of
+        # the assembled stream: up to 2 048 blocks behind a stored block that holds the 32 KiB of input in front of them (the
+        # dictionary that slice was primed with on the other GPU), compared with the input they must decode to
+        q = (rank + 1) % world
+        kblk = min(nblocks, 2048)
+        pre = comm.layout(int(d_ulen[:kblk].to(torch.int64).sum().item()), 0, 0)[2]     # compressed bytes of every rank's first kblk blocks
+        qlo = shard.shard_range(total_blocks, q, world)[0]
+        qoff = sum(sizes[:q])
+
+        def tile_bytes(first, count):                       # bytes [first, first + count) of the whole stream (negative: halo of block 0)
+            parts, pos = [], 0
+            while pos < count:
+                o = (first + pos) % uniq
+                k = min(uniq - o, count - pos)
+                parts.append(base[o:o + k])
+                pos += k
+            return torch.cat(parts)
+        d_v = torch.empty(5 + HALO + pre[q] + 66, dtype=torch.uint8, device=dev)
+        d_v[:5] = torch.tensor([0, 0x00, 0x80, 0xFF, 0x7F], dtype=torch.uint8, device=dev)     # stored block, not final, 32 768 bytes
+        d_v[5:5 + HALO] = tile_bytes(qlo * BLOCK - HALO, HALO)
+        d_v[5 + HALO:5 + HALO + pre[q]] = d_stream[qoff:qoff + pre[q]]
+        d_v[5 + HALO + pre[q]:] = 0
+        d_v[5 + HALO + pre[q]] = 3                           # empty final block
+        d_vo = torch.empty(HALO + kblk * BLOCK + 64, dtype=torch.uint8, device=dev)
+        vlen, vused = C.c_uint64(0), C.c_uint64(0)
+        rc = L.zngamd_inflate_raw_dev(h, ptr(d_v), 5 + HALO + pre[q] + 2, ptr(d_vo), HALO + kblk * BLOCK, C.byref(vlen), C.byref(vused))
+        assert rc == _lib.STREAM_END and vlen.value == HALO + kblk * BLOCK, (rc, vlen.value, vused.value, ctx.err())
+        assert torch.equal(d_vo[HALO:HALO + kblk * BLOCK], tile_bytes(qlo * BLOCK, kblk * BLOCK)), \
+            f"rank {rank}: the head of slice {q} in the assembled stream does not inflate to its input"
+        del d_v, d_vo
+        # (c) jobs of at most 4 GiB: rank 0 inflates the WHOLE assembled stream on the device and compares it with the input
+        if rank == 0 and total_size <= (4 << 30) and total_size % uniq == 0:
             d_stream[total:total + 66] = 0
             d_stream[total] = 3
             d_big = torch.empty(total_size + 64, dtype=torch.uint8, device=dev) if world > 1 else d_out
-            vlen, vused = C.c_uint64(0), C.c_uint64(0)
             rc = L.zngamd_inflate_raw_dev(h, ptr(d_stream), total + 2, ptr(d_big), total_size, C.byref(vlen), C.byref(vused))
             assert rc == _lib.STREAM_END and vlen.value == total_size and vused.value == total + 2, (rc, vlen.value, vused.value, ctx.err())
             assert bool((d_big[:total_size].view(-1, uniq) == base).all().item()), "the assembled stream does not inflate to the input"
             c = C.c_uint32(0)
             chk(L.zngamd_crc32_dev(h, 0, ptr(d_big), total_size, C.byref(c)), "crc32_dev")
-            assert c.value == whole_crc, "trailer CRC-32 folded from the ranks differs from the CRC-32 of the whole input"
+            assert c.value == whole_crc, "CRC-32 of the inflated stream differs from the trailer value"
             del d_big
-    elif exchange:
-        off, total, sizes, whole_crc, whole_len = gathered["layout"]
-        assert sizes[rank] == comp_bytes and off == sum(sizes[:rank]) and total == sum(sizes) and whole_len == total_size
     if blo == 0:
         d_comp[comp_bytes:comp_bytes + 66] = 0
         d_comp[comp_bytes] = 3

@@ -1318,7 +1318,11 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                 }
                 const unsigned long long deps = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
                 // far: the source ends below the segment (it starts more than 272 bytes in front of it): final bytes in memory
+#ifdef ZA_ABL_NO_FAR
+                const bool far = false;                                  // (timing only: far sources read garbage inside the image)
+#else
                 const bool far = src_a + TAIL < seg_start;
+#endif
                 const bool simple = mdist >= mlen && mlen <= 32u;      // copied by its own lane, at most two 16-byte batches
                 uint8_t *od = img + TAIL + (mdst - seg_start);          // my destination inside the image
                 // the far sources of the whole group are fetched at once (nothing in this group can change them)
@@ -1333,6 +1337,9 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                         ZaU4u v = fv, v2 = fv2;
                         if (!far) {
                             const uint8_t *sp = od - mdist;                 // inside the image: src_a >= seg_start - 272
+#ifdef ZA_ABL_NO_FAR
+                            if (sp < img) sp = img;
+#endif
                             v.x = *(const za_u32u *)sp; v.y = *(const za_u32u *)(sp + 4); v.z = *(const za_u32u *)(sp + 8); v.w = *(const za_u32u *)(sp + 12);
                             if (mlen > 16u) { v2.x = *(const za_u32u *)(sp + 16); v2.y = *(const za_u32u *)(sp + 20); v2.z = *(const za_u32u *)(sp + 24); v2.w = *(const za_u32u *)(sp + 28); }
                         }
@@ -1358,7 +1365,12 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                         const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
                         const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
                         const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
+#ifdef ZA_ABL_NO_FAR
+                        const bool cfar = false;
+                        if (cd - cdist + TAIL < seg_start) continue;
+#else
                         const bool cfar = cd - cdist + TAIL < seg_start;      // (then cdist > cl: no overlap)
+#endif
                         uint8_t *o = img + TAIL + (cd - seg_start);
                         const float rd = 1.0f / (float)cdist;
                         for (uint32_t base = 0; base < cl; base += 64) {
