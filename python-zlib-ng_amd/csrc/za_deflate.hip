@@ -958,18 +958,27 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             prefetch(k0 + ZA_TCH);
             uint32_t ke = k0 + ZA_TCH;
             if (ke > ntok) ke = ntok;
-            for (uint32_t k = k0; k < ke; k++) fn(myt[k - k0]);
+            // fn takes the token at tp[0] and may take the next one or two with it (tp[1], tp[2] are staged when `left` says so)
+            for (uint32_t k = k0; k < ke;) k += fn(myt + (k - k0), ke - k);
         }
     };
 
     // pass A: bit length of my segment
     uint32_t bits = 0;
     // (literal and match on one predicated path: a literal is "length part only")
-    for_each_token([&](uint32_t t) {
+    // Literals come in runs (most tokens of text are literals, several in a row): a round that starts on a literal takes up to
+    // two more literals with it -- fewer rounds for every lane, and the wave runs as long as its slowest lane.
+    for_each_token([&](const uint32_t *tp, uint32_t left) -> uint32_t {
+        const uint32_t t = tp[0];
         const bool m = (t & 0x80000000u) != 0u;
         const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
         const uint32_t c1 = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], c2 = codes[288 + dc];
         bits += (c1 >> 16) + (m ? (uint32_t)za_len_extra_bits(lc) + (c2 >> 16) + (uint32_t)za_dist_extra_bits(dc) : 0u);
+        const uint32_t t1 = left > 1u ? tp[1] : 0x80000000u, t2 = left > 2u ? tp[2] : 0x80000000u;
+        const bool two = !m && !(t1 & 0x80000000u), three = two && !(t2 & 0x80000000u);
+        const uint32_t b1 = codes[t1 & 0xFFu] >> 16, b2 = codes[t2 & 0xFFu] >> 16;
+        bits += (two ? b1 : 0u) + (three ? b2 : 0u);
+        return three ? 3u : two ? 2u : 1u;
     });
     const uint32_t incl = za_wave_incl_scan(bits);
     const uint32_t start = plan.header_bits + incl - bits;
@@ -997,7 +1006,8 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     // chunk index: for every 256-byte boundary of my segment the first token that starts at or behind it
     uint32_t op = (uint32_t)lane << ZA_SEG_SHIFT, nextb = op;
     uint32_t oend = op + ZA_SEG; if (oend > (uint32_t)n) oend = (uint32_t)n;
-    for_each_token([&](uint32_t t) {
+    for_each_token([&](const uint32_t *tp, uint32_t left) -> uint32_t {
+        const uint32_t t = tp[0];
         const bool m = (t & 0x80000000u) != 0u;
         const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
         const int ln = m ? za_len_extra_bits(lc) : 0, dn = za_dist_extra_bits(dc);
@@ -1014,7 +1024,16 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
         const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
         // literal / length code + extra fit in 20 bits, distance code + extra in 28 (0 bits for a literal)
         w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
-        w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : 0u, m ? (int)(cd >> 16) + dn : 0);
+        // second put: the distance part of a match -- or the one or two literals that follow a literal (their codes are
+        // at most ZA_LIMIT_L = 10 bits each)
+        const uint32_t t1 = left > 1u ? tp[1] : 0x80000000u, t2 = left > 2u ? tp[2] : 0x80000000u;
+        const bool two = !m && !(t1 & 0x80000000u), three = two && !(t2 & 0x80000000u);
+        const uint32_t c1 = codes[t1 & 0xFFu], c2 = codes[t2 & 0xFFu];
+        const uint32_t lits = (c1 & 0xFFFF) | (three ? (c2 & 0xFFFF) << (c1 >> 16) : 0u);
+        const int nlits = (int)(c1 >> 16) + (three ? (int)(c2 >> 16) : 0);
+        w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : two ? lits : 0u, m ? (int)(cd >> 16) + dn : two ? nlits : 0);
+        op += three ? 2u : two ? 1u : 0u;
+        return three ? 3u : two ? 2u : 1u;
     });
     for (; nextb < oend && lane < nseg; nextb += 1u << ZA_CHUNK_SHIFT)       // boundaries behind my last token start
         cidx[nextb >> ZA_CHUNK_SHIFT] = (w.w * 32u + (uint32_t)w.nb) | ((oend - nextb) << 23);

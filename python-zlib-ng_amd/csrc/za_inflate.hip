@@ -987,6 +987,9 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
 #endif
 #define ZA_IROW (4 * ZA_IROW_LOADS + 1)            // dwords per lane row (+ 1: odd stride)
 #define ZA_IROW_BYTES (16 * ZA_IROW_LOADS - 16)    // bytes consumed per row; the last 16 are look-ahead (a token takes up to 37 bits)
+#ifndef ZA_ILITS
+#define ZA_ILITS 3                 // literals a lane takes per round at most
+#endif
 #define ZA_ML_BITS 10              // literal/length table: every code of an indexed member is at most 10 bits long (ZA_LIMIT_L)
 #define ZA_MD_BITS 9               // distance table (ZA_LIMIT_D)
 
@@ -1187,9 +1190,33 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                     uint32_t used = l;
                     int err = (e == 0u) ? 2 : 0;        // (a lane that runs past its stop offset is caught behind the loop; rows never read outside the buffer)
                     if (!(e & 0x8000u)) {
+                        // Literals come in runs (text at level 6: 79 % of the tokens, 3.8 in a row on average), so a literal round
+                        // takes up to ZA_ILITS of them: the next codes are looked up in the same 64 bits, and the bytes go into the
+                        // open block together.  A further literal is taken while it stays inside the block and the segment.
                         const int o = pos - blk_base;
-                        const uint64_t by = (uint64_t)((e >> 4) & 0xFFu);
-                        if (o < 8) blk_lo |= by << (8 * o); else blk_hi |= by << (8 * (o - 8));
+                        uint32_t grp = (e >> 4) & 0xFFu;
+                        int nl = 1;
+#if ZA_ILITS >= 2
+                        {
+                            const uint32_t e1 = T.lut_l[(uint32_t)(b >> used) & ((1u << ZA_ML_BITS) - 1u)];
+                            const bool t1 = e1 != 0u && !(e1 & 0x8000u) && o + 1 < 16 && pos + 1 < end;
+                            if (t1) { grp |= ((e1 >> 4) & 0xFFu) << 8; used += e1 & 15u; nl = 2; }
+#if ZA_ILITS >= 3
+                            const uint32_t e2 = T.lut_l[(uint32_t)(b >> used) & ((1u << ZA_ML_BITS) - 1u)];
+                            const bool t2 = t1 && e2 != 0u && !(e2 & 0x8000u) && o + 2 < 16 && pos + 2 < end;
+                            if (t2) { grp |= ((e2 >> 4) & 0xFFu) << 16; used += e2 & 15u; nl = 3; }
+#if ZA_ILITS >= 4
+                            const uint32_t e3 = T.lut_l[(uint32_t)(b >> used) & ((1u << ZA_ML_BITS) - 1u)];
+                            const bool t3 = t2 && e3 != 0u && !(e3 & 0x8000u) && o + 3 < 16 && pos + 3 < end;
+                            if (t3) { grp |= ((e3 >> 4) & 0xFFu) << 24; used += e3 & 15u; nl = 4; }
+#endif
+#endif
+                        }
+#endif
+                        adv = nl;
+                        const uint64_t g = (uint64_t)grp;
+                        if (o < 8) { blk_lo |= g << (8 * o); if (o > 4) blk_hi |= g >> (8 * (8 - o)); }
+                        else blk_hi |= g << (8 * (o - 8));
                         blk_dirty = true;
                     } else {
                         // match: every validity test of the token is collected and branched on once

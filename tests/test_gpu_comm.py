@@ -1,6 +1,6 @@
 """Rehearsal of the multi-GPU exchange on one GPU: the same zngamd_comm_* calls bench.py --gpus N makes (RCCL communicator from a
-unique id, layout all-gather, exact-size grouped send / recv of the slices, barrier, max), with world size 1 -- RCCL sends the
-slice to itself.  The layout arithmetic for N > 1 is covered on the CPU (tests/test_cpu_library.py, gloo, world size 2)."""
+unique id, layout all-gather, exchange of the slices, barrier, max) with world size 1: the collectives run through RCCL, the
+own slice takes the device copy it takes at any N, only the send / receive pairs have no partner.  The layout arithmetic for N > 1 is covered on the CPU (tests/test_cpu_library.py, gloo, world size 2)."""
 import ctypes as C
 import os
 import subprocess
