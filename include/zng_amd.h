@@ -287,6 +287,11 @@ int zngamd_stream_deflate_end(zngamd_stream *strm);
 int zngamd_stream_inflate_init(zngamd_ctx *ctx, zngamd_stream *strm, int wbits);
 int zngamd_stream_inflate(zngamd_stream *strm, int flush);
 int zngamd_stream_inflate_set_dictionary(zngamd_stream *strm, const uint8_t *dict, uint32_t len);
+/* A caller that grows its output buffer (arrange_output_buffer, zlib_ngmodule.c:142-197) announces how much output it will take
+ * in total over the next calls (its max_length; UINT64_MAX = as much as the input yields): the engine then decodes that far in one
+ * batch and hands the bytes out as buffers arrive (zngamd_stream_pending says how many wait), instead of decoding the current
+ * block again for every doubling of a 16 KiB buffer.  0 (the default) = strictly avail_out, as zng_inflate. */
+int zngamd_stream_inflate_ahead(zngamd_stream *strm, uint64_t bytes);
 int zngamd_stream_inflate_copy(zngamd_stream *dst, const zngamd_stream *src);
 int zngamd_stream_inflate_end(zngamd_stream *strm);
 

@@ -43,6 +43,7 @@ struct ZsInflate {
     std::vector<uint8_t> zdict, window, buf;
     uint32_t start_bit = 0;
     uint64_t skip = 0, total = 0;
+    uint64_t ahead = 0;              // output the caller has announced it will take beyond avail_out (zngamd_stream_inflate_ahead)
     bool header_done = false, deflate_done = false, eof = false, want_dict = false;
     uint32_t check = 1;
 };
@@ -458,7 +459,10 @@ int zngamd_stream_inflate(zngamd_stream *s, int flush)
         if (s->avail_out == 0) { give_back(I.buf.size() > before ? I.buf.size() - before : 0); return (out0 != s->avail_out) ? ZNGAMD_OK : ZNGAMD_BUF_ERROR; }
         if (I.buf.empty()) return (fed || out0 != s->avail_out) ? ZNGAMD_OK : ZNGAMD_BUF_ERROR;
         // decode from the last block header; `skip` bytes of that block were delivered before
-        const uint64_t want = I.skip + s->avail_out;
+        // the caller's buffer -- or what it has announced it will take by growing that buffer: one engine call then decodes that
+        // far (a 16 KiB buffer doubled step by step would otherwise decode the same block again for every step)
+        const uint64_t room = std::max<uint64_t>(s->avail_out, I.ahead);
+        const uint64_t want = room > ~0ull - I.skip ? ~0ull : I.skip + room;
         uint64_t cap = std::max<uint64_t>(1u << 16, 8ull * I.buf.size() + I.skip);
         if (want < cap) cap = want;
         std::vector<uint8_t> out;
@@ -481,6 +485,7 @@ int zngamd_stream_inflate(zngamd_stream *s, int flush)
             else if (I.kind == 1) r = zngamd_adler32(c, v, out.data() + I.skip, nnew, &v);
             if (r) return zs_msg(s, ZNGAMD_MEM_ERROR, zngamd_last_error(c));
             I.check = v; I.total += nnew;
+            I.ahead = I.ahead > nnew ? I.ahead - nnew : 0;
             zs_put(st, out.data() + I.skip, nnew);
         }
         auto set_window = [&](uint64_t upto) {       // history = old window + out[0 .. upto)
@@ -521,6 +526,13 @@ int zngamd_stream_inflate(zngamd_stream *s, int flush)
     s->adler = I.check;
     if (I.eof && st->outq.empty()) return ZNGAMD_STREAM_END;
     if (fed == s->avail_in && out0 == s->avail_out && fed == 0) return ZNGAMD_BUF_ERROR;
+    return ZNGAMD_OK;
+}
+
+int zngamd_stream_inflate_ahead(zngamd_stream *s, uint64_t bytes)
+{
+    if (!s || !s->state || s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
+    s->state->i.ahead = bytes;
     return ZNGAMD_OK;
 }
 

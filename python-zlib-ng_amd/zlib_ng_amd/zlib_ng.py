@@ -351,6 +351,7 @@ def _slib():
         L.zngamd_stream_inflate_copy.argtypes = [P, P]
         L.zngamd_stream_inflate_end.argtypes = [P]
         L.zngamd_stream_pending.argtypes = [P, _C.POINTER(_C.c_uint64)]
+        L.zngamd_stream_inflate_ahead.argtypes = [P, _C.c_uint64]
         L._zs_ready = True
     return L
 
@@ -567,6 +568,7 @@ class _InflateStream:
         grow the output up to `limit` (None: no limit).  -> (output bytes, last return code, bytes of `view` not consumed)."""
         L, zst = _slib(), self._zst
         out = _OutBuf(zst, start_len, limit)
+        L.zngamd_stream_inflate_ahead(_C.byref(zst), limit if limit is not None else 0xFFFFFFFFFFFFFFFF)     # what this call will take in all
         n = view.nbytes
         base, keep = _lib._addr(view) if n else (None, None)
         pos, err = 0, _lib.OK
