@@ -25,6 +25,8 @@ _COMPRESS_LEVEL_BEST = zlib_ng.Z_BEST_COMPRESSION
 READ_BUFFER_SIZE = 512 * 1024
 
 FTEXT, FHCRC, FEXTRA, FNAME, FCOMMENT = 1, 2, 4, 8, 16
+_SMALL_WRITE = 32 * 1024           # writes shorter than this are collected ...
+_SMALL_BATCH = 1 << 20             # ... and go to the compressor in batches of this size
 READ, WRITE = gzip.READ, gzip.WRITE
 BadGzipFile = gzip.BadGzipFile
 
@@ -61,6 +63,7 @@ class GzipNGFile(gzip.GzipFile):
         if self.mode == WRITE:
             self.compress = zlib_ng.compressobj(compresslevel, zlib_ng.DEFLATED, -zlib_ng.MAX_WBITS,
                                                 zlib_ng.DEF_MEM_LEVEL, 0)
+            self._small, self._small_n = [], 0       # writes below _SMALL_WRITE wait here for a batch
         elif self.mode == READ:
             self._buffer = io.BufferedReader(_GzipReader(self.fileobj, READ_BUFFER_SIZE))
 
@@ -88,13 +91,45 @@ class GzipNGFile(gzip.GzipFile):
             raise ValueError("write() on closed GzipNGFile object")
         view = data if isinstance(data, bytes) else memoryview(data)
         nbytes = len(data) if isinstance(data, bytes) else view.nbytes
-        if nbytes:
+        if nbytes == 0:
+            return 0
+        if nbytes < _SMALL_WRITE:
+            # line-sized writes (the reference's benchmark_scripts/gzipwritelines.py): collected here and handed to the
+            # compressor a MiB at a time -- a call into the engine per line would cost more than the line
+            self._small.append(data if isinstance(data, bytes) else bytes(view))
+            self._small_n += nbytes
+            if self._small_n >= _SMALL_BATCH:
+                self._drain_small()
+        else:
+            self._drain_small()
             out = self.compress.compress(view)
             if out:                                  # (most calls only add to the engine's batch)
                 self.fileobj.write(out)
-            self.size += nbytes
-            self.offset += nbytes
+        self.size += nbytes
+        self.offset += nbytes
         return nbytes
+
+    def _drain_small(self):
+        if self._small_n:
+            parts, self._small, self._small_n = self._small, [], 0
+            out = self.compress.compress(parts[0] if len(parts) == 1 else b"".join(parts))
+            if out:
+                self.fileobj.write(out)
+
+    def flush(self, zlib_mode=zlib_ng.Z_SYNC_FLUSH):
+        if self.mode == WRITE and self.fileobj is not None:
+            self._drain_small()
+        return super().flush(zlib_mode)
+
+    def close(self):
+        if self.mode == WRITE and self.fileobj is not None:
+            try:
+                self._drain_small()
+            except Exception:
+                self._small, self._small_n = [], 0
+                super().close()
+                raise
+        super().close()
 
 
 GzipFile = GzipNGFile

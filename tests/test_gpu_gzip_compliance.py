@@ -831,3 +831,31 @@ def test_many_small_members_in_one_launch(G, fastq):
         a, b = _verdict(rd, CG, CZ.error), _verdict(rd, G, zlib_ng.error)
         assert a == b, (a[:1], b[:1])
     assert head > 0
+
+
+def test_line_sized_writes_are_collected(G, fastq, tmp_path):
+    """The reference's benchmark_scripts/gzipwritelines.py pattern: thousands of writes of one line each, with flushes, a large
+    write and a memoryview in between; the file is what one write of everything gives, for the stdlib and for our reader."""
+    lines = fastq[:2_000_000].splitlines(keepends=True)
+    p = tmp_path / "lines.gz"
+    big = fastq[2_000_000:2_300_000]
+    with G.open(p, "wb", compresslevel=6) as f:
+        for i, line in enumerate(lines):
+            assert f.write(line) == len(line)
+            if i == 1000:
+                f.flush()
+            if i == 5000:
+                assert f.write(memoryview(big)) == len(big)
+            if i == 7000:
+                assert f.write(bytearray(b"xyz")) == 3
+        assert f.tell() == sum(map(len, lines)) + len(big) + 3
+    want = b"".join(lines[:5001]) + big + b"".join(lines[5001:7001]) + b"xyz" + b"".join(lines[7001:])
+    assert CG.decompress(p.read_bytes()) == want
+    with G.open(p, "rb") as f:
+        assert b"".join(f) == want
+    # nothing written, and a single tiny write
+    for payload in (b"", b"a"):
+        q = tmp_path / "tiny.gz"
+        with G.open(q, "wb") as f:
+            f.write(payload)
+        assert CG.decompress(q.read_bytes()) == payload
