@@ -126,10 +126,11 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
         const unsigned long long V = __ballot(valid);
         const unsigned long long B0 = __ballot((cls & 1u) != 0u), B1 = __ballot((cls & 2u) != 0u);
         const unsigned long long m0 = V & ~B0 & ~B1, m1 = V & B0 & ~B1, m2 = V & ~B0 & B1, m3 = V & B0 & B1;
-        unsigned long long eq = (cls & 1u) ? B0 : ~B0;
-        eq &= (cls & 2u) ? B1 : ~B1;
-        eq &= V;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(eq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)eq, 0u));
+        // my place among this wave's entries of my class: the four class masks are wave-uniform (scalar registers), so
+        // four mbcnt pairs and a select are cheaper than building my class's mask per lane
+        auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+        const uint32_t r0 = below(m0), r1 = below(m1), r2 = below(m2), r3 = below(m3);
+        const uint32_t rank = (cls & 2u) ? ((cls & 1u) ? r3 : r2) : ((cls & 1u) ? r1 : r0);
         if (lane < ZA_CH_WAVES) {
             const uint32_t c01 = lane == 0 ? (uint32_t)__builtin_popcountll(m0) : (uint32_t)__builtin_popcountll(m1);
             const uint32_t c23 = lane == 2 ? (uint32_t)__builtin_popcountll(m2) : (uint32_t)__builtin_popcountll(m3);
@@ -151,9 +152,8 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
             wslot += all; wslot -= wslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
         }
         par ^= 1u;
-        uint32_t myslot = (uint32_t)__shfl((int)base, (int)cls, 64) + rank;   // < 320 + 256 + 64
-        myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
-        myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+        uint32_t myslot = (uint32_t)__shfl((int)base, (int)cls, 64) + rank;   // < 320 + 192 + 64 (at most three waves in front of mine)
+        myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;                   // one wrap is enough: < 2 * ZA_CH_STAGE
         if (valid)
             ring_all[cls][myslot] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
         __syncthreads();
@@ -286,8 +286,13 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
                 // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
                 // against them without branches (this also plays the role of zlib's quick-reject byte)
-                const uint32_t me0 = za_lds_ld32(win32, P), me1 = za_lds_ld32(win32, P + 4u),
-                               me2 = za_lds_ld32(win32, P + 8u), me3 = za_lds_ld32(win32, P + 12u);
+                uint32_t me0, me1, me2, me3;
+                {   // five aligned dwords and one shift amount (the ring has mirrored pad dwords behind its end)
+                    const uint32_t idx = P & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
+                    const uint32_t m0 = win32[w], m1 = win32[w + 1], m2 = win32[w + 2], m3 = win32[w + 3], m4 = win32[w + 4];
+                    me0 = __builtin_amdgcn_alignbyte(m1, m0, sh); me1 = __builtin_amdgcn_alignbyte(m2, m1, sh);
+                    me2 = __builtin_amdgcn_alignbyte(m3, m2, sh); me3 = __builtin_amdgcn_alignbyte(m4, m3, sh);
+                }
                 uint32_t q = P;
                 int qs = (int)(P % ZA_RING);                                 // ring slot of q, kept incrementally
                 uint32_t d = ring[qs];
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                         "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
                         "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
                         : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));     // 96 is not an inline constant
-                    int len = (int)min(fbit >> 3, 16u);
+                    int len = (int)min(fbit >> 3, FULL ? 16u : (uint32_t)cap);     // (cap <= 16 on the levels that compare 16 bytes)
                     if (FULL && len == 16 && cap > 16 && best_len < cap &&
                         (best_len < 16 || (uint8_t)za_lds_ld32(win32, q + (uint32_t)best_len) == (uint8_t)za_lds_ld32(win32, P + (uint32_t)best_len))) {
                         // levels that compare in full: at least 16 equal bytes -- finish the compare the long way (a candidate that
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                             len += 4;
                         }
                     }
-                    len = len < cap ? len : cap;
+                    if (FULL) len = len < cap ? len : cap;
                     const bool better = len > best_len;
                     best_len = better ? len : best_len;
                     best_dist = better ? dist : best_dist;
