@@ -15,6 +15,9 @@
 // up to 32 KiB of history), handing out only what is new -- exactly what the Python objects did before, now behind the C ABI.
 #include <memory>
 
+// no C++ exception leaves the C ABI: running out of host memory is zlib's Z_MEM_ERROR
+#define ZS_GUARD catch (const std::bad_alloc &) { return ZNGAMD_MEM_ERROR; } catch (...) { return ZNGAMD_STREAM_ERROR; }
+
 #define ZS_NO_FLUSH 0
 #define ZS_FINISH   4
 #define ZS_BLOCK    5
@@ -210,7 +213,7 @@ static int zs_deflate_emit(zngamd_stream *s, const uint8_t *direct, size_t direc
 extern "C" {
 
 int zngamd_stream_deflate_init(zngamd_ctx *c, zngamd_stream *s, int level, int method, int wbits, int mem_level, int strategy)
-{
+try {
     if (!c || !s) return ZNGAMD_STREAM_ERROR;
     s->state = nullptr; s->msg = nullptr; s->total_in = s->total_out = 0; s->adler = 1;
     if (level < -1 || level > 9 || method != 8 || mem_level < 1 || mem_level > 9 || strategy < 0 || strategy > 4) return ZNGAMD_STREAM_ERROR;
@@ -227,10 +230,10 @@ int zngamd_stream_deflate_init(zngamd_ctx *c, zngamd_stream *s, int level, int m
     s->state = st;
     s->adler = kind == 2 ? 0u : 1u;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_deflate_set_dictionary(zngamd_stream *s, const uint8_t *dict, uint32_t len)
-{
+try {
     if (!s || !s->state || !s->state->is_deflate || (!dict && len)) return ZNGAMD_STREAM_ERROR;
     ZsDeflate &d = s->state->d;
     if (d.started) return ZNGAMD_STREAM_ERROR;                    // zng_deflateSetDictionary: before the first deflate call
@@ -244,10 +247,10 @@ int zngamd_stream_deflate_set_dictionary(zngamd_stream *s, const uint8_t *dict, 
     const uint32_t keep = len > ZA_WIN ? (uint32_t)ZA_WIN : len;
     d.tail.assign(dict + (len - keep), dict + len);
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_deflate(zngamd_stream *s, int flush)
-{
+try {
     if (!s || !s->state || !s->state->is_deflate || flush < 0 || flush > ZS_BLOCK) return ZNGAMD_STREAM_ERROR;
     zngamd_stream_state *st = s->state;
     ZsDeflate &d = st->d;
@@ -275,36 +278,36 @@ int zngamd_stream_deflate(zngamd_stream *s, int flush)
     if (d.finished && st->outq.empty()) return ZNGAMD_STREAM_END;
     if (in0 == s->avail_in && out0 == s->avail_out && in0 == 0 && flush == ZS_NO_FLUSH) return ZNGAMD_BUF_ERROR;     // no progress possible
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_pending(const zngamd_stream *s, uint64_t *pending)
-{
+try {
     if (!s || !s->state || !pending) return ZNGAMD_STREAM_ERROR;
     *pending = s->state->outq.size() - s->state->outpos;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_deflate_copy(zngamd_stream *dst, const zngamd_stream *src)
-{
+try {
     if (!dst || !src || !src->state || !src->state->is_deflate) return ZNGAMD_STREAM_ERROR;
     *dst = *src;
     dst->state = new zngamd_stream_state(*src->state);
     dst->msg = nullptr;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_deflate_end(zngamd_stream *s)
-{
+try {
     if (!s || !s->state || !s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
     const bool busy = !s->state->d.finished && (s->state->d.started || !s->state->d.pending.empty());
     delete s->state;
     s->state = nullptr; s->msg = nullptr;
     return busy ? ZNGAMD_DATA_ERROR : ZNGAMD_OK;      // zng_deflateEnd: Z_DATA_ERROR when the stream was freed prematurely
-}
+} ZS_GUARD
 
 // ---- inflate ---------------------------------------------------------------------------------------------------------
 int zngamd_stream_inflate_init(zngamd_ctx *c, zngamd_stream *s, int wbits)
-{
+try {
     if (!c || !s) return ZNGAMD_STREAM_ERROR;
     s->state = nullptr; s->msg = nullptr; s->total_in = s->total_out = 0; s->adler = 1;
     int kind;
@@ -318,10 +321,10 @@ int zngamd_stream_inflate_init(zngamd_ctx *c, zngamd_stream *s, int wbits)
     st->i.kind = kind; st->i.wbits = wbits; st->i.header_done = kind == 0;
     s->state = st;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_inflate_set_dictionary(zngamd_stream *s, const uint8_t *dict, uint32_t len)
-{
+try {
     if (!s || !s->state || s->state->is_deflate || (!dict && len)) return ZNGAMD_STREAM_ERROR;
     ZsInflate &I = s->state->i;
     if (I.kind == 0) {                      // raw stream: the history the first block may refer to; any time before decoding starts
@@ -341,7 +344,7 @@ int zngamd_stream_inflate_set_dictionary(zngamd_stream *s, const uint8_t *dict, 
     I.buf.erase(I.buf.begin(), I.buf.begin() + 6);
     I.header_done = true; I.check = 1;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 // gzip member header at buf[0..): 1 = complete (*start = first deflate byte), 0 = more input needed, < 0 = error (msg set)
 static int zs_gzip_header_parse(zngamd_stream *s, const std::vector<uint8_t> &b, size_t *start)
@@ -428,7 +431,7 @@ static int zs_inflate_trailer(zngamd_stream *s)
 }
 
 int zngamd_stream_inflate(zngamd_stream *s, int flush)
-{
+try {
     if (!s || !s->state || s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
     zngamd_stream_state *st = s->state;
     ZsInflate &I = st->i;
@@ -451,7 +454,12 @@ int zngamd_stream_inflate(zngamd_stream *s, int flush)
     };
     if (!I.header_done) {
         const int r = zs_inflate_header(s);
-        if (r == ZNGAMD_NEED_DICT) return r;
+        if (r == ZNGAMD_NEED_DICT) {
+            // only the header stays here: what came behind it goes back to the caller, who offers it again once the dictionary
+            // is set (zng_inflate stops consuming at the dictionary id too) -- bytes behind the stream's end must reach `unused_data`
+            give_back(I.buf.size() > 6 ? I.buf.size() - 6 : 0);
+            return r;
+        }
         if (r < 0) return r;
         if (r == 0) return (fed || out0 != s->avail_out) ? ZNGAMD_OK : ZNGAMD_BUF_ERROR;
     }
@@ -527,30 +535,30 @@ int zngamd_stream_inflate(zngamd_stream *s, int flush)
     if (I.eof && st->outq.empty()) return ZNGAMD_STREAM_END;
     if (fed == s->avail_in && out0 == s->avail_out && fed == 0) return ZNGAMD_BUF_ERROR;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_inflate_ahead(zngamd_stream *s, uint64_t bytes)
-{
+try {
     if (!s || !s->state || s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
     s->state->i.ahead = bytes;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_inflate_copy(zngamd_stream *dst, const zngamd_stream *src)
-{
+try {
     if (!dst || !src || !src->state || src->state->is_deflate) return ZNGAMD_STREAM_ERROR;
     *dst = *src;
     dst->state = new zngamd_stream_state(*src->state);
     dst->msg = nullptr;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 int zngamd_stream_inflate_end(zngamd_stream *s)
-{
+try {
     if (!s || !s->state || s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
     delete s->state;
     s->state = nullptr; s->msg = nullptr;
     return ZNGAMD_OK;
-}
+} ZS_GUARD
 
 }  // extern "C"

@@ -696,3 +696,30 @@ def test_every_single_bit_flip_of_small_streams(Z, wbits):
                 if a != b:
                     differ.append(("object", pos, bit, a, b))
         assert not differ, (len(differ), differ[:6])
+
+
+def test_preset_dictionary_stream_fed_at_every_cut(Z):
+    """A zlib stream with a preset dictionary and bytes behind its end, fed to decompressobj in two pieces at every split point
+    (the dictionary is asked for in the middle of a call: what follows the dictionary id must not be lost): output, eof,
+    unused_data as CPython's zlib gives them."""
+    import zlib
+    src = bytes(range(256)) * 200
+    zdict = src[100:20100]
+    for n in (0, 1, 777):
+        d = src[30000:30000 + n]
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, 0, zdict)
+        blob = co.compress(d) + co.flush() + b"TAILBYTES"
+        for cut in range(0, len(blob) + 1, 1 if n < 100 else 7):
+            for limit in (0, 1000):
+                do, ref = Z.decompressobj(15, zdict), zlib.decompressobj(15, zdict)
+                got = want = b""
+                for obj, acc in ((do, "got"), (ref, "want")):
+                    out = obj.decompress(blob[:cut], limit)
+                    out += obj.decompress(obj.unconsumed_tail + blob[cut:], limit)
+                    while not obj.eof and obj.unconsumed_tail:
+                        out += obj.decompress(obj.unconsumed_tail, 100000)
+                    if acc == "got":
+                        got = out
+                    else:
+                        want = out
+                assert (got, do.eof, do.unused_data) == (want, ref.eof, ref.unused_data), (n, cut, limit)
