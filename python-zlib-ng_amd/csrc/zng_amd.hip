@@ -62,7 +62,7 @@ struct zngamd_ctx {
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
     uint32_t *d_crc_slice4 = nullptr;                                         // CRC slice-by-4 table of za_k_inflate_members
     // deflate workspaces (per chunk of units)
-    uint32_t chunk_units = 16384;                // units per launch: 1.4 MiB of workspace each (23 GB); fewer, fuller launches
+    uint32_t chunk_units = 32768;                // units per launch: 1.4 MiB of workspace each (46 GB at 4 GiB of input); fewer, fuller launches
     DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     // per call
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status;
@@ -83,6 +83,8 @@ struct zngamd_ctx {
     (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return ZNGAMD_E_HIP; } } while (0)
 
 static int fail(zngamd_ctx *c, int code, const char *msg) { c->err = msg; return code; }
+// no C++ exception leaves the C ABI (host allocations of the batch paths can fail): reported as ZNGAMD_MEM_ERROR
+#define ZA_ABI_GUARD catch (const std::bad_alloc &) { return ZNGAMD_MEM_ERROR; } catch (...) { return ZNGAMD_E_ARG; }
 
 
 static hipEvent_t ev_get(zngamd_ctx *c)
@@ -110,14 +112,14 @@ extern "C" {
 const char *zngamd_version(void) { return "zng_amd 0.1 (gfx950)"; }
 
 int zngamd_device_count(void)
-{
+try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} ZA_ABI_GUARD
 
 int zngamd_ctx_create(int device, zngamd_ctx **out)
-{
+try {
     if (!out) return ZNGAMD_E_ARG;
     *out = nullptr;
     int n = 0;
@@ -153,7 +155,7 @@ int zngamd_ctx_create(int device, zngamd_ctx **out)
     }
     *out = c;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 void zngamd_ctx_destroy(zngamd_ctx *c)
 {
@@ -179,58 +181,59 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
 const char *zngamd_last_error(zngamd_ctx *c) { return c ? c->err.c_str() : "no context"; }
 
 int zngamd_set_stream(zngamd_ctx *c, void *s)
-{
+try {
     if (!c) return ZNGAMD_E_ARG;
     (void)hipStreamSynchronize(c->stream);
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_sync(zngamd_ctx *c)
-{
+try {
     if (!c) return ZNGAMD_E_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_dmalloc(zngamd_ctx *c, size_t bytes, void **dptr)
-{
+try {
     if (!c || !dptr) return ZNGAMD_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(dptr, bytes ? bytes : 1));
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 int zngamd_dfree(zngamd_ctx *c, void *dptr) { if (!c) return ZNGAMD_E_ARG; HIPCHK(c, hipFree(dptr)); return ZNGAMD_OK; }
 int zngamd_h2d(zngamd_ctx *c, void *dst, const void *src, size_t bytes)
-{
+try {
     if (!c) return ZNGAMD_E_ARG;
     if (bytes) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
+
 int zngamd_d2h(zngamd_ctx *c, void *dst, const void *src, size_t bytes)
-{
+try {
     if (!c) return ZNGAMD_E_ARG;
     if (bytes) { HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_decode_paths(zngamd_ctx *c, uint64_t *members, int reset)
-{
+try {
     if (!c || !members) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     for (int i = 0; i < ZNGAMD_PATH_COUNT; i++) { members[i] = c->paths[i]; if (reset) c->paths[i] = 0; }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 int zngamd_profiling(zngamd_ctx *c, int on) { if (!c) return ZNGAMD_E_ARG; c->prof = on != 0; return ZNGAMD_OK; }
 int zngamd_kernel_times(zngamd_ctx *c, double *ms, uint64_t *launches, int reset)
-{
+try {
     if (!c) return ZNGAMD_E_ARG;
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (int i = 0; i < ZNGAMD_K_COUNT; i++) { if (ms) ms[i] = c->ms[i]; if (launches) launches[i] = c->launches[i]; if (reset) { c->ms[i] = 0; c->launches[i] = 0; } }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 // ---------------------------------------------------------------------------------------------
 // checksums
@@ -284,7 +287,7 @@ static int stage_in(zngamd_ctx *c, const uint8_t *in, uint64_t n, uint64_t pad_f
 }
 
 int zngamd_crc32_dev(zngamd_ctx *c, uint32_t crc, const void *dbuf, size_t len, uint32_t *out)
-{
+try {
     if (!c || !out) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -292,9 +295,10 @@ int zngamd_crc32_dev(zngamd_ctx *c, uint32_t crc, const void *dbuf, size_t len, 
     int r = checksum_dev(c, (const uint8_t *)dbuf, len, &v, nullptr);
     *out = v;
     return r;
-}
+} ZA_ABI_GUARD
+
 int zngamd_crc32(zngamd_ctx *c, uint32_t crc, const uint8_t *buf, size_t len, uint32_t *out)
-{
+try {
     if (!c || !out || (!buf && len)) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     int r = stage_in(c, buf, len);
@@ -303,9 +307,10 @@ int zngamd_crc32(zngamd_ctx *c, uint32_t crc, const uint8_t *buf, size_t len, ui
     r = checksum_dev(c, c->st_in.p, len, &v, nullptr);
     *out = v;
     return r;
-}
+} ZA_ABI_GUARD
+
 int zngamd_adler32(zngamd_ctx *c, uint32_t adler, const uint8_t *buf, size_t len, uint32_t *out)
-{
+try {
     if (!c || !out || (!buf && len)) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     int r = stage_in(c, buf, len);
@@ -315,7 +320,7 @@ int zngamd_adler32(zngamd_ctx *c, uint32_t adler, const uint8_t *buf, size_t len
     r = checksum_dev(c, c->st_in.p, len, nullptr, &v);
     *out = v;
     return r;
-}
+} ZA_ABI_GUARD
 
 // ---------------------------------------------------------------------------------------------
 // deflate
@@ -401,7 +406,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
 
 int zngamd_deflate_blocks_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
                               int level, void *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc, uint32_t *h_unit_block)
-{
+try {
     if (!c || (!blocks && n_blocks) || !d_slots || !d_unit_len || !d_unit_crc) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     std::vector<ZaUnit> hu;
@@ -413,7 +418,7 @@ int zngamd_deflate_blocks_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 static int gather_dev(zngamd_ctx *c, const uint8_t *d_slots, const uint32_t *d_unit_len, uint32_t n, uint32_t extra,
                       uint8_t *d_dst, uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off, uint64_t *total, bool do_copy,
@@ -438,7 +443,7 @@ static int gather_dev(zngamd_ctx *c, const uint8_t *d_slots, const uint32_t *d_u
 
 int zngamd_gather_dev(zngamd_ctx *c, const void *d_slots, const uint32_t *d_unit_len, uint32_t n_units, void *d_dst,
                       uint64_t dst_base, uint64_t dst_cap, uint64_t *d_unit_off, uint64_t *total_bytes)
-{
+try {
     if (!c || !d_slots || !d_unit_len || !d_dst || !total_bytes) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -447,7 +452,7 @@ int zngamd_gather_dev(zngamd_ctx *c, const void *d_slots, const uint32_t *d_unit
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 // shared by the two host-buffer entry points: input already staged at st_in.p
 // pinned host memory for results that are re-distributed on the host afterwards: a device-to-host copy into pinned memory
@@ -523,7 +528,7 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
 
 int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
                           int level, uint8_t *out, uint64_t out_cap_per_block, uint32_t *out_len, uint32_t *crc)
-{
+try {
     if (!c || (!in && in_len) || (!blocks && n_blocks) || !out || !out_len || !crc) return ZNGAMD_E_ARG;
     if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
     std::lock_guard<std::mutex> g(c->mu);
@@ -551,11 +556,11 @@ int zngamd_deflate_blocks(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, con
     }
     if (ret) c->err = "Compressed output exceeds buffer size";
     return ret;
-}
+} ZA_ABI_GUARD
 
 int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int level, int window_bits, uint8_t *out,
                           uint64_t out_cap, uint64_t *out_len, uint32_t *crc, uint32_t *adler)
-{
+try {
     if (!c || (!in && in_len) || !out || !out_len) return ZNGAMD_E_ARG;
     if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
     if (in_len > 0xFFFFFFFFull) return fail(c, ZNGAMD_E_ARG, "one-shot input limited to 4 GiB - 1");
@@ -570,10 +575,10 @@ int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int
     if (crc) { uint32_t v = 0; for (size_t u = 0; u < hu.size(); u++) v = u ? zngamd_crc32_combine(v, ucrc[u], hu[u].in_len) : ucrc[u]; *crc = v; }
     if (adler) { uint32_t a = 1; r = checksum_dev(c, c->st_in.p, in_len, nullptr, &a); if (r) return r; *adler = a; }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_debug_fetch(zngamd_ctx *c, int what, uint32_t unit, void *dst, size_t bytes)
-{
+try {
     if (!c || !dst) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     if (unit >= c->last_units || !c->last_single_chunk) return fail(c, ZNGAMD_E_ARG, "unit not resident");
@@ -593,7 +598,7 @@ int zngamd_debug_fetch(zngamd_ctx *c, int what, uint32_t unit, void *dst, size_t
     if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
     HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 // ---------------------------------------------------------------------------------------------
 // inflate
@@ -636,7 +641,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
 
 int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used, uint32_t *crc, uint32_t *adler)
-{
+try {
     if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     if (dict_len > ZA_WIN) { dict += dict_len - ZA_WIN; dict_len = ZA_WIN; }
@@ -674,12 +679,12 @@ int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const 
     }
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
-}
+} ZA_ABI_GUARD
 
 
 int zngamd_inflate_resume(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint32_t start_bit, const uint8_t *dict, uint32_t dict_len,
                           uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_bits, uint64_t *block_bits, uint64_t *block_out)
-{
+try {
     if (!c || (!in && in_len) || (!out && out_cap) || !out_len || !in_bits || !block_bits || !block_out || start_bit > 7) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     if (dict_len > ZA_WIN) { dict += dict_len - ZA_WIN; dict_len = ZA_WIN; }
@@ -714,7 +719,7 @@ int zngamd_inflate_resume(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uin
     if (res.status == ZA_I_OUTFULL) return ZNGAMD_E_OVERFLOW;          // out_cap reached: call again with more room
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
-}
+} ZA_ABI_GUARD
 
 // ---- two-pass reader for indexed members -----------------------------------------------------
 // allow_tail: the chain may stop before the end of the buffer (what follows is an incomplete member, or not an indexed
@@ -761,7 +766,7 @@ static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
 
 int zngamd_gzip_scan_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, zngamd_member *d_members, uint32_t max_members,
                          uint32_t *n_members, uint64_t *total_out)
-{
+try {
     if (!c || !d_in || !d_members || !n_members || !total_out) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -773,7 +778,7 @@ int zngamd_gzip_scan_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, zngam
     *n_members = (uint32_t)hm.size();
     HIPCHK(c, hipMemcpy(d_members, hm.data(), hm.size() * sizeof(ZaMember), hipMemcpyHostToDevice));
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const ZaMember *d_members, uint32_t n,
                                uint8_t *d_out, uint64_t out_cap, int32_t *d_status)
@@ -792,7 +797,7 @@ static int inflate_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_l
 
 int zngamd_gzip_inflate_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_member *d_members,
                                     uint32_t n_members, void *d_out, uint64_t out_cap, int32_t *d_status)
-{
+try {
     if (!c || !d_in || !d_members || !d_out || !d_status) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -801,11 +806,11 @@ int zngamd_gzip_inflate_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_gzip_inflate_plain_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_member *d_members,
                                           uint32_t n_members, void *d_out, uint64_t out_cap, int32_t *d_status)
-{
+try {
     if (!c || !d_in || !d_members || !d_out || !d_status) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -818,11 +823,11 @@ int zngamd_gzip_inflate_plain_members_dev(zngamd_ctx *c, const void *d_in, uint6
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_inflate_raw_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, void *d_out, uint64_t out_cap, uint64_t *out_len,
                            uint64_t *in_used)
-{
+try {
     if (!c || !d_in || !d_out || !out_len) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -839,10 +844,10 @@ int zngamd_inflate_raw_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, voi
     if (in_used) *in_used = (res.in_bits + 7) >> 3;
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
-}
+} ZA_ABI_GUARD
 
 int zngamd_crc32_fold_dev(zngamd_ctx *c, const uint32_t *d_crcs, uint32_t n, uint64_t each_len, uint64_t last_len, uint32_t *crc)
-{
+try {
     if (!c || (!d_crcs && n) || !crc) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -860,10 +865,10 @@ int zngamd_crc32_fold_dev(zngamd_ctx *c, const uint32_t *d_crcs, uint32_t n, uin
     }
     *crc = r;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_compare_dev(zngamd_ctx *c, const void *d_a, const void *d_b, uint64_t n, uint64_t *mismatches)
-{
+try {
     if (!c || (!d_a && n) || (!d_b && n) || !mismatches) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -880,7 +885,7 @@ int zngamd_compare_dev(zngamd_ctx *c, const void *d_a, const void *d_b, uint64_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *mismatches = bad;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 // ---- general gzip reader (host buffer) --------------------------------------------------------
 // Restates the member state machine of GzipReader_read_into_buffer (zlib_ngmodule.c:2443-2611):
@@ -1367,12 +1372,12 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
 }
 
 int zngamd_gunzip(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
-{
+try {
     if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     uint64_t used = 0;
     return gunzip_impl(c, in, in_len, false, out, out_cap, out_len, n_members, &used);
-}
+} ZA_ABI_GUARD
 
 // ---- one member that is larger than the caller's window: decoded block-wise across calls -------------------
 struct StreamRun { int status; uint64_t out_len; uint64_t in_bits; bool chunked; };
@@ -1457,7 +1462,7 @@ static int stream_step(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, ui
 
 int zngamd_gunzip_stream(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, int last, uint8_t *out, uint64_t out_cap,
                          uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
-{
+try {
     if (!c || !st || (!in && in_len) || (!out && out_cap) || !out_len || !in_consumed) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     *out_len = 0; *in_consumed = 0;
@@ -1481,15 +1486,15 @@ int zngamd_gunzip_stream(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, 
     }
     st->in_member = 0; st->start_bit = 0; st->crc = 0; st->window_len = 0; st->out_total = 0;
     return stream_step(c, st, in, in_len, doff, false, out, out_cap, out_len, n_members, in_consumed);
-}
+} ZA_ABI_GUARD
 
 int zngamd_gunzip_partial(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                           uint32_t *n_members, uint64_t *in_consumed)
-{
+try {
     if (!c || (!in && in_len) || (!out && out_cap) || !out_len || !in_consumed) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     return gunzip_impl(c, in, in_len, true, out, out_cap, out_len, n_members, in_consumed);
-}
+} ZA_ABI_GUARD
 
 // ---- indexed member writer ---------------------------------------------------------------------
 static int gzip_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, uint32_t block_size, int level,
@@ -1530,16 +1535,16 @@ static int gzip_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
 
 int zngamd_gzip_members_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, uint32_t block_size, int level, void *d_out,
                             uint64_t out_cap, uint64_t *out_len, uint32_t *n_members)
-{
+try {
     if (!c || (!d_in && in_len) || !d_out || !out_len) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return gzip_members_dev(c, (const uint8_t *)d_in, in_len, block_size, level, (uint8_t *)d_out, out_cap, out_len, n_members);
-}
+} ZA_ABI_GUARD
 
 int zngamd_gzip_members(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint32_t block_size, int level, uint8_t *out,
                         uint64_t out_cap, uint64_t *out_len)
-{
+try {
     if (!c || (!in && in_len) || !out || !out_len) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     int r = stage_in(c, in, in_len);
@@ -1554,7 +1559,7 @@ int zngamd_gzip_members(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, uint3
     if (total > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small");
     if (total) { const int rc_ = d2h_payload(c, out, c->st_aux.p, total); if (rc_) return rc_; }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 }  // extern "C"
 
@@ -1612,7 +1617,7 @@ struct zngamd_comm {
 extern "C" {
 
 int zngamd_comm_unique_id(uint8_t id[ZNGAMD_COMM_ID_BYTES])
-{
+try {
     static_assert(sizeof(ncclUniqueId) == ZNGAMD_COMM_ID_BYTES, "unique id size");
     if (!id) return ZNGAMD_E_ARG;
     RcclApi *a = rccl_api(nullptr);
@@ -1621,10 +1626,10 @@ int zngamd_comm_unique_id(uint8_t id[ZNGAMD_COMM_ID_BYTES])
     if (a->GetUniqueId(&u) != ncclSuccess) return ZNGAMD_E_HIP;
     memcpy(id, &u, sizeof u);
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_comm_create(zngamd_ctx *c, const uint8_t id[ZNGAMD_COMM_ID_BYTES], int rank, int world, zngamd_comm **out)
-{
+try {
     if (!c || !id || !out || world < 1 || rank < 0 || rank >= world) return ZNGAMD_E_ARG;
     *out = nullptr;
     std::string why;
@@ -1643,7 +1648,7 @@ int zngamd_comm_create(zngamd_ctx *c, const uint8_t id[ZNGAMD_COMM_ID_BYTES], in
     if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + a->GetErrorString(r); m->comm = nullptr; zngamd_comm_destroy(m); return ZNGAMD_E_HIP; }
     *out = m;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 void zngamd_comm_destroy(zngamd_comm *m)
 {
@@ -1662,7 +1667,7 @@ const char *zngamd_comm_last_error(zngamd_comm *m) { return m ? m->err.c_str() :
 
 int zngamd_comm_layout(zngamd_comm *m, uint64_t local_len, uint32_t local_crc, uint64_t local_ulen, uint64_t *sizes,
                        uint64_t *my_off, uint64_t *total, uint32_t *whole_crc, uint64_t *whole_ulen)
-{
+try {
     if (!m || !sizes || !my_off || !total) return ZNGAMD_E_ARG;
     HIPCHKM(m, hipSetDevice(m->ctx->device));
     const uint64_t mine[3] = {local_len, (uint64_t)local_crc, local_ulen};
@@ -1685,10 +1690,10 @@ int zngamd_comm_layout(zngamd_comm *m, uint64_t local_len, uint32_t local_crc, u
     if (whole_crc) *whole_crc = crc;
     if (whole_ulen) *whole_ulen = ul;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_comm_allgather_stream(zngamd_comm *m, const void *d_local, const uint64_t *sizes, void *d_stream, uint64_t stream_cap)
-{
+try {
     if (!m || !d_local || !sizes || !d_stream) return ZNGAMD_E_ARG;
     HIPCHKM(m, hipSetDevice(m->ctx->device));
     uint64_t total = 0, my_off = 0;
@@ -1713,17 +1718,17 @@ int zngamd_comm_allgather_stream(zngamd_comm *m, const void *d_local, const uint
         NCCLCHK(m, m->api->GroupEnd());
     }
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_comm_wait(zngamd_comm *m)
-{
+try {
     if (!m) return ZNGAMD_E_ARG;
     HIPCHKM(m, hipStreamSynchronize(m->stream));
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_comm_max_f64(zngamd_comm *m, double *value)
-{
+try {
     if (!m || !value) return ZNGAMD_E_ARG;
     HIPCHKM(m, hipSetDevice(m->ctx->device));
     HIPCHKM(m, hipMemcpyAsync(m->d_val, value, 8, hipMemcpyHostToDevice, m->stream));
@@ -1731,13 +1736,13 @@ int zngamd_comm_max_f64(zngamd_comm *m, double *value)
     HIPCHKM(m, hipMemcpyAsync(value, m->d_val + 1, 8, hipMemcpyDeviceToHost, m->stream));
     HIPCHKM(m, hipStreamSynchronize(m->stream));
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_comm_barrier(zngamd_comm *m)
-{
+try {
     double v = 0;
     return zngamd_comm_max_f64(m, &v);
-}
+} ZA_ABI_GUARD
 
 }  // extern "C"
 
