@@ -1488,7 +1488,15 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
 // Members whose extent is known up front without this engine's index (BGZF: 'B','C' subfield with the
 // block size; reference fixture tests/data/test.fastq.bgzip.gz): one wavefront per member runs the
 // sequential decoder, then checks CRC-32 and ISIZE against the trailer (zlib_ngmodule.c:2577-2599).
+// history ring and match queue of the one-wavefront-per-member decoder (16 KiB of LDS per wavefront, 9 per CU).  A queue of 512
+// entries (11 per CU) is 6 % faster on 8 192 zlib-written members of 128 KiB and 10 % slower on 4 097 BGZF members of 64 KiB
+// (fewer wavefronts than the GPU holds: occupancy is no help, shorter sweeps hurt); 256 entries cost 30 %; kept at 1 024
+#ifndef ZA_MEMBER_RING
 #define ZA_MEMBER_RING 4096
+#endif
+#ifndef ZA_MEMBER_Q
+#define ZA_MEMBER_Q 1024
+#endif
 __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                   const ZaMember *__restrict__ members,
                                                                   uint8_t *__restrict__ out, uint64_t out_cap,
@@ -1497,10 +1505,10 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
                                                                   int32_t *__restrict__ status_out)
 {
     __shared__ ZaInfTabs T;
-    __shared__ uint8_t win[ZA_MEMBER_RING];       // 4 KiB of history in LDS (16 members per CU); older sources come from the output
+    __shared__ uint8_t win[ZA_MEMBER_RING];       // the last bytes of history in LDS; older sources come from the output
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
-    __shared__ ZaParBufT<256, 1024> P;
+    __shared__ ZaParBufT<256, ZA_MEMBER_Q> P;
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
@@ -1512,7 +1520,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING, ZaParBufT<256, 1024>>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
+    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING, ZaParBufT<256, ZA_MEMBER_Q>>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
                                                                        0, nullptr, nullptr, 0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
