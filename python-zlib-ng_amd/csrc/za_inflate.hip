@@ -1232,10 +1232,13 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                         const bool bad_index = nxb == 7u || len < 4 || pos + len > end || nmatch + 2u > ZA_MATCHQ_PER_SEG;
                         if (bad_data || bad_index) err = (nxb == 7u || !bad_data) ? 1 : 2;
                         else {
-                            uint32_t gap = (uint32_t)(pos - prev_end);
-                            if (gap >= 511u) { push(gap); gap = 0; }
-                            push((uint32_t)(dist - 1) | ((uint32_t)(len - 3) << 15) | (gap << 23));
-                            adv = len;
+                            // one push per round: a run of 511 literals or more (rare) gets its entry now and the match is
+                            // decoded again in the next round, with no literals in front of it any more
+                            const uint32_t gap = (uint32_t)(pos - prev_end);
+                            const bool longgap = gap >= 511u;
+                            push(longgap ? gap : (uint32_t)(dist - 1) | ((uint32_t)(len - 3) << 15) | (gap << 23));
+                            adv = longgap ? 0 : len;
+                            used = longgap ? 0u : used;
                         }
                     }
                     if (err) { lane_err = err; done = true; adv = 0; used = 0; }

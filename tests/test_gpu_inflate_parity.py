@@ -105,6 +105,13 @@ def test_indexed_members_round_trip(ctx, fastq, level):
             assert ctx.decode_paths(True)["indexed"] == nm, "the indexed path did not decode these members"
         ocode, oout, onm = O.gunzip(stream, len(data) + 1)
         assert ocode == 0 and oout == data
+    # runs of more than 510 literals in front of a match (the queue entry of a match counts 9 bits of literals: longer runs
+    # get an entry of their own): 700 random bytes, then text, in every 2 KiB segment
+    mix = b"".join(rng.bytes(700) + fastq[i * 1348:(i + 1) * 1348] for i in range(150))
+    stream = ctx.gzip_members(mix, 131072, level)
+    ctx.decode_paths(True)
+    code, out, nm = ctx.gunzip(stream, len(mix))
+    assert code == 0 and out == mix and ctx.decode_paths(True)["indexed"] == nm == 3
     # corrupt one payload byte of an indexed stream: CRC / data error must surface
     stream = bytearray(ctx.gzip_members(fastq[:400000], 131072, level))
     stream[5000] ^= 0x10
