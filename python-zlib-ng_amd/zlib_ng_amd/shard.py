@@ -61,7 +61,7 @@ def gzip_frame(body_len_total, crc, size, level):
 _RDV_MAGIC = b"ZNGA"
 
 
-def rendezvous_bytes(rank, world, addr, port, payload=None, timeout=120.0, tries=8):
+def rendezvous_bytes(rank, world, addr, port, payload=None, timeout=900.0, tries=8):
     """Rank 0 hands `payload` (bytes) to the other ranks over TCP (one short connection each); every rank returns it.
     What a launcher without a key-value store needs to pass the 128-byte RCCL unique id around.  Rank 0 listens on the first
     free port of port .. port+tries-1; the others go round those ports until one answers with the magic word."""
