@@ -317,7 +317,7 @@ def main():
                    "writer": "system zlib " + zlib.ZLIB_RUNTIME_VERSION + f" level {args.level}, plain gzip members of 128 KiB",
                    "ms": round(min(f_ms), 3), "decompress_MBps": round(size / (min(f_ms) * 1e-3) / 1e6, 1),
                    "achieved": round(fbytes / (min(f_ms) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(fbytes / (min(f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                   "frac": round(fbytes / (min(f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(fbytes)}
         del d_for, d_tile, d_ft
 
     # ---- per-leg numbers -----------------------------------------------------------------------------
@@ -337,10 +337,11 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    traffic_step, traffic_src = {}, None
+    traffic_step, traffic_src, pmc_per_unit = {}, None, {}
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))                      # HBM bytes per unit from the PMC passes (profiles/run_pmc.sh)
+            pmc_per_unit = pj
             traffic_src = "PMC passes of build '%s' (profiles/pmc_traffic.json)" % pj.get("build", "?")
             for k in ("chains", "search", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
                 if pj.get("za_k_" + k):
@@ -381,6 +382,9 @@ def main():
                              "traffic_source": traffic_src},
         "hbm_traffic_bytes_per_step": traffic_step or None,
     }
+    if foreign is not None and pmc_per_unit.get("za_k_inflate_serial_members"):
+        foreign["traffic"] = int(pmc_per_unit["za_k_inflate_serial_members"] * nblocks)
+        foreign["traffic_source"] = traffic_src
 
     # ---- CPU baseline on this box's host cores (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
