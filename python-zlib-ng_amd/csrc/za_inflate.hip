@@ -1494,12 +1494,16 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
 // history ring and match queue of the one-wavefront-per-member decoder (16 KiB of LDS per wavefront, 9 per CU).  A queue of 512
 // entries (11 per CU) is 6 % faster on 8 192 zlib-written members of 128 KiB and 10 % slower on 4 097 BGZF members of 64 KiB
 // (fewer wavefronts than the GPU holds: occupancy is no help, shorter sweeps hurt); 256 entries cost 30 %; kept at 1 024
+// (`profiles/abl_foreign.sh`, `profiles/abl_bgzf.sh`)
 #ifndef ZA_MEMBER_RING
 #define ZA_MEMBER_RING 4096
 #endif
 #ifndef ZA_MEMBER_Q
 #define ZA_MEMBER_Q 1024
 #endif
+#ifndef ZA_MEMBER_BITS
+#define ZA_MEMBER_BITS 384             // bits per sub-sequence: 384 is 5 % faster than 256 on zlib-written 128 KiB members (fewer passes per
+#endif                                 // output byte, still 9 wavefronts per CU), equal on 64 KiB BGZF members; 512 needs a longer queue and loses
 __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                   const ZaMember *__restrict__ members,
                                                                   uint8_t *__restrict__ out, uint64_t out_cap,
@@ -1511,7 +1515,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     __shared__ uint8_t win[ZA_MEMBER_RING];       // the last bytes of history in LDS; older sources come from the output
     __shared__ int scratch[2];
     __shared__ uint32_t crct[256];
-    __shared__ ZaParBufT<256, ZA_MEMBER_Q> P;
+    __shared__ ZaParBufT<ZA_MEMBER_BITS, ZA_MEMBER_Q> P;
     const int lane = za_lane();
     const ZaMember m = members[blockIdx.x];
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
@@ -1523,7 +1527,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
     const uint8_t *src = in + m.in_off;
     uint8_t *dst = out + m.out_off;
     uint64_t bits = 0, op = 0;
-    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING, ZaParBufT<256, ZA_MEMBER_Q>>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
+    int status = za_inflate_serial_core<0, uint8_t, ZA_MEMBER_RING, ZaParBufT<ZA_MEMBER_BITS, ZA_MEMBER_Q>>(src, m.in_len, nullptr, 0, dst, m.out_len, T, win, scratch, P.stage, bits, op,
                                                                        0, nullptr, nullptr, 0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (status == ZA_I_END) {
         status = ZA_I_OK;
