@@ -342,8 +342,11 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     const uint32_t qb = P - (uint32_t)best_dist;
                     for (;;) {                                   // 8 bytes per round; most winners end in the first
                         const uint32_t o = (uint32_t)best_len;
-                        const uint32_t a0 = za_lds_ld32(win32, qb + o) ^ za_lds_ld32(win32, P + o);
-                        const uint32_t a1 = za_lds_ld32(win32, qb + o + 4u) ^ za_lds_ld32(win32, P + o + 4u);
+                        // eight bytes of each side from three aligned dwords (the ring's mirrored pad covers the overrun)
+                        const uint32_t is = (qb + o) & (ZA_BYTES - 1), ws = is >> 2, ip = (P + o) & (ZA_BYTES - 1), wp = ip >> 2;
+                        const uint32_t s0 = win32[ws], s1 = win32[ws + 1], s2 = win32[ws + 2], p0 = win32[wp], p1 = win32[wp + 1], p2 = win32[wp + 2];
+                        const uint32_t a0 = __builtin_amdgcn_alignbyte(s1, s0, is & 3u) ^ __builtin_amdgcn_alignbyte(p1, p0, ip & 3u);
+                        const uint32_t a1 = __builtin_amdgcn_alignbyte(s2, s1, is & 3u) ^ __builtin_amdgcn_alignbyte(p2, p1, ip & 3u);
                         uint32_t g0, g1;
                         asm("v_ffbl_b32 %0, %2\n\tv_ffbl_b32 %1, %3\n\tv_add_u32_e64 %1, %1, 32 clamp\n\tv_min_u32_e32 %0, %0, %1"
                             : "=&v"(g0), "=&v"(g1) : "v"(a0), "v"(a1));
