@@ -194,3 +194,21 @@ def test_rendezvous_skips_a_busy_port():
     ft.join(2)
     squat.close()
     assert got == {0: payload, 1: payload, 2: payload}
+
+
+def test_result_object_grows_and_is_cut_in_place():
+    """_lib._Out: the result of a call is an uninitialised bytes object held through a bare pointer; it is grown and finally
+    cut to size in place (no zero fill, no final copy) -- what the streaming bindings build their output in."""
+    import ctypes as C
+    from zlib_ng_amd import _lib
+    o = _lib._Out(10)
+    C.memmove(o.addr(), b"0123456789", 10)
+    o.resize(1 << 20)                                   # grows (the address may change, the bytes stay)
+    C.memmove(o.addr().value + 10, b"ab", 2)
+    r = o.take(12)
+    assert r == b"0123456789ab" and type(r) is bytes and sys.getrefcount(r) == 2
+    assert _lib._Out(16).take(0) == b""
+    big = _lib._Out(64)
+    C.memset(big.addr(), 0x41, 64)
+    assert big.take(64) == b"A" * 64                    # filled completely: handed over as it is
+    del o, big                                           # (objects that were never taken are released with their holder)
