@@ -254,8 +254,8 @@ int zngamd_gzip_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, 
  * zng_inflateCopy / zng_inflateEnd (:477, :667, :995, :1150, :446, :893): same fields, same flush values, same return codes
  * (ZNGAMD_OK 0, ZNGAMD_STREAM_END 1, ZNGAMD_NEED_DICT 2, ZNGAMD_STREAM_ERROR -2, ZNGAMD_DATA_ERROR -3, ZNGAMD_MEM_ERROR -4,
  * ZNGAMD_BUF_ERROR -5), `msg` set where zng_inflate sets it ("incorrect header check", "invalid window size", "incorrect data
- * check", ...).  deflate collects input until a flush or 8 MiB and compresses it as one dictionary-chained engine batch
- * (a piece of 8 MiB or more handed in at once is compressed where it lies); inflate keeps the compressed bytes from the last
+ * check", ...).  deflate collects input until a flush or 32 MiB and compresses it as one dictionary-chained engine batch
+ * (a piece of 32 MiB or more handed in at once is compressed where it lies); inflate keeps the compressed bytes from the last
  * block header on, decodes from there (bit offset + 32 KiB of history) and hands out what is new; input the stream does not
  * need yet comes back through avail_in, as with zng_inflate. */
 typedef struct zngamd_stream_state zngamd_stream_state;
