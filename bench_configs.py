@@ -51,12 +51,17 @@ def main():
 
     # ---- config 0: API plumbing on incompressible data (host buffers, PCIe in the loop)
     buf = os.urandom(1 << 20)
-    zlib_ng.compress(buf[:1000], 6)                # first call creates the context / workspaces
-    t0 = time.perf_counter(); c = zlib_ng.compress(buf, 6); t1 = time.perf_counter()
-    d = zlib_ng.decompress(c); t2 = time.perf_counter()
+    c = zlib_ng.compress(buf, 6)                   # first call creates the context and sizes the workspaces for 8 units
+    zlib_ng.decompress(c)
+    tc = td = None
+    for _ in range(3):                             # steady state: best of three
+        t0 = time.perf_counter(); c = zlib_ng.compress(buf, 6); t1 = time.perf_counter()
+        d = zlib_ng.decompress(c); t2 = time.perf_counter()
+        tc = t1 - t0 if tc is None else min(tc, t1 - t0)
+        td = t2 - t1 if td is None else min(td, t2 - t1)
     assert d == buf and zlib.decompress(c) == buf
-    out.append({"config": 0, "workload": "zlib_ng.compress/decompress level 6, 1 MiB os.urandom, host API",
-                "compressed_bytes": len(c), "compress_ms": round((t1 - t0) * 1e3, 2), "decompress_ms": round((t2 - t1) * 1e3, 2)})
+    out.append({"config": 0, "workload": "zlib_ng.compress/decompress level 6, 1 MiB os.urandom, host API, steady state",
+                "compressed_bytes": len(c), "compress_ms": round(tc * 1e3, 2), "decompress_ms": round(td * 1e3, 2)})
 
     # ---- host-buffer API on a large input: PCIe, staging and Python buffers inside the timed region
     big = corpus.text(64 << 20, seed=1).tobytes() * 4

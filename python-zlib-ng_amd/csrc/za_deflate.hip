@@ -914,7 +914,10 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
                     dst[1] = (uint8_t)(len & 0xFF); dst[2] = (uint8_t)(len >> 8);
                     dst[3] = (uint8_t)(~len & 0xFF); dst[4] = (uint8_t)((~len >> 8) & 0xFF);
                 }
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[5 + i] = data[off + i];
+                // the payload: 16 bytes per lane and round (both sides at any alignment), the tail bytewise
+                const uint32_t full = len & ~15u;
+                for (uint32_t i = 16u * (uint32_t)lane; i < full; i += 16u * 64u) *(ZaU4u *)(dst + 5 + i) = *(const ZaU4u *)(data + off + i);
+                for (uint32_t i = full + (uint32_t)lane; i < len; i += 64) dst[5 + i] = data[off + i];
             }
             total_bytes = (uint32_t)n + 5u * nchunks;
             if (!final && lane == 0) {
