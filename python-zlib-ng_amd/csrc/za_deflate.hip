@@ -391,9 +391,6 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 // eight lanes fetch the eight 16-byte pieces of one segment's 128-byte row, so an instruction touches eight whole lines,
 // and the pieces are written to the owning lane's LDS row.  A row keeps the previous chunk's last entry in front of the
 // chunk (slot 0): the token at a chunk's last position needs best[p + 1] (lazy rule) and is decided one chunk later.
-#ifndef ZA_PARSE_LITS
-#define ZA_PARSE_LITS 4             // literals a lane takes per round at most (runs of positions without any match)
-#endif
 #define ZA_PCH 32
 #define ZA_PROW (ZA_PCH + 1)          // carried entry + chunk (odd stride)
 #define ZA_DROW (ZA_PCH / 4 + 1)      // carried dword + chunk dwords (odd stride)
@@ -411,8 +408,8 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
 {
     __shared__ uint32_t hist[ZA_HIST_STRIDE];
     __shared__ uint32_t crct[256];
-    __shared__ uint32_t rowb[64 * ZA_PROW + 1];      // (+1: the look-ahead read of a segment's very last position)
-    __shared__ uint32_t rowd[64 * ZA_DROW];
+    __shared__ uint32_t rowb[64 * ZA_PROW + 3];      // (+3: the look-ahead reads at a segment's last positions)
+    __shared__ uint32_t rowd[64 * ZA_DROW + 1];
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const long long readable = (long long)(in_total - u.in_off);
@@ -472,9 +469,12 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     uint32_t crc_r = 0xFFFFFFFFu;
     int p = s0;
     uint32_t carry_b = 0, carry_d = 0;
-    // tokens leave in groups of four (one 16-byte store): single dword stores from 64 lanes to 64 different
-    // lines cost 3-4x their bytes in HBM write traffic
-    uint32_t tb0 = 0, tb1 = 0, tb2 = 0;
+    // Tokens are collected in the lane's own LDS row -- token j of a chunk takes slot j, which holds an entry the lane has
+    // already read (a token consumes at least one position) -- and leave at the end of the chunk TRANSPOSED, like the loads:
+    // eight lanes store the 16-byte pieces of one segment's tokens, so a store instruction touches a few whole lines.  (With
+    // every lane storing its own 16 bytes -- 64 lines per instruction -- the stores were what the token rounds waited for:
+    // 2.37 -> 1.62 ms per GiB with them switched off.)
+    uint32_t nchunk = 0;           // tokens of the current chunk in my row
     prefetch(0);
 #pragma unroll 1
     for (int c = 0; c < ZA_SEG / ZA_PCH; c++) {
@@ -522,15 +522,14 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                 // last position waits for the next chunk (its successor's entry is not here yet) unless the segment ends
                 const int lim = ce == s1 ? ce : ce - 1;
                 auto push = [&](uint32_t t) {
-                    const uint32_t k = ntok & 3u;
 #ifndef ZA_ABL_PARSE_NOSTORE
-                    if (k == 3u) *(uint4 *)(tok + (ntok & ~3u)) = make_uint4(tb0, tb1, tb2, t);
+                    myb[nchunk] = t;
 #endif
-                    tb0 = k == 0u ? t : tb0; tb1 = k == 1u ? t : tb1; tb2 = k == 2u ? t : tb2;
-                    ntok++;
+                    nchunk++;
                 };
                 while (p < lim) {
-                    const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2];
+                    const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2], e2 = myb[p - cb + 3], e3 = myb[p - cb + 4];
+                    const uint32_t lits3 = *(const za_u32u *)(bytes + (p - cb + 5));       // the three bytes behind this position's
                     const int len = (int)(b >> 16), nlen = (int)(bn >> 16);
                     const bool deferred = L.lazy && len < L.lazy && p + 1 < s1 && nlen > len;
                     const bool is_match = len >= ZA_MIN_MATCH && !deferred;
@@ -554,28 +553,45 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                     // lanes are the ones in literal runs: 1 775 rounds per unit of text against 722 tokens per lane without
                     // this, 550 with it.
                     if (len == 0) {
-#pragma unroll
-                        for (int e = 1; e <= ZA_PARSE_LITS - 1; e++) {
-                            if (p < lim && (myb[p - cb + 1] >> 16) == 0u) {
-                                const uint32_t l2 = bytes[p - cb + 4];
-                                push(l2);
-#ifndef ZA_ABL_PARSE_NOHIST
-                                atomicAdd(&hist[l2], 1u);
-#endif
-                                p++;
-                            }
-                        }
+                        // (their entries and bytes were read together with this position's: one LDS round trip for the round,
+                        // not one per literal -- at three waves per SIMD the dependent LDS reads are what a round waits for)
+                        const bool c1 = p < lim && (bn >> 16) == 0u;
+                        const bool c2 = c1 && p + 1 < lim && (e2 >> 16) == 0u;
+                        const bool c3 = c2 && p + 2 < lim && (e3 >> 16) == 0u;
+                        const uint32_t l1 = lits3 & 0xFFu, l2 = (lits3 >> 8) & 0xFFu, l3 = (lits3 >> 16) & 0xFFu;
+                        if (c1) { push(l1); atomicAdd(&hist[l1], 1u); }
+                        if (c2) { push(l2); atomicAdd(&hist[l2], 1u); }
+                        if (c3) { push(l3); atomicAdd(&hist[l3], 1u); }
+                        p += (c1 ? 1 : 0) + (c2 ? 1 : 0) + (c3 ? 1 : 0);
                     }
                 }
             }
             carry_b = myb[ZA_PCH]; carry_d = myd[ZA_PCH / 4];
         }
-    }
-    {   // the last, partial group of tokens
-        const uint32_t k = ntok & 3u, b = ntok & ~3u;
-        if (k > 0) tok[b] = tb0;
-        if (k > 1) tok[b + 1] = tb1;
-        if (k > 2) tok[b + 2] = tb2;
+        // ---- the chunk's tokens leave: lane (8 j + g, piece) stores tokens 4 piece .. 4 piece + 3 of segment 8 j + g
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#if !defined(ZA_ABL_PARSE_NOSTORE) && !defined(ZA_ABL_PARSE_NOGSTORE)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int sg = 8 * j + (lane >> 3);
+            const uint32_t cnt = (uint32_t)__shfl((int)nchunk, sg, 64), at = (uint32_t)__shfl((int)ntok, sg, 64);
+            const uint32_t first = 4u * (uint32_t)(lane & 7);
+            // (a chunk holds at most 33 tokens: the ninth piece, one token, is stored by piece 7's lane as well)
+            const uint32_t *r = rowb + sg * ZA_PROW;
+            uint32_t *dst = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + ((size_t)sg << ZA_SEG_SHIFT) + at;
+            // whole 16-byte pieces, the last one with up to three slots of no meaning behind the chunk's tokens: the next chunk's
+            // tokens land on them.  Only where that would leave the segment's 2 048 slots (a segment of nothing but literals)
+            // the last piece goes token by token.
+            if (first < cnt) {
+                if (at + first + 4u <= (uint32_t)ZA_SEG) { ZaU4u v; v.x = r[first]; v.y = r[first + 1]; v.z = r[first + 2]; v.w = r[first + 3]; *(ZaU4u *)(dst + first) = v; }
+                else for (uint32_t i = first; i < cnt && i < first + 4u; i++) dst[i] = r[i];
+            }
+            if ((lane & 7) == 7 && cnt > 32u) dst[32] = r[32];
+        }
+#endif
+        ntok += nchunk; nchunk = 0;
+        __builtin_amdgcn_wave_barrier();
     }
     // ---- fold the per-segment CRCs: crc(A||B) = crc(A) * x^(8|B|) ^ crc(B)
     uint32_t cseg = 0;
