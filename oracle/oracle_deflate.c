@@ -322,7 +322,16 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
                     hist[288 + dc]++;
                     p += len;
                 } else {
-                    t[nt++] = data[p]; hist[data[p]]++; p++;
+                    /* a position without any match: the literal takes up to two more such positions into its token word
+                     * (bytes in bits 0..23, count - 1 in bits 24..25), as far as the 32-position chunk reaches in which the
+                     * kernel decides it: chunks are counted from the segment start, and a position is decided in the chunk
+                     * of its successor (its successor's entry must be at hand) */
+                    uint32_t tk = data[p]; int nl = 1;
+                    hist[data[p]]++; p++;
+                    int lim = s * ZA_SEG + 32 * ((p - s * ZA_SEG) / 32 + 1);
+                    if (lim > end) lim = end;
+                    while (nl < 3 && p < lim && (best[p] >> 16) == 0) { tk |= (uint32_t)data[p] << (8 * nl); hist[data[p]]++; nl++; p++; }
+                    t[nt++] = tk | ((uint32_t)(nl - 1) << 24);
                 }
             }
             seg_ntok[s] = (uint32_t)nt;
@@ -455,7 +464,11 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
                     putbits(&w, codes[288 + dc], lens[288 + dc]);
                     putbits(&w, tk & 0x1FFFu, dist_extra[dc]);
                     op += len_base[lc] + (int)((tk >> 21) & 31u);
-                } else { putbits(&w, codes[tk], lens[tk]); op++; }
+                } else {                                  /* one to three literals */
+                    int nl = (int)((tk >> 24) & 3u) + 1;
+                    for (int i = 0; i < nl; i++) { uint32_t by = (tk >> (8 * i)) & 0xFFu; putbits(&w, codes[by], lens[by]); }
+                    op += nl;
+                }
             }
             for (; nextb < oend; nextb += 1 << ZA_CHUNK_SHIFT)          /* boundaries behind the last token start */
                 chunk_idx[nextb >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w) | ((uint32_t)(oend - nextb) << 23);

@@ -528,8 +528,8 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                     nchunk++;
                 };
                 while (p < lim) {
-                    const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2], e2 = myb[p - cb + 3], e3 = myb[p - cb + 4];
-                    const uint32_t lits3 = *(const za_u32u *)(bytes + (p - cb + 5));       // the three bytes behind this position's
+                    const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2], e2 = myb[p - cb + 3];
+                    const uint32_t lits2 = *(const za_u16u *)(bytes + (p - cb + 5));       // the two bytes behind this position's
                     const int len = (int)(b >> 16), nlen = (int)(bn >> 16);
                     const bool deferred = L.lazy && len < L.lazy && p + 1 < s1 && nlen > len;
                     const bool is_match = len >= ZA_MIN_MATCH && !deferred;
@@ -539,31 +539,24 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                     za_len_sym(is_match ? len : 3, lc, ln, le);
                     za_dist_sym(dist, dc, dn, de);
                     // a match token carries its symbols (length code << 26, extra << 21, distance code << 16, extra): the
-                    // packer, which is VALU-bound, needs no symbol arithmetic
-                    const uint32_t t = is_match ? (0x80000000u | ((uint32_t)lc << 26) | ((uint32_t)le << 21) | ((uint32_t)dc << 16) | (uint32_t)de) : lit;
-                    // rotating group of four tokens, stored as one 16-byte write
+                    // packer, which is VALU-bound, needs no symbol arithmetic.  A literal at a position without any match (entry
+                    // 0: a literal whatever the lazy rule says) takes up to two more such positions into its token word --
+                    // bytes in bits 0..23, count - 1 in bits 24..25 -- as far as this chunk's entries reach: most tokens of
+                    // text are literals, 3.8 in a row, and fewer token words are fewer stores here and fewer loads in the packer.
+                    // (Their entries and bytes were read together with this position's: one LDS round trip per round.)
+                    const bool c1 = len == 0 && p + 1 < ce && (bn >> 16) == 0u;
+                    const bool c2 = c1 && p + 2 < ce && (e2 >> 16) == 0u;
+                    const uint32_t l1 = lits2 & 0xFFu, l2 = (lits2 >> 8) & 0xFFu;
+                    const uint32_t t = is_match ? (0x80000000u | ((uint32_t)lc << 26) | ((uint32_t)le << 21) | ((uint32_t)dc << 16) | (uint32_t)de)
+                                                : lit | (c1 ? l1 << 8 : 0u) | (c2 ? l2 << 16 : 0u) | (((c1 ? 1u : 0u) + (c2 ? 1u : 0u)) << 24);
                     push(t);
 #ifndef ZA_ABL_PARSE_NOHIST
                     atomicAdd(&hist[is_match ? 257u + (uint32_t)lc : lit], 1u);
                     if (is_match) atomicAdd(&hist[288 + dc], 1u);
+                    if (c1) atomicAdd(&hist[l1], 1u);
+                    if (c2) atomicAdd(&hist[l2], 1u);
 #endif
-                    p += is_match ? len : 1;
-                    // A run of positions with no match at all (entry 0: literals whatever the lazy rule says) is taken in the same
-                    // round, up to three more.  The wave works through a chunk at the pace of its slowest lane, and the slowest
-                    // lanes are the ones in literal runs: 1 775 rounds per unit of text against 722 tokens per lane without
-                    // this, 550 with it.
-                    if (len == 0) {
-                        // (their entries and bytes were read together with this position's: one LDS round trip for the round,
-                        // not one per literal -- at three waves per SIMD the dependent LDS reads are what a round waits for)
-                        const bool c1 = p < lim && (bn >> 16) == 0u;
-                        const bool c2 = c1 && p + 1 < lim && (e2 >> 16) == 0u;
-                        const bool c3 = c2 && p + 2 < lim && (e3 >> 16) == 0u;
-                        const uint32_t l1 = lits3 & 0xFFu, l2 = (lits3 >> 8) & 0xFFu, l3 = (lits3 >> 16) & 0xFFu;
-                        if (c1) { push(l1); atomicAdd(&hist[l1], 1u); }
-                        if (c2) { push(l2); atomicAdd(&hist[l2], 1u); }
-                        if (c3) { push(l3); atomicAdd(&hist[l3], 1u); }
-                        p += (c1 ? 1 : 0) + (c2 ? 1 : 0) + (c3 ? 1 : 0);
-                    }
+                    p += is_match ? len : 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
                 }
             }
             carry_b = myb[ZA_PCH]; carry_d = myd[ZA_PCH / 4];
@@ -1028,27 +1021,23 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             prefetch(k0 + ZA_TCH);
             uint32_t ke = k0 + ZA_TCH;
             if (ke > ntok) ke = ntok;
-            // fn takes the token at tp[0] and may take the next one or two with it (tp[1], tp[2] are staged when `left` says so)
-            for (uint32_t k = k0; k < ke;) k += fn(myt + (k - k0), ke - k);
+            for (uint32_t k = k0; k < ke; k++) fn(myt[k - k0]);
         }
     };
 
     // pass A: bit length of my segment
     uint32_t bits = 0;
     // (literal and match on one predicated path: a literal is "length part only")
-    // Literals come in runs (most tokens of text are literals, several in a row): a round that starts on a literal takes up to
-    // two more literals with it -- fewer rounds for every lane, and the wave runs as long as its slowest lane.
-    for_each_token([&](const uint32_t *tp, uint32_t left) -> uint32_t {
-        const uint32_t t = tp[0];
+    // (literal and match on one predicated path: a literal token is "length part only" -- of one to three literals, which the
+    // parse put into one token word)
+    for_each_token([&](uint32_t t) {
         const bool m = (t & 0x80000000u) != 0u;
         const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
         const uint32_t c1 = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], c2 = codes[288 + dc];
         bits += (c1 >> 16) + (m ? (uint32_t)za_len_extra_bits(lc) + (c2 >> 16) + (uint32_t)za_dist_extra_bits(dc) : 0u);
-        const uint32_t t1 = left > 1u ? tp[1] : 0x80000000u, t2 = left > 2u ? tp[2] : 0x80000000u;
-        const bool two = !m && !(t1 & 0x80000000u), three = two && !(t2 & 0x80000000u);
-        const uint32_t b1 = codes[t1 & 0xFFu] >> 16, b2 = codes[t2 & 0xFFu] >> 16;
-        bits += (two ? b1 : 0u) + (three ? b2 : 0u);
-        return three ? 3u : two ? 2u : 1u;
+        const uint32_t nl = m ? 0u : (t >> 24) & 3u;                        // further literals in the word
+        const uint32_t b1 = codes[(t >> 8) & 0xFFu] >> 16, b2 = codes[(t >> 16) & 0xFFu] >> 16;
+        bits += (nl > 0u ? b1 : 0u) + (nl > 1u ? b2 : 0u);
     });
     const uint32_t incl = za_wave_incl_scan(bits);
     const uint32_t start = plan.header_bits + incl - bits;
@@ -1076,8 +1065,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     // chunk index: for every 256-byte boundary of my segment the first token that starts at or behind it
     uint32_t op = (uint32_t)lane << ZA_SEG_SHIFT, nextb = op;
     uint32_t oend = op + ZA_SEG; if (oend > (uint32_t)n) oend = (uint32_t)n;
-    for_each_token([&](const uint32_t *tp, uint32_t left) -> uint32_t {
-        const uint32_t t = tp[0];
+    for_each_token([&](uint32_t t) {
         const bool m = (t & 0x80000000u) != 0u;
         const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
         const int ln = m ? za_len_extra_bits(lc) : 0, dn = za_dist_extra_bits(dc);
@@ -1094,16 +1082,14 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
         const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
         // literal / length code + extra fit in 20 bits, distance code + extra in 28 (0 bits for a literal)
         w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
-        // second put: the distance part of a match -- or the one or two literals that follow a literal (their codes are
-        // at most ZA_LIMIT_L = 10 bits each)
-        const uint32_t t1 = left > 1u ? tp[1] : 0x80000000u, t2 = left > 2u ? tp[2] : 0x80000000u;
-        const bool two = !m && !(t1 & 0x80000000u), three = two && !(t2 & 0x80000000u);
-        const uint32_t c1 = codes[t1 & 0xFFu], c2 = codes[t2 & 0xFFu];
-        const uint32_t lits = (c1 & 0xFFFF) | (three ? (c2 & 0xFFFF) << (c1 >> 16) : 0u);
-        const int nlits = (int)(c1 >> 16) + (three ? (int)(c2 >> 16) : 0);
-        w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : two ? lits : 0u, m ? (int)(cd >> 16) + dn : two ? nlits : 0);
-        op += three ? 2u : two ? 1u : 0u;
-        return three ? 3u : two ? 2u : 1u;
+        // second put: the distance part of a match -- or the second and third literal of a literal token (their codes are at
+        // most ZA_LIMIT_L = 10 bits each)
+        const uint32_t nl = m ? 0u : (t >> 24) & 3u;
+        const uint32_t c1 = codes[(t >> 8) & 0xFFu], c2 = codes[(t >> 16) & 0xFFu];
+        const uint32_t lits = (c1 & 0xFFFF) | (nl > 1u ? (c2 & 0xFFFF) << (c1 >> 16) : 0u);
+        const int nlits = (int)(c1 >> 16) + (nl > 1u ? (int)(c2 >> 16) : 0);
+        w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : nl ? lits : 0u, m ? (int)(cd >> 16) + dn : nl ? nlits : 0);
+        op += nl;
     });
     for (; nextb < oend && lane < nseg; nextb += 1u << ZA_CHUNK_SHIFT)       // boundaries behind my last token start
         cidx[nextb >> ZA_CHUNK_SHIFT] = (w.w * 32u + (uint32_t)w.nb) | ((oend - nextb) << 23);
