@@ -33,7 +33,7 @@
 #define ZA_CH_SUB   (ZA_HASH_BITS - 2)        // bits of the per-wave table index
 
 __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, unsigned long long *gmask, uint32_t rd, int m, int pmin,
-                                                uint16_t *__restrict__ prevdist, int dict_len)
+                                                uint16_t *__restrict__ prevdist, int dict_len, uint32_t &gen)
 {
     const int lane = za_lane();
     const bool valid = lane < m;
@@ -57,21 +57,41 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
     const uint32_t rep = valid ? (uint32_t)vhead[h] : (uint32_t)lane;
     bool last = true;                                // highest lane of my bucket: leaves its position in the table
     if (__ballot(rep != (uint32_t)lane) != 0ull) {
-        // Some bucket is hit twice in this tile: order its lanes exactly and link later lanes to the nearest
-        // earlier one.  The lanes of a group collect their lane bits in a 64-bit LDS word named by the group
-        // number (three LDS operations instead of a 6-ballot bit-slice match-any: this kernel is VALU-bound).
-        volatile unsigned long long *vg = gmask;
-        vg[lane] = 0ull;
+        // Some bucket is hit twice in this tile: order its lanes exactly and link later lanes to the nearest earlier one.
+        // Fast way: every lane EXCHANGES its number (tagged with this call's generation, so no word has to be cleared) into a
+        // word named by the group number; what comes back is the lane of its group that the LDS served before it.  If the LDS
+        // serves the lanes of an instruction in ascending order that is the nearest earlier lane, and the word's final value is
+        // the group's last lane.  The order is not promised anywhere, so it is checked: any other order hands some lane a
+        // HIGHER number than its own, and then the careful way below runs instead.
+        uint32_t *g32 = (uint32_t *)gmask;
+        gen++;
+        const uint32_t tag = gen << 8;
+        const uint32_t old = valid ? atomicExch(&g32[rep], tag | (uint32_t)lane) : 0u;
         __builtin_amdgcn_wave_barrier();
-        if (valid) atomicOr(&gmask[rep], 1ull << lane);
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long eq = valid ? vg[rep] : 0ull;
-        const unsigned long long lower = eq & ((1ull << lane) - 1ull);
-        const unsigned long long higher = (eq >> lane) >> 1;
-        const int j = lower ? 63 - __builtin_clzll(lower) : lane;
-        const uint32_t Pj = __shfl(P, j, 64);
-        if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
-        last = !higher;
+        const uint32_t fin = valid ? ((volatile uint32_t *)g32)[rep] : 0u;
+        const bool has_pred = valid && (old & ~0xFFu) == tag;
+        const uint32_t pl = old & 0xFFu;
+        if (__ballot(has_pred && pl >= (uint32_t)lane) == 0ull) {
+            const uint32_t Pj = __shfl(P, (int)(has_pred ? pl : (uint32_t)lane), 64);
+            if (has_pred) d = P - Pj;
+            last = (fin & 0xFFu) == (uint32_t)lane;
+        } else {
+            // The lanes of a group collect their lane bits in a 64-bit LDS word named by the group number.
+            volatile unsigned long long *vg = gmask;
+            vg[lane] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) atomicOr(&gmask[rep], 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long eq = valid ? vg[rep] : 0ull;
+            const unsigned long long lower = eq & ((1ull << lane) - 1ull);
+            const unsigned long long higher = (eq >> lane) >> 1;
+            const int j = lower ? 63 - __builtin_clzll(lower) : lane;
+            const uint32_t Pj = __shfl(P, j, 64);
+            if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
+            last = !higher;
+            __builtin_amdgcn_wave_barrier();
+            vg[lane] = 0ull;                             // (no stale bit pattern may look like a tagged lane number later)
+        }
     }
     __builtin_amdgcn_wave_barrier();
     if (valid && last) vhead[h] = P16;
@@ -109,13 +129,15 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     uint32_t wrv = 0;          // lane c < 4: entries ever put into class c's ring (every wave keeps the same copy)
     uint32_t wslot = 0;        // lane c < 4: wrv mod ZA_CH_STAGE
     uint32_t rd = 0, rslot = 0;   // consumed entries of my class, and that number mod ZA_CH_STAGE
+    uint32_t gen = 0;             // generation tag of the dense insert's exchange words (gmask starts zeroed)
+    gmask_all[wave][lane] = 0ull;
     uint32_t par = 0;
     auto consume = [&](uint32_t upto, bool flush) {
         while (upto - rd >= 64u) {
-            za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, 64, pmin, prevdist, dict_len);
+            za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, 64, pmin, prevdist, dict_len, gen);
             rd += 64u; rslot += 64u; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
         }
-        if (flush && upto != rd) za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len);
+        if (flush && upto != rd) za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len, gen);
     };
     auto do_tile = [&](int tbase, const uint2 v) {
         // ---- classify: class = top two hash bits; rank = my place among this wave's entries of my class
