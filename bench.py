@@ -61,6 +61,11 @@ def main():
     ap.add_argument("--no-foreign", action="store_true", help="skip the foreign-member inflate leg (outside the timed region)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="0 = sized for ~10-30 s")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON result: file descriptor 1 is pointed at stderr for the run (RCCL prints a version
+    # banner on the first communicator, libraries print what they like) and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -436,7 +441,8 @@ def main():
     if foreign is not None:
         out["roofline_inflate_foreign"] = foreign
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.close()
