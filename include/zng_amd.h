@@ -317,6 +317,9 @@ int zngamd_comm_layout(zngamd_comm *comm, uint64_t local_len, uint32_t local_crc
  * whole stream on every rank.  Starts behind the work queued on ctx's stream so far and returns at once;
  * zngamd_comm_wait blocks until the exchange is done. */
 int zngamd_comm_allgather_stream(zngamd_comm *comm, const void *d_local, const uint64_t *sizes, void *d_stream, uint64_t stream_cap);
+/* where the slices lie in the assembled stream: offs[r] = sizes[0] + ... + sizes[r-1]; returns the total (pure arithmetic, no GPU:
+ * the placement rule of the exchange above and of a positional write, testable on its own) */
+uint64_t zngamd_comm_offsets(const uint64_t *sizes, int world, uint64_t *offs);
 int zngamd_comm_wait(zngamd_comm *comm);
 /* plumbing for a driver: barrier, and the maximum of one double over the ranks (step time of the slowest rank) */
 int zngamd_comm_barrier(zngamd_comm *comm);

@@ -1692,12 +1692,19 @@ try {
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 
+uint64_t zngamd_comm_offsets(const uint64_t *sizes, int world, uint64_t *offs)
+{
+    uint64_t run = 0;
+    for (int r = 0; r < world; r++) { if (offs) offs[r] = run; run += sizes ? sizes[r] : 0; }
+    return run;
+}
+
 int zngamd_comm_allgather_stream(zngamd_comm *m, const void *d_local, const uint64_t *sizes, void *d_stream, uint64_t stream_cap)
 try {
     if (!m || !d_local || !sizes || !d_stream) return ZNGAMD_E_ARG;
     HIPCHKM(m, hipSetDevice(m->ctx->device));
-    uint64_t total = 0, my_off = 0;
-    for (int r = 0; r < m->world; r++) { if (r < m->rank) my_off += sizes[r]; total += sizes[r]; }
+    std::vector<uint64_t> offs((size_t)m->world);
+    const uint64_t total = zngamd_comm_offsets(sizes, m->world, offs.data()), my_off = offs[(size_t)m->rank];
     if (total > stream_cap) { m->err = "stream buffer too small"; return ZNGAMD_BUF_ERROR; }
     // the slices are final once the work queued on the context's stream so far is done
     HIPCHKM(m, hipEventRecord(m->ev, m->ctx->stream));
@@ -1707,13 +1714,11 @@ try {
         HIPCHKM(m, hipMemcpyAsync(dst + my_off, d_local, sizes[m->rank], hipMemcpyDeviceToDevice, m->stream));
     if (m->world > 1) {
         NCCLCHK(m, m->api->GroupStart());
-        uint64_t off = 0;
         for (int r = 0; r < m->world; r++) {
             if (r != m->rank) {
                 if (sizes[m->rank]) NCCLCHK(m, m->api->Send(d_local, sizes[m->rank], ncclUint8, r, m->comm, m->stream));
-                if (sizes[r]) NCCLCHK(m, m->api->Recv(dst + off, sizes[r], ncclUint8, r, m->comm, m->stream));
+                if (sizes[r]) NCCLCHK(m, m->api->Recv(dst + offs[(size_t)r], sizes[r], ncclUint8, r, m->comm, m->stream));
             }
-            off += sizes[r];
         }
         NCCLCHK(m, m->api->GroupEnd());
     }

@@ -212,3 +212,23 @@ def test_result_object_grows_and_is_cut_in_place():
     C.memset(big.addr(), 0x41, 64)
     assert big.take(64) == b"A" * 64                    # filled completely: handed over as it is
     del o, big                                           # (objects that were never taken are released with their holder)
+
+
+def test_slice_offsets_of_the_exchange():
+    """zngamd_comm_offsets: where every rank's slice lies in the assembled stream (what zngamd_comm_allgather_stream places by and
+    what a positional write uses) -- exclusive prefix sums in rank order, for 1 .. 9 ranks, with empty slices and sizes beyond 4 GiB."""
+    import ctypes as C
+    import random
+    from zlib_ng_amd import _lib
+    L = _lib.load()
+    L.zngamd_comm_offsets.restype = C.c_uint64
+    L.zngamd_comm_offsets.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
+    rng = random.Random(5)
+    for world in range(1, 10):
+        for _ in range(20):
+            sizes = [rng.choice([0, 1, 7, 1 << 20, (5 << 30) + 3, rng.randrange(1 << 33)]) for _ in range(world)]
+            a, o = (C.c_uint64 * world)(*sizes), (C.c_uint64 * world)()
+            total = L.zngamd_comm_offsets(a, world, o)
+            assert total == sum(sizes)
+            assert list(o) == [sum(sizes[:r]) for r in range(world)]
+            assert L.zngamd_comm_offsets(a, world, None) == total
