@@ -70,9 +70,11 @@ __device__ __forceinline__ uint32_t za_hash6(uint32_t lo, uint32_t hi)
 
 __device__ __forceinline__ int za_lane() { return (int)(threadIdx.x & 63); }
 
-// wave-wide inclusive scan (64 lanes) with shuffles
+// wave-wide inclusive scan (64 lanes): DPP row shifts inside the rows of 16 lanes, then the two row broadcasts of gfx9 --
+// six VALU instructions with a DPP operand instead of six LDS-pipe shuffles
 __device__ __forceinline__ uint32_t za_wave_incl_scan(uint32_t v)
 {
+#ifdef ZA_SCAN_SHFL
     int lane = za_lane();
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -80,6 +82,16 @@ __device__ __forceinline__ uint32_t za_wave_incl_scan(uint32_t v)
         if (lane >= d) v += o;
     }
     return v;
+#else
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);       // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);       // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);       // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);       // row_shr:8  -> inclusive scan inside every row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#endif
 }
 __device__ __forceinline__ uint32_t za_wave_xor_reduce(uint32_t v)
 {
