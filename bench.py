@@ -16,6 +16,7 @@ value = uncompressed bytes of all ranks / (max over ranks of the step time): the
 through compress and then decompress.  Inputs are in HBM when the timed region starts.
 
     python bench.py                      # 1 GPU, 4 GiB shard
+    python bench.py --gpus N             # N ranks started by bench.py itself (fresh child processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -47,6 +48,58 @@ def host_cores():
     return n
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this process has not touched
+    the GPU or imported torch yet, and never does), one per GPU, with the environment a launcher would give them; relay rank 0's
+    JSON line; exit non-zero if any rank does.  Nothing here replaces a running program (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free port for the ranks' rendezvous (the RCCL id travels on port + 1 ...)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        print(f"bench.py: started rank {r} of {n} as pid {procs[-1].pid}", file=sys.stderr)
+    rc, line, failed_at, signalled = 0, b"", None, 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if r == 0:
+                line = procs[0].stdout.read()
+            if code != 0:
+                print(f"bench.py: rank {r} (pid {procs[r].pid}) exited with {code}", file=sys.stderr)
+                rc = rc or code
+                failed_at = failed_at or time.monotonic()
+        if alive:
+            time.sleep(0.05)
+            # a rank has failed: the others either fail by themselves within moments (same cause) or would wait for it in a
+            # collective for ever -- after a grace period end exactly those PIDs
+            if failed_at and signalled == 0 and time.monotonic() - failed_at > 5.0:
+                for q in sorted(alive):
+                    procs[q].terminate()
+                signalled = 1
+            elif failed_at and signalled == 1 and time.monotonic() - failed_at > 15.0:
+                for q in sorted(alive):
+                    procs[q].kill()
+                signalled = 2
+    if rc == 0 and line.strip():
+        sys.stdout.write(line.decode().strip().splitlines()[-1] + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc if rc > 0 else (1 if rc else 0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +114,8 @@ def main():
     ap.add_argument("--no-foreign", action="store_true", help="skip the foreign-member inflate leg (outside the timed region)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="0 = sized for ~10-30 s")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                  # does not return
     # stdout carries exactly ONE line, the JSON result: file descriptor 1 is pointed at stderr for the run (RCCL prints a version
     # banner on the first communicator, libraries print what they like) and the line is written to the saved descriptor at the end
     sys.stdout.flush()
@@ -81,7 +136,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     if not torch.cuda.is_available():
-        print("bench.py needs a GPU (the engine has no CPU path)", file=sys.stderr)
+        print(f"bench.py: rank {rank} of {world} needs a GPU (the engine has no CPU path)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -203,80 +258,102 @@ def main():
         dt = comm.max(dt)
 
     # ---- correctness of what was timed -------------------------------------------------------------
-    assert int((d_mstat != 0).sum().item()) == 0, "inflate reported member errors"
-    assert torch.equal(d_out[:size], d_in[:size]), "inflate output differs from the input"
+    # Every collective of the verification runs BEFORE the first assert, and the verdicts are exchanged afterwards: a rank whose
+    # check fails must not leave the others waiting for it in RCCL for ever (it would look like a hang, not like a failure).
+    kblk = min(nblocks, 2048)
+    pre = comm.layout(int(d_ulen[:kblk].to(torch.int64).sum().item()), 0, 0)[2] if exchange_stream else None   # compressed bytes of every rank's first kblk blocks
+    rccl_ranks = comm.count() if comm is not None else None
     comp_bytes = int(d_ulen.to(torch.int64).sum().item())
-    assert comp_bytes == comp_total.value
-    # The WHOLE dict-chained compressed stream -- with N > 1 the stream assembled from the slices of all ranks, on rank 0 -- is
-    # closed with an empty final block, inflated on the device by the chunk-parallel decoder (sync-flush points) and compared
-    # with the input; its CRC-32 must be the one the layout exchange folded; a prefix also goes through the system zlib.
-    if exchange:
-        off, total, sizes, whole_crc, whole_len = gathered["layout"]
-        assert sizes[rank] == comp_bytes and off == sum(sizes[:rank]) and total == sum(sizes) and whole_len == total_size
-        # the trailer CRC-32 folded from the ranks against the CRC-32 of the whole input, folded on the host from the tile's
-        if total_size % uniq == 0:
-            tile_crc, want = zlib.crc32(host), 0
-            for _ in range(total_size // uniq):
-                want = ctx.crc32_combine(want, tile_crc, uniq)
-            assert want == whole_crc, "trailer CRC-32 folded from the ranks differs from the CRC-32 of the whole input"
-    if exchange_stream:
-        # (a) my slice lies at its offset in my copy of the assembled stream
-        assert torch.equal(d_stream[off:off + comp_bytes], d_comp[:comp_bytes]), "my slice is not at its offset in the assembled stream"
-        # (b) every rank decodes the head of a slice ANOTHER rank compressed (rank r: slice r + 1), taken from its own copy of
-        # the assembled stream: up to 2 048 blocks behind a stored block that holds the 32 KiB of input in front of them (the
-        # dictionary that slice was primed with on the other GPU), compared with the input they must decode to
-        q = (rank + 1) % world
-        kblk = min(nblocks, 2048)
-        pre = comm.layout(int(d_ulen[:kblk].to(torch.int64).sum().item()), 0, 0)[2]     # compressed bytes of every rank's first kblk blocks
-        qlo = shard.shard_range(total_blocks, q, world)[0]
-        qoff = sum(sizes[:q])
 
-        def tile_bytes(first, count):                       # bytes [first, first + count) of the whole stream (negative: halo of block 0)
-            parts, pos = [], 0
-            while pos < count:
-                o = (first + pos) % uniq
-                k = min(uniq - o, count - pos)
-                parts.append(base[o:o + k])
-                pos += k
-            return torch.cat(parts)
-        d_v = torch.empty(5 + HALO + pre[q] + 66, dtype=torch.uint8, device=dev)
-        d_v[:5] = torch.tensor([0, 0x00, 0x80, 0xFF, 0x7F], dtype=torch.uint8, device=dev)     # stored block, not final, 32 768 bytes
-        d_v[5:5 + HALO] = tile_bytes(qlo * BLOCK - HALO, HALO)
-        d_v[5 + HALO:5 + HALO + pre[q]] = d_stream[qoff:qoff + pre[q]]
-        d_v[5 + HALO + pre[q]:] = 0
-        d_v[5 + HALO + pre[q]] = 3                           # empty final block
-        d_vo = torch.empty(HALO + kblk * BLOCK + 64, dtype=torch.uint8, device=dev)
-        vlen, vused = C.c_uint64(0), C.c_uint64(0)
-        rc = L.zngamd_inflate_raw_dev(h, ptr(d_v), 5 + HALO + pre[q] + 2, ptr(d_vo), HALO + kblk * BLOCK, C.byref(vlen), C.byref(vused))
-        assert rc == _lib.STREAM_END and vlen.value == HALO + kblk * BLOCK, (rc, vlen.value, vused.value, ctx.err())
-        assert torch.equal(d_vo[HALO:HALO + kblk * BLOCK], tile_bytes(qlo * BLOCK, kblk * BLOCK)), \
-            f"rank {rank}: the head of slice {q} in the assembled stream does not inflate to its input"
-        del d_v, d_vo
-        # (c) jobs of at most 4 GiB: rank 0 inflates the WHOLE assembled stream on the device and compares it with the input
-        if rank == 0 and total_size <= (4 << 30) and total_size % uniq == 0:
-            d_stream[total:total + 66] = 0
-            d_stream[total] = 3
-            d_big = torch.empty(total_size + 64, dtype=torch.uint8, device=dev) if world > 1 else d_out
-            rc = L.zngamd_inflate_raw_dev(h, ptr(d_stream), total + 2, ptr(d_big), total_size, C.byref(vlen), C.byref(vused))
-            assert rc == _lib.STREAM_END and vlen.value == total_size and vused.value == total + 2, (rc, vlen.value, vused.value, ctx.err())
-            assert bool((d_big[:total_size].view(-1, uniq) == base).all().item()), "the assembled stream does not inflate to the input"
-            c = C.c_uint32(0)
-            chk(L.zngamd_crc32_dev(h, 0, ptr(d_big), total_size, C.byref(c)), "crc32_dev")
-            assert c.value == whole_crc, "CRC-32 of the inflated stream differs from the trailer value"
-            del d_big
-    if blo == 0:
-        d_comp[comp_bytes:comp_bytes + 66] = 0
-        d_comp[comp_bytes] = 3
-        vlen, vused = C.c_uint64(0), C.c_uint64(0)
-        d_out.zero_()
-        rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
-        assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
-        assert torch.equal(d_out[:size], d_in[:size]), "the compressed stream does not inflate to the input"
-        nchk = min(nblocks, 64)
-        ul = d_ulen[:nchk].cpu().numpy().astype(np.int64)
-        pref = bytes(d_comp[:int(ul.sum())].cpu().numpy())
-        assert zlib.decompressobj(-15).decompress(pref) == bytes(d_in[:nchk * BLOCK].cpu().numpy()), \
-            "compressed stream does not inflate to the input (system zlib)"
+    def verify():
+        assert int((d_mstat != 0).sum().item()) == 0, "inflate reported member errors"
+        assert torch.equal(d_out[:size], d_in[:size]), "inflate output differs from the input"
+        assert comp_bytes == comp_total.value
+        # The WHOLE dict-chained compressed stream -- with N > 1 the stream assembled from the slices of all ranks, on rank 0 -- is
+        # closed with an empty final block, inflated on the device by the chunk-parallel decoder (sync-flush points) and compared
+        # with the input; its CRC-32 must be the one the layout exchange folded; a prefix also goes through the system zlib.
+        if exchange:
+            off, total, sizes, whole_crc, whole_len = gathered["layout"]
+            assert sizes[rank] == comp_bytes and off == sum(sizes[:rank]) and total == sum(sizes) and whole_len == total_size
+            # the trailer CRC-32 folded from the ranks against the CRC-32 of the whole input, folded on the host from the tile's
+            if total_size % uniq == 0:
+                tile_crc, want = zlib.crc32(host), 0
+                for _ in range(total_size // uniq):
+                    want = ctx.crc32_combine(want, tile_crc, uniq)
+                assert want == whole_crc, "trailer CRC-32 folded from the ranks differs from the CRC-32 of the whole input"
+        if exchange_stream:
+            # (a) my slice lies at its offset in my copy of the assembled stream
+            assert torch.equal(d_stream[off:off + comp_bytes], d_comp[:comp_bytes]), "my slice is not at its offset in the assembled stream"
+            # (b) every rank decodes the head of a slice ANOTHER rank compressed (rank r: slice r + 1), taken from its own copy of
+            # the assembled stream: up to 2 048 blocks behind a stored block that holds the 32 KiB of input in front of them (the
+            # dictionary that slice was primed with on the other GPU), compared with the input they must decode to
+            q = (rank + 1) % world
+            qlo = shard.shard_range(total_blocks, q, world)[0]
+            qoff = sum(sizes[:q])
+
+            def tile_bytes(first, count):                       # bytes [first, first + count) of the whole stream (negative: halo of block 0)
+                parts, pos = [], 0
+                while pos < count:
+                    o = (first + pos) % uniq
+                    k = min(uniq - o, count - pos)
+                    parts.append(base[o:o + k])
+                    pos += k
+                return torch.cat(parts)
+            d_v = torch.empty(5 + HALO + pre[q] + 66, dtype=torch.uint8, device=dev)
+            d_v[:5] = torch.tensor([0, 0x00, 0x80, 0xFF, 0x7F], dtype=torch.uint8, device=dev)     # stored block, not final, 32 768 bytes
+            d_v[5:5 + HALO] = tile_bytes(qlo * BLOCK - HALO, HALO)
+            d_v[5 + HALO:5 + HALO + pre[q]] = d_stream[qoff:qoff + pre[q]]
+            d_v[5 + HALO + pre[q]:] = 0
+            d_v[5 + HALO + pre[q]] = 3                           # empty final block
+            d_vo = torch.empty(HALO + kblk * BLOCK + 64, dtype=torch.uint8, device=dev)
+            vlen, vused = C.c_uint64(0), C.c_uint64(0)
+            rc = L.zngamd_inflate_raw_dev(h, ptr(d_v), 5 + HALO + pre[q] + 2, ptr(d_vo), HALO + kblk * BLOCK, C.byref(vlen), C.byref(vused))
+            assert rc == _lib.STREAM_END and vlen.value == HALO + kblk * BLOCK, (rc, vlen.value, vused.value, ctx.err())
+            assert torch.equal(d_vo[HALO:HALO + kblk * BLOCK], tile_bytes(qlo * BLOCK, kblk * BLOCK)), \
+                f"rank {rank}: the head of slice {q} in the assembled stream does not inflate to its input"
+            del d_v, d_vo
+            # (c) jobs of at most 4 GiB: rank 0 inflates the WHOLE assembled stream on the device and compares it with the input
+            if rank == 0 and total_size <= (4 << 30) and total_size % uniq == 0:
+                d_stream[total:total + 66] = 0
+                d_stream[total] = 3
+                d_big = torch.empty(total_size + 64, dtype=torch.uint8, device=dev) if world > 1 else d_out
+                rc = L.zngamd_inflate_raw_dev(h, ptr(d_stream), total + 2, ptr(d_big), total_size, C.byref(vlen), C.byref(vused))
+                assert rc == _lib.STREAM_END and vlen.value == total_size and vused.value == total + 2, (rc, vlen.value, vused.value, ctx.err())
+                assert bool((d_big[:total_size].view(-1, uniq) == base).all().item()), "the assembled stream does not inflate to the input"
+                c = C.c_uint32(0)
+                chk(L.zngamd_crc32_dev(h, 0, ptr(d_big), total_size, C.byref(c)), "crc32_dev")
+                assert c.value == whole_crc, "CRC-32 of the inflated stream differs from the trailer value"
+                del d_big
+        if blo == 0:
+            d_comp[comp_bytes:comp_bytes + 66] = 0
+            d_comp[comp_bytes] = 3
+            vlen, vused = C.c_uint64(0), C.c_uint64(0)
+            d_out.zero_()
+            rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
+            assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
+            assert torch.equal(d_out[:size], d_in[:size]), "the compressed stream does not inflate to the input"
+            nchk = min(nblocks, 64)
+            ul = d_ulen[:nchk].cpu().numpy().astype(np.int64)
+            pref = bytes(d_comp[:int(ul.sum())].cpu().numpy())
+            assert zlib.decompressobj(-15).decompress(pref) == bytes(d_in[:nchk * BLOCK].cpu().numpy()), \
+                "compressed stream does not inflate to the input (system zlib)"
+
+    verr = None
+    try:
+        verify()
+    except BaseException as e:          # noqa: BLE001 -- reported below, after the ranks have agreed on the verdict
+        verr = e
+    if exchange:
+        bad = comm.max(1.0 if verr is not None else 0.0)
+        if bad:
+            if verr is not None:
+                import traceback
+                traceback.print_exception(type(verr), verr, verr.__traceback__, file=sys.stderr)
+            print(f'bench.py: rank {rank}: verification failed on ' + ('this rank' if verr is not None else 'another rank'), file=sys.stderr)
+            comm.close()
+            sys.exit(1)
+    elif verr is not None:
+        raise verr
 
     # ---- foreign members: the same text as 128 KiB gzip members written by the SYSTEM zlib (no index, ordinary dynamic
     # headers), decoded one wavefront per member; outside the timed region, reported beside the headline inflate leg ----
@@ -362,7 +439,7 @@ def main():
     out = {
         "metric": "MB/s compress+decompress, 128 KiB blocks level 6",
         "value": round(total_size / dt * steps / 1e6, 1), "unit": "MB/s",
-        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"one stream of {total_size >> 20} MiB seeded Zipf-word text ({uniq >> 20} MiB distinct, tiled), {size >> 20} MiB per GPU "

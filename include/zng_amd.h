@@ -251,7 +251,8 @@ int zngamd_gzip_members_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len, 
 /* ---- streaming: the zng_stream calling convention ------------------------------------------------
  * What a binding of the reference swaps in for zng_deflateInit2 / zng_deflate / zng_deflateSetDictionary / zng_deflateCopy /
  * zng_deflateEnd (zlib_ngmodule.c:394, :552, :743, :401, :811) and zng_inflateInit2 / zng_inflate / zng_inflateSetDictionary /
- * zng_inflateCopy / zng_inflateEnd (:477, :667, :995, :1150, :446, :893): same fields, same flush values, same return codes
+ * zng_inflateCopy / zng_inflateEnd (:477, :667, :995, :1150, :446, :893): same fields, same flush values (Z_FULL_FLUSH forgets the history: nothing behind
+ * the flush point refers to anything in front of it), same return codes
  * (ZNGAMD_OK 0, ZNGAMD_STREAM_END 1, ZNGAMD_NEED_DICT 2, ZNGAMD_STREAM_ERROR -2, ZNGAMD_DATA_ERROR -3, ZNGAMD_MEM_ERROR -4,
  * ZNGAMD_BUF_ERROR -5), `msg` set where zng_inflate sets it ("incorrect header check", "invalid window size", "incorrect data
  * check", ...).  deflate collects input until a flush or 32 MiB and compresses it as one dictionary-chained engine batch
@@ -270,6 +271,9 @@ typedef struct zngamd_stream {
     zngamd_stream_state *state;
     uint32_t adler;           /* Adler-32 (zlib) or CRC-32 (gzip) of the uncompressed data so far; DICTID after ZNGAMD_NEED_DICT */
     uint32_t reserved;
+    /* zng_stream's allocator hooks, which the reference sets (zlib_ngmodule.c:210-212, :391-393, :474-476): accepted and never
+     * called -- the engine's memory is device memory and its own host buffers; a binding keeps those three lines as they are */
+    void *zalloc, *zfree, *opaque;
 } zngamd_stream;
 #define ZNGAMD_NO_FLUSH 0
 #define ZNGAMD_PARTIAL_FLUSH 1
@@ -283,6 +287,8 @@ int zngamd_stream_deflate_set_dictionary(zngamd_stream *strm, const uint8_t *dic
 int zngamd_stream_deflate_copy(zngamd_stream *dst, const zngamd_stream *src);
 /* output produced and not yet handed out (zng_deflatePending; also valid for an inflate stream): lets the caller size its buffer once */
 int zngamd_stream_pending(const zngamd_stream *strm, uint64_t *pending);
+/* zng_deflateReset (zlib_ngmodule.c:1725): the stream as deflate_init left it -- same level, container and window */
+int zngamd_stream_deflate_reset(zngamd_stream *strm);
 int zngamd_stream_deflate_end(zngamd_stream *strm);
 int zngamd_stream_inflate_init(zngamd_ctx *ctx, zngamd_stream *strm, int wbits);
 int zngamd_stream_inflate(zngamd_stream *strm, int flush);
@@ -293,6 +299,8 @@ int zngamd_stream_inflate_set_dictionary(zngamd_stream *strm, const uint8_t *dic
  * block again for every doubling of a 16 KiB buffer.  0 (the default) = strictly avail_out, as zng_inflate. */
 int zngamd_stream_inflate_ahead(zngamd_stream *strm, uint64_t bytes);
 int zngamd_stream_inflate_copy(zngamd_stream *dst, const zngamd_stream *src);
+/* zng_inflateReset (zlib_ngmodule.c:2525, :2715): the stream as inflate_init left it; the next input byte starts a new stream */
+int zngamd_stream_inflate_reset(zngamd_stream *strm);
 int zngamd_stream_inflate_end(zngamd_stream *strm);
 
 /* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU (gzip_ng_threaded.py:233-246 gives every worker thread a
@@ -307,6 +315,8 @@ int zngamd_comm_unique_id(uint8_t id[ZNGAMD_COMM_ID_BYTES]);
 int zngamd_comm_create(zngamd_ctx *ctx, const uint8_t id[ZNGAMD_COMM_ID_BYTES], int rank, int world, zngamd_comm **out);
 void zngamd_comm_destroy(zngamd_comm *comm);
 const char *zngamd_comm_last_error(zngamd_comm *comm);
+/* number of ranks the communicator really has, as RCCL reports it (ncclCommCount) -- not what the launcher's environment claims */
+int zngamd_comm_count(zngamd_comm *comm, int *ranks);
 /* layout of the one output stream: all-gather of {compressed bytes, CRC-32 of the rank's input, input bytes} (24 bytes per
  * rank), then on every rank: sizes[world], the offset of the own slice, the total, the CRC-32 of the whole input folded with
  * crc32_combine in rank order, and the whole input length -- what header / trailer and a positional write need */

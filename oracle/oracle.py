@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libza_oracle.so")
+_SO = os.environ.get("ZA_ORACLE_SO") or os.path.join(_HERE, "libza_oracle.so")      # ZA_ORACLE_SO: the sanitizer build (make asan)
 
 SEG = 2048
 MAX_UNIT = 131072
@@ -29,6 +29,8 @@ GZ_BAD_MAGIC, GZ_BAD_METHOD, GZ_BAD_HCRC, GZ_BAD_CRC, GZ_BAD_LENGTH, GZ_TRUNCATE
 
 
 def build(force=False):
+    if os.environ.get("ZA_ORACLE_SO"):
+        return _SO
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(_SO) or any(
             os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):

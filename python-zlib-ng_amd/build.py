@@ -37,5 +37,20 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_host_asan(out):
+    """The library with its HOST side under AddressSanitizer + UndefinedBehaviorSanitizer (hipcc applies -fsanitize to the host
+    compilation only for a plain gfx950 target and says so; the device code is the ordinary one), for the entry points that need
+    no GPU (tests/test_cpu_sanitizers.py; the reference's tox.ini:23-30 does the same for its extension).  GPU-side sanitizers
+    are not available on this pool."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-Wno-option-ignored", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--host-asan" in sys.argv:
+        print(build_host_asan(sys.argv[sys.argv.index("--host-asan") + 1]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

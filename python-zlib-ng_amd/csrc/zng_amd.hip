@@ -1574,6 +1574,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -1594,6 +1595,7 @@ static RcclApi *rccl_api(std::string *why)
     if (!h) { if (why) *why = std::string("librccl not found: ") + dlerror(); return nullptr; }
 #define ZA_SYM(field, name) do { api.field = (decltype(api.field))dlsym(h, name); if (!api.field) { if (why) *why = std::string("librccl lacks ") + name; return nullptr; } } while (0)
     ZA_SYM(GetUniqueId, "ncclGetUniqueId"); ZA_SYM(CommInitRank, "ncclCommInitRank"); ZA_SYM(CommDestroy, "ncclCommDestroy");
+    ZA_SYM(CommCount, "ncclCommCount");
     ZA_SYM(AllGather, "ncclAllGather"); ZA_SYM(AllReduce, "ncclAllReduce"); ZA_SYM(Send, "ncclSend"); ZA_SYM(Recv, "ncclRecv");
     ZA_SYM(GroupStart, "ncclGroupStart"); ZA_SYM(GroupEnd, "ncclGroupEnd"); ZA_SYM(GetErrorString, "ncclGetErrorString");
 #undef ZA_SYM
@@ -1664,6 +1666,15 @@ void zngamd_comm_destroy(zngamd_comm *m)
 }
 
 const char *zngamd_comm_last_error(zngamd_comm *m) { return m ? m->err.c_str() : "no communicator"; }
+
+// the number of ranks RCCL itself reports for the communicator (ncclCommCount), not what the launcher's environment says
+int zngamd_comm_count(zngamd_comm *m, int *ranks)
+try {
+    if (!m || !ranks) return ZNGAMD_E_ARG;
+    *ranks = 0;
+    NCCLCHK(m, m->api->CommCount(m->comm, ranks));
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
 
 int zngamd_comm_layout(zngamd_comm *m, uint64_t local_len, uint32_t local_crc, uint64_t local_ulen, uint64_t *sizes,
                        uint64_t *my_off, uint64_t *total, uint32_t *whole_crc, uint64_t *whole_ulen)

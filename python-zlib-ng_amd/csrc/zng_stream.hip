@@ -19,6 +19,7 @@
 #define ZS_GUARD catch (const std::bad_alloc &) { return ZNGAMD_MEM_ERROR; } catch (...) { return ZNGAMD_STREAM_ERROR; }
 
 #define ZS_NO_FLUSH 0
+#define ZS_FULL_FLUSH 3
 #define ZS_FINISH   4
 #define ZS_BLOCK    5
 #define ZS_BATCH    (32u << 20)
@@ -43,6 +44,7 @@ struct ZsDeflate {
 };
 struct ZsInflate {
     int kind = 1 /* 0 raw, 1 zlib, 2 gzip, 3 auto */, wbits = 15;
+    int kind0 = 1, wbits0 = 15;      // as given to inflate_init (auto-detection rewrites kind / wbits): what a reset goes back to
     std::vector<uint8_t> zdict, window, buf;
     uint32_t start_bit = 0;
     uint64_t skip = 0, total = 0;
@@ -164,6 +166,7 @@ static int zs_deflate_pending(zngamd_stream *s, bool final)
     zngamd_ctx *c = st->ctx;
     if (d.pending.empty()) { d.pending = d.tail; d.pend_tail = d.tail.size(); }        // (final with nothing collected)
     const size_t tl = d.pend_tail, n = d.pending.size() - tl;
+    if (n > (1u << 30)) return ZNGAMD_E_ARG;          // (cannot happen: collected input is emitted at 32 MiB, larger pieces go direct)
     zngamd_block B; B.off = tl; B.len = (uint32_t)n; B.dict_len = (uint32_t)tl; B.flags = ZNGAMD_FLAG_WBITS(d.wb) | (final ? ZNGAMD_FLAG_FINAL : 0u); B.reserved = 0;
     const uint64_t cap = n + n / 8 + (n / ZA_MAX_UNIT + 2) * 64 + 64;
     const size_t at = st->outq.size();
@@ -236,7 +239,9 @@ int zngamd_stream_deflate_set_dictionary(zngamd_stream *s, const uint8_t *dict, 
 try {
     if (!s || !s->state || !s->state->is_deflate || (!dict && len)) return ZNGAMD_STREAM_ERROR;
     ZsDeflate &d = s->state->d;
-    if (d.started) return ZNGAMD_STREAM_ERROR;                    // zng_deflateSetDictionary: before the first deflate call
+    // zng_deflateSetDictionary: before the first deflate call (nothing collected either), and never on a gzip stream -- no gzip
+    // decoder could supply the dictionary (Z_STREAM_ERROR for wrap == 2; the reference then raises ValueError("Invalid dictionary"))
+    if (d.started || d.kind == 2 || !d.pending.empty() || s->total_in != 0) return ZNGAMD_STREAM_ERROR;
     if (d.kind == 1) {
         uint32_t a = 1;
         const int r = zngamd_adler32(s->state->ctx, 1, dict, len, &a);
@@ -259,11 +264,16 @@ try {
     const uint64_t in0 = s->avail_in, out0 = s->avail_out;
     int r = ZNGAMD_OK;
     if (!d.finished) {
-        if (d.pending.empty() && s->avail_in >= ZS_BATCH) {
+        if (s->avail_in >= ZS_BATCH && !d.pending.empty()) {
+            // a large piece behind a small one: what was collected goes first, as a batch of its own, so that the large piece is
+            // compressed where it lies (and `pending`, whose length the engine takes as a u32, never holds more than 2 x 32 MiB)
+            r = zs_deflate_emit(s, nullptr, 0, false);
+        }
+        if (r == ZNGAMD_OK && d.pending.empty() && s->avail_in >= ZS_BATCH) {
             // a large piece with nothing pending: compressed where it lies (no copy of the payload)
             r = zs_deflate_emit(s, s->next_in, s->avail_in, flush == ZS_FINISH);
             if (r == ZNGAMD_OK) { s->next_in += s->avail_in; s->total_in += s->avail_in; s->avail_in = 0; }
-        } else {
+        } else if (r == ZNGAMD_OK) {
             if (s->avail_in) {
                 if (d.pending.empty()) { d.pending = d.tail; d.pend_tail = d.tail.size(); }
                 d.pending.insert(d.pending.end(), s->next_in, s->next_in + s->avail_in);
@@ -272,6 +282,9 @@ try {
             if (flush != ZS_NO_FLUSH || d.pending.size() - d.pend_tail >= ZS_BATCH) r = zs_deflate_emit(s, nullptr, 0, flush == ZS_FINISH);
         }
         if (r != ZNGAMD_OK) return zs_msg(s, r == ZNGAMD_E_HIP ? ZNGAMD_MEM_ERROR : r > 0 || r < -6 ? ZNGAMD_STREAM_ERROR : r, zngamd_last_error(st->ctx));
+        // Z_FULL_FLUSH: decompression can restart at this point, so nothing behind it may refer to anything in front of it --
+        // the history that would prime the next batch is forgotten (zng_deflate clears its hash table there)
+        if (flush == ZS_FULL_FLUSH) { d.tail.clear(); d.pend_tail = 0; }
     }
     zs_drain(s);
     s->adler = d.kind == 1 ? d.adler : d.crc;        // zlib: Adler-32; gzip and raw: CRC-32 of what has been compressed so far
@@ -293,6 +306,20 @@ try {
     *dst = *src;
     dst->state = new zngamd_stream_state(*src->state);
     dst->msg = nullptr;
+    return ZNGAMD_OK;
+} ZS_GUARD
+
+// zng_deflateReset (zlib_ngmodule.c:1725): back to the state right behind deflate_init -- level, container and window kept,
+// everything collected, the history, a preset dictionary and the checksums forgotten
+int zngamd_stream_deflate_reset(zngamd_stream *s)
+try {
+    if (!s || !s->state || !s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
+    zngamd_stream_state *st = s->state;
+    ZsDeflate fresh;
+    fresh.level = st->d.level; fresh.kind = st->d.kind; fresh.wb = st->d.wb;
+    st->d = fresh;
+    st->outq.clear(); st->outpos = 0; st->msg.clear();
+    s->msg = nullptr; s->total_in = s->total_out = 0; s->adler = fresh.kind == 2 ? 0u : 1u;
     return ZNGAMD_OK;
 } ZS_GUARD
 
@@ -318,7 +345,7 @@ try {
     else return ZNGAMD_STREAM_ERROR;
     zngamd_stream_state *st = new zngamd_stream_state();
     st->ctx = c; st->is_deflate = false;
-    st->i.kind = kind; st->i.wbits = wbits; st->i.header_done = kind == 0;
+    st->i.kind = st->i.kind0 = kind; st->i.wbits = st->i.wbits0 = wbits; st->i.header_done = kind == 0;
     s->state = st;
     return ZNGAMD_OK;
 } ZS_GUARD
@@ -483,8 +510,11 @@ try {
             if (code == ZNGAMD_E_OVERFLOW && cap < want) { cap = std::min<uint64_t>(cap * 4, want); continue; }      // our guess was short, not the caller's buffer
             break;
         }
-        if (code == ZNGAMD_E_HIP || code == ZNGAMD_E_ARG) return zs_msg(s, ZNGAMD_MEM_ERROR, zngamd_last_error(c));
+        if (code == ZNGAMD_E_HIP || code == ZNGAMD_E_ARG || code == ZNGAMD_MEM_ERROR) return zs_msg(s, ZNGAMD_MEM_ERROR, zngamd_last_error(c));
         if (code == ZNGAMD_DATA_ERROR) return zs_msg(s, ZNGAMD_DATA_ERROR, nullptr);
+        // "input ran out" is ZNGAMD_OK / ZNGAMD_BUF_ERROR and nothing else: any other code leaves the resume state as it is
+        if (code != ZNGAMD_OK && code != ZNGAMD_BUF_ERROR && code != ZNGAMD_STREAM_END && code != ZNGAMD_E_OVERFLOW)
+            return zs_msg(s, ZNGAMD_STREAM_ERROR, zngamd_last_error(c));
         const uint64_t nnew = out_len > I.skip ? out_len - I.skip : 0;
         if (nnew) {
             uint32_t v = I.check;
@@ -550,6 +580,21 @@ try {
     *dst = *src;
     dst->state = new zngamd_stream_state(*src->state);
     dst->msg = nullptr;
+    return ZNGAMD_OK;
+} ZS_GUARD
+
+// zng_inflateReset (zlib_ngmodule.c:2525, :2715): back to the state right behind inflate_init with the same wbits -- the next
+// byte offered is the first byte of a new stream (the gzip reader calls it between members)
+int zngamd_stream_inflate_reset(zngamd_stream *s)
+try {
+    if (!s || !s->state || s->state->is_deflate) return ZNGAMD_STREAM_ERROR;
+    zngamd_stream_state *st = s->state;
+    ZsInflate fresh;
+    fresh.wbits = st->i.wbits0; fresh.wbits0 = st->i.wbits0; fresh.kind = st->i.kind0; fresh.kind0 = st->i.kind0;
+    fresh.header_done = fresh.kind == 0;
+    st->i = fresh;
+    st->outq.clear(); st->outpos = 0; st->msg.clear();
+    s->msg = nullptr; s->total_in = s->total_out = 0; s->adler = 1;
     return ZNGAMD_OK;
 } ZS_GUARD
 

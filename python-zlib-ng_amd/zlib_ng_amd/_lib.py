@@ -35,9 +35,9 @@ SYMBOLS = [
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev", "zngamd_compare_dev", "zngamd_crc32_fold_dev",
     "zngamd_stream_deflate_init", "zngamd_stream_deflate", "zngamd_stream_deflate_set_dictionary", "zngamd_stream_deflate_copy", "zngamd_stream_pending", "zngamd_stream_inflate_ahead",
-    "zngamd_stream_deflate_end", "zngamd_stream_inflate_init", "zngamd_stream_inflate", "zngamd_stream_inflate_set_dictionary",
+    "zngamd_stream_deflate_end", "zngamd_stream_deflate_reset", "zngamd_stream_inflate_reset", "zngamd_stream_inflate_init", "zngamd_stream_inflate", "zngamd_stream_inflate_set_dictionary",
     "zngamd_stream_inflate_copy", "zngamd_stream_inflate_end",
-    "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_layout",
+    "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
     "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch",

@@ -156,6 +156,7 @@ class Comm:
         L.zngamd_comm_wait.argtypes = [C.c_void_p]
         L.zngamd_comm_barrier.argtypes = [C.c_void_p]
         L.zngamd_comm_max_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.zngamd_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         self.h = C.c_void_p()
         r = L.zngamd_comm_create(ctx.h, bytes(uid), rank, world, C.byref(self.h))
         if r != _lib.OK:
@@ -178,6 +179,12 @@ class Comm:
         """Start the exchange of the slices (device pointers as integers); wait() blocks until it is done."""
         arr = (C.c_uint64 * self.world)(*sizes)
         self._chk(self.L.zngamd_comm_allgather_stream(self.h, C.c_void_p(d_local), arr, C.c_void_p(d_stream), int(stream_cap)))
+
+    def count(self):
+        """ranks of the communicator as RCCL reports them (ncclCommCount)"""
+        n = C.c_int(0)
+        self._chk(self.L.zngamd_comm_count(self.h, C.byref(n)))
+        return n.value
 
     def wait(self):
         self._chk(self.L.zngamd_comm_wait(self.h))

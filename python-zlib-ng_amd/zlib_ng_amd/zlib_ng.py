@@ -333,7 +333,8 @@ import ctypes as _C
 class _ZStream(_C.Structure):                # zngamd_stream
     _fields_ = [("next_in", _C.c_void_p), ("avail_in", _C.c_uint32), ("total_in", _C.c_uint64),
                 ("next_out", _C.c_void_p), ("avail_out", _C.c_uint32), ("total_out", _C.c_uint64),
-                ("msg", _C.c_char_p), ("state", _C.c_void_p), ("adler", _C.c_uint32), ("reserved", _C.c_uint32)]
+                ("msg", _C.c_char_p), ("state", _C.c_void_p), ("adler", _C.c_uint32), ("reserved", _C.c_uint32),
+                ("zalloc", _C.c_void_p), ("zfree", _C.c_void_p), ("opaque", _C.c_void_p)]
 
 
 def _slib():
@@ -345,6 +346,8 @@ def _slib():
         L.zngamd_stream_deflate_set_dictionary.argtypes = [P, vp, _C.c_uint32]
         L.zngamd_stream_deflate_copy.argtypes = [P, P]
         L.zngamd_stream_deflate_end.argtypes = [P]
+        L.zngamd_stream_deflate_reset.argtypes = [P]
+        L.zngamd_stream_inflate_reset.argtypes = [P]
         L.zngamd_stream_inflate_init.argtypes = [vp, P, _C.c_int]
         L.zngamd_stream_inflate.argtypes = [P, _C.c_int]
         L.zngamd_stream_inflate_set_dictionary.argtypes = [P, vp, _C.c_uint32]

@@ -232,3 +232,24 @@ def test_slice_offsets_of_the_exchange():
             assert total == sum(sizes)
             assert list(o) == [sum(sizes[:r]) for r in range(world)]
             assert L.zngamd_comm_offsets(a, world, None) == total
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher (WORLD_SIZE unset): the parent, which never touches the GPU, starts two FRESH
+    child processes with distinct ranks; on this GPU-less box each one stops at "needs a GPU" with exit code 2 and the parent
+    passes that on (the SCALE run of the driver may use exactly this command)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+    assert r.stdout.strip() == ""
+    started = [ln for ln in r.stderr.splitlines() if "started rank" in ln]
+    assert len(started) == 2 and "rank 0 of 2" in started[0] and "rank 1 of 2" in started[1]
+    pids = {ln.split("pid")[-1].strip() for ln in started}
+    assert len(pids) == 2
+    for rank in (0, 1):
+        assert f"rank {rank} of 2 needs a GPU" in r.stderr
+        assert any(f"rank {rank} (pid" in ln and "exited with 2" in ln for ln in r.stderr.splitlines())

@@ -478,3 +478,95 @@ def test_compressobj_respects_small_windows():
         assert zlib.decompress(zlib_ng.compress(data, 6, wb), wb) == data, wb
         if 9 <= wb <= 15:
             assert (blob[0] >> 4) + 8 == wb                       # CINFO says what was used
+
+
+def test_full_flush_is_a_restart_point():
+    """Compress.flush(Z_FULL_FLUSH) (zlib_ngmodule.c:718-784 -> zng_deflate(Z_FULL_FLUSH)): decompression can restart behind
+    the flush point, so the bytes behind it must decode with a FRESH raw decompressor that has seen nothing before -- no match
+    may reach back across the point.  Z_SYNC_FLUSH gives no such promise (and with this repetitive input does reach back)."""
+    import zlib
+    from zlib_ng_amd import corpus, zlib_ng
+    a = corpus.text(200000, seed=11).tobytes()
+    b = a[-30000:] + corpus.text(100000, seed=12).tobytes()        # starts with what the history holds: tempting matches
+    for wb in (-15, 15, 31):
+        co = zlib_ng.compressobj(6, zlib_ng.DEFLATED, wb)
+        first = co.compress(a) + co.flush(zlib_ng.Z_FULL_FLUSH)
+        second = co.compress(b) + co.flush()
+        assert zlib.decompress(first + second, wb) == a + b, wb
+        assert first.endswith(b"\x00\x00\xff\xff")
+        tail_len = {-15: 0, 15: 4, 31: 8}[wb]
+        raw_second = second[:len(second) - tail_len] if tail_len else second
+        fresh = zlib.decompressobj(-15)
+        assert fresh.decompress(raw_second) == b, wb              # a fresh decoder: nothing in front of the flush point is needed
+        ours = zlib_ng.decompressobj(-15)
+        assert ours.decompress(raw_second) + ours.flush() == b, wb
+    # several full flushes in a row, small pieces (the collected-input path)
+    co = zlib_ng.compressobj(6, zlib_ng.DEFLATED, -15)
+    pieces, blobs = [a[i * 5000:(i + 1) * 5000] for i in range(8)], []
+    for p in pieces:
+        blobs.append(co.compress(p) + co.flush(zlib_ng.Z_FULL_FLUSH))
+    blobs.append(co.flush())
+    for p, blob in zip(pieces, blobs):
+        assert zlib.decompressobj(-15).decompress(blob) == p
+    # the sync flush keeps the history (the contrast that shows the test can fail)
+    co = zlib_ng.compressobj(6, zlib_ng.DEFLATED, -15)
+    first = co.compress(a) + co.flush(zlib_ng.Z_SYNC_FLUSH)
+    second = co.compress(b) + co.flush()
+    assert zlib.decompress(first + second, -15) == a + b
+    with pytest.raises(zlib.error):
+        zlib.decompressobj(-15).decompress(second)
+
+
+def test_gzip_compressobj_rejects_a_preset_dictionary():
+    """zng_deflateSetDictionary returns Z_STREAM_ERROR on a gzip stream (no gzip decoder could supply the dictionary); the
+    reference raises ValueError("Invalid dictionary") (zlib_ngmodule.c:401-416)."""
+    from zlib_ng_amd import zlib_ng
+    with pytest.raises(ValueError, match="Invalid dictionary"):
+        zlib_ng.compressobj(6, zlib_ng.DEFLATED, 31, zdict=b"abcdefgh" * 100)
+    zlib_ng.compressobj(6, zlib_ng.DEFLATED, 15, zdict=b"abcdefgh" * 100)       # zlib and raw containers take one
+    zlib_ng.compressobj(6, zlib_ng.DEFLATED, -15, zdict=b"abcdefgh" * 100)
+
+
+def test_stream_reset_entry_points():
+    """zngamd_stream_deflate_reset / _inflate_reset (zng_deflateReset zlib_ngmodule.c:1725, zng_inflateReset :2525, :2715):
+    a stream is reused for a second, independent stream; the first one's history and checksums are gone."""
+    import ctypes as C
+    import zlib
+    from zlib_ng_amd import _lib, corpus, zlib_ng
+    L = zlib_ng._slib()
+    ctx = zlib_ng._ctx()
+    a = corpus.text(150000, seed=21).tobytes()
+    b = a[-20000:] + corpus.text(50000, seed=22).tobytes()
+
+    def run(fn, zst, data, flush):
+        out = bytearray()
+        buf = C.create_string_buffer(1 << 20)
+        keep = C.create_string_buffer(bytes(data), len(data)) if data else None
+        zst.next_in = C.cast(keep, C.c_void_p).value if data else None
+        zst.avail_in = len(data)
+        while True:
+            zst.next_out = C.cast(buf, C.c_void_p).value
+            zst.avail_out = len(buf)
+            err = fn(C.byref(zst), flush)
+            out += buf.raw[:len(buf) - zst.avail_out]
+            assert err in (_lib.OK, _lib.STREAM_END, _lib.BUF_ERROR), (err, zst.msg)
+            if err == _lib.STREAM_END or (zst.avail_in == 0 and zst.avail_out != 0):
+                return bytes(out), err
+    zst = zlib_ng._ZStream()
+    assert L.zngamd_stream_deflate_init(ctx.h, C.byref(zst), 6, 8, 31, 8, 0) == _lib.OK
+    first, err = run(L.zngamd_stream_deflate, zst, a, 4)
+    assert err == _lib.STREAM_END and zlib.decompress(first, 31) == a
+    assert L.zngamd_stream_deflate_reset(C.byref(zst)) == _lib.OK
+    assert zst.total_in == 0 and zst.total_out == 0
+    second, err = run(L.zngamd_stream_deflate, zst, b, 4)
+    assert err == _lib.STREAM_END and zlib.decompress(second, 31) == b          # a complete stream of its own: header, no reach into `a`
+    assert L.zngamd_stream_deflate_end(C.byref(zst)) == _lib.OK
+    # inflate: two gzip members through one stream with a reset in between (what GzipReader does between members)
+    zst = zlib_ng._ZStream()
+    assert L.zngamd_stream_inflate_init(ctx.h, C.byref(zst), 47) == _lib.OK     # auto-detect: the reset must go back to "auto"
+    got, err = run(L.zngamd_stream_inflate, zst, first, 2)
+    assert err == _lib.STREAM_END and got == a
+    assert L.zngamd_stream_inflate_reset(C.byref(zst)) == _lib.OK
+    got, err = run(L.zngamd_stream_inflate, zst, zlib.compress(b, 6), 2)        # a zlib stream this time
+    assert err == _lib.STREAM_END and got == b
+    assert L.zngamd_stream_inflate_end(C.byref(zst)) == _lib.OK
