@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
 #define ZA_IROW_LOADS 4            // 16-byte loads per row of staged input
 #endif
 #define ZA_IROW (4 * ZA_IROW_LOADS + 1)            // dwords per lane row (+ 1: odd stride)
-#define ZA_IROW_BYTES (16 * ZA_IROW_LOADS - 16)    // bytes consumed per row; the last 16 are look-ahead (a token takes up to 37 bits)
+#define ZA_IROW_BYTES (16 * ZA_IROW_LOADS - 16)    // bytes consumed per row; the last 16 are look-ahead (a round of the member decoder takes up to 97 bits)
 #ifndef ZA_ILITS
 #define ZA_ILITS 3                 // literals a lane takes per round at most
 #endif
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                                                               const ZaMember *__restrict__ members,
                                                               uint8_t *__restrict__ out, uint64_t out_cap,
                                                               uint32_t *__restrict__ matchq,       // [grid][64][ZA_MATCHQ_PER_SEG]
-                                                              const uint32_t *__restrict__ crc_slice4,   // [4][256]: slice-by-4 tables
+                                                              const uint32_t *__restrict__ crc_tabs,     // [4][256] slice-by-4 tables | [8][16] advance over 2 016 zero bytes | [128] x^(8 * 32 k)
                                                               const uint32_t *__restrict__ x8k_table,
                                                               int32_t *__restrict__ status_out)
 {
@@ -1101,17 +1101,21 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
         __syncthreads();
     }
 
-    // ---- phase A: every lane decodes its own segment.
+    // ---- phase A: every lane decodes its own segment into two compact streams: the segment's LITERAL BYTES, written to the
+    // front of the segment's own 2 KiB of the output buffer (phase B expands them in place; nothing else lives there yet), and
+    // one 4-byte QUEUE ENTRY per match.
     // A dependent 8-byte global load per token would cost microseconds, so each lane's compressed bytes are staged through an
     // LDS row: row r holds the 64 bytes at the lane's (16-byte aligned) origin + 48 r; a lane decodes while its read position is
     // inside the first 48 bytes of the row, and the next row (four aligned 16-byte loads) is already in flight in registers.
     uint32_t *myq = matchq + ((size_t)blockIdx.x * 64 + (size_t)lane) * ZA_MATCHQ_PER_SEG;
     uint32_t nmatch = 0;       // queue entries of my segment
+    uint32_t nlit = 0;         // literal bytes of my segment
     int lane_err = 0;          // 0 ok, 1 index mismatch, 2 data error
     {
         uint32_t *myrow = rows + lane * ZA_IROW;
         const bool act = lane < nseg;
         int pos = lane << ZA_SEG_SHIFT;
+        const int seg0 = pos;
         int end = pos + ZA_SEG; if (end > n) end = n;
         uint32_t bp = my_start;
         if (act && (my_stop > in_bits || my_stop < my_start)) lane_err = 1;
@@ -1121,23 +1125,18 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
         const uint32_t org_bit = my_start - ((uint32_t)(a0 - org) * 8u + (my_start & 7u));      // bit offset (from src bit 0) of the origin; may be "negative" (wraps): only differences are used
         const uint8_t *lim = in + in_total;
         bool done = !act || lane_err != 0 || pos >= end;
-        // Output of this lane is collected in a 16-byte block and stored once per block: literal bytes land in it, match bytes
-        // are left zero -- phase B overwrites them later, and no other lane owns bytes of this block (segment starts are
-        // multiples of 16 inside the member).  Inside the loop only whole blocks are stored; the block that is open when the
-        // segment ends is stored behind the loop (bytewise where it holds the member's last bytes).
+        // The literal bytes are collected in a 16-byte block (nlit & 15 bytes of it are taken) and leave as one 16-byte store
+        // per block: 36 stores for the 570 literal bytes of an average 2 KiB of text.
+        uint8_t *litp = dst + seg0;
         uint64_t blk_lo = 0, blk_hi = 0;
-        bool blk_dirty = false;                                 // a literal was put into the block
-        int blk_base = pos;                                     // multiple of 16
-        // queue entries: distance - 1 | (length - 3) << 15 | (literals since the previous match) << 23; runs of 511 literals and
-        // more go into an entry of their own (length field 0 -- a real match of an indexed member is at least 4 long).
-        // Entries leave four at a time as one 16-byte store.
+        // Queue entries: distance - 1 | (length - 3) << 15 | (literals since the previous entry) << 23.  A run of literals is cut
+        // into entries of its own (length field 0: the word is the count) before it exceeds 32, so that phase B moves every run
+        // with two 16-byte copies.  Entries leave four at a time as one 16-byte store.
         uint32_t qb0 = 0, qb1 = 0, qb2 = 0;
-        int prev_end = pos;
+        uint32_t gap = 0;                                       // literals since the previous entry: < 27 between two rounds
         auto push = [&](uint32_t ent) {
             const uint32_t k = nmatch & 3u;
-#ifndef ZA_ABL_NO_ASTORE
             if (k == 3u) *(uint4 *)(myq + (nmatch & ~3u)) = make_uint4(qb0, qb1, qb2, ent);
-#endif
             qb0 = k == 0u ? ent : qb0; qb1 = k == 1u ? ent : qb1; qb2 = k == 2u ? ent : qb2;
             nmatch++;
         };
@@ -1172,8 +1171,9 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
             __builtin_amdgcn_wave_barrier();
             prefetch(r + 1);
             const uint32_t row_bit0 = org_bit + (uint32_t)ZA_IROW_BYTES * 8u * r;
-            // one token per lane and round, on one path: no break / continue inside (the compiler otherwise copies the whole lane
-            // state at every edge)
+            // One round per lane = up to six literals AND the match behind them, on one straight path: text at level 6 is runs
+            // of 3.8 literals between matches, so most rounds take a whole run with its match and no lane waits in a branch the
+            // others do not take.  No break / continue inside (the compiler otherwise copies the whole lane state at every edge).
 #pragma unroll 1
             for (;;) {
                 const uint32_t rel = bp - row_bit0;                 // < 384 while inside the row's first 48 bytes
@@ -1181,93 +1181,91 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                 if (__ballot(go) == 0ull) break;
                 if (go) {
                     const uint32_t w = rel >> 5, sh = rel & 31u;
-                    // 64 bits starting at bit `rel` of the row (3 dwords; a token takes at most 10 + 5 + 9 + 13 = 37)
-                    const uint32_t d0 = myrow[w], d1 = myrow[w + 1], d2 = myrow[w + 2];
-                    const uint64_t b = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);   // two funnel shifts, no branch on sh == 0
-                    const uint32_t e = T.lut_l[(uint32_t)b & ((1u << ZA_ML_BITS) - 1u)];
-                    const uint32_t l = e & 15u;
-                    int adv = 1;
-                    uint32_t used = l;
-                    int err = (e == 0u) ? 2 : 0;        // (a lane that runs past its stop offset is caught behind the loop; rows never read outside the buffer)
-                    if (!(e & 0x8000u)) {
-                        // Literals come in runs (text at level 6: 79 % of the tokens, 3.8 in a row on average), so a literal round
-                        // takes up to ZA_ILITS of them: the next codes are looked up in the same 64 bits, and the bytes go into the
-                        // open block together.  A further literal is taken while it stays inside the block and the segment.
-                        const int o = pos - blk_base;
-                        uint32_t grp = (e >> 4) & 0xFFu;
-                        int nl = 1;
-#if ZA_ILITS >= 2
-                        {
-                            const uint32_t e1 = T.lut_l[(uint32_t)(b >> used) & ((1u << ZA_ML_BITS) - 1u)];
-                            const bool t1 = e1 != 0u && !(e1 & 0x8000u) && o + 1 < 16 && pos + 1 < end;
-                            if (t1) { grp |= ((e1 >> 4) & 0xFFu) << 8; used += e1 & 15u; nl = 2; }
-#if ZA_ILITS >= 3
-                            const uint32_t e2 = T.lut_l[(uint32_t)(b >> used) & ((1u << ZA_ML_BITS) - 1u)];
-                            const bool t2 = t1 && e2 != 0u && !(e2 & 0x8000u) && o + 2 < 16 && pos + 2 < end;
-                            if (t2) { grp |= ((e2 >> 4) & 0xFFu) << 16; used += e2 & 15u; nl = 3; }
-#if ZA_ILITS >= 4
-                            const uint32_t e3 = T.lut_l[(uint32_t)(b >> used) & ((1u << ZA_ML_BITS) - 1u)];
-                            const bool t3 = t2 && e3 != 0u && !(e3 & 0x8000u) && o + 3 < 16 && pos + 3 < end;
-                            if (t3) { grp |= ((e3 >> 4) & 0xFFu) << 24; used += e3 & 15u; nl = 4; }
-#endif
-#endif
+                    // 128 bits starting at bit `rel` of the row (5 dwords): six literals take at most 60, a match 10 + 5 + 9 + 13
+                    const uint32_t d0 = myrow[w], d1 = myrow[w + 1], d2 = myrow[w + 2], d3 = myrow[w + 3], d4 = myrow[w + 4];
+                    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+                    const uint32_t h2 = __builtin_amdgcn_alignbit(d3, d2, sh), h3 = __builtin_amdgcn_alignbit(d4, d3, sh);
+                    const int room = end - pos;                       // >= 1
+                    // -- up to six literals, three at a time: each code is looked up in the 32 bits at hand (bit offsets <= 20),
+                    // then the window moves on by what the three took.  (Runs of literals are long-tailed -- 15 % of them are longer
+                    // than nine -- and the lanes with the long runs are the ones the whole wave waits for.)
+                    auto lit3 = [&](uint32_t win, int left, bool on, uint32_t &bits, uint32_t &bytes) -> uint32_t {
+                        const uint32_t e0 = T.lut_l[win & ((1u << ZA_ML_BITS) - 1u)];
+                        const bool l0 = on && e0 != 0u && e0 < 0x8000u && left > 0;
+                        uint32_t u = l0 ? (e0 & 15u) : 0u;
+                        uint32_t g = l0 ? (e0 >> 4) : 0u;
+                        const uint32_t e1 = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_ML_BITS)];
+                        const bool l1 = l0 && e1 != 0u && e1 < 0x8000u && left > 1;
+                        u += l1 ? (e1 & 15u) : 0u;
+                        g |= l1 ? (e1 >> 4) << 8 : 0u;
+                        const uint32_t e2 = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_ML_BITS)];
+                        const bool l2 = l1 && e2 != 0u && e2 < 0x8000u && left > 2;
+                        u += l2 ? (e2 & 15u) : 0u;
+                        g |= l2 ? (e2 >> 4) << 16 : 0u;
+                        bits = u; bytes = g;
+                        return (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u);
+                    };
+                    uint32_t u1, g1, u2, g2b;
+                    const uint32_t n1 = lit3(lo, room, true, u1, g1);
+                    const uint32_t lo1 = __builtin_amdgcn_alignbit(hi, lo, u1), hi1 = __builtin_amdgcn_alignbit(h2, hi, u1), h21 = __builtin_amdgcn_alignbit(h3, h2, u1);
+                    const uint32_t n2 = lit3(lo1, room - 3, n1 == 3u, u2, g2b);
+                    const uint32_t nl = n1 + n2, u = u1 + u2;
+                    const uint64_t grp = (uint64_t)g1 | ((uint64_t)g2b << 24);
+                    // -- the token behind them (64 bits from there on)
+                    const uint32_t m_lo = __builtin_amdgcn_alignbit(hi1, lo1, u2), m_hi = __builtin_amdgcn_alignbit(h21, hi1, u2);
+                    const uint32_t em = T.lut_l[m_lo & ((1u << ZA_ML_BITS) - 1u)];
+                    const uint32_t l = em & 15u, nxb = (em >> 12) & 7u;
+                    const uint32_t len = ((em >> 4) & 0xFFu) + 3u + __builtin_amdgcn_ubfe(m_lo, l, nxb);
+                    const uint32_t used = l + nxb;                                    // <= 15
+                    const uint32_t d = T.lut_d[__builtin_amdgcn_ubfe(m_lo, used, ZA_MD_BITS)];
+                    const uint32_t dl = d & 15u, dnx = (d >> 4) & 15u;
+                    const uint32_t off2 = used + dl;                                  // <= 24
+                    const uint32_t dist = (d >> 8) + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(m_hi, m_lo, off2), 0u, dnx);
+                    const int pos1 = pos + (int)nl;
+                    // a match is due unless the segment ends behind the literals or a fourth literal follows
+                    const bool want = pos1 < end && !(em != 0u && em < 0x8000u);
+                    const bool bad_data = em == 0u || ((em & 0x7000u) != 0x7000u && (d == 0u || (int)dist > pos1));
+                    // end of block inside a segment, a length this queue cannot hold, a match across the segment end, queue full
+                    const bool bad_index = (em & 0x7000u) == 0x7000u || len < 4u || pos1 + (int)len > end || nmatch + 2u > ZA_MATCHQ_PER_SEG;
+                    const bool take = want && !bad_data && !bad_index;
+                    const int err = want && !take ? (bad_data && (em & 0x7000u) != 0x7000u ? 2 : 1) : 0;
+                    // -- the literals go into the open block
+                    if (nl) {
+                        const uint32_t o = nlit & 15u, s8 = (o & 7u) * 8u;
+                        const uint64_t t = grp << s8;
+                        const uint64_t sp = s8 ? grp >> (64u - s8) : 0ull;           // bytes that cross into the next half
+                        if (o < 8u) { blk_lo |= t; blk_hi |= sp; } else blk_hi |= t;
+                        if (o + nl >= 16u) {
+                            ZaU4u v; v.x = (uint32_t)blk_lo; v.y = (uint32_t)(blk_lo >> 32); v.z = (uint32_t)blk_hi; v.w = (uint32_t)(blk_hi >> 32);
+                            *(ZaU4u *)(litp + (nlit & ~15u)) = v;
+                            blk_lo = o >= 8u ? sp : 0ull;                             // what did not fit opens the next block (o + nl > 16 needs o >= 11)
+                            blk_hi = 0;
                         }
-#endif
-                        adv = nl;
-                        const uint64_t g = (uint64_t)grp;
-                        if (o < 8) { blk_lo |= g << (8 * o); if (o > 4) blk_hi |= g >> (8 * (8 - o)); }
-                        else blk_hi |= g << (8 * (o - 8));
-                        blk_dirty = true;
-                    } else {
-                        // match: every validity test of the token is collected and branched on once
-                        const uint32_t nxb = (e >> 12) & 7u;
-                        const int len = (int)(((e >> 4) & 0xFFu) + 3u + ((uint32_t)(b >> l) & ((1u << nxb) - 1u)));
-                        used = l + nxb;
-                        const uint32_t d = T.lut_d[(uint32_t)(b >> used) & ((1u << ZA_MD_BITS) - 1u)];
-                        const uint32_t dl = d & 15u, dnx = (d >> 4) & 15u;
-                        const int dist = (int)((d >> 8) + ((uint32_t)(b >> (used + dl)) & ((1u << dnx) - 1u)));
-                        used += dl + dnx;
-                        const bool bad_data = d == 0u || dist > pos;
-                        // end of block inside a segment, a length this queue cannot hold, a match across the segment end, queue full
-                        const bool bad_index = nxb == 7u || len < 4 || pos + len > end || nmatch + 2u > ZA_MATCHQ_PER_SEG;
-                        if (bad_data || bad_index) err = (nxb == 7u || !bad_data) ? 1 : 2;
-                        else {
-                            // one push per round: a run of 511 literals or more (rare) gets its entry now and the match is
-                            // decoded again in the next round, with no literals in front of it any more
-                            const uint32_t gap = (uint32_t)(pos - prev_end);
-                            const bool longgap = gap >= 511u;
-                            push(longgap ? gap : (uint32_t)(dist - 1) | ((uint32_t)(len - 3) << 15) | (gap << 23));
-                            adv = longgap ? 0 : len;
-                            used = longgap ? 0u : used;
-                        }
+                        nlit += nl;
                     }
-                    if (err) { lane_err = err; done = true; adv = 0; used = 0; }
-                    pos += adv; bp += used;
-                    if (!(e & 0x8000u)) { } else prev_end = pos;
-                    if (pos - blk_base >= 16) {
-                        // a whole block lies behind me: it goes out if a literal was put into it
-#ifndef ZA_ABL_NO_ASTORE
-                        if (blk_dirty) { ZaU4u v; v.x = (uint32_t)blk_lo; v.y = (uint32_t)(blk_lo >> 32); v.z = (uint32_t)blk_hi; v.w = (uint32_t)(blk_hi >> 32); *(ZaU4u *)(dst + blk_base) = v; }
-#endif
-                        blk_lo = 0; blk_hi = 0; blk_dirty = false;
-                        blk_base = pos & ~15;
-                    }
+                    // -- one queue entry per round at most: the match with the literals in front of it, or a long run's count
+                    const uint32_t g2 = gap + nl;                     // <= 26 + 6
+                    if (take) push((dist - 1u) | ((len - 3u) << 15) | (g2 << 23));
+                    else if (g2 >= 27u) push(g2);
+                    gap = (take || g2 >= 27u) ? 0u : g2;
+                    pos = pos1 + (take ? (int)len : 0);
+                    bp += u + (take ? off2 + dnx : 0u);
+                    if (err) { lane_err = err; done = true; }
                     if (pos >= end) done = true;
                 }
             }
         }
-        if (act && blk_dirty && !lane_err) {                    // the block that was open when the segment ended
-            if (blk_base + 16 <= n) { ZaU4u v; v.x = (uint32_t)blk_lo; v.y = (uint32_t)(blk_lo >> 32); v.z = (uint32_t)blk_hi; v.w = (uint32_t)(blk_hi >> 32); *(ZaU4u *)(dst + blk_base) = v; }
-            else for (int k = blk_base; k < n; k++) { const int o = k - blk_base; dst[k] = (uint8_t)(o < 8 ? blk_lo >> (8 * o) : blk_hi >> (8 * (o - 8))); }
+        if (act && !lane_err && (nlit & 15u)) {                 // the block that was open when the segment ended
+            const uint32_t b = nlit & ~15u;
+            if (seg0 + (int)b + 16 <= n) { ZaU4u v; v.x = (uint32_t)blk_lo; v.y = (uint32_t)(blk_lo >> 32); v.z = (uint32_t)blk_hi; v.w = (uint32_t)(blk_hi >> 32); *(ZaU4u *)(litp + b) = v; }
+            else for (uint32_t k = b; k < nlit; k++) { const uint32_t o = k - b; litp[k] = (uint8_t)(o < 8 ? blk_lo >> (8 * o) : blk_hi >> (8 * (o - 8))); }
         }
-#ifndef ZA_ABL_NO_ASTORE
         {   // the last, partial group of queue entries
             const uint32_t k = nmatch & 3u, b4 = nmatch & ~3u;
             if (k > 0) myq[b4] = qb0;
             if (k > 1) myq[b4 + 1] = qb1;
             if (k > 2) myq[b4 + 2] = qb2;
         }
-#endif
         if (act && !lane_err && bp != my_stop) lane_err = 1;
         if (act && !lane_err && lane == nseg - 1) {     // the last segment must be followed by end-of-block
             const uint32_t e = T.lut_l[(uint32_t)za_peek(src, bp) & ((1u << ZA_ML_BITS) - 1u)];         // bp == my_stop <= in_bits
@@ -1277,47 +1275,68 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
     }
     const unsigned long long e1 = __ballot(lane_err == 1), e2 = __ballot(lane_err == 2);
     if (e1 || e2) { if (lane == 0) status_out[blockIdx.x] = e2 ? ZA_I_DATA : ZA_I_INDEX; return; }
-    __threadfence_block();       // literals and the match queues are visible to the whole wave
+    __threadfence_block();       // the literal bytes and the match queues are visible to the whole wave
 
-    // ---- phase B: resolve matches in output order, segment by segment, 64 at a time, inside an LDS image of the segment.
-    // The image (in the row area) holds the segment's 2 KiB as phase A left them (literals in place) behind the last 272 bytes
-    // of the output in front of the segment.  A match whose source starts inside the image is copied LDS to LDS; the others
-    // (their source ends below the segment: final bytes in memory) with one or two 16-byte global loads into the image.
-    // Inside a group a match waits for the lanes that write what it reads (exact masks from two shuffle binary searches);
-    // those rounds cost LDS round trips instead of the store-fence-load round trips through L2 they cost when the matches
-    // were copied in memory.  The finished segment leaves as 64 x 32 bytes, coalesced.
+    // ---- phase B: expand, segment by segment in output order, inside an LDS image of the segment.
+    // The image (in the row area) is the segment's 2 KiB behind the last 272 bytes of the output in front of it.  The segment's
+    // literal bytes are loaded RIGHT-ALIGNED into it: literal k of nlit sits at seg_len - nlit + k, at or behind its final place,
+    // and the expansion moves every run of literals down to where it belongs while the matches fill the gaps -- in ascending
+    // order, so a run never lands on bytes that are still to be moved (all lanes of a group read before any of them writes).
+    // 64 queue entries at a time: destinations from a wave prefix sum, the literal runs move (two 16-byte copies each at most),
+    // then the matches: LDS to LDS when the source starts inside the image, with one or two 16-byte global loads when it lies
+    // further back (final bytes in memory).  Inside a group a match waits for the lanes that write what it reads (exact masks
+    // from two shuffle binary searches).  CRC-32 is taken from the finished image as it leaves (32 bytes per lane, slice-by-4,
+    // the state carried over the 2 016 bytes of the other lanes by eight table reads), so the output is never read back.
+    uint32_t crc_r = lane == 0 ? 0xFFFFFFFFu : 0u;              // raw CRC state of "my bytes, zeros elsewhere" (lane 0 carries the preset)
 #ifndef ZA_ABL_NO_B
     {
         uint8_t *img = (uint8_t *)rows;                            // [0, 272): output in front of the segment, [272, 272 + 2048): the segment
         const uint32_t TAIL = 272u;
-        static_assert(sizeof(uint32_t) * 64 * ZA_IROW >= 272 + ZA_SEG + 32, "segment image");
+        uint32_t *crct = (uint32_t *)&T;                           // slice-by-4 tables take the place of the decode tables
+        uint32_t *advt = rows + (TAIL + ZA_SEG + 32) / 4;          // [8][16]: state advanced over 2 016 zero bytes, by nibble
+        static_assert(sizeof(uint32_t) * 64 * ZA_IROW >= 272 + ZA_SEG + 32 + 512, "segment image + advance table");
+        static_assert(sizeof(ZaMemTabs) >= 4096, "slice tables");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 1024; i += 64) crct[i] = crc_tabs[i];
+        for (int i = lane; i < 128; i += 64) advt[i] = crc_tabs[1024 + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (int s = 0; s < nseg; s++) {
-            const uint32_t cnt = __shfl(nmatch, s, 64);
+            const uint32_t cnt = __shfl(nmatch, s, 64), lits = __shfl(nlit, s, 64);
             const uint32_t *q = matchq + ((size_t)blockIdx.x * 64 + (size_t)s) * ZA_MATCHQ_PER_SEG;
             const uint32_t seg_start = (uint32_t)s << ZA_SEG_SHIFT;
             const uint32_t seg_len = (uint32_t)n - seg_start < (uint32_t)ZA_SEG ? (uint32_t)n - seg_start : (uint32_t)ZA_SEG;
             uint32_t ent_next = (uint32_t)lane < cnt ? q[lane] : 0u;
-            // image: the tail of the previous segment moves to the front (it is final), the segment comes from memory
+            // image: the tail of the previous segment moves to the front (it is final); the literal bytes come from memory,
+            // piece by piece of 16 bytes where a piece holds any (image byte x is literal byte x - shift)
             __builtin_amdgcn_wave_barrier();
             uint32_t t0 = 0, t1 = 0;
             if (s > 0) { t0 = ((const uint32_t *)(img + ZA_SEG))[lane]; if (lane < 4) t1 = ((const uint32_t *)(img + ZA_SEG))[64 + lane]; }
             {
-                const uint32_t o = (uint32_t)lane * 32u;
-                ZaU4u a = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
-                if (o + 32u <= seg_len) { a = *(const ZaU4u *)(dst + seg_start + o); b2 = *(const ZaU4u *)(dst + seg_start + o + 16); }
-                else if (o < seg_len) {
-                    uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (uint32_t k = 0; k < 32u && o + k < seg_len; k++) t[k >> 2] |= (uint32_t)dst[seg_start + o + k] << (8 * (k & 3));
-                    a.x = t[0]; a.y = t[1]; a.z = t[2]; a.w = t[3]; b2.x = t[4]; b2.y = t[5]; b2.z = t[6]; b2.w = t[7];
+                const int shift = (int)(seg_len - lits);             // match bytes of the segment
+                ZaU4u pc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int x = lane * 32 + 16 * j, o = x - shift;      // image offset of the piece, and where it starts in the literal bytes
+                    if (x < (int)seg_len && o + 16 > 0) {
+                        // (bytes in front of the first literal or behind the last are of no meaning; they must only be readable)
+                        if ((o >= 0 || m.out_off + seg_start >= 16u) && m.out_off + seg_start + (uint64_t)(o + 16) <= out_cap) pc[j] = *(const ZaU4u *)(dst + seg_start + o);
+                        else {
+                            uint32_t t[4] = {0, 0, 0, 0};
+                            for (int k = 0; k < 16; k++) if (o + k >= 0 && o + k < (int)lits) t[k >> 2] |= (uint32_t)dst[seg_start + o + k] << (8 * (k & 3));
+                            pc[j].x = t[0]; pc[j].y = t[1]; pc[j].z = t[2]; pc[j].w = t[3];
+                        }
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (s > 0) { ((uint32_t *)img)[lane] = t0; if (lane < 4) ((uint32_t *)img)[64 + lane] = t1; }
-                *(uint4 *)(img + TAIL + o) = make_uint4(a.x, a.y, a.z, a.w);
-                *(uint4 *)(img + TAIL + o + 16) = make_uint4(b2.x, b2.y, b2.z, b2.w);
+                *(uint4 *)(img + TAIL + lane * 32) = make_uint4(pc[0].x, pc[0].y, pc[0].z, pc[0].w);
+                *(uint4 *)(img + TAIL + lane * 32 + 16) = make_uint4(pc[1].x, pc[1].y, pc[1].z, pc[1].w);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t segpos = seg_start;                               // output position behind the entries handled so far
+            uint32_t mrem = seg_len - lits;                            // match bytes at or behind segpos: how far the literals there sit above their place
             for (uint32_t g = 0; g < cnt; g += 64) {
                 const bool hasq = g + (uint32_t)lane < cnt;
                 const uint32_t ent = ent_next;
@@ -1325,10 +1344,42 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                 const uint32_t l3 = (ent >> 15) & 0xFFu;
                 const bool has = hasq && l3 != 0u;                      // a real match (length field 0: a run of literals)
                 const uint32_t mlen = has ? l3 + 3u : 0u, mdist = (ent & 0x7FFFu) + 1u;
-                const uint32_t adv = !hasq ? 0u : has ? (ent >> 23) + mlen : ent;      // literals in front of the match + the match
-                const uint32_t incl = za_wave_incl_scan(adv);
+                const uint32_t glit = !hasq ? 0u : has ? (ent >> 23) : ent;       // literals in front of the match (<= 32)
+                const uint32_t incl = za_wave_incl_scan(glit + mlen), incm = za_wave_incl_scan(mlen);
                 const uint32_t mdst = segpos + incl - mlen;
+                const uint32_t up = mrem - (incm - mlen);               // my literals sit `up` bytes above their place
                 segpos += (uint32_t)__shfl((int)incl, 63, 64);
+                mrem -= (uint32_t)__shfl((int)incm, 63, 64);
+                uint8_t *od = img + TAIL + (mdst - seg_start);          // my match's destination inside the image; my literals end there
+                // the runs of literals move down: every lane reads its run, then every lane writes it
+                if (__ballot(glit != 0u && up != 0u) != 0ull) {
+                    const uint8_t *sp = od - glit + up;
+                    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+                    const bool mv = glit != 0u && up != 0u;
+                    if (mv) {
+                        a0 = *(const za_u32u *)sp; a1 = *(const za_u32u *)(sp + 4); a2 = *(const za_u32u *)(sp + 8); a3 = *(const za_u32u *)(sp + 12);
+                        if (glit > 16u) { b0 = *(const za_u32u *)(sp + 16); b1 = *(const za_u32u *)(sp + 20); b2 = *(const za_u32u *)(sp + 24); b3 = *(const za_u32u *)(sp + 28); }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (mv) {
+                        uint8_t *o = od - glit;
+                        uint32_t rem = glit;
+                        if (glit > 16u) {
+                            *(za_u32u *)o = a0; *(za_u32u *)(o + 4) = a1; *(za_u32u *)(o + 8) = a2; *(za_u32u *)(o + 12) = a3;
+                            o += 16; a0 = b0; a1 = b1; a2 = b2; a3 = b3; rem = glit - 16u;
+                        }
+                        if (rem & 16u) { *(za_u32u *)o = a0; *(za_u32u *)(o + 4) = a1; *(za_u32u *)(o + 8) = a2; *(za_u32u *)(o + 12) = a3; }
+                        else {
+                            if (rem & 8u) { *(za_u32u *)o = a0; *(za_u32u *)(o + 4) = a1; o += 8; a0 = a2; a1 = a3; }
+                            if (rem & 4u) { *(za_u32u *)o = a0; o += 4; a0 = a1; }
+                            if (rem & 2u) { *(za_u16u *)o = (uint16_t)a0; o += 2; a0 >>= 16; }
+                            if (rem & 1u) *o = (uint8_t)a0;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 bool done = !has;
                 unsigned long long pending = __ballot(!done);
                 // Which matches of this group write bytes that mine reads?  Destinations are disjoint and ascending with
@@ -1354,7 +1405,6 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                 const bool far = src_a + TAIL < seg_start;
 #endif
                 const bool simple = mdist >= mlen && mlen <= 32u;      // copied by its own lane, at most two 16-byte batches
-                uint8_t *od = img + TAIL + (mdst - seg_start);          // my destination inside the image
                 // the far sources of the whole group are fetched at once (nothing in this group can change them)
                 ZaU4u fv = {0, 0, 0, 0}, fv2 = {0, 0, 0, 0};
                 if (has && far && simple) {
@@ -1423,65 +1473,64 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                     pending = __ballot(!done);
                 }
             }
-            // the finished segment: 32 bytes per lane, coalesced (its last, partial piece bytewise)
+            // the finished segment: 32 bytes per lane, coalesced (its last, partial piece bytewise), CRC-32 on the way out
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             {
                 const uint32_t o = (uint32_t)lane * 32u;
+#ifndef ZA_ABL_NO_CRC
+                if (s > 0 && o < seg_len) {                              // my state crosses the 2 016 bytes of the other lanes
+                    uint32_t a = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a ^= advt[16 * k + ((crc_r >> (4 * k)) & 15u)];
+                    crc_r = a;
+                }
+#endif
                 if (o + 32u <= seg_len) {
                     const uint4 a = *(const uint4 *)(img + TAIL + o), b2 = *(const uint4 *)(img + TAIL + o + 16);
                     ZaU4u va = {a.x, a.y, a.z, a.w}, vb = {b2.x, b2.y, b2.z, b2.w};
                     *(ZaU4u *)(dst + seg_start + o) = va; *(ZaU4u *)(dst + seg_start + o + 16) = vb;
-                } else for (uint32_t k = 0; k < 32u && o + k < seg_len; k++) dst[seg_start + o + k] = img[TAIL + o + k];
+#ifndef ZA_ABL_NO_CRC
+                    const uint32_t wv[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        crc_r ^= wv[k];
+                        crc_r = crct[768 + (crc_r & 0xFFu)] ^ crct[512 + ((crc_r >> 8) & 0xFFu)] ^ crct[256 + ((crc_r >> 16) & 0xFFu)] ^ crct[crc_r >> 24];
+                    }
+#endif
+                } else for (uint32_t k = 0; k < 32u && o + k < seg_len; k++) {
+                    const uint8_t bv = img[TAIL + o + k];
+                    dst[seg_start + o + k] = bv;
+#ifndef ZA_ABL_NO_CRC
+                    crc_r = crct[(crc_r ^ bv) & 0xFFu] ^ (crc_r >> 8);
+#endif
+                }
             }
             __threadfence_block();       // later segments read these bytes from memory
         }
     }
 #endif
-    // the CRC slice tables take the place of the segment image
-    __builtin_amdgcn_wave_barrier();
-    uint32_t *crct = rows;
-    static_assert(sizeof(uint32_t) * 64 * ZA_IROW >= 4096, "slice tables");
-    for (int i = lane; i < 1024; i += 64) crct[i] = crc_slice4[i];
 
     // ---- verify against the member trailer (CRC32, ISIZE), zlib_ngmodule.c:2577-2599
 #ifdef ZA_ABL_NO_CRC
     const uint32_t c = za_ld32(src + m.in_len);
 #else
-    __syncthreads();
     uint32_t c = 0;
     {
-        // lane per 2 KiB segment, 16 bytes per load with the next load in flight, slice-by-4 (four independent table reads per
-        // dword instead of a chain of four); the per-segment values are folded as in za_wave_crc32
-        const int s0 = lane << ZA_SEG_SHIFT;
-        int s1 = s0 + ZA_SEG; if (s1 > n) s1 = n;
-        if (lane < nseg) {
-            uint32_t r = 0xFFFFFFFFu;
-            int p = s0;
-            ZaU4u cur = {0, 0, 0, 0};
-            if (p + 16 <= s1) cur = *(const ZaU4u *)(dst + p);
-            for (; p + 16 <= s1; p += 16) {
-                ZaU4u nx = {0, 0, 0, 0};
-                if (p + 32 <= s1) nx = *(const ZaU4u *)(dst + p + 16);
-                const uint32_t wv[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    r ^= wv[k];
-                    r = crct[768 + (r & 0xFFu)] ^ crct[512 + ((r >> 8) & 0xFFu)] ^ crct[256 + ((r >> 16) & 0xFFu)] ^ crct[r >> 24];
-                }
-                cur = nx;
-            }
-            for (; p < s1; p++) r = crct[(r ^ dst[p]) & 0xFFu] ^ (r >> 8);
-            c = r ^ 0xFFFFFFFFu;
-            if (lane < nseg - 1) {
-                // crc(A||B) = crc(A) * x^(8|B|) ^ crc(B);  |B| = (nseg-2-lane) full segments + the tail
-                const int tail = n - ((nseg - 1) << ZA_SEG_SHIFT);
-                uint32_t xt = 0x80000000u, sq = 0x00800000u;       // x^0, x^8
-                for (int mm = tail; mm; mm >>= 1) { if (mm & 1) xt = za_multmodp(sq, xt); sq = za_multmodp(sq, sq); }
-                c = za_multmodp(za_multmodp(x8k_table[nseg - 2 - lane], xt), c);
-            }
+        // my state stands behind my last byte: the bytes between there and the end of the member are zeros to it -- a few
+        // table steps for the odd bytes, one GF(2) product with x^(8 * 32 k) for the rest (k < 128: two segments at most)
+        const uint32_t first = (uint32_t)lane * 32u;
+        if (first < (uint32_t)n) {
+            const uint32_t s_last = ((uint32_t)n - 1u - first) >> ZA_SEG_SHIFT;
+            uint32_t endp = (s_last << ZA_SEG_SHIFT) + first + 32u;
+            if (endp > (uint32_t)n) endp = (uint32_t)n;
+            const uint32_t after = (uint32_t)n - endp;
+            const uint32_t *crct = (const uint32_t *)&T;
+            uint32_t r = crc_r;
+            for (uint32_t k = 0; k < (after & 31u); k++) r = crct[r & 0xFFu] ^ (r >> 8);
+            c = (after >> 5) ? za_multmodp(crc_tabs[1152 + (after >> 5)], r) : r;
         }
-        c = za_wave_xor_reduce(c);
+        c = za_wave_xor_reduce(c) ^ 0xFFFFFFFFu;
     }
 #endif
     const uint32_t want_crc = za_ld32(src + m.in_len), want_len = za_ld32(src + m.in_len + 4);

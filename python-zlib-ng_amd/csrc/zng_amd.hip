@@ -144,12 +144,20 @@ try {
         hipMemcpy(c->d_x8k, x8k, sizeof x8k, hipMemcpyHostToDevice) != hipSuccess) {
         zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
     }
-    {   // CRC slice-by-4 table of the indexed-member decoder
-        std::vector<uint32_t> s4(1024);
+    {   // tables of the indexed-member decoder's CRC-32: [0, 1024) slice-by-4; [1024, 1152) the raw state advanced over 2 016 zero
+        // bytes (what the other 63 lanes hold of a 2 KiB segment), one 16-entry table per nibble of the state; [1152, 1280)
+        // x^(8 * 32 k) mod P for k < 128
+        std::vector<uint32_t> s4(1280);
         for (int i = 0; i < 256; i++) s4[i] = tab[i];
         for (int t = 1; t < 4; t++) for (int i = 0; i < 256; i++) s4[256 * t + i] = (s4[256 * (t - 1) + i] >> 8) ^ tab[s4[256 * (t - 1) + i] & 0xFF];
-        if (hipMalloc((void **)&c->d_crc_slice4, 4096) != hipSuccess ||
-            hipMemcpy(c->d_crc_slice4, s4.data(), 4096, hipMemcpyHostToDevice) != hipSuccess) {
+        uint32_t x32 = 0x00800000u;                               // x^8 -> x^(8*32): squared five times
+        for (int i = 0; i < 5; i++) x32 = za_multmodp(x32, x32);
+        uint32_t xs = 0x80000000u;
+        for (int k = 0; k < 128; k++) { s4[1152 + k] = xs; xs = za_multmodp(xs, x32); }
+        const uint32_t x2016 = s4[1152 + 63];                     // x^(8 * 2016)
+        for (int k = 0; k < 8; k++) for (uint32_t v = 0; v < 16; v++) s4[1024 + 16 * k + v] = za_multmodp(x2016, v << (4 * k));
+        if (hipMalloc((void **)&c->d_crc_slice4, s4.size() * 4) != hipSuccess ||
+            hipMemcpy(c->d_crc_slice4, s4.data(), s4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
         }
     }
