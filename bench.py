@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-foreign", action="store_true", help="skip the foreign-member inflate leg (outside the timed region)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="0 = sized for ~10-30 s")
+    ap.add_argument("--no-api", action="store_true", help="skip the drop-in API leg (host buffers over PCIe; outside the timed region)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)                  # does not return
@@ -517,6 +518,60 @@ def main():
             out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
     if foreign is not None:
         out["roofline_inflate_foreign"] = foreign
+    # ---- the drop-in API over host buffers (PCIe, Python call overhead and fresh result objects included): NEVER `value`,
+    # outside the timed region, rank 0 at N = 1 only.  One-shot calls on 256 MiB of the same text; the reference's own streaming
+    # benchmark (benchmark_scripts/gzipwrite128kblocks.py:6-12, gzipread128kblocks.py:5-9): a gzip file written and read back
+    # through gzip_ng_threaded.open in 128 KiB calls.
+    if rank == 0 and world == 1 and not args.no_api:
+        from zlib_ng_amd import zlib_ng, gzip_ng_threaded
+        api_n = min(256 << 20, uniq * max(1, (256 << 20) // uniq))
+        blob = bytes(np.tile(host, (api_n + uniq - 1) // uniq)[:api_n])
+
+        def best_of(fn, reps=3):
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t)
+                del r
+            return min(ts)
+        comp_blob = zlib_ng.compress(blob, args.level, 31)
+        assert zlib.decompress(comp_blob, 31) == blob
+        t_c = best_of(lambda: zlib_ng.compress(blob, args.level, 31))
+        assert zlib_ng.decompress(comp_blob, 31) == blob
+        t_d = best_of(lambda: zlib_ng.decompress(comp_blob, 31))
+        CALL = 128 * 1024
+        mvb = memoryview(blob)
+
+        import tempfile
+        tmpdir = tempfile.mkdtemp(prefix="zng_bench_")
+        gz_path = os.path.join(tmpdir, "api.gz")
+
+        def w128():
+            with gzip_ng_threaded.open(gz_path, "wb", compresslevel=args.level, threads=8, block_size=CALL) as f:
+                for o in range(0, api_n, CALL):
+                    f.write(mvb[o:o + CALL])
+        w128()
+        gz = open(gz_path, "rb").read()
+        assert zlib.decompress(gz, 31) == blob
+        t_w = best_of(w128, 2)
+
+        def r128():
+            got = 0
+            with gzip_ng_threaded.open(gz_path, "rb", threads=8, block_size=CALL) as f:
+                while True:
+                    b = f.read(CALL)
+                    if not b:
+                        break
+                    got += len(b)
+            assert got == api_n
+        t_r = best_of(r128, 2)
+        os.remove(gz_path)
+        os.rmdir(tmpdir)
+        out["api"] = {"compress_MBps": round(api_n / t_c / 1e6, 1), "decompress_MBps": round(api_n / t_d / 1e6, 1),
+                      "threaded_write_MBps": round(api_n / t_w / 1e6, 1), "threaded_read_MBps": round(api_n / t_r / 1e6, 1),
+                      "note": f"host buffers, PCIe and fresh result objects included; {api_n >> 20} MiB of the same text, level {args.level}: zlib_ng.compress / "
+                              "decompress (gzip container) one-shot; gzip_ng_threaded.open(threads=8, block_size=128 KiB) written to and read from a temporary file "
+                              "in 128 KiB calls; best of 2-3"}
+        del blob, comp_blob, gz
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -219,12 +219,20 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
 #define ZA_BYTES          65536            // byte ring (power of two)
 #define ZA_LOOKAHEAD      272              // bytes staged beyond the tile: max match 258 + wide compares
 
+// byte-aligned dword of the byte ring at absolute position `addr` (the ring has mirrored pad dwords behind its end)
 __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t addr)
 {
     const uint32_t idx = addr & (ZA_BYTES - 1), w = idx >> 2;
     return __builtin_amdgcn_alignbyte(win32[w + 1], win32[w], idx & 3u);     // win32 has 4 mirrored pad dwords
 }
 
+// `best` entry of a position: distance (bits 0..15) | length - 3 (bits 16..23, 0: no match) | the position's own byte << 24 --
+// the parse kernel then needs nothing but these entries (no second pass over the input)
+
+// (Measured this round and dropped -- the kernel is bound by its instruction count, neither by LDS latency nor by LDS bank
+// cycles: two or four positions of a thread searched at once, their chain walks interleaved by hand, 6.82 -> 6.80 / 7.13 ms per
+// GiB; a candidate's 16 bytes as ONE unaligned ds_read_b128 -- the LDS takes wide reads at any byte address -- 9.4 ms; as three
+// aligned ds_read_b64 and a select per dword 7.57 ms.)
 // FULL: candidates are compared in full (levels with cap 258); otherwise on 16 bytes, winner extended afterwards
 template <bool FULL>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
@@ -300,21 +308,22 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             if (seg_end > n) seg_end = n;
             int maxlen = seg_end - p;
             if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
+            // the result: distance (bits 0..15) | length - 3 (bits 16..23); the position's own byte travels in the top byte
             uint32_t result = 0;
+            const uint32_t P = (uint32_t)(ZA_WIN + p);
+            // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
+            // against them without branches (this also plays the role of zlib's quick-reject byte)
+            uint32_t me0, me1, me2, me3;
+            {   // five aligned dwords and one shift amount (the ring has mirrored pad dwords behind its end)
+                const uint32_t idx = P & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
+                const uint32_t m0 = win32[w], m1 = win32[w + 1], m2 = win32[w + 2], m3 = win32[w + 3], m4 = win32[w + 4];
+                me0 = __builtin_amdgcn_alignbyte(m1, m0, sh); me1 = __builtin_amdgcn_alignbyte(m2, m1, sh);
+                me2 = __builtin_amdgcn_alignbyte(m3, m2, sh); me3 = __builtin_amdgcn_alignbyte(m4, m3, sh);
+            }
             if (maxlen >= ZA_MIN_MATCH) {
-                const uint32_t P = (uint32_t)(ZA_WIN + p);
                 const int cap = L.cap < maxlen ? L.cap : maxlen;             // bytes compared per candidate
                 const int nice = L.nice < cap ? L.nice : cap;
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
-                // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
-                // against them without branches (this also plays the role of zlib's quick-reject byte)
-                uint32_t me0, me1, me2, me3;
-                {   // five aligned dwords and one shift amount (the ring has mirrored pad dwords behind its end)
-                    const uint32_t idx = P & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
-                    const uint32_t m0 = win32[w], m1 = win32[w + 1], m2 = win32[w + 2], m3 = win32[w + 3], m4 = win32[w + 4];
-                    me0 = __builtin_amdgcn_alignbyte(m1, m0, sh); me1 = __builtin_amdgcn_alignbyte(m2, m1, sh);
-                    me2 = __builtin_amdgcn_alignbyte(m3, m2, sh); me3 = __builtin_amdgcn_alignbyte(m4, m3, sh);
-                }
                 uint32_t q = P;
                 int qs = (int)(P % ZA_RING);                                 // ring slot of q, kept incrementally
                 uint32_t d = ring[qs];
@@ -379,9 +388,13 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     best_len = best_len < maxlen ? best_len : maxlen;
                 }
                 if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
-                    result = ((uint32_t)best_len << 16) | (uint32_t)best_dist;
+                    result = ((uint32_t)(best_len - 3) << 16) | (uint32_t)best_dist;
             }
-            best[p] = result;
+#ifdef ZA_ABL_SEARCH_NOLIT
+            best[p] = result;                                                 // (timing only: the parse then sees zero bytes)
+#else
+            best[p] = __builtin_amdgcn_perm(me0, result, 0x04020100u);       // byte 3 = my byte (byte 0 of me0), bytes 0..2 = result
+#endif
         }
         // ---- put the next tile into the rings.  No barrier is needed in front of these stores: they land at least
         // 65536-4096-272-32768 byte slots / 40960-4096-32768 link slots behind any walk of this tile that is still
@@ -404,10 +417,10 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 // ------------------------------------------------------------------------------------------------
 // k_parse  (+ histogram + CRC-32)
 // ------------------------------------------------------------------------------------------------
-// One wave per unit, one lane per 2 KiB segment.  Each lane walks its own stream of `best` entries and
-// input bytes; a dependent global load per token would cost microseconds, so both streams are staged
-// through LDS in chunks of 32 positions per lane (rows with an odd dword stride: conflict free), with
-// the next chunk's global loads in flight while the current one is parsed.
+// One wave per unit, one lane per 2 KiB segment.  Each lane walks its own stream of `best` entries -- which carry the
+// positions' own bytes (top byte of an entry), so the input is not read here at all; a dependent global load per token would cost
+// microseconds, so the stream is staged through LDS in chunks of 32 positions per lane (rows with an odd dword stride:
+// conflict free), with the next chunk's global loads in flight while the current one is parsed.
 // The loads are TRANSPOSED: a lane does not fetch its own row (64 lanes x 16 bytes in 64 different cache lines per
 // instruction = 64 memory requests, and the kernel was bound by the request rate of L2, not by bytes or instructions) --
 // eight lanes fetch the eight 16-byte pieces of one segment's 128-byte row, so an instruction touches eight whole lines,
@@ -415,26 +428,22 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 // chunk (slot 0): the token at a chunk's last position needs best[p + 1] (lazy rule) and is decided one chunk later.
 #define ZA_PCH 32
 #define ZA_PROW (ZA_PCH + 1)          // carried entry + chunk (odd stride)
-#define ZA_DROW (ZA_PCH / 4 + 1)      // carried dword + chunk dwords (odd stride)
+#define ZA_BLEN(b) (((b) >> 16) & 0xFFu)      // length - 3 of a `best` entry, 0 = no match
 
 struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };
 
-__global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in, uint64_t in_total,
-                                                 const ZaUnit *__restrict__ units,
+__global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ units,
                                                  const uint32_t *__restrict__ best_ws, uint32_t *__restrict__ tok_ws,
                                                  uint32_t *__restrict__ segtok_ws, uint32_t *__restrict__ hist_ws,
                                                  uint32_t *__restrict__ crc_out,
                                                  const uint32_t *__restrict__ crc_table,   // [256]
                                                  const uint32_t *__restrict__ x8k_table,   // [64] x^(8*2048*k)
-                                                 ZaLevel L, int level)
+                                                 ZaLevel L)
 {
     __shared__ uint32_t hist[ZA_HIST_STRIDE];
     __shared__ uint32_t crct[256];
     __shared__ uint32_t rowb[64 * ZA_PROW + 3];      // (+3: the look-ahead reads at a segment's last positions)
-    __shared__ uint32_t rowd[64 * ZA_DROW + 1];
     const ZaUnit u = units[blockIdx.x];
-    const uint8_t *data = in + u.in_off;
-    const long long readable = (long long)(in_total - u.in_off);
     const int n = (int)u.in_len;
     const int lane = za_lane();
     const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
@@ -446,43 +455,22 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     int s1 = s0 + ZA_SEG;
     if (s1 > n) s1 = n;
     const bool active = lane < nseg;
-    const bool do_parse = level > 0;
     const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
-    uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + s0;
     uint32_t *myb = rowb + lane * ZA_PROW;
-    uint32_t *myd = rowd + lane * ZA_DROW;
+    const uint32_t lazyf = L.lazy > 3 ? (uint32_t)(L.lazy - 3) : 0u;       // the lazy limit in the entries' length field
 
     uint4 pb[8];                   // piece lane & 7 of the `best` rows of segments 8 j + (lane >> 3)
-    uint4 pd[2];                   // piece lane & 1 of the data rows of segments 32 j + (lane >> 1)
     auto prefetch = [&](int c) {
         const int rel = c * ZA_PCH;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + rel;
             pb[j] = make_uint4(0, 0, 0, 0);
-#ifdef ZA_ABL_NO_NT
-            if (do_parse && c < ZA_SEG / ZA_PCH && sg < nseg && off < n) pb[j] = *(const uint4 *)(best + off + 4 * (lane & 7));   // rows are 128-byte aligned
-#else
-            // (streamed once: a non-temporal load keeps these 4 N bytes from pushing the input lines -- a quarter of a line
-            // per chunk -- out of L2 between two chunks)
-            if (do_parse && c < ZA_SEG / ZA_PCH && sg < nseg && off < n) {
+            // (streamed once: a non-temporal load)
+            if (c < ZA_SEG / ZA_PCH && sg < nseg && off < n) {
                 typedef uint32_t za_v4u __attribute__((ext_vector_type(4)));
                 const za_v4u v = __builtin_nontemporal_load((const za_v4u *)(best + off + 4 * (lane & 7)));   // rows are 128-byte aligned
                 pb[j] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-#endif
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int sg = 32 * j + (lane >> 1), off = (sg << ZA_SEG_SHIFT) + rel + 16 * (lane & 1);
-            pd[j] = make_uint4(0, 0, 0, 0);
-            if (c < ZA_SEG / ZA_PCH && sg < nseg && off < n) {
-                if ((long long)off + 16 <= readable) { const ZaU4u v = *(const ZaU4u *)(data + off); pd[j] = make_uint4(v.x, v.y, v.z, v.w); }
-                else {                                           // the very end of the caller's buffer
-                    uint32_t t[4] = {0, 0, 0, 0};
-                    for (int k = 0; k < 16; k++) if ((long long)(off + k) < readable) t[k >> 2] |= (uint32_t)data[off + k] << (8 * (k & 3));
-                    pd[j] = make_uint4(t[0], t[1], t[2], t[3]);
-                }
             }
         }
     };
@@ -490,12 +478,10 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     uint32_t ntok = 0;
     uint32_t crc_r = 0xFFFFFFFFu;
     int p = s0;
-    uint32_t carry_b = 0, carry_d = 0;
+    uint32_t carry_b = 0;
     // Tokens are collected in the lane's own LDS row -- token j of a chunk takes slot j, which holds an entry the lane has
     // already read (a token consumes at least one position) -- and leave at the end of the chunk TRANSPOSED, like the loads:
-    // eight lanes store the 16-byte pieces of one segment's tokens, so a store instruction touches a few whole lines.  (With
-    // every lane storing its own 16 bytes -- 64 lines per instruction -- the stores were what the token rounds waited for:
-    // 2.37 -> 1.62 ms per GiB with them switched off.)
+    // eight lanes store the 16-byte pieces of one segment's tokens, so a store instruction touches a few whole lines.
     uint32_t nchunk = 0;           // tokens of the current chunk in my row
     prefetch(0);
 #pragma unroll 1
@@ -509,66 +495,55 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
             uint32_t *r = rowb + (8 * j + (lane >> 3)) * ZA_PROW + 1 + 4 * (lane & 7);
             r[0] = pb[j].x; r[1] = pb[j].y; r[2] = pb[j].z; r[3] = pb[j].w;
         }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            uint32_t *r = rowd + (32 * j + (lane >> 1)) * ZA_DROW + 1 + 4 * (lane & 1);
-            r[0] = pd[j].x; r[1] = pd[j].y; r[2] = pd[j].z; r[3] = pd[j].w;
-        }
-        myb[0] = carry_b; myd[0] = carry_d;
+        myb[0] = carry_b;
         __builtin_amdgcn_wave_barrier();
         prefetch(c + 1);
         int ce = cb + ZA_PCH;
         if (ce > s1) ce = s1;
         if (active && cb < s1) {
-            // CRC-32 over this chunk's bytes (zng_crc32_z at zlib_ngmodule.c:1741)
-            const uint8_t *bytes = (const uint8_t *)myd;          // byte of position q at bytes[q - cb + 4]
+            // CRC-32 over this chunk's bytes (zng_crc32_z at zlib_ngmodule.c:1741): the top bytes of four entries make a dword
 #ifndef ZA_ABL_PARSE_NOCRC
             {
                 int k = cb;
-                for (; k + 4 <= ce; k += 4) {                     // one row dword, four table steps
-                    const uint32_t w4 = myd[1 + ((k - cb) >> 2)];
+                for (; k + 4 <= ce; k += 4) {
+                    const uint32_t *e = myb + 1 + (k - cb);
+                    const uint32_t w4 = __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0703u) | __builtin_amdgcn_perm(e[3], e[2], 0x07030c0cu);
                     crc_r = crct[(crc_r ^ w4) & 0xFF] ^ (crc_r >> 8);
                     crc_r = crct[(crc_r ^ (w4 >> 8)) & 0xFF] ^ (crc_r >> 8);
                     crc_r = crct[(crc_r ^ (w4 >> 16)) & 0xFF] ^ (crc_r >> 8);
                     crc_r = crct[(crc_r ^ (w4 >> 24)) & 0xFF] ^ (crc_r >> 8);
                 }
-                for (; k < ce; k++) crc_r = crct[(crc_r ^ bytes[k - cb + 4]) & 0xFF] ^ (crc_r >> 8);
+                for (; k < ce; k++) crc_r = crct[(crc_r ^ (myb[1 + k - cb] >> 24)) & 0xFF] ^ (crc_r >> 8);
             }
 #endif
-#ifdef ZA_ABL_PARSE_NOTOK
-            if (false) {
-#else
-            if (do_parse) {
-#endif
+            {
                 // one token per lane and round, literal and match on one predicated path (no divergent if/else); the chunk's
                 // last position waits for the next chunk (its successor's entry is not here yet) unless the segment ends
                 const int lim = ce == s1 ? ce : ce - 1;
                 auto push = [&](uint32_t t) {
-#ifndef ZA_ABL_PARSE_NOSTORE
                     myb[nchunk] = t;
-#endif
                     nchunk++;
                 };
                 while (p < lim) {
                     const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2], e2 = myb[p - cb + 3];
-                    const uint32_t lits2 = *(const za_u16u *)(bytes + (p - cb + 5));       // the two bytes behind this position's
-                    const int len = (int)(b >> 16), nlen = (int)(bn >> 16);
-                    const bool deferred = L.lazy && len < L.lazy && p + 1 < s1 && nlen > len;
-                    const bool is_match = len >= ZA_MIN_MATCH && !deferred;
-                    const uint32_t lit = bytes[p - cb + 4];
+                    const uint32_t lf = ZA_BLEN(b), nlf = ZA_BLEN(bn);
+                    const bool deferred = lazyf && lf < lazyf && p + 1 < s1 && nlf > lf;
+                    const bool is_match = lf != 0u && !deferred;
+                    const int len = (int)lf + 3;
+                    const uint32_t lit = b >> 24;
                     const int dist = is_match ? (int)(b & 0xFFFFu) : 1;
                     int lc, ln, le, dc, dn, de;
                     za_len_sym(is_match ? len : 3, lc, ln, le);
                     za_dist_sym(dist, dc, dn, de);
                     // a match token carries its symbols (length code << 26, extra << 21, distance code << 16, extra): the
-                    // packer, which is VALU-bound, needs no symbol arithmetic.  A literal at a position without any match (entry
-                    // 0: a literal whatever the lazy rule says) takes up to two more such positions into its token word --
+                    // packer, which is VALU-bound, needs no symbol arithmetic.  A literal at a position without any match (length
+                    // field 0: a literal whatever the lazy rule says) takes up to two more such positions into its token word --
                     // bytes in bits 0..23, count - 1 in bits 24..25 -- as far as this chunk's entries reach: most tokens of
                     // text are literals, 3.8 in a row, and fewer token words are fewer stores here and fewer loads in the packer.
-                    // (Their entries and bytes were read together with this position's: one LDS round trip per round.)
-                    const bool c1 = len == 0 && p + 1 < ce && (bn >> 16) == 0u;
-                    const bool c2 = c1 && p + 2 < ce && (e2 >> 16) == 0u;
-                    const uint32_t l1 = lits2 & 0xFFu, l2 = (lits2 >> 8) & 0xFFu;
+                    // (Their entries were read together with this position's: one LDS round trip per round.)
+                    const bool c1 = lf == 0u && p + 1 < ce && nlf == 0u;
+                    const bool c2 = c1 && p + 2 < ce && ZA_BLEN(e2) == 0u;
+                    const uint32_t l1 = bn >> 24, l2 = e2 >> 24;
                     const uint32_t t = is_match ? (0x80000000u | ((uint32_t)lc << 26) | ((uint32_t)le << 21) | ((uint32_t)dc << 16) | (uint32_t)de)
                                                 : lit | (c1 ? l1 << 8 : 0u) | (c2 ? l2 << 16 : 0u) | (((c1 ? 1u : 0u) + (c2 ? 1u : 0u)) << 24);
                     push(t);
@@ -581,12 +556,11 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
                     p += is_match ? len : 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
                 }
             }
-            carry_b = myb[ZA_PCH]; carry_d = myd[ZA_PCH / 4];
+            carry_b = myb[ZA_PCH];
         }
         // ---- the chunk's tokens leave: lane (8 j + g, piece) stores tokens 4 piece .. 4 piece + 3 of segment 8 j + g
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#if !defined(ZA_ABL_PARSE_NOSTORE) && !defined(ZA_ABL_PARSE_NOGSTORE)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int sg = 8 * j + (lane >> 3);
@@ -604,7 +578,6 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
             }
             if ((lane & 7) == 7 && cnt > 32u) dst[32] = r[32];
         }
-#endif
         ntok += nchunk; nchunk = 0;
         __builtin_amdgcn_wave_barrier();
     }
@@ -626,6 +599,19 @@ __global__ __launch_bounds__(64) void za_k_parse(const uint8_t *__restrict__ in,
     if (lane == 0) hist[256] = 1;
     __syncthreads();
     for (int i = lane; i < ZA_HIST_STRIDE; i += 64) hist_ws[(size_t)blockIdx.x * ZA_HIST_STRIDE + i] = hist[i];
+}
+
+// level 0 (stored blocks): nothing to parse, only the unit's CRC-32
+__global__ __launch_bounds__(64) void za_k_unit_crc(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                    uint32_t *__restrict__ crc_out, const uint32_t *__restrict__ crc_table,
+                                                    const uint32_t *__restrict__ x8k_table)
+{
+    __shared__ uint32_t crct[256];
+    const ZaUnit u = units[blockIdx.x];
+    for (int i = za_lane(); i < 256; i += 64) crct[i] = crc_table[i];
+    __syncthreads();
+    const uint32_t c = za_wave_crc32(in + u.in_off, (int)u.in_len, crct, x8k_table);
+    if (za_lane() == 0) crc_out[blockIdx.x] = c;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(zngamd_member) == sizeof(ZaMember), "member layout");
@@ -75,6 +76,7 @@ struct zngamd_ctx {
     // profiling
     uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // pinned host staging for device-to-host results (grow-only)
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};              // ends of the staged device-to-host pieces
     bool prof = false; std::vector<EvPair> evs; std::vector<hipEvent_t> pool;
     double ms[ZNGAMD_K_COUNT] = {0}; uint64_t launches[ZNGAMD_K_COUNT] = {0};
 };
@@ -178,6 +180,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
     c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto &e : c->ev_copy) if (e) (void)hipEventDestroy(e);
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
     if (c->d_crc_slice4) (void)hipFree(c->d_crc_slice4);
@@ -395,10 +398,13 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
               if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L);
               else hipLaunchKernelGGL(za_k_search<false>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L); }
+            { ProfScope ps(c, ZNGAMD_K_PARSE);
+              hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
+                                 d_unit_crc + c0, c->d_crc_table, c->d_x8k, L); }
+        } else {       // level 0: stored blocks, nothing to search or parse -- only the units' CRC-32
+            ProfScope ps(c, ZNGAMD_K_PARSE);
+            hipLaunchKernelGGL(za_k_unit_crc, dim3(m), dim3(64), 0, c->stream, d_in, du, d_unit_crc + c0, c->d_crc_table, c->d_x8k);
         }
-        { ProfScope ps(c, ZNGAMD_K_PARSE);
-          hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, d_in, in_len, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
-                             d_unit_crc + c0, c->d_crc_table, c->d_x8k, L, level); }
         { ProfScope ps(c, ZNGAMD_K_PLAN);
           hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
                              d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE, (uint32_t)ZNGAMD_SLOT_STRIDE, level); }
@@ -478,26 +484,54 @@ static int host_stage(zngamd_ctx *c, size_t bytes, uint8_t **p)
     return ZNGAMD_OK;
 }
 
-// Decoded payload to the caller's buffer.  Up to ZNGAMD_BOUNCE_MAX bytes go through the pinned staging buffer and one
-// memcpy: an asynchronous copy straight into fresh pageable memory (a Python bytes object made for this call, cut to size
-// and soon freed) makes the driver pin its pages and unpin them when the memory is unmapped right after, measured at 25 ms
-// of fixed cost for a 3 MiB result.  Larger results are copied with the synchronous hipMemcpy, which pipelines through
-// the runtime's own pinned buffers (256 MiB: 22 ms, against 39 ms for the asynchronous copy).
-#define ZNGAMD_BOUNCE_MAX (32ull << 20)
+// Host copies of payload: several threads for large pieces.  A result usually lands in memory the process has never touched
+// (a Python bytes object made for this call): the first touch of a page costs far more than the copy, one thread reaches
+// 12 GB/s there, and the device-to-host DMA itself 56 GB/s (profiles/r03_pcie.txt).
+static void par_memcpy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t piece = 4u << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t t = std::min<size_t>(std::min<size_t>(hw ? hw / 2 : 4, 8), n / piece);
+    if (const char *e = getenv("ZNGAMD_COPY_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) t = std::min<size_t>((size_t)v, std::max<size_t>(n / (1u << 20), 1)); }
+    if (t <= 1) { memcpy(dst, src, n); return; }
+    const size_t step = ((n / t) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    th.reserve(t);
+    for (size_t i = 1; i < t; i++) {
+        const size_t o = i * step;
+        if (o >= n) break;
+        th.emplace_back([=] { memcpy(dst + o, src + o, std::min(step, n - o)); });
+    }
+    memcpy(dst, src, std::min(step, n));
+    for (auto &x : th) x.join();
+}
+
+// Decoded / compressed payload to the caller's buffer, PIPELINED through two halves of the pinned staging buffer: the DMA of
+// piece k + 1 runs while the host threads copy piece k into the caller's (usually fresh) memory.  Copying straight into fresh
+// pageable memory makes the driver pin its pages and unpin them when the object is cut to size afterwards -- 25 ms of fixed
+// cost for a 3 MiB result, and 12 GB/s at best for a large one.
+#define ZNGAMD_D2H_PIECE (32ull << 20)
 static int d2h_payload(zngamd_ctx *c, uint8_t *dst, const uint8_t *src_dev, uint64_t n)
 {
     if (!n) return ZNGAMD_OK;
-    if (n <= ZNGAMD_BOUNCE_MAX) {
-        uint8_t *st = nullptr;
-        int r = host_stage(c, n, &st);
-        if (r) return r;
-        HIPCHK(c, hipMemcpyAsync(st, src_dev, n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        memcpy(dst, st, n);
-        return ZNGAMD_OK;
+    const uint64_t piece = std::min<uint64_t>(ZNGAMD_D2H_PIECE, n);
+    uint8_t *st = nullptr;
+    int r = host_stage(c, n <= piece ? n : 2 * piece, &st);
+    if (r) return r;
+    if (!c->ev_copy[0]) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy[1], hipEventDisableTiming)); }
+    const uint64_t np = (n + piece - 1) / piece;
+    for (uint64_t k = 0; k <= np; k++) {
+        if (k < np) {
+            const uint64_t o = k * piece, ln = std::min(piece, n - o);
+            HIPCHK(c, hipMemcpyAsync(st + (k & 1) * piece, src_dev + o, ln, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_copy[k & 1], c->stream));
+        }
+        if (k > 0) {
+            const uint64_t o = (k - 1) * piece, ln = std::min(piece, n - o);
+            HIPCHK(c, hipEventSynchronize(c->ev_copy[(k - 1) & 1]));
+            par_memcpy(dst + o, st + ((k - 1) & 1) * piece, ln);
+        }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(dst, src_dev, n, hipMemcpyDeviceToHost));        // the synchronous copy pipelines through the runtime's own pinned buffers
     return ZNGAMD_OK;
 }
 
@@ -527,7 +561,8 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
     HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-    if (total) HIPCHK(c, hipMemcpyAsync(direct ? direct_out : stage, c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (total && !direct) HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (total && direct) { const int rc_ = d2h_payload(c, direct_out, c->st_out.p, total); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_OVERFLOW, "unit overflowed its slot");
@@ -605,6 +640,10 @@ try {
     }
     if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
     HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    if (what == 1) {     // the kernels' entry (distance | (length - 3) << 16 | the position's byte << 24) in the documented form len << 16 | dist
+        uint32_t *e = (uint32_t *)dst;
+        for (size_t i = 0; i < bytes / 4; i++) { const uint32_t lf = (e[i] >> 16) & 0xFFu; e[i] = lf ? ((lf + 3u) << 16) | (e[i] & 0xFFFFu) : 0u; }
+    }
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 

@@ -213,6 +213,8 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self._write_thread = None                    # file write of the last bulk batch, still running
         self._coalesce_limit = max(8 * block_size, 32 << 20)     # writes below this are collected up to this many bytes
         self._small, self._small_n = None, 0
+        self._small_other = None                     # the second collecting buffer: one fills while the other is compressed
+        self._batch_thread, self._batch_error = None, None
         self._write_error = None
         self.running = False
         self.raw, self.closefd = open_as_binary_stream(filename, mode)
@@ -258,36 +260,65 @@ class _ThreadedGzipWriter(io.RawIOBase):
             self._small = bytearray(R + self._coalesce_limit)       # [room for the 32 KiB in front][collected bytes]
         n = self._small_n
         if n + nbytes > self._coalesce_limit:
-            self._flush_small()
+            self._flush_small(wait=False)            # the full buffer is compressed and written while the other one fills
             n = 0
         self._small[R + n:R + n + nbytes] = b
         self._small_n = n + nbytes
         return nbytes
 
-    def _flush_small(self):
+    def _flush_small(self, wait=True):
         """The collected bytes as ONE engine batch: the tail of what was written before is put in front of them in the
-        same buffer, so the first block is primed like every other."""
+        same buffer, so the first block is primed like every other.  The batch runs on a thread of its own (the engine call
+        and the file write release the GIL) while the caller goes on filling the second buffer -- the reference's worker
+        threads compress while write() returns (gzip_ng_threaded.py:299-322); wait=True returns when the batch is through."""
         n, self._small_n = self._small_n, 0
-        if not n:
-            return
-        for q in self.input_queues:
-            q.join()
-        with self.lock:
-            if self.exception:
-                raise self.exception
-        R, bs, buf = DEFLATE_WINDOW_SIZE, self.block_size, self._small
-        tail = memoryview(self.previous_block)[-R:]
-        t = tail.nbytes
-        buf[R - t:R] = tail
-        view = memoryview(buf)[R - t:R + n]
-        self._emit(view, [(t + o, min(bs, n - o), min(R, t + o), 0) for o in range(0, n, bs)])
-        self._size += n
-        last = n - ((n - 1) // bs) * bs
-        self.previous_block = bytes(buf[R + n - last:R + n])
+        if n:
+            self._join_batch()                       # batches are strictly in order: CRC folding and the file are sequential
+            for q in self.input_queues:
+                q.join()
+            with self.lock:
+                if self.exception:
+                    raise self.exception
+            R, bs, buf = DEFLATE_WINDOW_SIZE, self.block_size, self._small
+            tail = memoryview(self.previous_block)[-R:]
+            t = tail.nbytes
+            buf[R - t:R] = tail
+            view = memoryview(buf)[R - t:R + n]
+            blocks = [(t + o, min(bs, n - o), min(R, t + o), 0) for o in range(0, n, bs)]
+            self._size += n
+            last = n - ((n - 1) // bs) * bs
+            self.previous_block = bytes(buf[R + n - last:R + n])
+            if wait or sys.is_finalizing():
+                self._emit(view, blocks)
+            else:
+                self._batch_thread = threading.Thread(target=self._emit_guarded, args=(view, blocks), name="zng-amd-writer-batch")
+                self._batch_thread.start()
+                if self._small_other is None:
+                    self._small_other = bytearray(len(buf))
+                self._small, self._small_other = self._small_other, buf
+        if wait:
+            self._join_batch()
+
+    def _emit_guarded(self, view, blocks):
+        try:
+            self._emit(view, blocks)
+        except BaseException as exc:                 # raised by the next call of the owner
+            self._batch_error = exc
+
+    def _join_batch(self):
+        t, self._batch_thread = self._batch_thread, None
+        if t is not None:
+            t.join()
+        if self._batch_error is not None:
+            exc, self._batch_error = self._batch_error, None
+            with self.lock:
+                self.exception = exc
+            raise exc
 
     def _write_bulk(self, view, nbytes):
         """A write of many blocks at once: same cutting and priming as block by block, but the blocks go to the engine as
         slices of one buffer (no per-block objects, no queue round trips).  Queued blocks are finished first."""
+        self._join_batch()
         for q in self.input_queues:
             q.join()
         with self.lock:

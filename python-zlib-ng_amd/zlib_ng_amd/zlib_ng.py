@@ -135,12 +135,14 @@ def compress(data, /, level=Z_DEFAULT_COMPRESSION, wbits=MAX_WBITS):
     mv = _view(data)
     _check_level(level)
     kind, wb = _container(wbits)
-    raw, crc, adler = _ctx().deflate_stream(mv, level, wb)
+    # header and trailer are written into the result object around the engine's bytes (no concatenation: that would copy the
+    # whole payload once more)
     if kind == "raw":
-        return raw
+        return _ctx().deflate_stream(mv, level, wb)[0]
     if kind == "zlib":
-        return _zlib_header(level, wb) + raw + _struct.pack(">I", adler)
-    return _gzip_header(level) + raw + _struct.pack("<II", crc, mv.nbytes & 0xFFFFFFFF)
+        return _ctx().deflate_stream(mv, level, wb, _zlib_header(level, wb), lambda crc, adler: _struct.pack(">I", adler))[0]
+    size = mv.nbytes & 0xFFFFFFFF
+    return _ctx().deflate_stream(mv, level, wb, _gzip_header(level), lambda crc, adler: _struct.pack("<II", crc, size))[0]
 
 
 def _inflate_all(body, zdict=b"", hint=0):
