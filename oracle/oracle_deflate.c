@@ -10,7 +10,7 @@
  * this file byte for byte, stage by stage.
  *
  *   stage 1  hash chains        prevdist[p] = distance to the nearest earlier position whose
- *                               6-byte hash lands in the same 13-bit bucket (u16 head table)
+ *                               6-byte hash lands in the same 13-bit bucket, if within 32 768
  *   stage 2  match search       best[p] = longest match among the first `chain` chain entries,
  *                               nearest wins ties, truncated at the 2 KiB segment end
  *   stage 3  parse              per 2 KiB segment, greedy (levels 1-3) or one-step lazy (4-9)
@@ -60,17 +60,21 @@ static inline uint32_t hash6(const uint8_t *p)
 /* ---------------- stage 1 ---------------- */
 static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *prevdist)
 {
-    static __thread uint16_t head[1 << ZA_HASH_BITS];
-    memset(head, 0, sizeof head);
-    int pmin = ZA_WIN - dict_len;
+    /* head[h] = the nearest earlier position of bucket h, or none.  No 16-bit wrap-around: a bucket's link is the true
+     * nearest earlier position of the bucket if that lies within 32 768 and not in front of the dictionary, else none --
+     * so the links of a position do not depend on whether positions further back than its window were ever seen (what lets
+     * the chain kernel carry its tables from one unit of a stream to the next instead of inserting the dictionary again). */
+    static __thread int32_t head[1 << ZA_HASH_BITS];
+    for (int i = 0; i < (1 << ZA_HASH_BITS); i++) head[i] = -1;
     for (int p = -dict_len; p < n; p++) {
         int i = p + dict_len;
         if (p + ZA_HASH_BYTES > n) { prevdist[i] = 0; continue; }
-        uint32_t P = (uint32_t)(ZA_WIN + p);
+        int32_t P = ZA_WIN + p;
         uint32_t h = hash6(data + p);
-        uint32_t d = (P - head[h]) & 0xFFFFu;
-        prevdist[i] = (uint16_t)((d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin) ? d : 0);
-        head[h] = (uint16_t)(P & 0xFFFFu);
+        int32_t q = head[h];
+        int32_t d = q >= 0 ? P - q : 0;
+        prevdist[i] = (uint16_t)((d >= 1 && d <= ZA_WIN) ? d : 0);
+        head[h] = P;
     }
 }
 

@@ -20,6 +20,9 @@
 
 #define ZA_FLAG_FINAL 1u
 #define ZA_FLAG_FLATHDR 2u      // dynamic header in its flat form (4-bit code lengths at fixed offsets): indexed members
+#define ZA_FLAG_CARRY   4u      // (set by the host) the unit's 32 KiB dictionary is the tail of the unit in front of it in the batch:
+                                // inside a run the chain tables are carried over instead of inserting the dictionary again
+#define ZA_FLAG_RUNHEAD 8u      // (set by the host) first unit of a chain-kernel run: its dictionary IS inserted, its links are all in its own row
 #define ZA_LIMIT_L     10       // longest literal/length code the encoder emits: one 2^10-entry table decodes every symbol
 #define ZA_LIMIT_D     9        // longest distance code
 #define ZA_CHUNK_SHIFT 11       // index granularity of indexed members: one entry per 2 KiB segment

@@ -98,33 +98,31 @@ __device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *
     if (valid) prevdist[(int)P - ZA_WIN + dict_len] = (uint16_t)d;
 }
 
+// The head table holds positions as 16 bits, so it must never hold an entry older than 65 535 positions when it is read
+// (the spec knows no aliasing: a bucket's link is the true nearest earlier position or nothing).  Every wave therefore SWEEPS
+// its table every ZA_CH_SWEEP positions: entries older than the window are set to "old" (an age that no lookup accepts and
+// that stays below 65 536 until the next sweep).  The same pass rebases the table when a run moves on to its next unit.
+#define ZA_CH_SWEEP 24576u      // positions between two sweeps
+#define ZA_CH_OLD   36864u      // the age an old entry is given at a sweep: 36864 + 24576 + the insert lag of a tile < 65536
+#define ZA_CH_KEEP  (ZA_WIN + 512u)   // entries up to this age are kept (the inserts lag at most a tile and a group behind a sweep)
+
+// One workgroup per RUN of consecutive units (run_start[r] .. run_start[r + 1]).  Inside a run a unit marked ZA_FLAG_CARRY --
+// its 32 KiB dictionary is the tail of the unit in front of it -- does not insert that dictionary again: the tables are
+// carried over (a quarter of a unit's positions, the same quarter deflateSetDictionary costs the reference's threads for
+// every block).  The links are the same either way: a bucket's link names the nearest earlier position of the bucket, and
+// whether positions in front of the dictionary are known or not changes nothing -- they are out of reach.
 __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                                const uint32_t *__restrict__ run_start,
                                                                 uint16_t *__restrict__ prev_ws)
 {
     __shared__ uint16_t head_all[ZA_CH_WAVES][1 << ZA_CH_SUB];
     __shared__ uint32_t ring_all[ZA_CH_WAVES][ZA_CH_STAGE];
     __shared__ unsigned long long gmask_all[ZA_CH_WAVES][64];   // scratch of the dense insert
     __shared__ uint32_t cnt[2][ZA_CH_WAVES][ZA_CH_WAVES];    // [tile parity][producer wave][class] entries of a tile
-    const ZaUnit u = units[blockIdx.x];
-    const uint8_t *data = in + u.in_off;
-    const int n = (int)u.in_len, dict_len = (int)u.dict_len;
-    uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;
     const int lane = za_lane();
     const uint32_t wave = threadIdx.x >> 6;
     uint16_t *head = head_all[wave];
-    for (int i = lane; i < (1 << ZA_CH_SUB) / 2; i += 64) ((uint32_t *)head)[i] = 0;
-    const int total = dict_len + n;
-    const int pmin = ZA_WIN - dict_len;
-    const bool can_load = total >= ZA_HASH_BYTES;          // uniform: the unit + dictionary hold at least one 6-byte context
-    const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available (may be < -dict_len)
-    // A tile is 256 positions: wave w hashes positions [64 w, 64 w + 64) of it -- every position is hashed once.
-    // loads are unconditional from a clamped position (no branch per tile); `valid` masks them later
-    auto load_tile = [&](int tbase) -> uint2 {
-        int p = tbase + 64 * (int)wave + lane - dict_len;
-        p = p > pclamp_hi ? pclamp_hi : p;
-        p = p < -dict_len ? -dict_len : p;
-        return can_load ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
-    };
+    uint32_t *head32 = (uint32_t *)head;
     // Two barriers per tile: class counts visible -> every wave places its entries -> rings complete -> consume.
     uint32_t wrv = 0;          // lane c < 4: entries ever put into class c's ring (every wave keeps the same copy)
     uint32_t wslot = 0;        // lane c < 4: wrv mod ZA_CH_STAGE
@@ -132,77 +130,138 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
     uint32_t gen = 0;             // generation tag of the dense insert's exchange words (gmask starts zeroed)
     gmask_all[wave][lane] = 0ull;
     uint32_t par = 0;
-    auto consume = [&](uint32_t upto, bool flush) {
-        while (upto - rd >= 64u) {
-            za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, 64, pmin, prevdist, dict_len, gen);
-            rd += 64u; rslot += 64u; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+    uint32_t psweep = 0;          // position of the last sweep (in the current unit's numbering)
+    // every entry of my table: back by `rebase` positions (a new unit counts from its own start), then "old" if out of reach of `pr`
+    auto sweep = [&](uint32_t pr, uint32_t rebase, bool fresh) {
+        const uint32_t old = (pr - ZA_CH_OLD) & 0xFFFFu;
+        asm volatile("" ::: "memory");                           // (the table is read as u16 elsewhere: no reordering across the sweep)
+        for (int i = lane; i < (1 << ZA_CH_SUB) / 2; i += 64) {
+            uint32_t w = head32[i];
+            uint32_t lo = (w - rebase) & 0xFFFFu, hi = ((w >> 16) - rebase) & 0xFFFFu;
+            if (fresh || ((pr - lo) & 0xFFFFu) > ZA_CH_KEEP) lo = old;
+            if (fresh || ((pr - hi) & 0xFFFFu) > ZA_CH_KEEP) hi = old;
+            head32[i] = lo | (hi << 16);
         }
-        if (flush && upto != rd) za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len, gen);
+        asm volatile("" ::: "memory");
+        psweep = pr;
     };
-    auto do_tile = [&](int tbase, const uint2 v) {
-        // ---- classify: class = top two hash bits; rank = my place among this wave's entries of my class
-        const int i = tbase + 64 * (int)wave + lane, p = i - dict_len;
-        const bool valid = (i < total) && (p + ZA_HASH_BYTES <= n);
-        const uint32_t h = za_hash6(v.x, v.y);
-        const uint32_t cls = h >> ZA_CH_SUB;
-        const unsigned long long V = __ballot(valid);
-        const unsigned long long B0 = __ballot((cls & 1u) != 0u), B1 = __ballot((cls & 2u) != 0u);
-        const unsigned long long m0 = V & ~B0 & ~B1, m1 = V & B0 & ~B1, m2 = V & ~B0 & B1, m3 = V & B0 & B1;
-        // my place among this wave's entries of my class: the four class masks are wave-uniform (scalar registers), so
-        // four mbcnt pairs and a select are cheaper than building my class's mask per lane
-        auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-        const uint32_t r0 = below(m0), r1 = below(m1), r2 = below(m2), r3 = below(m3);
-        const uint32_t rank = (cls & 2u) ? ((cls & 1u) ? r3 : r2) : ((cls & 1u) ? r1 : r0);
-        if (lane < ZA_CH_WAVES) {
-            const uint32_t c01 = lane == 0 ? (uint32_t)__builtin_popcountll(m0) : (uint32_t)__builtin_popcountll(m1);
-            const uint32_t c23 = lane == 2 ? (uint32_t)__builtin_popcountll(m2) : (uint32_t)__builtin_popcountll(m3);
-            cnt[par][wave][lane] = lane < 2 ? c01 : c23;
-        }
-        __syncthreads();
-        // ---- lane c < 4 adds up class c over the producer waves: where my wave's entries start, and the new cursor
-        uint32_t base = 0;
-        if (lane < ZA_CH_WAVES) {
-            uint32_t before = 0, all = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < ZA_CH_WAVES; w++) {
-                const uint32_t c = cnt[par][w][lane];
-                before += w < wave ? c : 0u;
-                all += c;
+    const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
+    uint32_t n_prev = 0;
+#pragma unroll 1
+    for (uint32_t ui = u0; ui < u1; ui++) {
+        const ZaUnit u = units[ui];
+        const uint8_t *data = in + u.in_off;
+        const int n = (int)u.in_len, dict_len = (int)u.dict_len;
+        uint16_t *prevdist = prev_ws + (size_t)ui * ZA_PREV_STRIDE;
+#ifdef ZA_ABL_NO_CARRY
+        const bool carry = false;
+#else
+        const bool carry = ui > u0 && (u.flags & ZA_FLAG_CARRY) != 0u;
+#endif
+        const int total = dict_len + n;
+        const int pmin = ZA_WIN - dict_len;
+        // a carried unit starts with the last five positions of the unit in front of it: they had fewer than six bytes left
+        // there and have them now (their links go to this unit's own row: that unit's links say "never inserted", which is
+        // what a search of THAT unit must see)
+        const int first = carry ? dict_len - (ZA_HASH_BYTES - 1) : 0;
+        __syncthreads();                                       // (every wave is through with the unit in front)
+        if (carry) sweep((uint32_t)ZA_WIN, n_prev, false);
+        else sweep((uint32_t)pmin, 0u, true);
+        n_prev = (uint32_t)n;
+        const bool can_load = total >= ZA_HASH_BYTES;          // uniform: the unit + dictionary hold at least one 6-byte context
+        const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available (may be < -dict_len)
+        // A tile is 256 positions: wave w hashes positions [64 w, 64 w + 64) of it -- every position is hashed once.
+        // loads are unconditional from a clamped position (no branch per tile); `valid` masks them later
+        auto load_tile = [&](int tbase) -> uint2 {
+            int p = tbase + 64 * (int)wave + lane - dict_len;
+            p = p > pclamp_hi ? pclamp_hi : p;
+            p = p < -dict_len ? -dict_len : p;
+            return can_load ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
+        };
+        auto consume = [&](uint32_t upto, bool flush) {
+            while (upto - rd >= 64u) {
+                za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, 64, pmin, prevdist, dict_len, gen);
+                rd += 64u; rslot += 64u; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
             }
-            base = wslot + before;                         // < 320 + 256
-            wrv += all;
-            wslot += all; wslot -= wslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
-        }
-        par ^= 1u;
-        uint32_t myslot = (uint32_t)__shfl((int)base, (int)cls, 64) + rank;   // < 320 + 192 + 64 (at most three waves in front of mine)
-        myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;                   // one wrap is enough: < 2 * ZA_CH_STAGE
-        if (valid)
-            ring_all[cls][myslot] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+            if (flush && upto != rd) {
+                za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len, gen);
+                rslot += upto - rd; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+                rd = upto;
+            }
+        };
+        auto do_tile = [&](int tbase, const uint2 v) {
+            // ---- the table is swept on time (all four waves at the same tile, each its own table); what is still pending of my
+            // class goes in first -- an entry may wait long for its group of 64 to fill, and it must see the table as it was
+            const uint32_t ptile = (uint32_t)(ZA_WIN + tbase - dict_len);
+            if ((int)(ptile - psweep) >= (int)ZA_CH_SWEEP) {
+                consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), true);
+                sweep(ptile, 0u, false);
+            }
+            // ---- classify: class = top two hash bits; rank = my place among this wave's entries of my class
+            const int i = tbase + 64 * (int)wave + lane, p = i - dict_len;
+            const bool valid = (i >= first) && (i < total) && (p + ZA_HASH_BYTES <= n);
+            const uint32_t h = za_hash6(v.x, v.y);
+            const uint32_t cls = h >> ZA_CH_SUB;
+            const unsigned long long V = __ballot(valid);
+            const unsigned long long B0 = __ballot((cls & 1u) != 0u), B1 = __ballot((cls & 2u) != 0u);
+            const unsigned long long m0 = V & ~B0 & ~B1, m1 = V & B0 & ~B1, m2 = V & ~B0 & B1, m3 = V & B0 & B1;
+            // my place among this wave's entries of my class: the four class masks are wave-uniform (scalar registers), so
+            // four mbcnt pairs and a select are cheaper than building my class's mask per lane
+            auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+            const uint32_t r0 = below(m0), r1 = below(m1), r2 = below(m2), r3 = below(m3);
+            const uint32_t rank = (cls & 2u) ? ((cls & 1u) ? r3 : r2) : ((cls & 1u) ? r1 : r0);
+            if (lane < ZA_CH_WAVES) {
+                const uint32_t c01 = lane == 0 ? (uint32_t)__builtin_popcountll(m0) : (uint32_t)__builtin_popcountll(m1);
+                const uint32_t c23 = lane == 2 ? (uint32_t)__builtin_popcountll(m2) : (uint32_t)__builtin_popcountll(m3);
+                cnt[par][wave][lane] = lane < 2 ? c01 : c23;
+            }
+            __syncthreads();
+            // ---- lane c < 4 adds up class c over the producer waves: where my wave's entries start, and the new cursor
+            uint32_t base = 0;
+            if (lane < ZA_CH_WAVES) {
+                uint32_t before = 0, all = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < ZA_CH_WAVES; w++) {
+                    const uint32_t c = cnt[par][w][lane];
+                    before += w < wave ? c : 0u;
+                    all += c;
+                }
+                base = wslot + before;                         // < 320 + 256
+                wrv += all;
+                wslot += all; wslot -= wslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+            }
+            par ^= 1u;
+            uint32_t myslot = (uint32_t)__shfl((int)base, (int)cls, 64) + rank;   // < 320 + 192 + 64 (at most three waves in front of mine)
+            myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;                   // one wrap is enough: < 2 * ZA_CH_STAGE
+            if (valid)
+                ring_all[cls][myslot] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
+            __syncthreads();
+            // ---- consume my class in dense groups of 64, in position order
+            consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), false);
+        };
+        // four tiles of loads stay in flight ahead of the one being classified
+        const int t0 = carry ? dict_len - 256 : 0;               // (a carried unit: one tile in front of the unit for its five late positions)
+        uint2 va = load_tile(t0), vb = load_tile(t0 + 256), vc = load_tile(t0 + 512), vd = load_tile(t0 + 768);
         __syncthreads();
-        // ---- consume my class in dense groups of 64, in position order
-        consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), false);
-    };
-    // four tiles of loads stay in flight ahead of the one being classified
-    uint2 va = load_tile(0), vb = load_tile(256), vc = load_tile(512), vd = load_tile(768);
-    __syncthreads();
-    for (int tbase = 0; tbase < total; tbase += 1024) {
-        do_tile(tbase, va);
-        if (tbase + 256 >= total) break;
-        va = load_tile(tbase + 1024);
-        do_tile(tbase + 256, vb);
-        if (tbase + 512 >= total) break;
-        vb = load_tile(tbase + 1280);
-        do_tile(tbase + 512, vc);
-        if (tbase + 768 >= total) break;
-        vc = load_tile(tbase + 1536);
-        do_tile(tbase + 768, vd);
-        vd = load_tile(tbase + 1792);
-    }
-    consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), true);
-    // positions with fewer than 6 bytes left are never inserted: their link is 0
-    if (wave == 0 && lane < ZA_HASH_BYTES - 1) {
-        const int p = n - 1 - lane;
-        if (p >= -dict_len) prevdist[p + dict_len] = 0;
+        for (int tbase = t0; tbase < total; tbase += 1024) {
+            do_tile(tbase, va);
+            if (tbase + 256 >= total) break;
+            va = load_tile(tbase + 1024);
+            do_tile(tbase + 256, vb);
+            if (tbase + 512 >= total) break;
+            vb = load_tile(tbase + 1280);
+            do_tile(tbase + 512, vc);
+            if (tbase + 768 >= total) break;
+            vc = load_tile(tbase + 1536);
+            do_tile(tbase + 768, vd);
+            vd = load_tile(tbase + 1792);
+        }
+        consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), true);
+        // positions with fewer than 6 bytes left are never inserted: their link is 0
+        if (wave == 0 && lane < ZA_HASH_BYTES - 1) {
+            const int p = n - 1 - lane;
+            if (p >= -dict_len && (!carry || p >= -(ZA_HASH_BYTES - 1))) prevdist[p + dict_len] = 0;
+        }
     }
 }
 
@@ -247,6 +306,16 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
     const uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;     // index p + dict_len
+    // A carried unit (ZA_FLAG_CARRY, set where the chain kernel did carry its tables: not at the head of a run) has no links
+    // of its dictionary in its own row: they are the links of the last 32 KiB of the unit in front of it, in THAT unit's row
+    // -- except the last five positions, which that unit never inserted and this one did (its own row).
+    const bool carried = (u.flags & ZA_FLAG_CARRY) != 0u && (u.flags & ZA_FLAG_RUNHEAD) == 0u && blockIdx.x > 0;
+    const uint16_t *dictlinks = prevdist;                                          // index p + dict_len, p < 0
+    if (carried) {
+        const ZaUnit up = units[blockIdx.x - 1];
+        dictlinks = prev_ws + (size_t)(blockIdx.x - 1) * ZA_PREV_STRIDE + up.dict_len + up.in_len - dict_len;
+    }
+    auto link_at = [&](int p) -> uint16_t { return (p >= -(ZA_HASH_BYTES - 1) ? prevdist : dictlinks)[p + dict_len]; };
     uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     const int tid = (int)threadIdx.x;
     // bytes that may be read starting at data[0] without leaving the caller's buffer
@@ -270,7 +339,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     {
         int need_links = ZA_SEARCH_TILE < n ? ZA_SEARCH_TILE : n;
         for (int p = links_loaded + tid; p < need_links; p += ZA_SEARCH_THREADS)
-            ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = prevdist[p + dict_len];
+            ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = link_at(p);
         links_loaded = need_links;
         int need_bytes = ZA_SEARCH_TILE + ZA_LOOKAHEAD;
         if (need_bytes > n) need_bytes = n;

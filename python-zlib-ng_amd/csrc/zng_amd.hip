@@ -66,8 +66,11 @@ struct zngamd_ctx {
     uint32_t chunk_units = 32768;                // units per launch: 1.4 MiB of workspace each (46 GB at 4 GiB of input); fewer, fuller launches
     DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     // per call
-    DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status;
+    DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status, runs;
     uint32_t last_units = 0; bool last_single_chunk = false;
+    std::vector<ZaUnit> last_hu;                 // the units of the last deflate call as the kernels saw them (zngamd_debug_fetch)
+    uint32_t chain_slots = 1536;                 // chain-kernel workgroups the device holds at once: CUs x 6
+    uint32_t chain_run = 0;                      // ZNGAMD_CHAIN_RUN: fixed run length of the chain kernel (0 = sized to the device)
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
     DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
@@ -132,6 +135,8 @@ try {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZNGAMD_E_HIP; }
     c->stream = c->own_stream;
     if (const char *e = getenv("ZNGAMD_CHUNK_UNITS")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chunk_units = (uint32_t)v; }
+    if (const char *e = getenv("ZNGAMD_CHAIN_RUN")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chain_run = (uint32_t)v; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->chain_slots = (uint32_t)cus * 6u; }
     // tables: CRC-32 byte table and x^(8*2048*k) mod P
     uint32_t tab[256], x8k[64];
     for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); tab[i] = v; }
@@ -178,7 +183,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->plan.release(); c->units.release(); c->segbits.release(); c->cidx.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
-    c->st_off.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
+    c->st_off.release(); c->runs.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto &e : c->ev_copy) if (e) (void)hipEventDestroy(e);
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
@@ -362,6 +367,11 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
             u.dict_len = (uint32_t)std::min<uint64_t>(ZA_WIN, (uint64_t)B.dict_len + rel);
             u.flags = (B.flags & ZNGAMD_FLAG_FLATHDR) | ((k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u);
             u.block = b;
+            // the unit's whole 32 KiB dictionary is the tail of the unit in front of it: the chain tables may be carried over
+            if (!hu.empty()) {
+                const ZaUnit &pv = hu.back();
+                if (u.dict_len == ZA_WIN && pv.in_len >= ZA_WIN && pv.in_off + pv.in_len == u.in_off) u.flags |= ZA_FLAG_CARRY;
+            }
             hu.push_back(u);
         }
     }
@@ -385,16 +395,45 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     }
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
     HIPCHK(c, c->codes.ensure((size_t)ch * ZA_CODE_STRIDE)); HIPCHK(c, c->plan.ensure(ch));
-    HIPCHK(c, hipMemcpyAsync(c->units.p, hu.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
+    // Runs of the chain kernel: one workgroup walks a run of consecutive units and carries its tables from unit to unit where
+    // the next unit's dictionary is the tail of the one before (ZA_FLAG_CARRY); a run costs its first unit's dictionary
+    // again, so longer runs save more (a quarter of the positions at most) -- but workgroups are handed out in order, and a
+    // launch ends with its last workgroup: runs of L units for the first four fifths of a launch, short ones behind them to
+    // fill the tail, and L bounded by what keeps every slot of the device busy at least twice.  Runs never cross a launch.
+    std::vector<ZaUnit> hv(hu);
+    std::vector<uint32_t> run_start;
+    for (uint32_t c0 = 0; c0 < n; c0 += ch) {
+        const uint32_t m = std::min(ch, n - c0);
+        const uint32_t L = c->chain_run ? c->chain_run : std::min<uint32_t>(8u, std::max<uint32_t>(1u, m / (2u * c->chain_slots)));
+        const uint32_t Ls = c->chain_run ? c->chain_run : std::max<uint32_t>(1u, L / 4u);
+        const uint32_t big_end = c->chain_run ? m : (uint32_t)((uint64_t)m * 4 / 5 / L * L);
+        uint32_t next_cut = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            ZaUnit &u = hv[c0 + i];
+            const bool cut = i == next_cut || !(u.flags & ZA_FLAG_CARRY);
+            if (cut) { u.flags |= ZA_FLAG_RUNHEAD; run_start.push_back(i); next_cut = i + (i < big_end ? L : Ls); }
+        }
+        run_start.push_back(m);                                  // (the runs of one launch: starts relative to the launch, then its end)
+    }
+    HIPCHK(c, c->runs.ensure(run_start.size()));
+    HIPCHK(c, hipMemcpyAsync(c->runs.p, run_start.data(), run_start.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->units.p, hv.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // (hv and run_start are locals)
+    c->last_hu = hv;
     // (no memset of the slots: the pack kernel zeroes the few words it merges with atomic OR and writes the rest whole)
     ZaLevel L = ZA_LEVELS[level];
     L.max_dist = (max_dist < 1 || max_dist > ZA_WIN) ? ZA_WIN : max_dist;
+    size_t run_pos = 0;
     for (uint32_t c0 = 0; c0 < n; c0 += ch) {
         const uint32_t m = std::min(ch, n - c0);
         const ZaUnit *du = c->units.p + c0;
+        uint32_t nruns = 0;
+        while (run_start[run_pos + nruns] != m) nruns++;
+        const uint32_t *d_runs = c->runs.p + run_pos;
+        run_pos += nruns + 1;
         if (level > 0) {
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
-              hipLaunchKernelGGL(za_k_chains, dim3(m), dim3(64 * ZA_CH_WAVES), 0, c->stream, d_in, du, c->prev.p); }
+              hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(64 * ZA_CH_WAVES), 0, c->stream, d_in, du, d_runs, c->prev.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
               if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L);
               else hipLaunchKernelGGL(za_k_search<false>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L); }
@@ -640,6 +679,16 @@ try {
     }
     if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
     HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    if (what == 0 && unit < c->last_hu.size() && (c->last_hu[unit].flags & ZA_FLAG_CARRY) && !(c->last_hu[unit].flags & ZA_FLAG_RUNHEAD) && unit > 0) {
+        // a unit whose chain tables were carried over: the links of its dictionary are the links of the last 32 KiB of the unit in
+        // front of it (that unit's row) -- all but the last five, which this unit inserted itself; links that reach in front of
+        // the dictionary are "no link" for this unit
+        const ZaUnit &u = c->last_hu[unit], &pv = c->last_hu[unit - 1];
+        const size_t nd = std::min<size_t>(bytes / 2, u.dict_len - (ZA_HASH_BYTES - 1));
+        uint16_t *d16 = (uint16_t *)dst;
+        HIPCHK(c, hipMemcpy(d16, c->prev.p + (size_t)(unit - 1) * ZA_PREV_STRIDE + pv.dict_len + pv.in_len - u.dict_len, nd * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nd; i++) if (d16[i] > i) d16[i] = 0;
+    }
     if (what == 1) {     // the kernels' entry (distance | (length - 3) << 16 | the position's byte << 24) in the documented form len << 16 | dist
         uint32_t *e = (uint32_t *)dst;
         for (size_t i = 0; i < bytes / 4; i++) { const uint32_t lf = (e[i] >> 16) & 0xFFu; e[i] = lf ? ((lf + 3u) << 16) | (e[i] & 0xFFFFu) : 0u; }

@@ -127,3 +127,53 @@ def test_caller_stream_and_sync(ctx):
     assert ctx.crc32(b"penguin") == zlib.crc32(b"penguin")
     assert ctx.L.zngamd_sync(ctx.h) == 0
     assert ctx.L.zngamd_level_ok(6) == 1 and ctx.L.zngamd_level_ok(10) == 0 and ctx.L.zngamd_level_ok(-1) == 1
+
+
+def test_chain_tables_carried_across_units_equal_the_oracle(monkeypatch):
+    """The chain kernel walks RUNS of consecutive units and carries its tables over instead of inserting each unit's 32 KiB
+    dictionary again (ZNGAMD_CHAIN_RUN forces short runs; large batches get them by themselves).  The bytes must not depend
+    on where runs are cut: every unit against the oracle, which knows no runs -- mixed block sizes (units of 128 KiB and
+    shorter, blocks of several units), a block without dictionary in the middle (a run must break there), a short block whose
+    successor's dictionary spans two units (no carry), levels 1 / 6 / 9; and the chain links of carried units stage by stage."""
+    from oracle import oracle as O
+    from zlib_ng_amd import _lib, corpus
+    B = 131072
+    data = corpus.text(30 * B, seed=21).tobytes()
+    sizes = [B, B, B, 3 * B, 100000, B, 20000, B, B, 2 * B + 777, B, B, 50000, B]
+    for run in ("3", "5", "1", "64"):
+        monkeypatch.setenv("ZNGAMD_CHAIN_RUN", run)
+        ctx = _lib.Context(device=0)
+        L, h = ctx.L, ctx.h
+        blocks_py, off = [], 0
+        for i, sz in enumerate(sizes):
+            dl = 0 if i in (0, 6) else min(32768, off)          # block 6 starts afresh: no dictionary
+            blocks_py.append((off, sz, dl))
+            off += sz
+        total = off
+        d_in = Dev(ctx, total + 64); d_in.put(data[:total] + bytes(64))
+        nb = len(blocks_py)
+        blocks = (_lib.Block * nb)(*[_lib.Block(o, s, d, 0, 0) for o, s, d in blocks_py])
+        nu = L.zngamd_count_units(blocks, nb)
+        for level in (1, 6, 9):
+            d_slots, d_len, d_crc = Dev(ctx, nu * _lib.SLOT_STRIDE), Dev(ctx, nu * 4), Dev(ctx, nu * 4)
+            ublock = (C.c_uint32 * nu)()
+            assert L.zngamd_deflate_blocks_dev(h, d_in.p, total, blocks, nb, level, d_slots.p, d_len.p, d_crc.p, ublock) == 0, ctx.err()
+            lens, crcs = d_len.get(dtype=np.uint32), d_crc.get(dtype=np.uint32)
+            slots = d_slots.get()
+            u = 0
+            for bi, (o, s, d) in enumerate(blocks_py):
+                for k in range((s + B - 1) // B):
+                    lo, hi = o + k * B, min(o + (k + 1) * B, o + s)
+                    dl = min(32768, d + k * B)
+                    ref, rcrc, dbg = O.deflate_unit(data[lo:hi], data[lo - dl:lo], level=level, debug=True)
+                    got = slots[u * _lib.SLOT_STRIDE:u * _lib.SLOT_STRIDE + int(lens[u])].tobytes()
+                    assert got == ref and int(crcs[u]) == rcrc, (run, level, bi, k)
+                    if level == 6:                             # the links themselves, dictionary part included
+                        links = np.frombuffer(ctx.debug_fetch(0, u, 2 * (dl + hi - lo)), dtype=np.uint16)
+                        assert np.array_equal(links, dbg["prevdist"]), (run, bi, k, int(np.argmax(links != dbg["prevdist"])))
+                    u += 1
+            assert u == nu
+            for dv in (d_slots, d_len, d_crc):
+                dv.free()
+        d_in.free()
+        del ctx
