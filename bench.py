@@ -407,32 +407,61 @@ def main():
     steps = args.steps
     deflate_ms = sum(kt[k][0] for k in ("chains", "search", "parse", "plan", "pack", "gather")) / steps
     inflate_ms = (kt["scan"][0] + kt["inflate"][0]) / steps
+    # The roofline of the step's dominant LEG: deflate = the kernels chains + search + parse + plan + pack + gather
+    # together move N_in + C_out algorithmic bytes per unit -- no single one of them can be credited with those bytes -- so the
+    # leg is priced as one: algorithmic bytes of one launch set (the whole shard) / the sum of its kernels' average launch times.
+    # (`roofline_dominant_kernel` prices the longest single kernel with the bytes its own role makes it move.)
+    legs = {"deflate": deflate_ms, "inflate": inflate_ms}
+    dom_leg = max(legs, key=legs.get)
     dom = max(("chains", "search", "parse", "plan", "pack", "inflate"), key=lambda k: kt[k][0])
     launches = max(1, kt[dom][1])
     avg_ms = kt[dom][0] / launches
-    # algorithmic bytes per launch of the dominant kernel: deflate N_in + C_out, inflate C_in + N_out
-    per_step_bytes = size + (ms_len.value if dom == "inflate" else comp_bytes)
     launches_per_step = launches / steps
-    alg_bytes = per_step_bytes / launches_per_step
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
+    if dom_leg == "deflate":
+        leg_kernels = ("chains", "search", "parse", "plan", "pack", "gather")
+        leg_bytes = size + comp_bytes
+        leg_name = "deflate pipeline: za_k_chains + za_k_search + za_k_parse + za_k_plan + za_k_pack + za_k_gather"
+    else:
+        leg_kernels = ("scan", "inflate")
+        leg_bytes = size + ms_len.value
+        leg_name = "inflate: za_k_scan_members + za_k_inflate_members"
+    leg_ms = sum(kt[k][0] for k in leg_kernels) / steps
+    leg_sets = max(1.0, max(kt[k][1] for k in leg_kernels) / steps)          # launch sets per step (1: every kernel takes the whole shard)
+    achieved = leg_bytes / (leg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": leg_name,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes)}
+                "avg_launch_ms": round(leg_ms / leg_sets, 4), "alg_bytes_per_launch": int(leg_bytes / leg_sets),
+                "units_per_launch": int(nblocks / leg_sets)}
+    # bytes the dominant kernel's own role makes it move per input byte N (by design, not measured): chains read N + dictionary,
+    # write 2 B links; search reads links and input, writes 4 B entries; parse reads the entries, writes tokens; ...
+    own = {"chains": 1.0 + 2.0, "search": 2.0 + 1.0 + 4.0, "parse": 4.0 + 0.8, "pack": 1.6 + comp_bytes / size, "plan": 0.02,
+           "inflate": (ms_len.value + size) / size}
+    dom_bytes = own[dom] * size / launches_per_step
+    roofline_dom = {"bound": "hbm", "kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
+                    "avg_launch_ms": round(avg_ms, 4), "own_bytes_per_launch": int(dom_bytes),
+                    "achieved": round(dom_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dom_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": "bytes this kernel's own role makes it read and write (links, entries, tokens included), by design"}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic_step, traffic_src, pmc_per_unit = {}, None, {}
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))                      # HBM bytes per unit from the PMC passes (profiles/run_pmc.sh)
             pmc_per_unit = pj
-            traffic_src = "PMC passes of build '%s' (profiles/pmc_traffic.json)" % pj.get("build", "?")
+            traffic_src = "PMC passes of build '%s' taken at %s units per launch (profiles/pmc_traffic.json), scaled to %d units" % (
+                pj.get("build", "?"), pj.get("units_per_launch", "?"), nblocks)
             for k in ("chains", "search", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
                 if pj.get("za_k_" + k):
                     traffic_step[k] = int(pj["za_k_" + k] * nblocks)
-            per_unit = pj.get(roofline["kernel"])
-            if per_unit:
-                roofline["traffic"] = int(per_unit * nblocks / launches_per_step)
+            names = {"scan": "scan_members", "inflate": "inflate_members"}
+            tr = [traffic_step.get(names.get(k, k)) for k in leg_kernels]
+            if all(t is not None for t in tr if True) and any(tr):
+                roofline["traffic"] = int(sum(t or 0 for t in tr) / leg_sets)
                 roofline["traffic_source"] = traffic_src
+            per_unit = pj.get(roofline_dom["kernel"])
+            if per_unit:
+                roofline_dom["traffic"] = int(per_unit * nblocks / launches_per_step)
         except Exception:
             pass
 
@@ -453,6 +482,7 @@ def main():
         "ratio": round(size / comp_bytes, 4),
         "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kt.items() if v[1]},
         "roofline": roofline,
+        "roofline_dominant_kernel": roofline_dom,
         "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains+search+parse+plan+pack+gather",
                                       "achieved": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},

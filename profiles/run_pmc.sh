@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC collection (separate passes; --pmc is never combined with trace domains other than kernel-trace).
-# usage: [PASSES="sq sq2 fetch write rdreq"] profiles/run_pmc.sh <tag> [bench args]
+# usage: [PASSES="sq sq2 fetch write rdreq"] [SIZE_MIB=4096] profiles/run_pmc.sh <tag> [bench args]
 # rdreq: the L2's memory-side read requests by size (TCC_EA0_RDREQ_32B / _64B / _128B): bytes = 32 a + 64 b + 128 c, the
 # calibration of FETCH_SIZE for this code's own access patterns (FETCH_SIZE tallies gfx950's 128-byte requests at 64).
 set -e
@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/pmc_$TAG
 PASSES=${PASSES:-"sq sq2 fetch write rdreq"}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--size-mib 1024 --steps 1 --warmup 1 --no-cpu-baseline $@"
+ARGS="--size-mib ${SIZE_MIB:-4096} --steps 1 --warmup 1 --no-cpu-baseline --no-api $@"      # the shape the driver times: 32 768 units per launch
 for P in $PASSES; do
   case $P in
     sq)    C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" ;;
