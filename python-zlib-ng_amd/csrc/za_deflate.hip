@@ -963,35 +963,9 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
 // ------------------------------------------------------------------------------------------------
 // k_pack
 // ------------------------------------------------------------------------------------------------
-// Per-lane bit packer.  The first word a lane touches (it may share it with the previous lane or
-// with the header) and its trailing partial word are merged with atomic OR; words in between are
-// owned by the lane alone and stored directly.
-#define ZA_TCH 32      // tokens staged per lane and chunk in k_pack
-
-// Per-lane LSB-first bit writer.  The first word a lane touches and its trailing partial word may be shared with a
-// neighbour (or with the header): they are merged with atomic OR into words that hold zero (the pack kernel zeroes exactly
-// those words itself).  The words in between are the lane's alone and stored directly.  (Collecting four words for one
-// 16-byte store was measured: 5.8 -> 6.9 ms per 4 GiB -- the kernel is bound by its instruction count, not by its stores.)
-struct ZaLaneW {
-    uint32_t *out; uint32_t cap_words; uint32_t w; uint64_t acc; int nb; bool first; bool ovf;
-    __device__ void init(uint32_t *o, uint32_t cap, uint32_t bitpos)
-    {
-        out = o; cap_words = cap; w = bitpos >> 5; nb = (int)(bitpos & 31u); acc = 0; first = true; ovf = false;
-    }
-    __device__ void put(uint32_t v, int n)
-    {
-        acc |= (uint64_t)v << nb; nb += n;
-        if (nb >= 32) {
-            if (w < cap_words) { if (first) atomicOr(&out[w], (uint32_t)acc); else out[w] = (uint32_t)acc; }
-            else ovf = true;
-            first = false; w++; acc >>= 32; nb -= 32;
-        }
-    }
-    __device__ void finish()
-    {
-        if (nb > 0 && (uint32_t)acc != 0u) { if (w < cap_words) atomicOr(&out[w], (uint32_t)acc); else ovf = true; }
-    }
-};
+// One wave per unit.  Stored blocks are copied; fixed and dynamic blocks are packed token-parallel (see below): 64 token words
+// per step, places from a wave prefix sum over their bit lengths, bits ORed into an LDS ring, complete dwords stored 64 at a time.
+#define ZA_PK_RING 256  // dwords of the packer's output ring (a power of two; a group of 64 token words fills at most 96)
 
 __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
                                                 const uint32_t *__restrict__ tok_ws, const uint32_t *__restrict__ segtok_ws,
@@ -1002,7 +976,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
                                                 uint32_t *__restrict__ status)
 {
     __shared__ uint32_t codes[ZA_CODE_STRIDE];
-    __shared__ uint32_t rowt[64 * (ZA_TCH + 1)];
+    __shared__ uint32_t ring[ZA_PK_RING];            // the open dwords of the unit's bit stream
     const ZaUnit u = units[blockIdx.x];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len;
@@ -1062,139 +1036,91 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     }
 
     for (int i = lane; i < ZA_CODE_STRIDE; i += 64) codes[i] = code_ws[(size_t)blockIdx.x * ZA_CODE_STRIDE + i];
+    for (int i = lane; i < ZA_PK_RING; i += 64) ring[i] = 0;
     __syncthreads();
-    const uint32_t *tok = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + ((size_t)lane << ZA_SEG_SHIFT);
-    const uint32_t ntok = lane < nseg ? segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] : 0u;
-    uint32_t maxtok = ntok;
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(maxtok, d, 64); maxtok = o > maxtok ? o : maxtok; }
-    uint32_t *myt = rowt + lane * (ZA_TCH + 1);
-
-    // Walk my tokens in chunks of ZA_TCH staged through LDS (next chunk's loads in flight meanwhile).  The loads are
-    // transposed as in k_parse: eight lanes fetch the eight 16-byte pieces of one segment's 128-byte token row.
-    __shared__ uint32_t sntok[64];
-    sntok[lane] = ntok;
-    __syncthreads();
+    // ---- token-parallel packing.  The unit's bit stream is produced in order, one segment after the other, 64 token words at a
+    // time: lane j takes word j of the group (one coalesced 256-byte load, the next group's already in flight), looks its codes
+    // up, a wave prefix sum over the bit lengths gives every word its place, and the lanes OR their bits into an LDS ring of the
+    // stream's open dwords; dwords that are complete leave at once, 64 per store.  No second walk over the tokens to size the
+    // segments first (their starts fall out of the running offset), no lane waiting for the segment with the most tokens, no
+    // lane writing single dwords into lines of its own (the packer's 45 KB of output cost 365 KB of memory writes that way).
     const uint32_t *tok_unit = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE;
-    auto for_each_token = [&](auto &&fn) {
-        uint4 pt[ZA_TCH / 4];
-        auto prefetch = [&](uint32_t k0) {
-#pragma unroll
-            for (int j = 0; j < ZA_TCH / 4; j++) {
-                const int sg = 8 * j + (lane >> 3);
-                pt[j] = make_uint4(0, 0, 0, 0);
-                if (k0 < sntok[sg]) pt[j] = *(const uint4 *)(tok_unit + ((size_t)sg << ZA_SEG_SHIFT) + k0 + 4 * (lane & 7));
-            }
-        };
-        prefetch(0);
-#pragma unroll 1
-        for (uint32_t k0 = 0; k0 < maxtok; k0 += ZA_TCH) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < ZA_TCH / 4; j++) {
-                uint32_t *r = rowt + (8 * j + (lane >> 3)) * (ZA_TCH + 1) + 4 * (lane & 7);
-                r[0] = pt[j].x; r[1] = pt[j].y; r[2] = pt[j].z; r[3] = pt[j].w;
-            }
-            __builtin_amdgcn_wave_barrier();
-            prefetch(k0 + ZA_TCH);
-            uint32_t ke = k0 + ZA_TCH;
-            if (ke > ntok) ke = ntok;
-            for (uint32_t k = k0; k < ke; k++) fn(myt[k - k0]);
+    const uint32_t mycnt = lane < nseg ? segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] : 0u;
+    uint32_t bitpos = plan.header_bits;            // (wave-uniform) bits of the stream so far
+    uint32_t wbase = bitpos >> 5;                  // the first dword that is still open; ring slot = dword index mod ZA_PK_RING
+    if ((bitpos & 31u) && lane == 0) ring[wbase & (ZA_PK_RING - 1)] = wbase < cap_words ? slot32[wbase] : 0u;     // the header's last, partial dword (plan kernel)
+    __syncthreads();
+    // `v` (at most 37 bits... 48 with a fixed block's longer codes) of `nb` bits from every lane, in lane order, behind `bitpos`
+    auto emit = [&](uint64_t v, uint32_t nb) {
+        const uint32_t incl = za_wave_incl_scan(nb);
+        const uint32_t p = bitpos + incl - nb;
+        const uint32_t w = p >> 5, sh = p & 31u;
+        if (nb) {
+            const uint64_t x = v << sh;
+            const uint32_t top = sh ? (uint32_t)(v >> (64u - sh)) : 0u;
+            atomicOr(&ring[w & (ZA_PK_RING - 1)], (uint32_t)x);
+            if ((uint32_t)(x >> 32)) atomicOr(&ring[(w + 1u) & (ZA_PK_RING - 1)], (uint32_t)(x >> 32));
+            if (top) atomicOr(&ring[(w + 2u) & (ZA_PK_RING - 1)], top);
         }
-    };
-
-    // pass A: bit length of my segment
-    uint32_t bits = 0;
-    // (literal and match on one predicated path: a literal is "length part only")
-    // (literal and match on one predicated path: a literal token is "length part only" -- of one to three literals, which the
-    // parse put into one token word)
-    for_each_token([&](uint32_t t) {
-        const bool m = (t & 0x80000000u) != 0u;
-        const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
-        const uint32_t c1 = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], c2 = codes[288 + dc];
-        bits += (c1 >> 16) + (m ? (uint32_t)za_len_extra_bits(lc) + (c2 >> 16) + (uint32_t)za_dist_extra_bits(dc) : 0u);
-        const uint32_t nl = m ? 0u : (t >> 24) & 3u;                        // further literals in the word
-        const uint32_t b1 = codes[(t >> 8) & 0xFFu] >> 16, b2 = codes[(t >> 16) & 0xFFu] >> 16;
-        bits += (nl > 0u ? b1 : 0u) + (nl > 1u ? b2 : 0u);
-    });
-    const uint32_t incl = za_wave_incl_scan(bits);
-    const uint32_t start = plan.header_bits + incl - bits;
-    const uint32_t end_all = plan.header_bits + __shfl(incl, 63, 64);      // bit offset of EOB
-    if (lane < nseg) segbits[lane] = start;
-    else segbits[lane] = end_all;
-    if (lane == 0) segbits[ZA_MAX_SEGS] = end_all;
-
-    // The words that are merged with atomic OR must hold zero: every lane's first word (shared with its predecessor's
-    // tail) unless it is the header's last word, which the plan kernel wrote, and the words from the end of the last
-    // segment on (end-of-block code, padding, sync marker).  Everything else is written whole, so the slots need no memset.
-    {
-        const uint32_t first_free = (plan.header_bits + 31u) >> 5;       // words below hold header bits written by the plan kernel
-        if (lane < nseg && (start >> 5) >= first_free && (start >> 5) < cap_words) slot32[start >> 5] = 0;
-        if (lane == 0) {
-            for (uint32_t k = end_all >> 5; k < (end_all >> 5) + 4u; k++)
-                if (k >= first_free && k < cap_words) slot32[k] = 0;
-        }
-        __threadfence_block();
+        bitpos += (uint32_t)__shfl((int)incl, 63, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the complete dwords leave (at most 64 x 48 bits = 96 of them per call)
+        const uint32_t nw = (bitpos >> 5) - wbase;
+        for (uint32_t i = (uint32_t)lane; i < nw; i += 64) {
+            const uint32_t d = wbase + i;
+            const uint32_t val = ring[d & (ZA_PK_RING - 1)];
+            ring[d & (ZA_PK_RING - 1)] = 0;
+            if (d < cap_words) slot32[d] = val; else ovf = true;
+        }
+        wbase += nw;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int sg = 0; sg < nseg; sg++) {
+        const uint32_t cnt = (uint32_t)__shfl((int)mycnt, sg, 64);
+        if (lane == 0) { segbits[sg] = bitpos; cidx[sg] = bitpos; }      // (index entries: the codec forces a token boundary at every segment start)
+        const uint32_t *tk = tok_unit + ((size_t)sg << ZA_SEG_SHIFT);
+        uint32_t tnext = (uint32_t)lane < cnt ? tk[lane] : 0u;
+        for (uint32_t g = 0; g < cnt; g += 64) {
+            const uint32_t t = tnext;
+            tnext = g + 64u + (uint32_t)lane < cnt ? tk[g + 64u + lane] : 0u;
+            const bool has = g + (uint32_t)lane < cnt;
+            const bool m = (t & 0x80000000u) != 0u;
+            const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
+            const int ln = m ? za_len_extra_bits(lc) : 0, dn = za_dist_extra_bits(dc);
+            const uint32_t le = m ? (t >> 21) & 31u : 0u, de = t & 0x1FFFu;
+            const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
+            // literal / length code + extra (at most 20 bits), then the distance part of a match (at most 28) -- or the second and
+            // third literal of a literal word
+            const uint32_t nl = m ? 0u : (t >> 24) & 3u;
+            const uint32_t c1 = codes[(t >> 8) & 0xFFu], c2 = codes[(t >> 16) & 0xFFu];
+            const uint32_t a = (cl & 0xFFFFu) | (le << (cl >> 16)), an = (cl >> 16) + (uint32_t)ln;
+            const uint32_t lits = (c1 & 0xFFFFu) | (nl > 1u ? (c2 & 0xFFFFu) << (c1 >> 16) : 0u);
+            const uint32_t nlits = (c1 >> 16) + (nl > 1u ? (c2 >> 16) : 0u);
+            const uint32_t b = m ? (cd & 0xFFFFu) | (de << (cd >> 16)) : nl ? lits : 0u;
+            const uint32_t bn = m ? (cd >> 16) + (uint32_t)dn : nl ? nlits : 0u;
+            emit(has ? (uint64_t)a | ((uint64_t)b << an) : 0ull, has ? an + bn : 0u);
+        }
     }
-    // pass B: emit
-    ZaLaneW w;
-    w.init(slot32, cap_words, start);
-    // chunk index: for every 256-byte boundary of my segment the first token that starts at or behind it
-    uint32_t op = (uint32_t)lane << ZA_SEG_SHIFT, nextb = op;
-    uint32_t oend = op + ZA_SEG; if (oend > (uint32_t)n) oend = (uint32_t)n;
-    for_each_token([&](uint32_t t) {
-        const bool m = (t & 0x80000000u) != 0u;
-        const int lc = (int)((t >> 26) & 31u), dc = m ? (int)((t >> 16) & 31u) : 0;
-        const int ln = m ? za_len_extra_bits(lc) : 0, dn = za_dist_extra_bits(dc);
-        const uint32_t le = m ? (t >> 21) & 31u : 0u, de = t & 0x1FFFu;
-        while (nextb <= op) {
-            cidx[nextb >> ZA_CHUNK_SHIFT] = (w.w * 32u + (uint32_t)w.nb) | ((op - nextb) << 23);
-            nextb += 1u << ZA_CHUNK_SHIFT;
-        }
-        {   // length of the token from its symbols (literal: 1)
-            const uint32_t l8 = (uint32_t)lc;
-            const uint32_t mlen = l8 < 8u ? 3u + l8 : l8 == 28u ? 258u : ((4u + (l8 & 3u)) << ((l8 >> 2) - 1u)) + 3u + le;
-            op += m ? mlen : 1u;
-        }
-        const uint32_t cl = codes[m ? 257u + (uint32_t)lc : (t & 0xFFu)], cd = codes[288 + dc];
-        // literal / length code + extra fit in 20 bits, distance code + extra in 28 (0 bits for a literal)
-        w.put((cl & 0xFFFF) | ((uint32_t)le << (cl >> 16)), (int)(cl >> 16) + ln);
-        // second put: the distance part of a match -- or the second and third literal of a literal token (their codes are at
-        // most ZA_LIMIT_L = 10 bits each)
-        const uint32_t nl = m ? 0u : (t >> 24) & 3u;
-        const uint32_t c1 = codes[(t >> 8) & 0xFFu], c2 = codes[(t >> 16) & 0xFFu];
-        const uint32_t lits = (c1 & 0xFFFF) | (nl > 1u ? (c2 & 0xFFFF) << (c1 >> 16) : 0u);
-        const int nlits = (int)(c1 >> 16) + (nl > 1u ? (int)(c2 >> 16) : 0);
-        w.put(m ? (cd & 0xFFFF) | ((uint32_t)de << (cd >> 16)) : nl ? lits : 0u, m ? (int)(cd >> 16) + dn : nl ? nlits : 0);
-        op += nl;
-    });
-    for (; nextb < oend && lane < nseg; nextb += 1u << ZA_CHUNK_SHIFT)       // boundaries behind my last token start
-        cidx[nextb >> ZA_CHUNK_SHIFT] = (w.w * 32u + (uint32_t)w.nb) | ((oend - nextb) << 23);
-    if (lane == 0) cidx[((uint32_t)n + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT] = end_all;
-    w.finish();
-    ovf = w.ovf;
-    // tail: EOB, then final padding or the sync-flush marker (empty stored block)
-    if (lane == 0) {
-        ZaLaneW t;
-        t.init(slot32, cap_words, end_all);
+    const uint32_t end_all = bitpos;                              // bit offset of the end-of-block code
+    for (int i = lane; i <= ZA_MAX_SEGS; i += 64) if (i >= nseg) segbits[i] = end_all;
+    if (lane == 0) { segbits[ZA_MAX_SEGS] = end_all; cidx[nseg] = end_all; }
+    // tail: EOB, then final padding or the sync-flush marker (empty stored block): one more group with a single word
+    {
         const uint32_t ce = codes[256];
-        t.put(ce & 0xFFFF, (int)(ce >> 16));
-        uint32_t bitpos = end_all + (ce >> 16);
-        if (!final) { t.put(0, 3); bitpos += 3; }
-        const uint32_t padded = (bitpos + 7u) & ~7u;
-        if (padded != bitpos) t.put(0, (int)(padded - bitpos));
-        t.finish();
+        uint64_t v = ce & 0xFFFFu;
+        uint32_t nb = ce >> 16;
+        if (!final) nb += 3;                                      // 000: a stored block, not final
+        const uint32_t endbit = end_all + nb;
+        const uint32_t padded = (endbit + 7u) & ~7u;
+        nb += padded - endbit;
         total_bytes = padded >> 3;
-        if (!final) {
-            if (total_bytes + 4 <= out_stride) {
-                // byte stores: the marker may start at any byte; these bytes are zero so far and no
-                // other lane touches them (they lie beyond every token)
-                slot[total_bytes + 2] = 0xFF; slot[total_bytes + 3] = 0xFF;
-            } else t.ovf = true;
-            total_bytes += 4;
-        }
-        if (total_bytes > out_stride) t.ovf = true;
-        ovf = ovf || t.ovf;
+        if (!final) { v |= 0xFFFF0000ull << nb; nb += 32; total_bytes += 4; }      // LEN = 0, NLEN = 0xFFFF
+        emit(lane == 0 ? v : 0ull, lane == 0 ? nb : 0u);
+        // the last, partial dword
+        if ((bitpos & 31u) && lane == 0) { if (wbase < cap_words) slot32[wbase] = ring[wbase & (ZA_PK_RING - 1)]; else ovf = true; }
+        if (total_bytes > out_stride) ovf = true;
     }
     const unsigned long long anyovf = __ballot(ovf);
     if (lane == 0) {
