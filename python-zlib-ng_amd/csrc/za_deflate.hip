@@ -344,7 +344,12 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         int need_bytes = ZA_SEARCH_TILE + ZA_LOOKAHEAD;
         if (need_bytes > n) need_bytes = n;
         need_bytes = (need_bytes + 3) & ~3;
-        for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, load_bytes(p));
+        // (the plain loop -- every dword inside the caller's buffer and the dictionary: all but a unit at an end of the buffer or
+        // with a dictionary of odd length -- keeps eight loads in flight; the careful one, with its branches, one)
+        if (bytes_loaded == -dict_len && (long long)need_bytes <= readable)
+            for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, za_ld32(data + p));
+        else
+            for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, load_bytes(p));
         bytes_loaded = need_bytes;
     }
     __syncthreads();
@@ -364,10 +369,22 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             const int p = links_loaded + tid + k * ZA_SEARCH_THREADS;
             nl[k] = p < need_links ? prevdist[p + dict_len] : (uint16_t)0;
         }
+        // (Plain predicated loads where the whole tile lies inside the caller's buffer -- a wave-uniform test.  The careful
+        // form has branches with byte loads inside, and a register that a pending load may still write cannot be reused
+        // without waiting: the compiler then waits for ALL loads in flight right here, links included, and every tile paid
+        // the whole memory latency with all sixteen waves idle.)
+        if ((long long)need_bytes <= readable) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
-            nb[k] = p < need_bytes ? load_bytes(p) : 0u;
+            for (int k = 0; k < 2; k++) {
+                const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
+                nb[k] = p < need_bytes ? za_ld32(data + p) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
+                nb[k] = p < need_bytes ? load_bytes(p) : 0u;
+            }
         }
 #pragma unroll 1
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
