@@ -308,6 +308,7 @@ def main():
             d_v[5 + HALO + pre[q]] = 3                           # empty final block
             d_vo = torch.empty(HALO + kblk * BLOCK + 64, dtype=torch.uint8, device=dev)
             vlen, vused = C.c_uint64(0), C.c_uint64(0)
+            torch.cuda.synchronize()             # (what torch wrote above must be there before the engine's stream reads it)
             rc = L.zngamd_inflate_raw_dev(h, ptr(d_v), 5 + HALO + pre[q] + 2, ptr(d_vo), HALO + kblk * BLOCK, C.byref(vlen), C.byref(vused))
             assert rc == _lib.STREAM_END and vlen.value == HALO + kblk * BLOCK, (rc, vlen.value, vused.value, ctx.err())
             assert torch.equal(d_vo[HALO:HALO + kblk * BLOCK], tile_bytes(qlo * BLOCK, kblk * BLOCK)), \
@@ -318,6 +319,7 @@ def main():
                 d_stream[total:total + 66] = 0
                 d_stream[total] = 3
                 d_big = torch.empty(total_size + 64, dtype=torch.uint8, device=dev) if world > 1 else d_out
+                torch.cuda.synchronize()
                 rc = L.zngamd_inflate_raw_dev(h, ptr(d_stream), total + 2, ptr(d_big), total_size, C.byref(vlen), C.byref(vused))
                 assert rc == _lib.STREAM_END and vlen.value == total_size and vused.value == total + 2, (rc, vlen.value, vused.value, ctx.err())
                 assert bool((d_big[:total_size].view(-1, uniq) == base).all().item()), "the assembled stream does not inflate to the input"
@@ -330,6 +332,7 @@ def main():
             d_comp[comp_bytes] = 3
             vlen, vused = C.c_uint64(0), C.c_uint64(0)
             d_out.zero_()
+            torch.cuda.synchronize()             # (torch's stream and the engine's are not ordered with each other)
             rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
             assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
             assert torch.equal(d_out[:size], d_in[:size]), "the compressed stream does not inflate to the input"
@@ -386,6 +389,7 @@ def main():
             ft[b] = _lib.Member(o + 10, ln - 18, b * BLOCK, BLOCK, 0, 0, 0)
         d_ft = torch.frombuffer(bytearray(bytes(ft)), dtype=torch.uint8).to(dev)
         d_out.zero_()
+        torch.cuda.synchronize()                 # (torch's stream and the engine's are not ordered with each other)
         f_ms = []
         for it in range(2):
             ctx.profiling(True); ctx.kernel_times(reset=True)
@@ -426,7 +430,7 @@ def main():
         leg_bytes = size + ms_len.value
         leg_name = "inflate: za_k_scan_members + za_k_inflate_members"
     leg_ms = sum(kt[k][0] for k in leg_kernels) / steps
-    leg_sets = max(1.0, max(kt[k][1] for k in leg_kernels) / steps)          # launch sets per step (1: every kernel takes the whole shard)
+    leg_sets = max(1.0, kt[leg_kernels[0] if dom_leg == "deflate" else "inflate"][1] / steps)   # launch sets per step (1: every kernel takes the whole shard)
     achieved = leg_bytes / (leg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": leg_name,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -806,6 +806,41 @@ __device__ void za_canon_serial(const uint8_t *lens, int n, uint16_t *codes)
     }
 }
 
+// all lanes: the same canonical codes, without lane 0 walking every symbol -- lengths counted with LDS atomics, the first code of
+// every length by lane (15 steps each), a symbol's place among the symbols of its length from ballots (symbols in index order)
+__device__ void za_canon_wave(const uint8_t *lens, int n, uint16_t *codes, uint32_t *scratch32 /* 32 dwords of LDS */)
+{
+    const int lane = za_lane();
+    uint32_t *cnt = scratch32, *first = scratch32 + 16;
+    __syncthreads();
+    if (lane < 16) cnt[lane] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const uint32_t l = lens[i]; if (l) atomicAdd(&cnt[l], 1u); }
+    __syncthreads();
+    if (lane >= 1 && lane < 16) {
+        uint32_t code = 0;
+        for (int b = 1; b <= lane; b++) code = (code + (b > 1 ? cnt[b - 1] : 0u)) << 1;
+        first[lane] = code;
+    }
+    __syncthreads();
+    uint32_t run[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) run[b] = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t l = i < n ? lens[i] : 0u;
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t b = 1; b <= 15; b++) {
+            const unsigned long long m = __ballot(l == b);
+            if (l == b) rank = run[b] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            run[b] += (uint32_t)__builtin_popcountll(m);
+        }
+        if (i < n) codes[i] = l ? (uint16_t)(__brev(first[l] + rank) >> (32u - l)) : (uint16_t)0;
+    }
+    __syncthreads();
+}
+
 // serial LSB-first bit writer into a zero-initialised, 4-byte aligned slot (plain stores: the plan
 // kernel is the first writer of its slot)
 struct ZaBitW {
@@ -860,9 +895,25 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
     if (lane == 0) { za_lengths_serial(S, 30, ZA_LIMIT_D, S.lens + 288); S.lens[318] = S.lens[319] = 0; }
     __syncthreads();
 
+    // canonical codes and the exact data costs: by all lanes (lane 0 alone walked 600 symbols through LDS, one round trip each)
+    za_canon_wave(S.lens, 286, S.codes, S.A);
+    za_canon_wave(S.lens + 288, 30, S.codes + 288, S.A);
+    uint32_t cost_dd = 0, cost_df = 0;
+    for (int s = lane; s < 286; s += 64) {
+        const uint32_t f = hist[s];
+        const int ex = s >= 257 ? za_len_extra_bits(s - 257) : 0;
+        const int fx = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+        cost_dd += f * (uint32_t)(S.lens[s] + ex);
+        cost_df += f * (uint32_t)(fx + ex);
+    }
+    if (lane < 30) {
+        const uint32_t f = hist[288 + lane];
+        const int ex = za_dist_extra_bits(lane);
+        cost_dd += f * (uint32_t)(S.lens[288 + lane] + ex);
+        cost_df += f * (uint32_t)(5 + ex);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { cost_dd += __shfl_xor(cost_dd, d, 64); cost_df += __shfl_xor(cost_df, d, 64); }
     if (lane == 0) {
-        za_canon_serial(S.lens, 286, S.codes);
-        za_canon_serial(S.lens + 288, 30, S.codes + 288);
         int hlit = 286; while (hlit > 257 && S.lens[hlit - 1] == 0) hlit--;
         int hdist = 30; while (hdist > 1 && S.lens[288 + hdist - 1] == 0) hdist--;
         for (int i = 0; i < hlit; i++) S.seq[i] = S.lens[i];
@@ -902,21 +953,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         za_canon_serial(S.cl_lens, 19, S.cl_codes);
         int hclen = 19; while (hclen > 4 && S.cl_lens[za_cl_order[hclen - 1]] == 0) hclen--;
         // exact costs
-        unsigned long long data_dyn = 0, data_fix = 0;
-        for (int s = 0; s < 286; s++) {
-            const uint32_t f = hist[s];
-            if (!f) continue;
-            const int ex = s >= 257 ? za_len_extra_bits(s - 257) : 0;
-            const int fx = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-            data_dyn += (unsigned long long)f * (unsigned)(S.lens[s] + ex);
-            data_fix += (unsigned long long)f * (unsigned)(fx + ex);
-        }
-        for (int s = 0; s < 30; s++) {
-            const uint32_t f = hist[288 + s];
-            const int ex = za_dist_extra_bits(s);
-            data_dyn += (unsigned long long)f * (unsigned)(S.lens[288 + s] + ex);
-            data_fix += (unsigned long long)f * (unsigned)(5 + ex);
-        }
+        const unsigned long long data_dyn = cost_dd, data_fix = cost_df;        // (at most 131 072 tokens of at most 48 bits: 32 bits hold the sums)
         unsigned long long hdr_dyn = 3 + 5 + 5 + 4 + 3ull * (unsigned)hclen;
         for (int k = 0; k < nt; k++) {
             const int s = S.cltok[k] & 0xFF;
