@@ -296,33 +296,38 @@ __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t 
 template <bool FULL>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                  const ZaUnit *__restrict__ units,
+                                                                 const uint32_t *__restrict__ run_start,
                                                                  const uint16_t *__restrict__ prev_ws,
                                                                  uint32_t *__restrict__ best_ws, ZaLevel L)
 {
     __shared__ uint16_t ring[ZA_RING];
     __shared__ uint32_t win32[ZA_BYTES / 4 + 8];
     uint8_t *win8 = (uint8_t *)win32;
-    const ZaUnit u = units[blockIdx.x];
+    const int tid = (int)threadIdx.x;
+    // One workgroup per RUN of consecutive units -- the chain kernel's runs.  Behind the head of a run every unit's dictionary
+    // is the tail of the unit in front of it, and the window of that unit is still in the rings: the walk goes on where it
+    // stood instead of staging 32 KiB of links and bytes again with all sixteen waves waiting.  `goff` = the run's positions
+    // in front of the current unit: the rings are indexed by goff + 32768 + p, everything else by p.
+    const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
+    uint32_t goff = 0;
+    int carry_bytes = 0, n_prev = 0;
+#pragma unroll 1
+    for (uint32_t ui = u0; ui < u1; ui++) {
+    const ZaUnit u = units[ui];
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
-    const uint16_t *prevdist = prev_ws + (size_t)blockIdx.x * ZA_PREV_STRIDE;     // index p + dict_len
-    // A carried unit (ZA_FLAG_CARRY, set where the chain kernel did carry its tables: not at the head of a run) has no links
-    // of its dictionary in its own row: they are the links of the last 32 KiB of the unit in front of it, in THAT unit's row
-    // -- except the last five positions, which that unit never inserted and this one did (its own row).
-    const bool carried = (u.flags & ZA_FLAG_CARRY) != 0u && (u.flags & ZA_FLAG_RUNHEAD) == 0u && blockIdx.x > 0;
-    const uint16_t *dictlinks = prevdist;                                          // index p + dict_len, p < 0
-    if (carried) {
-        const ZaUnit up = units[blockIdx.x - 1];
-        dictlinks = prev_ws + (size_t)(blockIdx.x - 1) * ZA_PREV_STRIDE + up.dict_len + up.in_len - dict_len;
-    }
-    auto link_at = [&](int p) -> uint16_t { return (p >= -(ZA_HASH_BYTES - 1) ? prevdist : dictlinks)[p + dict_len]; };
-    uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
-    const int tid = (int)threadIdx.x;
+    const uint16_t *prevdist = prev_ws + (size_t)ui * ZA_PREV_STRIDE;     // index p + dict_len
+    const bool carried = ui > u0;           // (the host cuts a run wherever a unit's dictionary is not the tail of its predecessor)
+    uint32_t *best = best_ws + (size_t)ui * ZA_BEST_STRIDE;
     // bytes that may be read starting at data[0] without leaving the caller's buffer
     const long long readable = (long long)(in_total - u.in_off);
-    int links_loaded = -dict_len;        // positions p < links_loaded have their chain link in the ring
-    int bytes_loaded = -dict_len;        // positions p < bytes_loaded have their byte in the byte ring
-    bytes_loaded &= ~3;                  // staged in aligned dwords (P is a multiple of 4 when p is)
+    goff = carried ? goff + (uint32_t)n_prev : 0u;
+    int links_loaded = carried ? 0 : -dict_len;                        // positions p < links_loaded have their chain link in the ring
+    int bytes_loaded = carried ? carry_bytes - n_prev : (-dict_len) & ~3;   // positions p < bytes_loaded have their byte in the byte ring (aligned dwords)
+    if (carried && tid < ZA_HASH_BYTES - 1)
+        // the last five positions of the unit in front: never inserted there (their links in the ring say so), inserted by
+        // this unit's chain pass (its own row)
+        ring[(goff + (uint32_t)(ZA_WIN - (ZA_HASH_BYTES - 1) + tid)) % ZA_RING] = prevdist[dict_len - (ZA_HASH_BYTES - 1) + tid];
     auto load_bytes = [&](int p) -> uint32_t {          // dword of input at p (a multiple of 4), zero outside the unit
         if (p >= -dict_len && (long long)p + 4 <= readable) return za_ld32(data + p);
         uint32_t v = 0;                                   // edges: before the dictionary start or past the caller's buffer
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         return v;
     };
     auto store_bytes = [&](int p, uint32_t v) {
-        const uint32_t w = ((uint32_t)(ZA_WIN + p) & (ZA_BYTES - 1)) >> 2;
+        const uint32_t w = ((goff + (uint32_t)(ZA_WIN + p)) & (ZA_BYTES - 1)) >> 2;
         win32[w] = v;
         if (w < 8) win32[w + ZA_BYTES / 4] = v;
     };
@@ -339,14 +344,14 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     {
         int need_links = ZA_SEARCH_TILE < n ? ZA_SEARCH_TILE : n;
         for (int p = links_loaded + tid; p < need_links; p += ZA_SEARCH_THREADS)
-            ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = link_at(p);
+            ring[(goff + (uint32_t)(ZA_WIN + p)) % ZA_RING] = prevdist[p + dict_len];
         links_loaded = need_links;
         int need_bytes = ZA_SEARCH_TILE + ZA_LOOKAHEAD;
         if (need_bytes > n) need_bytes = n;
         need_bytes = (need_bytes + 3) & ~3;
         // (the plain loop -- every dword inside the caller's buffer and the dictionary: all but a unit at an end of the buffer or
         // with a dictionary of odd length -- keeps eight loads in flight; the careful one, with its branches, one)
-        if (bytes_loaded == -dict_len && (long long)need_bytes <= readable)
+        if ((carried || bytes_loaded == -dict_len) && (long long)need_bytes <= readable)
             for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, za_ld32(data + p));
         else
             for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, load_bytes(p));
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
             // the result: distance (bits 0..15) | length - 3 (bits 16..23); the position's own byte travels in the top byte
             uint32_t result = 0;
-            const uint32_t P = (uint32_t)(ZA_WIN + p);
+            const uint32_t P = goff + (uint32_t)(ZA_WIN + p);
             // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
             // against them without branches (this also plays the role of zlib's quick-reject byte)
             uint32_t me0, me1, me2, me3;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int p = links_loaded + tid + k * ZA_SEARCH_THREADS;
-            if (p < need_links) ring[(uint32_t)(ZA_WIN + p) % ZA_RING] = nl[k];
+            if (p < need_links) ring[(goff + (uint32_t)(ZA_WIN + p)) % ZA_RING] = nl[k];
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -497,6 +502,8 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         }
         links_loaded = need_links; bytes_loaded = need_bytes;
         __syncthreads();
+    }
+    carry_bytes = bytes_loaded; n_prev = n;
     }
 }
 

@@ -370,7 +370,7 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
             // the unit's whole 32 KiB dictionary is the tail of the unit in front of it: the chain tables may be carried over
             if (!hu.empty()) {
                 const ZaUnit &pv = hu.back();
-                if (u.dict_len == ZA_WIN && pv.in_len >= ZA_WIN && pv.in_off + pv.in_len == u.in_off) u.flags |= ZA_FLAG_CARRY;
+                if (u.dict_len == ZA_WIN && pv.in_len >= ZA_WIN && (pv.in_len & 3u) == 0u && pv.in_off + pv.in_len == u.in_off) u.flags |= ZA_FLAG_CARRY;   // (a multiple of 4: the search stages its byte ring in aligned dwords)
             }
             hu.push_back(u);
         }
@@ -435,8 +435,8 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
               hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(64 * ZA_CH_WAVES), 0, c->stream, d_in, du, d_runs, c->prev.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
-              if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L);
-              else hipLaunchKernelGGL(za_k_search<false>, dim3(m), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, c->prev.p, c->best.p, L); }
+              if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
+              else hipLaunchKernelGGL(za_k_search<false>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L); }
             { ProfScope ps(c, ZNGAMD_K_PARSE);
               hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
                                  d_unit_crc + c0, c->d_crc_table, c->d_x8k, L); }
