@@ -69,6 +69,8 @@ struct zngamd_ctx {
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status, runs;
     uint32_t last_units = 0; bool last_single_chunk = false;
     std::vector<ZaUnit> last_hu;                 // the units of the last deflate call as the kernels saw them (zngamd_debug_fetch)
+    std::vector<ZaUnit> plan_in; std::vector<uint32_t> plan_runs; uint32_t plan_ch = 0;     // the unit table the device holds was planned from this one: a caller that compresses batch after batch of the same shape pays for the planning once
+    std::vector<zngamd_block> blocks_in; std::vector<ZaUnit> blocks_hu; uint64_t blocks_len = 0;
     uint32_t chain_slots = 1536;                 // chain-kernel workgroups the device holds at once: CUs x 6
     uint32_t chain_run = 0;                      // ZNGAMD_CHAIN_RUN: fixed run length of the chain kernel (0 = sized to the device)
     // staging
@@ -400,26 +402,33 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     // again, so longer runs save more (a quarter of the positions at most) -- but workgroups are handed out in order, and a
     // launch ends with its last workgroup: runs of L units for the first four fifths of a launch, short ones behind them to
     // fill the tail, and L bounded by what keeps every slot of the device busy at least twice.  Runs never cross a launch.
-    std::vector<ZaUnit> hv(hu);
-    std::vector<uint32_t> run_start;
-    for (uint32_t c0 = 0; c0 < n; c0 += ch) {
-        const uint32_t m = std::min(ch, n - c0);
-        const uint32_t L = c->chain_run ? c->chain_run : std::min<uint32_t>(8u, std::max<uint32_t>(1u, m / (2u * c->chain_slots)));
-        const uint32_t Ls = c->chain_run ? c->chain_run : std::max<uint32_t>(1u, L / 4u);
-        const uint32_t big_end = c->chain_run ? m : (uint32_t)((uint64_t)m * 4 / 5 / L * L);
-        uint32_t next_cut = 0;
-        for (uint32_t i = 0; i < m; i++) {
-            ZaUnit &u = hv[c0 + i];
-            const bool cut = i == next_cut || !(u.flags & ZA_FLAG_CARRY);
-            if (cut) { u.flags |= ZA_FLAG_RUNHEAD; run_start.push_back(i); next_cut = i + (i < big_end ? L : Ls); }
+    const bool same_plan = c->plan_ch == ch && c->plan_in.size() == hu.size() && c->last_hu.size() == hu.size() &&
+                           memcmp(c->plan_in.data(), hu.data(), hu.size() * sizeof(ZaUnit)) == 0;
+    if (!same_plan) {
+        std::vector<ZaUnit> hv(hu);
+        std::vector<uint32_t> run_start;
+        for (uint32_t c0 = 0; c0 < n; c0 += ch) {
+            const uint32_t m = std::min(ch, n - c0);
+            const uint32_t L = c->chain_run ? c->chain_run : std::min<uint32_t>(8u, std::max<uint32_t>(1u, m / (2u * c->chain_slots)));
+            const uint32_t Ls = c->chain_run ? c->chain_run : std::max<uint32_t>(1u, L / 4u);
+            const uint32_t big_end = c->chain_run ? m : (uint32_t)((uint64_t)m * 4 / 5 / L * L);
+            uint32_t next_cut = 0;
+            for (uint32_t i = 0; i < m; i++) {
+                ZaUnit &u = hv[c0 + i];
+                const bool cut = i == next_cut || !(u.flags & ZA_FLAG_CARRY);
+                if (cut) { u.flags |= ZA_FLAG_RUNHEAD; run_start.push_back(i); next_cut = i + (i < big_end ? L : Ls); }
+            }
+            run_start.push_back(m);                                  // (the runs of one launch: starts relative to the launch, then its end)
         }
-        run_start.push_back(m);                                  // (the runs of one launch: starts relative to the launch, then its end)
+        HIPCHK(c, c->runs.ensure(run_start.size()));
+        HIPCHK(c, hipMemcpyAsync(c->runs.p, run_start.data(), run_start.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->units.p, hv.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));                  // (hv and run_start are locals)
+        c->last_hu.swap(hv);
+        c->plan_runs.swap(run_start);
+        c->plan_in = hu; c->plan_ch = ch;
     }
-    HIPCHK(c, c->runs.ensure(run_start.size()));
-    HIPCHK(c, hipMemcpyAsync(c->runs.p, run_start.data(), run_start.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->units.p, hv.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                  // (hv and run_start are locals)
-    c->last_hu = hv;
+    const std::vector<uint32_t> &run_start = c->plan_runs;
     // (no memset of the slots: the pack kernel zeroes the few words it merges with atomic OR and writes the rest whole)
     ZaLevel L = ZA_LEVELS[level];
     L.max_dist = (max_dist < 1 || max_dist > ZA_WIN) ? ZA_WIN : max_dist;
@@ -462,9 +471,17 @@ int zngamd_deflate_blocks_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, 
 try {
     if (!c || (!blocks && n_blocks) || !d_slots || !d_unit_len || !d_unit_crc) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
-    std::vector<ZaUnit> hu;
-    int r = build_units(c, blocks, n_blocks, in_len, hu);
-    if (r) return r;
+    // (a caller that compresses batch after batch with the same block table -- the reference's writer does, block size and
+    // dictionary rule never change -- pays for cutting the blocks into units once)
+    int r = ZNGAMD_OK;
+    if (!(n_blocks && c->blocks_in.size() == n_blocks && c->blocks_len == in_len &&
+          memcmp(c->blocks_in.data(), blocks, (size_t)n_blocks * sizeof(zngamd_block)) == 0)) {
+        c->blocks_in.clear();
+        r = build_units(c, blocks, n_blocks, in_len, c->blocks_hu);
+        if (r) return r;
+        c->blocks_in.assign(blocks, blocks + n_blocks); c->blocks_len = in_len;
+    }
+    const std::vector<ZaUnit> &hu = c->blocks_hu;
     if (h_unit_block) for (size_t i = 0; i < hu.size(); i++) h_unit_block[i] = hu[i].block;
     r = deflate_units_dev(c, (const uint8_t *)d_in, in_len, hu, level, (uint8_t *)d_slots, d_unit_len, d_unit_crc);
     if (r) return r;
