@@ -66,11 +66,19 @@ def main():
     # ---- host-buffer API on a large input: PCIe, staging and Python buffers inside the timed region
     big = corpus.text(64 << 20, seed=1).tobytes() * 4
     zlib_ng.compress(big[:1 << 20], 6)
-    t0 = time.perf_counter(); c = zlib_ng.compress(big, 6); t1 = time.perf_counter()
-    d = zlib_ng.decompress(c, bufsize=len(big)); t2 = time.perf_counter()
+    first_c = first_d = best_c = best_d = None
+    for it in range(3):                            # the first call of a size also sizes the workspaces and the pinned staging buffers
+        c = d = None
+        t0 = time.perf_counter(); c = zlib_ng.compress(big, 6); t1 = time.perf_counter()
+        d = zlib_ng.decompress(c, bufsize=len(big)); t2 = time.perf_counter()
+        if it == 0:
+            first_c, first_d = t1 - t0, t2 - t1
+        best_c = t1 - t0 if best_c is None else min(best_c, t1 - t0)
+        best_d = t2 - t1 if best_d is None else min(best_d, t2 - t1)
     assert d == big
-    out.append({"config": "0b", "workload": "zlib_ng.compress/decompress level 6, 256 MiB text, host API (PCIe inclusive)",
-                "compress_MBps": round(len(big) / (t1 - t0) / 1e6, 1), "decompress_MBps": round(len(big) / (t2 - t1) / 1e6, 1),
+    out.append({"config": "0b", "workload": "zlib_ng.compress/decompress level 6, 256 MiB text, host API (PCIe inclusive), best of 3",
+                "compress_MBps": round(len(big) / best_c / 1e6, 1), "decompress_MBps": round(len(big) / best_d / 1e6, 1),
+                "first_call_compress_MBps": round(len(big) / first_c / 1e6, 1), "first_call_decompress_MBps": round(len(big) / first_d / 1e6, 1),
                 "ratio": round(len(big) / len(c), 4)})
     del big, c, d
 
