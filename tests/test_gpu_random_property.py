@@ -129,3 +129,39 @@ def test_windowed_reader_random_streams(monkeypatch, fastq):
                 break
             got += part
         assert bytes(got) == want, (trial, len(got), len(want))
+
+
+def test_random_block_tables_and_chain_runs_match_oracle(monkeypatch, fastq):
+    """Random tables of blocks (sizes from 0 to several units, dictionaries taken or not), random run lengths of the chain and
+    search kernels (ZNGAMD_CHAIN_RUN: where tables and windows are carried from unit to unit and where they are not), random
+    workspace chunking, random levels: every block must come out as the concatenation of the oracle's units, which knows
+    neither runs nor chunks (the wide version of this is profiles/fuzz_chain_runs.py)."""
+    from oracle import oracle as O
+    from zlib_ng_amd import _lib
+    rng = np.random.default_rng(3026)
+    B = 131072
+    for case in range(14):
+        monkeypatch.setenv("ZNGAMD_CHAIN_RUN", str(int(rng.choice([1, 2, 3, 5, 9, 1000]))))
+        monkeypatch.setenv("ZNGAMD_CHUNK_UNITS", str(int(rng.choice([4, 7, 32768]))))
+        ctx = _lib.Context(device=0)
+        nblk = int(rng.integers(2, 14))
+        sizes = [int(rng.choice([B, B, B, 2 * B, 3 * B + 5, 100000, 40000, 32768, 32764, 20000, 6, 1, 0, int(rng.integers(1, 2 * B))])) for _ in range(nblk)]
+        level = int(rng.integers(1, 10))
+        if level >= 8:
+            sizes = [min(s, 70001) for s in sizes]
+        blocks, off = [], 0
+        for i, sz in enumerate(sizes):
+            dl = 0 if (i == 0 or rng.integers(0, 6) == 0) else min(32768, off)
+            blocks.append((off, sz, dl, 0))
+            off += sz
+        data = _stitch(rng, fastq, off + 1)[:off]
+        outs, crcs, ovf = ctx.deflate_blocks(data, blocks, level, max(sizes) + max(sizes) // 8 + 1000)
+        assert not ovf
+        for (o, s, d, _), out, crc in zip(blocks, outs, crcs):
+            ref = b""
+            for k in range(max(1, (s + B - 1) // B)):
+                lo, hi = o + k * B, min(o + (k + 1) * B, o + s)
+                udl = min(32768, d + k * B)
+                ref += O.deflate_unit(data[lo:hi], data[lo - udl:lo], level=level)[0]
+            assert out == ref and crc == zlib.crc32(data[o:o + s]), (case, level, sizes, os.environ["ZNGAMD_CHAIN_RUN"])
+        del ctx
