@@ -856,7 +856,26 @@ static int scan_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
     if (n == 0 || n > max_c) return ZNGAMD_E_ARG;
     std::vector<ZaCand> hc(n);
     HIPCHK(c, hipMemcpy(hc.data(), c->cands.p, (size_t)n * sizeof(ZaCand), hipMemcpyDeviceToHost));
-    std::sort(hc.begin(), hc.end(), [](const ZaCand &a, const ZaCand &b) { return a.off < b.off; });
+    // order by offset (the kernel hands the candidates out in the order its atomics happened): no comparison sort of the whole
+    // table -- it was a millisecond of every inflate step for 32 768 members -- but a counting pass over buckets of 16 KiB of
+    // stream, which hold a member or two, and a sort inside the few buckets that hold more
+    {
+        const unsigned SH = 14;
+        const size_t nbk = (size_t)(in_len >> SH) + 2;
+        if (nbk <= 4 * (size_t)n + 1024) {
+            std::vector<uint32_t> start(nbk + 1, 0u);
+            for (const ZaCand &cd : hc) start[(size_t)(cd.off >> SH) + 1]++;
+            for (size_t b = 0; b < nbk; b++) start[b + 1] += start[b];
+            std::vector<ZaCand> so(n);
+            std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+            for (const ZaCand &cd : hc) so[fill[(size_t)(cd.off >> SH)]++] = cd;
+            for (size_t b = 0; b < nbk; b++)
+                if (start[b + 1] - start[b] > 1)
+                    std::sort(so.begin() + start[b], so.begin() + start[b + 1], [](const ZaCand &a, const ZaCand &b2) { return a.off < b2.off; });
+            hc.swap(so);
+        } else std::sort(hc.begin(), hc.end(), [](const ZaCand &a, const ZaCand &b) { return a.off < b.off; });
+    }
+    hm.reserve(n);
     // keep the chain that starts at offset 0 and tiles the stream exactly (signature hits inside
     // compressed data are skipped because nothing points at them)
     uint64_t pos = 0, outp = 0;
