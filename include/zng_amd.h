@@ -103,6 +103,16 @@ int zngamd_deflate_blocks(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
                           uint8_t *out, uint64_t out_cap_per_block,
                           uint32_t *out_len, uint32_t *crc);
 
+/* The same blocks, their outputs back to back in `out` (block b at the sum of out_len[0 .. b-1]; *total = all of them): what a
+ * writer that only concatenates the blocks needs (the reference's writer thread, src/zlib_ng/gzip_ng_threaded.py:382-398) --
+ * the packed stream is copied from the device straight into `out`, no per-block slots in between.  A block whose output
+ * reaches block_cap is an overflow as above (ZNGAMD_E_OVERFLOW, out_len[b] = 0xFFFFFFFF; `out` is then not to be used);
+ * ZNGAMD_BUF_ERROR with *total = the size needed when out_cap is too small. */
+int zngamd_deflate_blocks_packed(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                                 const zngamd_block *blocks, uint32_t n_blocks, int level,
+                                 uint8_t *out, uint64_t out_cap, uint64_t block_cap,
+                                 uint32_t *out_len, uint32_t *crc, uint64_t *total);
+
 /* Device-resident form.  d_in holds the input; blocks are cut into units as above.
  * d_slots must hold n_units * ZNGAMD_SLOT_STRIDE bytes, where n_units = zngamd_count_units(...).
  * Per-unit results stay on the device: d_unit_len[u], d_unit_crc[u]; unit -> block map in h_unit_block

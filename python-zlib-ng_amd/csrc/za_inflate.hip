@@ -394,6 +394,78 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         if (!emit) { endp = bp; cnt = c; nm = k; st = s; farrel = fr; }
     };
 
+    // The counting passes (what a sweep mostly consists of: 4.3 of them, each as long as its slowest lane) take the tokens in
+    // ROUNDS, like phase A of za_k_inflate_members: up to six literals and the token behind them on one straight path, looked
+    // up in a 128-bit window of the staged stream that is fetched once per round (five LDS reads issued together) and moved
+    // with v_alignbit -- no 64-bit shifts, no refill test per symbol, no branch per symbol kind.  Codes longer than the
+    // first-level table (entry 0) and invalid ones take the bit-serial decode in the token stage; a literal run ends in front
+    // of them.  Same results as run(false, ...): symbols that start before `lim` are counted, nothing else.
+    auto run_count = [&](uint32_t from, uint32_t lim) {
+        uint32_t bp = from, c = 0, k = 0;
+        int s = 0, fr = -(1 << 30);
+        auto lit3 = [&](uint32_t win, uint32_t room, bool on, uint32_t &bits) -> uint32_t {
+            const uint32_t e0 = T.lut_l[win & ((1u << ZA_LUT_L_BITS) - 1u)];
+            const bool l0 = on && (e0 - 1u) < 0xFFFu;                       // assigned and a literal: (symbol << 4) | length, symbol < 256
+            uint32_t u = l0 ? (e0 & 15u) : 0u;
+            const uint32_t e1 = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_LUT_L_BITS)];
+            const bool l1 = l0 && (e1 - 1u) < 0xFFFu && u < room;
+            u += l1 ? (e1 & 15u) : 0u;
+            const uint32_t e2 = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_LUT_L_BITS)];
+            const bool l2 = l1 && (e2 - 1u) < 0xFFFu && u < room;
+            u += l2 ? (e2 & 15u) : 0u;
+            bits = u;
+            return (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u);
+        };
+#pragma unroll 1
+        while (s == 0 && bp < lim) {
+            const uint32_t w = bp >> 5, sh = bp & 31u;
+            const uint32_t d0 = P->stage[w], d1 = P->stage[w + 1], d2 = P->stage[w + 2], d3 = P->stage[w + 3], d4 = P->stage[w + 4];
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            const uint32_t h2 = __builtin_amdgcn_alignbit(d3, d2, sh), h3 = __builtin_amdgcn_alignbit(d4, d3, sh);
+            const uint32_t room = lim - bp;                                 // > 0
+            uint32_t u1, u2;
+            const uint32_t n1 = lit3(lo, room, true, u1);                   // first-level codes are <= 10 bits: three fit the 32 at hand
+            const uint32_t lo1 = __builtin_amdgcn_alignbit(hi, lo, u1), hi1 = __builtin_amdgcn_alignbit(h2, hi, u1), h21 = __builtin_amdgcn_alignbit(h3, h2, u1);
+            const bool more = n1 == 3u && u1 < room;
+            const uint32_t n2 = lit3(lo1, more ? room - u1 : 0u, more, u2);
+            const uint32_t u = u1 + u2;                                     // <= 60
+            c += n1 + n2;
+            // -- the token behind them, whatever it is (a seventh literal, a literal with a long code, end of block, a match)
+            const bool tok = u < room;
+            const uint32_t m_lo = __builtin_amdgcn_alignbit(hi1, lo1, u2), m_hi = __builtin_amdgcn_alignbit(h21, hi1, u2);
+            uint32_t em = T.lut_l[m_lo & ((1u << ZA_LUT_L_BITS) - 1u)];
+            if (tok && em == 0u) em = za_slow_decode(m_lo, T.cnt_l, T.sym_l, 15);
+            const uint32_t sym = em >> 4, l = em & 15u;
+            const bool is_len = tok && sym > 256u && sym <= 285u;
+            int nx = 0, dnx = 0;
+            const int lbase = za_len_base(is_len ? (int)sym - 257 : 0, nx);
+            const uint32_t len = (uint32_t)lbase + __builtin_amdgcn_ubfe(m_lo, l, (uint32_t)nx);
+            const uint32_t used = l + (uint32_t)nx;                          // <= 20
+            const uint32_t x = __builtin_amdgcn_alignbit(m_hi, m_lo, used);  // the distance code and its extra bits: <= 28 bits
+            uint32_t d = T.lut_d[x & ((1u << ZA_LUT_D_BITS) - 1u)];
+            if (is_len && d == 0u) d = za_slow_decode(x, T.cnt_d, T.sym_d, 15);
+            const uint32_t ds = d >> 4, dl = d & 15u;
+            const bool dist_ok = d != 0u && ds < 30u;
+            const int dbase = za_dist_base(dist_ok ? (int)ds : 0, dnx);
+            const uint32_t dist = (uint32_t)dbase + __builtin_amdgcn_ubfe(x, dl, (uint32_t)dnx);
+            const bool bad = tok && (em == 0u || sym > 285u || (is_len && !dist_ok));
+            if (bad) { s = 2; bp += u; }
+            else if (tok) {
+                uint32_t adv = l;
+                if (sym < 256u) c++;
+                else if (sym == 256u) s = 1;
+                else {
+                    if (MODE == 1) { const int f = (int)dist - (int)c; if (f > fr) fr = f; }
+                    c += len; k++;
+                    adv = used + dl + (uint32_t)dnx;
+                }
+                bp += u + adv;
+            }
+            else bp += u;
+        }
+        endp = bp; cnt = c; nm = k; st = s; farrel = fr;
+    };
+
     uint32_t start = b0 + (uint32_t)lane * S;
     const uint32_t lim = b0 + ((uint32_t)lane + 1u) * S;
     bool dirty = true;
@@ -404,7 +476,13 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         its = it;
         if (dirty) {
             if (start == ZA_PS_NONE) { st = 3; endp = 0; cnt = 0; nm = 0; farrel = -(1 << 30); }
-            else run(false, start, lim, 0, 0, 0);
+            else {
+#ifdef ZA_PS_OLD_COUNT
+                run(false, start, lim, 0, 0, 0);
+#else
+                run_count(start, lim);
+#endif
+            }
         }
         const uint32_t handed = (uint32_t)__shfl_up((int)(st == 0 ? endp : ZA_PS_NONE), 1, 64);
         const bool ch = lane > 0 && handed != start;

@@ -10,6 +10,7 @@
 #include "../../include/zng_amd.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +94,20 @@ static int fail(zngamd_ctx *c, int code, const char *msg) { c->err = msg; return
 // no C++ exception leaves the C ABI (host allocations of the batch paths can fail): reported as ZNGAMD_MEM_ERROR
 #define ZA_ABI_GUARD catch (const std::bad_alloc &) { return ZNGAMD_MEM_ERROR; } catch (...) { return ZNGAMD_E_ARG; }
 
+
+// ZNGAMD_TRACE=1: wall clock of the host phases of a call on stderr, the stream drained at the end of each so that a phase
+// owns what it launched (diagnostics only: the drains cost time; profiles/time_threaded_rw.py and time_oneshot.py read it)
+static bool trace_on() { static const bool on = getenv("ZNGAMD_TRACE") != nullptr; return on; }
+struct PhaseClock {
+    zngamd_ctx *c; const char *name; std::chrono::steady_clock::time_point t;
+    PhaseClock(zngamd_ctx *c_, const char *n) : c(c_), name(n) { if (trace_on()) t = std::chrono::steady_clock::now(); }
+    ~PhaseClock()
+    {
+        if (!trace_on()) return;
+        if (c) (void)hipStreamSynchronize(c->stream);
+        fprintf(stderr, "zng_amd trace: %-34s %9.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count());
+    }
+};
 
 static hipEvent_t ev_get(zngamd_ctx *c)
 {
@@ -267,6 +282,7 @@ uint32_t zngamd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
 static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *crc_io, uint32_t *adler_io)
 {
     if (n == 0) return ZNGAMD_OK;
+    PhaseClock pc(c, "checksum of a device buffer");
     const uint64_t nspan = (n + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT;
     if (nspan > 0x7FFFFFFFull) return fail(c, ZNGAMD_E_ARG, "buffer too large");
     HIPCHK(c, c->ck.ensure(nspan));
@@ -297,6 +313,7 @@ static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *c
 
 static int stage_in(zngamd_ctx *c, const uint8_t *in, uint64_t n, uint64_t pad_front = 0)
 {
+    PhaseClock pc(c, "stage_in (host -> device)");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, c->st_in.ensure(pad_front + n + 64));
     if (n) HIPCHK(c, hipMemcpyAsync(c->st_in.p + pad_front, in, n, hipMemcpyHostToDevice, c->stream));
@@ -570,6 +587,7 @@ static void par_memcpy(uint8_t *dst, const uint8_t *src, size_t n)
 static int d2h_payload(zngamd_ctx *c, uint8_t *dst, const uint8_t *src_dev, uint64_t n)
 {
     if (!n) return ZNGAMD_OK;
+    PhaseClock pc(c, "d2h_payload (device -> caller)");
     const uint64_t piece = std::min<uint64_t>(ZNGAMD_D2H_PIECE, n);
     uint8_t *st = nullptr;
     int r = host_stage(c, n <= piece ? n : 2 * piece, &st);
@@ -596,16 +614,19 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
                                const uint8_t **packed, int max_dist = ZA_WIN,
                                uint8_t *direct_out = nullptr, uint64_t direct_cap = 0, uint64_t *direct_len = nullptr)
 {
-    int r = build_units(c, blocks, n_blocks, in_len, hu);
+    int r;
+    { PhaseClock pc(nullptr, "build_units"); r = build_units(c, blocks, n_blocks, in_len, hu); }
     if (r) return r;
     const uint32_t n = (uint32_t)hu.size();
     HIPCHK(c, c->st_slots.ensure((size_t)n * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(n)); HIPCHK(c, c->st_crc.ensure(n));
-    r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p, max_dist);
+    { PhaseClock pc(c, "deflate kernels");
+      r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p, max_dist); }
     if (r) return r;
     // upper bound of the packed size without a round trip: every unit fits its slot
     HIPCHK(c, c->st_out.ensure((size_t)n * ZNGAMD_SLOT_STRIDE));
     uint64_t total = 0;
-    r = gather_dev(c, c->st_slots.p, c->st_len.p, n, 0, c->st_out.p, 0, (uint64_t)n * ZNGAMD_SLOT_STRIDE, nullptr, &total, true);
+    { PhaseClock pc(c, "gather");
+      r = gather_dev(c, c->st_slots.p, c->st_len.p, n, 0, c->st_out.p, 0, (uint64_t)n * ZNGAMD_SLOT_STRIDE, nullptr, &total, true); }
     if (r) return r;
     // one-shot callers take the packed stream straight into their buffer (no intermediate copy)
     const bool direct = direct_out != nullptr;
@@ -614,6 +635,7 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
     uint8_t *stage = nullptr;
     if (!direct) { int rs = host_stage(c, total, &stage); if (rs) return rs; *packed = stage; }
     std::vector<uint32_t> st(n);
+    PhaseClock pc(c, "results to the host");
     HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
@@ -651,6 +673,38 @@ try {
         crc[b] = bc;
         if (tot >= out_cap_per_block) { out_len[b] = 0xFFFFFFFFu; ret = ZNGAMD_E_OVERFLOW; continue; }
         memcpy(out + (size_t)b * out_cap_per_block, packed + start, tot);
+        out_len[b] = (uint32_t)tot;
+    }
+    if (ret) c->err = "Compressed output exceeds buffer size";
+    return ret;
+} ZA_ABI_GUARD
+
+int zngamd_deflate_blocks_packed(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                                 int level, uint8_t *out, uint64_t out_cap, uint64_t block_cap, uint32_t *out_len, uint32_t *crc, uint64_t *total)
+try {
+    if (!c || (!in && in_len) || (!blocks && n_blocks) || !out || !out_len || !crc || !total) return ZNGAMD_E_ARG;
+    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    std::lock_guard<std::mutex> g(c->mu);
+    *total = 0;
+    int r = stage_in(c, in, in_len);
+    if (r) return r;
+    std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; const uint8_t *packed = nullptr;
+    const uint32_t wb = n_blocks ? (blocks[0].flags >> 8) & 15u : 0u;
+    if (wb != 0 && wb < 9) return fail(c, ZNGAMD_STREAM_ERROR, "window bits must be 9..15");
+    r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, &packed, wb ? (1 << wb) : ZA_WIN, out, out_cap, total);
+    if (r) return r;
+    int ret = ZNGAMD_OK;
+    size_t u = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        uint64_t tot = 0; uint32_t bc = 0;
+        bool first = true;
+        for (; u < hu.size() && hu[u].block == b; u++) {
+            tot += ulen[u];
+            bc = first ? ucrc[u] : zngamd_crc32_combine(bc, ucrc[u], hu[u].in_len);
+            first = false;
+        }
+        crc[b] = bc;
+        if (tot >= block_cap) { out_len[b] = 0xFFFFFFFFu; ret = ZNGAMD_E_OVERFLOW; continue; }
         out_len[b] = (uint32_t)tot;
     }
     if (ret) c->err = "Compressed output exceeds buffer size";
@@ -1088,6 +1142,10 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     const uint32_t max_s = (uint32_t)std::min<uint64_t>(avail / 4 + 1024, 1u << 25);
     HIPCHK(c, c->ccand.ensure((size_t)max_c + 1)); HIPCHK(c, c->csurv.ensure(max_s));
     uint32_t *d_n = (uint32_t *)((uint8_t *)c->d_small + 128);          // [0] candidates, [1] survivors
+    PhaseClock pc_all(c, "chunk-parallel inflate, all of it");
+    auto *pc = new PhaseClock(c, "  sync scan + candidates");
+    struct PcOwner { PhaseClock *&p; ~PcOwner() { delete p; } } pc_owner{pc};
+    auto phase = [&](const char *name) { delete pc; pc = nullptr; pc = new PhaseClock(c, name); };
     HIPCHK(c, hipMemsetAsync(d_n, 0, 8, c->stream));
     {   ProfScope ps(c, ZNGAMD_K_SCAN);
         const uint64_t threads = (avail + 15) / 16;
@@ -1105,7 +1163,8 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     // A stream written block-parallel (the reference's threaded writer, pigz, this engine) has a sync point every block: when
     // no stretch of more than 2 MiB is without one, those are boundaries enough and the bit-level header finder (a pass over
     // every bit offset of the stream, about as dear as the decode itself) is not run.
-    bool dense = cnt[0] >= 8;
+    static const uint32_t dense_min = getenv("ZNGAMD_DENSE_MIN") ? (uint32_t)atol(getenv("ZNGAMD_DENSE_MIN")) : 8u;
+    bool dense = cnt[0] >= dense_min;
     if (dense) {
         std::sort(cand.begin(), cand.end());
         uint64_t prev = o.start_bit, gap = 0;
@@ -1140,6 +1199,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     const uint32_t n = (uint32_t)cand.size();
     if (getenv("ZNGAMD_DEBUG")) fprintf(stderr, "zng_amd: chunk finder: %u sync hits, %u header survivors, %u candidates\n", cnt[0], cnt[1], n);
     if (n < 8 || n > max_c) return chunk_bail(3);                    // too few boundaries to be worth it
+    phase("  count pass");
     HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(n));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
@@ -1153,6 +1213,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // follow the chain of real block boundaries from the start of the stream, then group blocks into chunks:
     // about 4096 of them (12 marker decoders fit a CU), none below 32 KiB (a chunk's tail is the next window)
+    phase("  chain of blocks on the host");
     std::vector<ZaChunk> blocks;
     uint64_t acc = 0, end_bit = 0;
     bool ended = false;
@@ -1174,7 +1235,8 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
             i = (size_t)(it - cand.begin());
         }
     }
-    const uint64_t target = std::max<uint64_t>(32u << 10, acc / 4096);
+    static const uint64_t chunk_div = getenv("ZNGAMD_CHUNK_DIV") ? (uint64_t)atol(getenv("ZNGAMD_CHUNK_DIV")) : 4096u;
+    const uint64_t target = std::max<uint64_t>(32u << 10, acc / chunk_div);
     std::vector<ZaChunk> chain;
     for (size_t b = 0; b < blocks.size();) {
         ZaChunk cur = blocks[b++];
@@ -1194,6 +1256,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     const uint32_t groups = (m + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
     HIPCHK(c, c->cchunks.ensure(m)); HIPCHK(c, c->out16.ensure(acc + 64)); HIPCHK(c, c->winbuf.ensure((size_t)groups * ZA_WIN));
     HIPCHK(c, c->ccomp.ensure((size_t)m * ZA_WIN));
+    phase("  marker decode");
     HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->cres.ensure(m));
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
@@ -1210,6 +1273,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         if (res[k].status != ((last && ended) ? ZA_I_END : ZA_I_SYNC) || res[k].out_len != chain[k].out_len || res[k].bits != chain[k].end_bit) return chunk_bail(7);
         if (res[k].max_back > chain[k].out_off + o.dict_len) return chunk_bail(8);       // reference before the start of the stream
     }
+    phase("  windows + resolve");
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
       hipLaunchKernelGGL(za_k_chunk_compose, dim3(groups), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->ccomp.p);
       hipLaunchKernelGGL(za_k_chunk_chain, dim3(1), dim3(1024), 0, c->stream, c->ccomp.p, m, c->winbuf.p, o.d_dict, o.dict_len);
@@ -1323,10 +1387,17 @@ static int hop_plain_members(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, 
     return ZNGAMD_OK;
 }
 
+struct StreamRun { int status; uint64_t out_len; uint64_t in_bits; bool chunked; };
+static int stream_finish(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, uint64_t doff, bool last, const StreamRun &run,
+                         uint32_t dl, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed);
+
 // partial: more input may follow -- complete members are decoded, an incomplete last one is left alone and
 // *in_consumed tells where it starts (ZNGAMD_OK; nothing consumed = the window holds no complete member yet).
+// With a stream state (st, partial only) a FIRST member that runs past the window is not left alone: the blocks of it that
+// are complete were decoded on the way to finding that out, so they are handed out and the state says where the next
+// window continues (what zngamd_gunzip_stream would otherwise do in a second pass over the same window).
 static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool partial, uint8_t *out, uint64_t out_cap,
-                       uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
+                       uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed, zngamd_gz_state *st = nullptr)
 {
     *out_len = 0;
     *in_consumed = 0;
@@ -1455,10 +1526,17 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
             uint64_t piece = rest;
             if (members > 0) piece = std::min<uint64_t>(rest, std::max<uint64_t>(4ull << 20, 2 * last_member_bytes));
             int cr;
+            const bool may_continue = partial && st && members == 0 && op == 0 && pos == 0;
+            ChunkOpts copts; copts.allow_cut = may_continue;
             for (;;) {
-                cr = inflate_chunked_dev(c, c->st_in.p + doff, piece, c->st_out.p + op, out_cap - op, &clen, &cused, ChunkOpts(), &ci);
+                cr = inflate_chunked_dev(c, c->st_in.p + doff, piece, c->st_out.p + op, out_cap - op, &clen, &cused, copts, &ci);
                 if (piece < rest && ci.cut) { piece = std::min<uint64_t>(rest, piece * 4); continue; }      // the member is longer than the piece: more
                 break;
+            }
+            if (may_continue && cr == 0 && !ci.ended) {           // the member goes on behind the window: its complete blocks are out
+                st->in_member = 0; st->start_bit = 0; st->crc = 0; st->window_len = 0; st->out_total = 0;
+                StreamRun run; run.status = ZA_I_INPUT; run.out_len = clen; run.in_bits = ci.end_bit; run.chunked = true;
+                return stream_finish(c, st, in, in_len, doff, false, run, 0, out, out_cap, out_len, n_members, in_consumed);
             }
             const bool cut = ci.cut;
             if (cr < 0 && cr != ZNGAMD_BUF_ERROR) return cr;
@@ -1512,7 +1590,6 @@ try {
 } ZA_ABI_GUARD
 
 // ---- one member that is larger than the caller's window: decoded block-wise across calls -------------------
-struct StreamRun { int status; uint64_t out_len; uint64_t in_bits; bool chunked; };
 
 // Decodes the deflate stream that starts at bit `start_bit` of d_def[0] with `dict_len` bytes of history.  With allow_cut a
 // stream that runs past the buffer is decoded up to its last complete block: status ZA_I_INPUT, in_bits = where the next
@@ -1550,6 +1627,15 @@ static int stream_step(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, ui
     r = decode_stream_prefix(c, c->st_in.p + front + doff, in_len - doff, st->start_bit & 7u, c->st_in.p, dl, c->st_out.p, out_cap, !last, &run, &needed);
     if (r == ZNGAMD_BUF_ERROR) { *out_len = needed > out_cap ? needed : out_cap; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
     if (r) return r;
+    return stream_finish(c, st, in, in_len, doff, last, run, dl, out, out_cap, out_len, n_members, in_consumed);
+}
+
+// What follows the decode of a piece of a member that is continued across windows (run: how far it got; the decoded bytes are
+// at st_out): CRC fold, trailer check at the end of the member, hand-out, and the state the next window continues with.
+static int stream_finish(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, uint64_t doff, bool last, const StreamRun &run,
+                         uint32_t dl, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
+{
+    int r;
     if (run.status != ZA_I_END && run.status != ZA_I_INPUT) { c->err = "invalid deflate data"; return map_status(run.status); }
     if (run.status == ZA_I_INPUT && last) {
         if (run.out_len) { const int rc_ = d2h_payload(c, out, c->st_out.p, run.out_len); if (rc_) return rc_; }
@@ -1600,7 +1686,7 @@ try {
     *out_len = 0; *in_consumed = 0;
     if (n_members) *n_members = 0;
     if (st->in_member) return stream_step(c, st, in, in_len, 0, last != 0, out, out_cap, out_len, n_members, in_consumed);
-    int r = gunzip_impl(c, in, in_len, !last, out, out_cap, out_len, n_members, in_consumed);
+    int r = gunzip_impl(c, in, in_len, !last, out, out_cap, out_len, n_members, in_consumed, last ? nullptr : st);
     if (r != ZNGAMD_OK || last || *in_consumed > 0 || in_len == 0) return r;
     // not even the first member is complete in this window: start it and hand out the blocks that are
     uint64_t doff = 0; bool za = false; uint32_t hl = 0;

@@ -31,7 +31,7 @@ SYMBOLS = [
     "zngamd_device_count", "zngamd_ctx_create", "zngamd_ctx_destroy", "zngamd_last_error", "zngamd_version",
     "zngamd_set_stream", "zngamd_sync", "zngamd_dmalloc", "zngamd_dfree", "zngamd_h2d", "zngamd_d2h",
     "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
-    "zngamd_deflate_blocks", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
+    "zngamd_deflate_blocks", "zngamd_deflate_blocks_packed", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev", "zngamd_compare_dev", "zngamd_crc32_fold_dev",
     "zngamd_stream_deflate_init", "zngamd_stream_deflate", "zngamd_stream_deflate_set_dictionary", "zngamd_stream_deflate_copy", "zngamd_stream_pending", "zngamd_stream_inflate_ahead",
@@ -96,6 +96,8 @@ def load():
         L.zngamd_level_ok.argtypes = [C.c_int]
         L.zngamd_deflate_blocks.argtypes = [vp, u8p, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
                                             u8p, C.c_uint64, u32p, u32p]
+        L.zngamd_deflate_blocks_packed.argtypes = [vp, u8p, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
+                                                   u8p, C.c_uint64, C.c_uint64, u32p, u32p, C.POINTER(C.c_uint64)]
         L.zngamd_count_units.argtypes = [C.POINTER(Block), C.c_uint32]
         L.zngamd_count_units.restype = C.c_uint32
         L.zngamd_deflate_blocks_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
@@ -188,11 +190,33 @@ _py.PyBytes_AsString.restype = C.c_void_p
 _py.PyBytes_AsString.argtypes = [C.py_object]
 
 
+_HUGE_MIN = 8 << 20
+try:
+    _madvise = C.CDLL(None, use_errno=True).madvise
+    _madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    _madvise.restype = C.c_int
+except Exception:                                    # pragma: no cover
+    _madvise = None
+
+
+def _advise_huge(addr, n):
+    """Fresh memory of a large buffer is first touched by the engine's copy threads or a file read, one page fault per 4 KiB
+    (21 000 for an 88 MB result, more time than the copy itself) -- with transparent huge pages one per 2 MiB, where the
+    system allows them on request.  A refusal changes nothing."""
+    if n >= _HUGE_MIN and _madvise is not None:
+        lo = (addr + 0x1FFFFF) & ~0x1FFFFF
+        hi = (addr + n) & ~0x1FFFFF
+        if hi > lo:
+            _madvise(C.c_void_p(lo), C.c_size_t(hi - lo), 14)       # MADV_HUGEPAGE
+
+
 def _new_bytes(n):
     """A fresh, uninitialised bytes object of n >= 1 bytes for the engine to fill, and its address: no zero fill,
     and no copy when the engine fills it completely."""
     obj = _py.PyBytes_FromStringAndSize(None, max(int(n), 1))
-    return obj, C.c_void_p(_py.PyBytes_AsString(obj))
+    addr = _py.PyBytes_AsString(obj)
+    _advise_huge(addr, int(n))
+    return obj, C.c_void_p(addr)
 
 
 new_buffer = _new_bytes          # for callers that keep an output buffer across calls (see Context.gunzip_stream)
@@ -212,15 +236,6 @@ _raw_resize = C.PYFUNCTYPE(C.c_int, C.POINTER(C.c_void_p), C.c_ssize_t)(("_PyByt
 _raw_decref = C.PYFUNCTYPE(None, C.c_void_p)(("Py_DecRef", C.pythonapi))
 
 
-_HUGE_MIN = 8 << 20
-try:
-    _madvise = C.CDLL(None, use_errno=True).madvise
-    _madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
-    _madvise.restype = C.c_int
-except Exception:                                    # pragma: no cover
-    _madvise = None
-
-
 class _Out:
     """An engine output buffer on its way to becoming the result: a fresh bytes object that Python has not seen yet (it is
     held through a bare pointer with its single reference), so it can be cut to the produced length in place
@@ -232,15 +247,7 @@ class _Out:
         self.ptr = C.c_void_p(_raw_new(None, self.cap))
         if not self.ptr.value:
             raise MemoryError("cannot allocate the result")
-        if self.cap >= _HUGE_MIN and _madvise is not None:
-            # a large result is fresh memory: first touched by the engine's copy threads, one page fault per 4 KiB (21 000 for an
-            # 88 MB result, more time than the copy itself) -- with transparent huge pages one per 2 MiB, where the system allows
-            # them on request
-            a = _raw_buf(self.ptr)
-            lo = (a + 0x1FFFFF) & ~0x1FFFFF
-            hi = (a + self.cap) & ~0x1FFFFF
-            if hi > lo:
-                _madvise(C.c_void_p(lo), C.c_size_t(hi - lo), 14)       # MADV_HUGEPAGE; a refusal changes nothing
+        _advise_huge(_raw_buf(self.ptr), self.cap)
 
     def addr(self):
         return C.c_void_p(_raw_buf(self.ptr))
@@ -279,6 +286,61 @@ class _Out:
 
 def _take(obj, n):
     return obj if n == len(obj) else obj[:n]
+
+
+# Large host buffers of the streaming writers and readers (collected input, packed output, file windows).  Fresh memory costs a
+# page fault per 4 KiB on first touch -- 3.3 us each on the GPU boxes, 54 ms for a 64 MiB buffer, more than compressing it -- so
+# such buffers ask for transparent huge pages and go back to a small process-wide pool when their owner closes (like the
+# contexts' device workspaces, which also live as long as the process): the next file opened finds them warm.
+_POOL_MAX_BYTES = max(0, int(os.environ.get("ZNGAMD_HOST_POOL_MIB", "1024"))) << 20      # (0: nothing is kept)
+_buffer_pool, _buffer_pool_lock = [], threading.Lock()
+
+
+def take_buffer(n):
+    """A bytearray of at least n bytes (contents arbitrary), warm if the pool has one."""
+    n = max(int(n), 1)
+    with _buffer_pool_lock:
+        best = None
+        for i, b in enumerate(_buffer_pool):
+            if len(b) >= n and (best is None or len(b) < len(_buffer_pool[best])):
+                best = i
+        if best is not None and len(_buffer_pool[best]) <= 2 * n + (1 << 20):
+            return _buffer_pool.pop(best)
+    buf = bytearray(n)
+    if n >= _HUGE_MIN:
+        anchor = C.c_char.from_buffer(buf)
+        _advise_huge(C.addressof(anchor), n)
+        del anchor
+    return buf
+
+
+def give_buffer(buf):
+    """Hand a buffer from take_buffer() back (nothing may still read or write it)."""
+    if not isinstance(buf, bytearray) or len(buf) < (1 << 20):
+        return
+    with _buffer_pool_lock:
+        if sum(len(b) for b in _buffer_pool) + len(buf) <= _POOL_MAX_BYTES:
+            _buffer_pool.append(buf)
+
+
+def take_window(n):
+    """(buffer, address) for Context.gunzip_stream(into=...): a pooled buffer the engine decodes a window into."""
+    buf = take_buffer(n)
+    anchor = C.c_char.from_buffer(buf)
+    addr = C.c_void_p(C.addressof(anchor))
+    del anchor
+    return buf, addr
+
+
+def block_table(blocks):
+    """(ctypes table, count) of a list of (off, len, dict_len, flags) for Context.deflate_blocks."""
+    n = len(blocks)
+    arr = (Block * max(n, 1))()
+    for i, (off, ln, dl, fl) in enumerate(blocks):
+        if ln > 0xFFFFFFFF or dl > 0xFFFFFFFF:            # ctypes would cut the u32 fields silently
+            raise OverflowError("a block is limited to 4 GiB - 1 bytes: split it")
+        arr[i] = Block(off, ln, dl, fl, 0)
+    return arr, n
 
 
 class Context:
@@ -345,20 +407,36 @@ class Context:
         return self.L.zngamd_crc32_combine(crc1 & 0xFFFFFFFF, crc2 & 0xFFFFFFFF, len2)
 
     # ---- deflate
-    def deflate_blocks(self, buf, blocks, level, out_cap, joined=False):
-        """blocks: list of (off, len, dict_len, flags).  -> (list of bytes|None, list of crc, overflowed); with joined=True
-        the first element is ONE bytes object, the blocks' outputs back to back (a writer that only concatenates them
-        saves the allocation and release of one object per block) and a list of lengths is appended to the result."""
-        n = len(blocks)
-        arr = (Block * max(n, 1))()
-        for i, (off, ln, dl, fl) in enumerate(blocks):
-            if ln > 0xFFFFFFFF or dl > 0xFFFFFFFF:            # ctypes would cut the u32 fields silently
-                raise OverflowError("a block is limited to 4 GiB - 1 bytes: split it")
-            arr[i] = Block(off, ln, dl, fl, 0)
+    def deflate_blocks(self, buf, blocks, level, out_cap, joined=False, into=None):
+        """blocks: list of (off, len, dict_len, flags), or a table made by block_table() (a writer whose batches have the
+        same shape makes it once).  -> (list of bytes|None, list of crc, overflowed); with joined=True the first element is
+        ONE object, the blocks' outputs back to back (a writer that only concatenates them saves the allocation and release
+        of one object per block) and a list of lengths is appended to the result: the engine copies the packed stream
+        straight into it (zngamd_deflate_blocks_packed).  `into` (joined only): a bytearray of at least n * out_cap bytes
+        that takes the output -- the result is then a memoryview of its filled part (a writer that keeps two of them
+        writes into warm memory; a fresh object costs a page fault per 4 KiB)."""
+        arr, n = blocks if isinstance(blocks, tuple) and len(blocks) == 2 and isinstance(blocks[0], C.Array) else block_table(blocks)
         p, keep = _addr(buf)
         lens = (C.c_uint32 * max(n, 1))()
         crcs = (C.c_uint32 * max(n, 1))()
         need = max(n, 1) * out_cap
+        if joined:
+            total = C.c_uint64(0)
+            if into is not None and len(into) >= need:
+                anchor = C.c_char.from_buffer(into)
+                r = self.L.zngamd_deflate_blocks_packed(self.h, p, memoryview(buf).nbytes, arr, n, level,
+                                                        C.cast(C.addressof(anchor), C.c_void_p), len(into), out_cap,
+                                                        C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p), C.byref(total))
+                del anchor
+                self._chk(r, (OK, E_OVERFLOW))
+                res = None if r == E_OVERFLOW else memoryview(into)[:total.value]
+            else:
+                out = _Out(need)
+                r = self.L.zngamd_deflate_blocks_packed(self.h, p, memoryview(buf).nbytes, arr, n, level, out.addr(), need, out_cap,
+                                                        C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p), C.byref(total))
+                self._chk(r, (OK, E_OVERFLOW))
+                res = None if r == E_OVERFLOW else out.take(total.value)
+            return res, list(crcs[:n]), r == E_OVERFLOW, list(lens[:n])
         # The per-block outputs land in a buffer that lives with the context: device-to-host copies into memory that has
         # been touched (and registered by the runtime) before run several times faster than into fresh pages.  The lock
         # covers the call and the slicing (engine calls of one context are serial anyway).
@@ -373,13 +451,6 @@ class Context:
             self._chk(r, (OK, E_OVERFLOW))
             res = []
             mv = memoryview(out)
-            if joined:
-                if r == E_OVERFLOW:
-                    res = None
-                else:
-                    res = b"".join([mv[i * out_cap:i * out_cap + lens[i]] for i in range(n)])
-                del mv
-                return res, list(crcs[:n]), r == E_OVERFLOW, list(lens[:n])
             for i in range(n):
                 if lens[i] == 0xFFFFFFFF:
                     res.append(None)
@@ -561,18 +632,21 @@ def contexts(limit=None):
     return out
 
 
-def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap):
+def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=None):
     """deflate_blocks(joined=True) over several contexts: the blocks are cut into contiguous ranges of about equal input,
     one per context; every range goes to its GPU as the slice of `buf` it needs (its blocks and the dictionary in front of
     its first block -- the previous range's input tail), the ranges run side by side (the engine calls release the GIL) and
     the results come back in block order.  This is the reference's worker fan-out (gzip_ng_threaded.py:233-246, :316-321)
     with contiguous ranges in place of round-robin, and its in-order drain (:382-398).
-    -> (packed bytes, crcs, overflowed, lens) like Context.deflate_blocks(joined=True)."""
+    -> (packed bytes, crcs, overflowed, lens) like Context.deflate_blocks(joined=True); `into` and `table` (block_table(blocks),
+    made once by a caller whose batches repeat) serve the one-GPU case."""
     n = len(blocks)
-    total = sum(b[1] for b in blocks)
     g = min(len(ctxs), n)
-    if g <= 1 or total < (8 << 20) or sys.is_finalizing():      # (no new threads while the interpreter shuts down)
-        return ctxs[0].deflate_blocks(buf, blocks, level, out_cap, joined=True)
+    if g <= 1 or sys.is_finalizing():      # (no new threads while the interpreter shuts down)
+        return ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into)
+    total = sum(b[1] for b in blocks)
+    if total < (8 << 20):
+        return ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into)
     mv = memoryview(buf)
     if mv.format != "B" or mv.ndim != 1:
         mv = mv.cast("B")

@@ -18,6 +18,7 @@ starts a new one; `close()` after the buffered writer's implicit flush leaves a 
 """
 import builtins
 import collections
+import ctypes
 import io
 import multiprocessing
 import os
@@ -29,6 +30,7 @@ import threading
 from . import _lib, gzip_ng, zlib_ng
 
 DEFLATE_WINDOW_SIZE = 2 ** 15
+_UNLOCKED_COPY_FROM = 32 * 1024          # pieces from this size on are copied with the interpreter lock released
 
 
 def open(filename, mode="rb", compresslevel=gzip_ng._COMPRESS_LEVEL_TRADEOFF, encoding=None, errors=None,
@@ -48,10 +50,14 @@ def open(filename, mode="rb", compresslevel=gzip_ng._COMPRESS_LEVEL_TRADEOFF, en
     if "r" in mode:
         stream = io.BufferedReader(_ThreadedGzipReader(filename, block_size=block_size))
     else:
+        # The reference buffers block_size bytes in front of its writer (gzip_ng_threaded.py:70-75).  The writer below collects
+        # small writes itself, so this buffer only has to spare it a Python call per line: at most 64 KiB - 1, which lets the
+        # reference's benchmark pattern (128 KiB per call, benchmark_scripts/gzipwrite128kblocks.py) and anything larger reach
+        # the writer without being copied here first -- io.BufferedWriter hands on what is longer than its buffer as it is.
         stream = FlushableBufferedWriter(
             _ThreadedGzipWriter(filename, mode.replace("t", "b"), block_size=block_size, level=compresslevel,
                                 threads=threads),
-            buffer_size=block_size)
+            buffer_size=max(io.DEFAULT_BUFFER_SIZE, min(block_size, 1 << 16) - 1))
     return io.TextIOWrapper(stream, encoding, errors, newline) if "t" in mode else stream
 
 
@@ -85,6 +91,7 @@ class _ThreadedGzipReader(io.RawIOBase):
         self._finished = False                       # pump has ended (end of stream or failure)
         self._failure = None
         self._current = memoryview(b"")
+        self._current_addr, self._current_keep = 0, None   # where the unread rest of the window lies (copies without the interpreter lock)
         self._token = None                           # buffer of the window being consumed (goes back to the inner reader)
         self._closed = False
         self._stop = False
@@ -137,9 +144,19 @@ class _ThreadedGzipReader(io.RawIOBase):
             if piece is None:
                 return 0
             self._current, self._token = piece
+            self._current_addr, self._current_keep = _lib._addr(self._current)
+            self._current_addr = self._current_addr.value or 0
         n = min(len(out), len(self._current))
-        out[:n] = self._current[:n]
+        if n >= _UNLOCKED_COPY_FROM and self._current_addr and not out.readonly:
+            # (the pump thread needs the interpreter lock between its file read and its engine call: a consumer that copies
+            # with the lock held makes it wait for the switch interval each time)
+            anchor = ctypes.c_char.from_buffer(out)
+            ctypes.memmove(ctypes.addressof(anchor), self._current_addr, n)
+            del anchor
+        else:
+            out[:n] = self._current[:n]
         self._current = self._current[n:]
+        self._current_addr += n
         self.pos += n
         return n
 
@@ -159,6 +176,12 @@ class _ThreadedGzipReader(io.RawIOBase):
         with self._cv:
             self._cv.notify_all()
         self._pump_thread.join()
+        self._current = memoryview(b"")
+        self._current_addr, self._current_keep = 0, None
+        self.fileobj._give_back(self._token)         # window buffers go back to the inner reader, and with it to the pool
+        self._token = None
+        while self._parked:
+            self.fileobj._give_back(self._parked.popleft()[1])
         self.fileobj.close()
         if self.closefd:
             self.raw.close()
@@ -211,9 +234,16 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self._crc = 0
         self._size = 0
         self._write_thread = None                    # file write of the last bulk batch, still running
-        self._coalesce_limit = max(8 * block_size, 32 << 20)     # writes below this are collected up to this many bytes
+        # writes below this are collected up to this many bytes: a batch of 64 MiB is 512 units of work for 1 024 SIMDs -- the
+        # kernels of a 32 MiB batch took 1.7 ms, four times the time per byte of a full device
+        self._coalesce_limit = max(8 * block_size, 64 << 20)
         self._small, self._small_n = None, 0
+        self._small_view = None                      # writable view of _small: a slice assignment through it is one memcpy
+        self._small_addr = 0                         # its address: large pieces are copied with the interpreter lock released
         self._small_other = None                     # the second collecting buffer: one fills while the other is compressed
+        self._packed = [None, None]                  # output buffers of the batches, used in turn (one is written to the file
+        self._packed_turn = 0                        # while the next batch fills the other): warm memory, no object per batch
+        self._table_key, self._table = None, None    # block table of the last batch: batches of one shape share it
         self._batch_thread, self._batch_error = None, None
         self._write_error = None
         self.running = False
@@ -241,9 +271,10 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self.output_worker.join()
 
     def write(self, b):
-        self._check_closed()
-        with self.lock:
-            if self.exception:
+        if self._closed:
+            raise ValueError("I/O operation on closed file")
+        if self.exception is not None:
+            with self.lock:
                 raise self.exception
         nbytes = b.nbytes if isinstance(b, memoryview) else len(b)
         if nbytes >= self._coalesce_limit:
@@ -257,14 +288,33 @@ class _ThreadedGzipWriter(io.RawIOBase):
         # more than the compression itself.)
         R = DEFLATE_WINDOW_SIZE
         if self._small is None:
-            self._small = bytearray(R + self._coalesce_limit)       # [room for the 32 KiB in front][collected bytes]
+            self._adopt_small(_lib.take_buffer(R + self._coalesce_limit))  # [room for the 32 KiB in front][collected bytes]
         n = self._small_n
         if n + nbytes > self._coalesce_limit:
             self._flush_small(wait=False)            # the full buffer is compressed and written while the other one fills
             n = 0
-        self._small[R + n:R + n + nbytes] = b
+        if nbytes >= _UNLOCKED_COPY_FROM:
+            # The copy of a large piece runs with the interpreter lock released (a foreign call): the batch thread needs the lock
+            # between its engine call, the file write and its bookkeeping, and a caller that never lets go of it -- a loop of
+            # write() calls does not -- makes every one of those wait for the interpreter's switch interval (5 ms; a batch
+            # takes 4).
+            src, keep = _lib._addr(b)
+            ctypes.memmove(self._small_addr + R + n, src, nbytes)
+            del keep
+        else:
+            try:
+                self._small_view[R + n:R + n + nbytes] = b          # (a bytearray slice assignment copies a memoryview twice)
+            except (TypeError, ValueError):                         # not a flat byte buffer: through the bytearray
+                self._small[R + n:R + n + nbytes] = b
         self._small_n = n + nbytes
         return nbytes
+
+    def _adopt_small(self, buf):
+        self._small = buf
+        self._small_view = memoryview(buf)
+        anchor = ctypes.c_char.from_buffer(buf)
+        self._small_addr = ctypes.addressof(anchor)                 # (the bytearray is never resized: the address stays)
+        del anchor
 
     def _flush_small(self, wait=True):
         """The collected bytes as ONE engine batch: the tail of what was written before is put in front of them in the
@@ -284,24 +334,28 @@ class _ThreadedGzipWriter(io.RawIOBase):
             t = tail.nbytes
             buf[R - t:R] = tail
             view = memoryview(buf)[R - t:R + n]
-            blocks = [(t + o, min(bs, n - o), min(R, t + o), 0) for o in range(0, n, bs)]
+            key = (t, n, bs)
+            if key != self._table_key:
+                blocks = [(t + o, min(bs, n - o), min(R, t + o), 0) for o in range(0, n, bs)]
+                self._table_key, self._table = key, (blocks, _lib.block_table(blocks))
+            blocks, table = self._table
             self._size += n
             last = n - ((n - 1) // bs) * bs
             self.previous_block = bytes(buf[R + n - last:R + n])
             if wait or sys.is_finalizing():
-                self._emit(view, blocks)
+                self._emit(view, blocks, table)
             else:
-                self._batch_thread = threading.Thread(target=self._emit_guarded, args=(view, blocks), name="zng-amd-writer-batch")
+                self._batch_thread = threading.Thread(target=self._emit_guarded, args=(view, blocks, table), name="zng-amd-writer-batch")
                 self._batch_thread.start()
-                if self._small_other is None:
-                    self._small_other = bytearray(len(buf))
-                self._small, self._small_other = self._small_other, buf
+                other = self._small_other if self._small_other is not None else _lib.take_buffer(len(buf))
+                self._small_other = buf
+                self._adopt_small(other)
         if wait:
             self._join_batch()
 
-    def _emit_guarded(self, view, blocks):
+    def _emit_guarded(self, view, blocks, table):
         try:
-            self._emit(view, blocks)
+            self._emit(view, blocks, table)
         except BaseException as exc:                 # raised by the next call of the owner
             self._batch_error = exc
 
@@ -348,17 +402,28 @@ class _ThreadedGzipWriter(io.RawIOBase):
         self.previous_block = bytes(view[nbytes - last:nbytes])
         return nbytes
 
-    def _emit(self, buf, blocks):
+    def _emit(self, buf, blocks, table=None):
         """One engine batch (spread over the writer's GPUs) and the write of its output."""
         cap = self.block_size + max(self.block_size // 10, 500)
-        packed, crcs, overflowed, _ = _lib.deflate_blocks_multi(self._contexts(), buf, blocks, self.level, cap)
+        turn = self._packed_turn
+        self._packed_turn = turn ^ 1
+        need = len(blocks) * cap
+        into = self._packed[turn]
+        if into is None or len(into) < need:                     # (the file write of the batch before last, which used it, is through)
+            _lib.give_buffer(into)
+            into = self._packed[turn] = _lib.take_buffer(need)
+        packed, crcs, overflowed, _ = _lib.deflate_blocks_multi(self._contexts(), buf, blocks, self.level, cap, into=into, table=table)
         if overflowed:
             raise OverflowError(f"Compressed output exceeds buffer size of {cap}")
-        for (_, ln, _, _), crc in zip(blocks, crcs):
-            self._crc = zlib_ng.crc32_combine(self._crc, crc, ln)
+        crc, combine = self._crc, zlib_ng.crc32_combine
+        for (_, ln, _, _), c in zip(blocks, crcs):
+            crc = combine(crc, c, ln)
+        self._crc = crc
         # the file write of this batch runs beside the compression of the next one (the engine call and the write
         # both release the GIL); the previous batch's write has to be through first: the order is the stream
         self._settle_write()
+        if not isinstance(self.raw, (io.FileIO, io.BufferedWriter, io.BufferedRandom, io.BytesIO)):
+            packed = bytes(packed)                   # an object of the caller's: it may keep what it is given
         if sys.is_finalizing():                      # closed by the garbage collector at exit: a thread started now never runs
             self.raw.write(packed)
             return
@@ -415,6 +480,16 @@ class _ThreadedGzipWriter(io.RawIOBase):
         if self.closefd:
             self.raw.close()
         self._closed = True
+        self._release_buffers()
+
+    def _release_buffers(self):
+        """The collecting and output buffers go back to the process-wide pool (no batch and no file write is running)."""
+        self._small_view = None
+        for b in (self._small, self._small_other, self._packed[0], self._packed[1]):
+            if b is not None:
+                _lib.give_buffer(b)
+        self._small = self._small_other = None
+        self._packed = [None, None]
 
     @property
     def closed(self):

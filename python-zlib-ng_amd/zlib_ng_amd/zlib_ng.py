@@ -796,18 +796,36 @@ class _GzipReader:
         self._error = None       # raised once the buffered good bytes are gone
         self._first = True
         self._state = _lib.GzState()      # where a member larger than the window is being continued
-        self._out = None                  # decoded window (object, address); reused, so its pages are faulted in once
+        self._release_windows()
+        self._out = None                  # decoded window (buffer, address); reused, so its pages are faulted in once
         self._spare = []                  # buffers given back by a consumer that took whole windows (_take_window)
+        self._in_buf = None               # the compressed window: one buffer, refilled (the engine call is through by then)
+
+    def _release_windows(self):
+        """Window buffers go back to the process-wide pool (_lib.take_buffer): the next reader finds them warm."""
+        self._buf = b""
+        for pair in [getattr(self, "_out", None)] + list(getattr(self, "_spare", [])):
+            if pair is not None:
+                _lib.give_buffer(pair[0])
+        _lib.give_buffer(getattr(self, "_in_buf", None))
+        self._out, self._spare, self._in_buf = None, [], None
 
     # -- compressed input, one window at a time
     def _read_window(self, carry):
         """The unconsumed tail of the previous window followed by up to one window of new input, in one buffer."""
         if not self._is_file:
             self._in_eof = True
-            return carry + bytes(_view(self._fp)) if self._first else carry
+            return bytes(carry) + bytes(_view(self._fp)) if self._first else carry
         keep = len(carry)
-        obj, buf = _lib.new_fillable(keep + self._window)      # not zero-filled: only what the file delivers is ever touched
-        buf[:keep] = carry
+        need = keep + self._window
+        old = self._in_buf
+        if old is None or len(old) < need:
+            self._in_buf = _lib.take_buffer(need)            # (pooled, not zero-filled by us: only what the file delivers is used)
+        buf = memoryview(self._in_buf)[:need]
+        if keep:
+            buf[:keep] = carry                               # (the carry may lie in the old buffer, or at the front of this one)
+        if old is not None and old is not self._in_buf:
+            _lib.give_buffer(old)
         got = keep
         into = getattr(self._fp, "readinto", None)
         while got < len(buf):
@@ -824,8 +842,7 @@ class _GzipReader:
                 n = len(chunk)
                 buf[got:got + n] = chunk
             got += n
-        buf.release()
-        return memoryview(obj)[:got]
+        return buf[:got]
 
     def _set_error(self, code, data, ctx):
         msg = ctx.err()
@@ -862,7 +879,9 @@ class _GzipReader:
                     self._out = self._spare.pop()        # a window buffer the threaded reader's consumer has finished with
                 if self._out is None or len(self._out[0]) < cap:
                     self._buf = b""                      # drop the view of the old buffer before replacing it
-                    self._out = _lib.new_buffer(cap + cap // 4)   # head-room: windows differ a little in size
+                    if self._out is not None:
+                        _lib.give_buffer(self._out[0])
+                    self._out = _lib.take_window(cap + cap // 4)  # head-room: windows differ a little in size
                 cap = len(self._out[0])
                 code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, into=self._out)
                 if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
@@ -952,8 +971,11 @@ class _GzipReader:
     def _give_back(self, token):
         """A window buffer handed out by _take_window is free again (its pages are faulted in and known to the driver:
         decoding into it again is much cheaper than into a fresh one)."""
-        if token is not None and len(self._spare) < 3:
-            self._spare.append(token)
+        if token is not None:
+            if len(self._spare) < 3 and not self._closed:
+                self._spare.append(token)
+            else:
+                _lib.give_buffer(token[0])
 
     def readall(self):
         self._check()
@@ -1014,6 +1036,8 @@ class _GzipReader:
 
     def close(self):
         self._closed = True
+        with self._lock:
+            self._release_windows()
 
     def readable(self):
         return True
