@@ -82,6 +82,9 @@ int      zngamd_adler32(zngamd_ctx *ctx, uint32_t adler, const uint8_t *buf, siz
 int      zngamd_crc32_dev(zngamd_ctx *ctx, uint32_t crc, const void *dbuf, size_t len, uint32_t *out);
 /* scalar GF(2) arithmetic on three integers (no data pass) */
 uint32_t zngamd_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+/* the same over a run of pieces: crc of (what `crc` covers, followed by n pieces of lens[i] bytes whose CRC-32s are crcs[i]) -- the fold
+ * the reference's writer thread does block by block (src/zlib_ng/gzip_ng_threaded.py:392-396), as one call */
+uint32_t zngamd_crc32_combine_many(uint32_t crc, const uint32_t *crcs, const uint64_t *lens, uint32_t n);
 
 /* ---- deflate ---- */
 int zngamd_level_ok(int level);   /* 1 for -1..9, else 0 ("Bad compression level") */

@@ -8,7 +8,7 @@ ctx = _lib.default_context()
 names = ["sweeps", "lanes_kept", "sync_passes", "t_sync", "t_emit", "t_resolve", "sweeps_empty", "seq_rounds", "blocks", "t_tables",
          "ring_refills", "out_bytes", "eob_in_sweep", "lanes_exact", "resolve_rounds", "matches"]
 def stats():
-    a = (ctypes.c_ulonglong * 16)()
+    a = (ctypes.c_ulonglong * 32)()
     assert L.zngamd_debug_ps_stats(a) == 0
     return dict(zip(names, list(a)))
 fq = gzip.open(os.path.join(ROOT, "tests", "golden", "test.fastq.gz")).read()

@@ -47,6 +47,14 @@ def timed(owner, name, label):
 W = gzip_ng_threaded._ThreadedGzipWriter
 timed(_lib, "deflate_blocks_multi", "writer: engine batch")
 timed(W, "_write_later", "writer: file write")
+if os.environ.get("TIME_WRITE_CALLS"):
+    timed(W, "write", "writer: inside write() itself (all calls)")
+    timed(W, "_flush_small", "writer: _flush_small")
+    timed(W, "_end_gzip_stream", "writer: _end_gzip_stream")
+    timed(W, "stop", "writer: stop")
+    timed(W, "_release_buffers", "writer: _release_buffers")
+    timed(W, "close", "writer: raw close()")
+    timed(W, "flush", "writer: raw flush()")
 timed(W, "_join_batch", "writer: caller waits for the batch in front")
 timed(W, "_settle_write", "writer: batch waits for the file write in front")
 R = zlib_ng._GzipReader
@@ -67,12 +75,22 @@ def report(title, dt):
 
 for rep in range(3):
     t = time.perf_counter()
-    with gzip_ng_threaded.open(path, "wb", compresslevel=6, threads=8, block_size=CALL) as f:
-        for o in range(0, n, CALL):
-            f.write(mvb[o:o + CALL])
-    report(f"write {mib} MiB in {CALL >> 10} KiB calls (run {rep})", time.perf_counter() - t)
+    f = gzip_ng_threaded.open(path, "wb", compresslevel=6, threads=8, block_size=CALL)
+    t_open = time.perf_counter()
+    for o in range(0, n, CALL):
+        f.write(mvb[o:o + CALL])
+    t_loop = time.perf_counter()
+    f.close()
+    t_end = time.perf_counter()
+    report(f"write {mib} MiB in {CALL >> 10} KiB calls (run {rep}; open {(t_open - t) * 1e3:.1f} ms, the calls {(t_loop - t_open) * 1e3:.1f} ms, close {(t_end - t_loop) * 1e3:.1f} ms)", t_end - t)
 if mib <= 1024:
     assert zlib.decompress(open(path, "rb").read(), 31) == blob
+for rep in range(3):                # as the reference's own benchmark does it (benchmark_scripts/gzipwrite128kblocks.py): to os.devnull
+    t = time.perf_counter()
+    with gzip_ng_threaded.open(os.devnull, "wb", compresslevel=6, threads=8, block_size=CALL) as f:
+        for o in range(0, n, CALL):
+            f.write(mvb[o:o + CALL])
+    report(f"write {mib} MiB to os.devnull in {CALL >> 10} KiB calls (run {rep})", time.perf_counter() - t)
 for rep in range(3):
     t = time.perf_counter()
     got = 0

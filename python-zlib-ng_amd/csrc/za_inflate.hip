@@ -36,6 +36,8 @@ struct ZaInfTabs {
     uint16_t lut_l[1 << ZA_LUT_L_BITS];   // (sym<<4)|len, 0 = longer than the LUT or unassigned
     uint16_t lut_d[1 << ZA_LUT_D_BITS];
     uint16_t cnt_l[16], cnt_d[16];
+    uint16_t fst_l[16], fst_d[16];        // first code of each length (as a number, most significant bit first) and the place of
+    uint16_t idx_l[16], idx_d[16];        // its symbol in sym_*: the codes of one length are consecutive (za_long_decode)
     uint16_t sym_l[288], sym_d[32];
     uint8_t lens[320];
     int status;
@@ -62,13 +64,33 @@ __device__ __forceinline__ uint32_t za_slow_decode(uint32_t v, const uint16_t *c
     return 0;
 }
 
+// A code longer than the first-level table in one step (the bit-serial walk above costs fifteen dependent LDS reads, and a wave
+// takes it whenever ONE of its lanes meets such a code -- rare per symbol, but with 64 lanes nearly every round): the stream's
+// bits reversed are the code with its first bit on top, the codes of length l are the integers fst[l] .. fst[l] + cnt[l] - 1,
+// and no extension of a shorter code reaches fst[l] (canonical order), so at most one length answers.  `from` = first length
+// the table does not hold.  Returns (sym << 4) | len, 0 = no such code.
+__device__ __forceinline__ uint32_t za_long_decode(uint32_t v, const uint16_t *cnt, const uint16_t *fst, const uint16_t *idx, const uint16_t *sym, int from)
+{
+    const uint32_t r = __builtin_bitreverse32(v);
+    uint32_t hit = 0;
+#pragma unroll
+    for (int l = 15; l >= 8; l--) {
+        if (l >= from) {
+            const uint32_t rel = (r >> (32 - l)) - (uint32_t)fst[l];
+            if (rel < (uint32_t)cnt[l]) hit = (((uint32_t)idx[l] + rel) << 4) | (uint32_t)l;
+        }
+    }
+    if (hit) hit = ((uint32_t)sym[hit >> 4] << 4) | (hit & 15u);
+    return hit;
+}
+
 // Build count/symbol arrays and the LUT from lens[0..n), n <= 320, by the whole wave.  Returns <0 for an
 // over-subscribed set, >0 for an incomplete one, 0 otherwise; *shared_maxlen = longest code.
 // Every lane holds the lengths of symbols lane, lane + 64, ...; the number of codes of each length is a sum of
 // ballot population counts (wave-uniform, so it lives in scalar registers), and a symbol's slot in the canonical
 // order is the offset of its length plus the number of lower symbols of that length, again from the ballots.
 __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_t *sym, uint16_t *lut, int lut_bits,
-                              int *shared_status, int *shared_maxlen)
+                              int *shared_status, int *shared_maxlen, uint16_t *fst = nullptr, uint16_t *idx = nullptr)
 {
     const int lane = za_lane();
     __syncthreads();
@@ -97,6 +119,12 @@ __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_
 #pragma unroll
         for (int l = 0; l <= 15; l++) cnt[l] = (uint16_t)c[l];
         *shared_status = st; *shared_maxlen = maxlen;
+        if (fst) {
+            int first = 0, index = 0;
+            fst[0] = 0; idx[0] = 0;
+#pragma unroll
+            for (int l = 1; l <= 15; l++) { fst[l] = (uint16_t)first; idx[l] = (uint16_t)index; index += c[l]; first = (first + c[l]) << 1; }
+        }
     }
     if (st >= 0) {
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -176,8 +204,8 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         __syncthreads();
         for (int i = lane; i < 320; i += 64)
             T.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : i < 318 ? 5 : 0);
-        za_build_table(T.lens, 288, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1]);
-        za_build_table(T.lens + 288, 30, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1]);
+        za_build_table(T.lens, 288, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
+        za_build_table(T.lens + 288, 30, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
         return ZA_I_OK;
     }
     if (bitpos + 14 > in_bits) return ZA_I_INPUT;
@@ -263,10 +291,10 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
     for (int i = nlen + lane; i < 288; i += 64) T.lens[i] = 0;
     __syncthreads();
     int maxl;
-    st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1]);
+    st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
     maxl = scratch[1];
     if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
-    st = za_build_table(T.lens + 288, ndist, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1]);
+    st = za_build_table(T.lens + 288, ndist, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
     maxl = scratch[1];
     if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
     return ZA_I_OK;
@@ -291,8 +319,14 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 #define ZA_PS_MAXIT  6
 #endif
 #define ZA_PS_NONE   0xFFFFFFFFu
+#ifndef ZA_PS_LITS
+#define ZA_PS_LITS 3                 // a counting round: up to this many literals ...
+#endif
+#ifndef ZA_PS_LIT_GROUPS
+#define ZA_PS_LIT_GROUPS 1           // ... this many times, then the token behind them
+#endif
 #ifdef ZA_PS_STATS
-__device__ unsigned long long za_ps_stat[16];
+__device__ unsigned long long za_ps_stat[32];     // 16: rounds of the counting passes (as the wave runs them), 17: their core clock cycles, 18: tokens counted
 #define ZA_STAT_ADD(i, v) do { if (za_lane() == 0) atomicAdd(&za_ps_stat[i], (unsigned long long)(v)); } while (0)
 #define ZA_STAT_T() wall_clock64()
 #else
@@ -352,7 +386,8 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         w += 2;
         while (bp < lim) {
             if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
-            uint32_t e = za_decode_sym(bb, T.lut_l, ZA_LUT_L_BITS, T.cnt_l, T.sym_l);
+            uint32_t e = T.lut_l[(uint32_t)bb & ((1u << ZA_LUT_L_BITS) - 1u)];
+            if (!e) e = za_long_decode((uint32_t)bb, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, ZA_LUT_L_BITS + 1);
             if (!e) { s = 2; break; }
             const int sym = (int)(e >> 4);
             uint32_t used = e & 15u;
@@ -370,7 +405,8 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             used += (uint32_t)nx;
             bp += used; bb >>= used; nb -= used;
             if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
-            e = za_decode_sym(bb, T.lut_d, ZA_LUT_D_BITS, T.cnt_d, T.sym_d);
+            e = T.lut_d[(uint32_t)bb & ((1u << ZA_LUT_D_BITS) - 1u)];
+            if (!e) e = za_long_decode((uint32_t)bb, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, ZA_LUT_D_BITS + 1);
             const int ds = (int)(e >> 4);
             if (!e || ds >= 30) { s = 2; break; }
             used = e & 15u;
@@ -404,20 +440,27 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         uint32_t bp = from, c = 0, k = 0;
         int s = 0, fr = -(1 << 30);
         auto lit3 = [&](uint32_t win, uint32_t room, bool on, uint32_t &bits) -> uint32_t {
-            const uint32_t e0 = T.lut_l[win & ((1u << ZA_LUT_L_BITS) - 1u)];
-            const bool l0 = on && (e0 - 1u) < 0xFFFu;                       // assigned and a literal: (symbol << 4) | length, symbol < 256
-            uint32_t u = l0 ? (e0 & 15u) : 0u;
-            const uint32_t e1 = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_LUT_L_BITS)];
-            const bool l1 = l0 && (e1 - 1u) < 0xFFFu && u < room;
-            u += l1 ? (e1 & 15u) : 0u;
-            const uint32_t e2 = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_LUT_L_BITS)];
-            const bool l2 = l1 && (e2 - 1u) < 0xFFFu && u < room;
-            u += l2 ? (e2 & 15u) : 0u;
+            uint32_t u = 0, n = 0;
+            bool l = on;
+#pragma unroll
+            for (int i = 0; i < ZA_PS_LITS; i++) {
+                const uint32_t e = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_LUT_L_BITS)];
+                l = l && (e - 1u) < 0xFFFu && u < room;                     // assigned and a literal ((symbol << 4) | length, symbol < 256) that starts before the limit
+                u += l ? (e & 15u) : 0u;
+                n += l ? 1u : 0u;
+            }
             bits = u;
-            return (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u);
+            return n;
         };
+#ifdef ZA_PS_STATS
+        const unsigned long long cy0 = clock64();
+        uint32_t wave_rounds = 0;
+#endif
 #pragma unroll 1
         while (s == 0 && bp < lim) {
+#ifdef ZA_PS_STATS
+            wave_rounds++;
+#endif
             const uint32_t w = bp >> 5, sh = bp & 31u;
             const uint32_t d0 = P->stage[w], d1 = P->stage[w + 1], d2 = P->stage[w + 2], d3 = P->stage[w + 3], d4 = P->stage[w + 4];
             const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
@@ -426,15 +469,19 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             uint32_t u1, u2;
             const uint32_t n1 = lit3(lo, room, true, u1);                   // first-level codes are <= 10 bits: three fit the 32 at hand
             const uint32_t lo1 = __builtin_amdgcn_alignbit(hi, lo, u1), hi1 = __builtin_amdgcn_alignbit(h2, hi, u1), h21 = __builtin_amdgcn_alignbit(h3, h2, u1);
-            const bool more = n1 == 3u && u1 < room;
+#if ZA_PS_LIT_GROUPS == 1
+            const uint32_t n2 = 0; u2 = 0;
+#else
+            const bool more = n1 == (uint32_t)ZA_PS_LITS && u1 < room;
             const uint32_t n2 = lit3(lo1, more ? room - u1 : 0u, more, u2);
+#endif
             const uint32_t u = u1 + u2;                                     // <= 60
             c += n1 + n2;
             // -- the token behind them, whatever it is (a seventh literal, a literal with a long code, end of block, a match)
             const bool tok = u < room;
             const uint32_t m_lo = __builtin_amdgcn_alignbit(hi1, lo1, u2), m_hi = __builtin_amdgcn_alignbit(h21, hi1, u2);
             uint32_t em = T.lut_l[m_lo & ((1u << ZA_LUT_L_BITS) - 1u)];
-            if (tok && em == 0u) em = za_slow_decode(m_lo, T.cnt_l, T.sym_l, 15);
+            if (tok && em == 0u) em = za_long_decode(m_lo, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, ZA_LUT_L_BITS + 1);
             const uint32_t sym = em >> 4, l = em & 15u;
             const bool is_len = tok && sym > 256u && sym <= 285u;
             int nx = 0, dnx = 0;
@@ -443,7 +490,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             const uint32_t used = l + (uint32_t)nx;                          // <= 20
             const uint32_t x = __builtin_amdgcn_alignbit(m_hi, m_lo, used);  // the distance code and its extra bits: <= 28 bits
             uint32_t d = T.lut_d[x & ((1u << ZA_LUT_D_BITS) - 1u)];
-            if (is_len && d == 0u) d = za_slow_decode(x, T.cnt_d, T.sym_d, 15);
+            if (is_len && d == 0u) d = za_long_decode(x, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, ZA_LUT_D_BITS + 1);
             const uint32_t ds = d >> 4, dl = d & 15u;
             const bool dist_ok = d != 0u && ds < 30u;
             const int dbase = za_dist_base(dist_ok ? (int)ds : 0, dnx);
@@ -464,6 +511,20 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             else bp += u;
         }
         endp = bp; cnt = c; nm = k; st = s; farrel = fr;
+#ifdef ZA_PS_STATS
+        {
+            uint32_t mx = 0;
+            unsigned long long am = __ballot(1);
+            const int first_lane = __builtin_ctzll(am);
+            while (am) { const int j = __builtin_ctzll(am); am &= am - 1ull; const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)wave_rounds, j); mx = v > mx ? v : mx; }
+            if (za_lane() == first_lane) {
+                atomicAdd(&za_ps_stat[16], (unsigned long long)mx); atomicAdd(&za_ps_stat[17], (unsigned long long)(clock64() - cy0));
+                atomicAdd(&za_ps_stat[19], 1ull);
+            }
+            atomicAdd(&za_ps_stat[20], (unsigned long long)wave_rounds);
+            atomicAdd(&za_ps_stat[18], (unsigned long long)(k + 0u));
+        }
+#endif
     };
 
     uint32_t start = b0 + (uint32_t)lane * S;
@@ -926,7 +987,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                 for (;;) {
                     if (o > 64u - 15u) break;                                        // next code may be cut: new window
                     uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)eL, (int)o);
-                    if (!e) e = za_slow_decode((uint32_t)(W >> o), T.cnt_l, T.sym_l, 15);         // o <= 49: 15 bits are there
+                    if (!e) e = za_long_decode((uint32_t)(W >> o), T.cnt_l, T.fst_l, T.idx_l, T.sym_l, ZA_LUT_L_BITS + 1);         // o <= 49: 15 bits are there
                     if (!e) { status = (bitpos + o + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
                     int sym = (int)(e >> 4);
                     const uint32_t l = e & 15u;
@@ -946,7 +1007,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     if (o2 > 64u - 15u) break;                                       // distance code may be cut: new window
                     if (nx) len += (int)((W >> (o + l)) & ((1u << nx) - 1u));       // o + l < 64 here
                     uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)eD, (int)o2);
-                    if (!e2) e2 = za_slow_decode((uint32_t)(W >> o2), T.cnt_d, T.sym_d, 15);
+                    if (!e2) e2 = za_long_decode((uint32_t)(W >> o2), T.cnt_d, T.fst_d, T.idx_d, T.sym_d, ZA_LUT_D_BITS + 1);
                     if (!e2) { status = (bitpos + o2 + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
                     const int ds = (int)(e2 >> 4);
                     if (ds >= 30) { status = ZA_I_DATA; break; }

@@ -30,7 +30,7 @@ K_NAMES = ["chains", "search", "parse", "plan", "pack", "gather", "scan", "infla
 SYMBOLS = [
     "zngamd_device_count", "zngamd_ctx_create", "zngamd_ctx_destroy", "zngamd_last_error", "zngamd_version",
     "zngamd_set_stream", "zngamd_sync", "zngamd_dmalloc", "zngamd_dfree", "zngamd_h2d", "zngamd_d2h",
-    "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_level_ok",
+    "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_crc32_combine_many", "zngamd_level_ok",
     "zngamd_deflate_blocks", "zngamd_deflate_blocks_packed", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev", "zngamd_compare_dev", "zngamd_crc32_fold_dev",
@@ -93,6 +93,8 @@ def load():
         L.zngamd_crc32_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_uint32)]
         L.zngamd_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
         L.zngamd_crc32_combine.restype = C.c_uint32
+        L.zngamd_crc32_combine_many.argtypes = [C.c_uint32, u32p, C.POINTER(C.c_uint64), C.c_uint32]
+        L.zngamd_crc32_combine_many.restype = C.c_uint32
         L.zngamd_level_ok.argtypes = [C.c_int]
         L.zngamd_deflate_blocks.argtypes = [vp, u8p, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
                                             u8p, C.c_uint64, u32p, u32p]
@@ -330,6 +332,15 @@ def take_window(n):
     addr = C.c_void_p(C.addressof(anchor))
     del anchor
     return buf, addr
+
+
+def crc32_combine_many(crc, crcs, lens):
+    """crc32_combine over a run of pieces in one call (a writer thread that folds 512 blocks one foreign call at a time hands
+    the interpreter lock back and forth 1 000 times while its caller wants it)."""
+    n = len(crcs)
+    a = (C.c_uint32 * max(n, 1))(*crcs)
+    b = (C.c_uint64 * max(n, 1))(*lens)
+    return load().zngamd_crc32_combine_many(crc & 0xFFFFFFFF, a, b, n)
 
 
 def block_table(blocks):

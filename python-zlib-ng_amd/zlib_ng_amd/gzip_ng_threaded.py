@@ -92,6 +92,7 @@ class _ThreadedGzipReader(io.RawIOBase):
         self._failure = None
         self._current = memoryview(b"")
         self._current_addr, self._current_keep = 0, None   # where the unread rest of the window lies (copies without the interpreter lock)
+        self._calls = 0
         self._token = None                           # buffer of the window being consumed (goes back to the inner reader)
         self._closed = False
         self._stop = False
@@ -147,9 +148,10 @@ class _ThreadedGzipReader(io.RawIOBase):
             self._current_addr, self._current_keep = _lib._addr(self._current)
             self._current_addr = self._current_addr.value or 0
         n = min(len(out), len(self._current))
-        if n >= _UNLOCKED_COPY_FROM and self._current_addr and not out.readonly:
-            # (the pump thread needs the interpreter lock between its file read and its engine call: a consumer that copies
-            # with the lock held makes it wait for the switch interval each time)
+        self._calls += 1
+        if n >= _UNLOCKED_COPY_FROM and (self._calls & 7) == 0 and self._current_addr and not out.readonly:
+            # (the pump thread needs the interpreter lock between its file read and its engine call: a consumer that always
+            # copies with the lock held makes it wait for the switch interval each time; every eighth copy lets go of it)
             anchor = ctypes.c_char.from_buffer(out)
             ctypes.memmove(ctypes.addressof(anchor), self._current_addr, n)
             del anchor
@@ -237,6 +239,11 @@ class _ThreadedGzipWriter(io.RawIOBase):
         # writes below this are collected up to this many bytes: a batch of 64 MiB is 512 units of work for 1 024 SIMDs -- the
         # kernels of a 32 MiB batch took 1.7 ms, four times the time per byte of a full device
         self._coalesce_limit = max(8 * block_size, 64 << 20)
+        # ... reached in steps: the first batch is 8 MiB, every later one twice the one before -- the engine starts on the first
+        # bytes while the caller is still writing (a file of 256 MiB in four batches of 64 spent two of its five time slots
+        # with only one side working)
+        self._batch_limit = min(self._coalesce_limit, max(8 * block_size, 8 << 20))
+        self._calls = 0
         self._small, self._small_n = None, 0
         self._small_view = None                      # writable view of _small: a slice assignment through it is one memcpy
         self._small_addr = 0                         # its address: large pieces are copied with the interpreter lock released
@@ -268,6 +275,11 @@ class _ThreadedGzipWriter(io.RawIOBase):
     def stop(self):
         """Stop without caring for queued work."""
         self.running = False
+        for q in self.input_queues:                  # wake the worker now: it looks at `running` every 50 ms otherwise, and
+            try:                                     # close() of a file of 256 MiB spent most of its time in this join
+                q.put_nowait(None)
+            except queue.Full:
+                pass
         self.output_worker.join()
 
     def write(self, b):
@@ -290,14 +302,18 @@ class _ThreadedGzipWriter(io.RawIOBase):
         if self._small is None:
             self._adopt_small(_lib.take_buffer(R + self._coalesce_limit))  # [room for the 32 KiB in front][collected bytes]
         n = self._small_n
-        if n + nbytes > self._coalesce_limit:
+        if n + nbytes > self._batch_limit:
             self._flush_small(wait=False)            # the full buffer is compressed and written while the other one fills
             n = 0
-        if nbytes >= _UNLOCKED_COPY_FROM:
-            # The copy of a large piece runs with the interpreter lock released (a foreign call): the batch thread needs the lock
-            # between its engine call, the file write and its bookkeeping, and a caller that never lets go of it -- a loop of
-            # write() calls does not -- makes every one of those wait for the interpreter's switch interval (5 ms; a batch
-            # takes 4).
+            if nbytes > self._batch_limit:
+                self._batch_limit = min(self._coalesce_limit, max(2 * self._batch_limit, nbytes))
+        self._calls += 1
+        if nbytes >= _UNLOCKED_COPY_FROM and (self._calls & 7) == 0 and self._batch_thread is not None:
+            # While a batch is under way, every eighth large piece is copied with the interpreter lock released (a foreign call):
+            # the batch thread needs the lock between its engine call, the file write and its bookkeeping, and a caller that never
+            # lets go of it -- a loop of write() calls does not -- makes every one of those wait for the interpreter's switch
+            # interval (5 ms; a batch takes 4).  Not every piece: taking the lock back costs the caller several microseconds
+            # whenever another thread holds it (16 us per 128 KiB call against 9).
             src, keep = _lib._addr(b)
             ctypes.memmove(self._small_addr + R + n, src, nbytes)
             del keep
@@ -323,6 +339,7 @@ class _ThreadedGzipWriter(io.RawIOBase):
         threads compress while write() returns (gzip_ng_threaded.py:299-322); wait=True returns when the batch is through."""
         n, self._small_n = self._small_n, 0
         if n:
+            self._batch_limit = min(self._coalesce_limit, 2 * self._batch_limit)
             self._join_batch()                       # batches are strictly in order: CRC folding and the file are sequential
             for q in self.input_queues:
                 q.join()
@@ -415,10 +432,7 @@ class _ThreadedGzipWriter(io.RawIOBase):
         packed, crcs, overflowed, _ = _lib.deflate_blocks_multi(self._contexts(), buf, blocks, self.level, cap, into=into, table=table)
         if overflowed:
             raise OverflowError(f"Compressed output exceeds buffer size of {cap}")
-        crc, combine = self._crc, zlib_ng.crc32_combine
-        for (_, ln, _, _), c in zip(blocks, crcs):
-            crc = combine(crc, c, ln)
-        self._crc = crc
+        self._crc = _lib.crc32_combine_many(self._crc, crcs, [b[1] for b in blocks])
         # the file write of this batch runs beside the compression of the next one (the engine call and the write
         # both release the GIL); the previous batch's write has to be through first: the order is the stream
         self._settle_write()
@@ -506,19 +520,29 @@ class _ThreadedGzipWriter(io.RawIOBase):
             batch, origins = [], []
             q = self.input_queues[self._drain_index % nq]
             try:
-                batch.append(q.get(timeout=0.05))
+                item = q.get(timeout=0.05)
             except queue.Empty:
                 if not self._alive():
                     return
                 continue
+            if item is None:                         # stop()'s wake-up call
+                q.task_done()
+                if not self._alive():
+                    return
+                continue
+            batch.append(item)
             origins.append(q)
             self._drain_index += 1
             while len(batch) < self._batch_blocks:
                 q = self.input_queues[self._drain_index % nq]
                 try:
-                    batch.append(q.get_nowait())
+                    item = q.get_nowait()
                 except queue.Empty:
                     break
+                if item is None:
+                    q.task_done()
+                    break
+                batch.append(item)
                 origins.append(q)
                 self._drain_index += 1
             try:

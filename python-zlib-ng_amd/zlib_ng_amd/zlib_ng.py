@@ -800,10 +800,18 @@ class _GzipReader:
         self._out = None                  # decoded window (buffer, address); reused, so its pages are faulted in once
         self._spare = []                  # buffers given back by a consumer that took whole windows (_take_window)
         self._in_buf = None               # the compressed window: one buffer, refilled (the engine call is through by then)
+        self._ahead = None                # the next window's file bytes being read on a thread of their own (_start_ahead)
 
     def _release_windows(self):
         """Window buffers go back to the process-wide pool (_lib.take_buffer): the next reader finds them warm."""
         self._buf = b""
+        if getattr(self, "_ahead", None) is not None:        # a read-ahead still running: wait, drop what it read
+            try:
+                ahead = self._join_ahead()
+                if ahead is not None:
+                    _lib.give_buffer(ahead[0])
+            except BaseException:
+                pass
         for pair in [getattr(self, "_out", None)] + list(getattr(self, "_spare", [])):
             if pair is not None:
                 _lib.give_buffer(pair[0])
@@ -811,12 +819,87 @@ class _GzipReader:
         self._out, self._spare, self._in_buf = None, [], None
 
     # -- compressed input, one window at a time
+    _AHEAD_FRONT = 4 << 20        # room kept in front of a window read ahead, for the unconsumed tail of the window before it
+
+    def _file_read_into(self, buf):
+        """Fill `buf` from the file -> (bytes delivered, end of file seen).  Touches nothing but the file."""
+        got, eof = 0, False
+        into = getattr(self._fp, "readinto", None)
+        while got < len(buf):
+            if into is not None:
+                n = into(buf[got:])
+                if not n:
+                    eof = True
+                    break
+            else:
+                chunk = self._fp.read(len(buf) - got)
+                if not chunk:
+                    eof = True
+                    break
+                n = len(chunk)
+                buf[got:got + n] = chunk
+            got += n
+        return got, eof
+
+    def _start_ahead(self):
+        """Read the next window's bytes from the file on a thread of its own while the engine decodes this one (both release
+        the interpreter lock): into a second buffer, behind room for the tail this window will leave over."""
+        if not self._is_file or self._in_eof or self._ahead is not None or self._closed or _sys.is_finalizing():
+            return
+        front, want = self._AHEAD_FRONT, self._window
+        buf = _lib.take_buffer(front + want)
+        box = {}
+
+        def work():
+            try:
+                box["got"], box["eof"] = self._file_read_into(memoryview(buf)[front:front + want])
+            except BaseException as exc:                 # raised by the reader's own thread when it takes the window over
+                box["error"] = exc
+        t = _threading.Thread(target=work, name="zng-amd-read-ahead")
+        t.start()
+        self._ahead = (t, buf, box, front)
+
+    def _join_ahead(self):
+        """-> (buffer, front room, bytes read, end of file) of the window read ahead, None when there is none."""
+        if self._ahead is None:
+            return None
+        t, buf, box, front = self._ahead
+        self._ahead = None
+        t.join()
+        if "error" in box:
+            _lib.give_buffer(buf)
+            raise box["error"]
+        return buf, front, box["got"], box["eof"]
+
     def _read_window(self, carry):
         """The unconsumed tail of the previous window followed by up to one window of new input, in one buffer."""
         if not self._is_file:
             self._in_eof = True
             return bytes(carry) + bytes(_view(self._fp)) if self._first else carry
         keep = len(carry)
+        ahead = self._join_ahead()
+        if ahead is not None:
+            buf, front, got, eof = ahead
+            old = self._in_buf
+            if keep <= front:                                    # the tail goes in front of what was read ahead: no copy of the window
+                view = memoryview(buf)
+                if keep:
+                    view[front - keep:front] = carry
+                self._in_buf = buf
+                if old is not None:
+                    _lib.give_buffer(old)                        # (the carry was copied out of it above)
+                self._in_eof = eof
+                return view[front - keep:front + got]
+            joined = _lib.take_buffer(keep + got)                # a tail longer than the room (a member without block boundaries for megabytes)
+            view = memoryview(joined)
+            view[:keep] = carry
+            view[keep:keep + got] = memoryview(buf)[front:front + got]
+            _lib.give_buffer(buf)
+            self._in_buf = joined
+            if old is not None:
+                _lib.give_buffer(old)
+            self._in_eof = eof
+            return view[:keep + got]
         need = keep + self._window
         old = self._in_buf
         if old is None or len(old) < need:
@@ -826,23 +909,10 @@ class _GzipReader:
             buf[:keep] = carry                               # (the carry may lie in the old buffer, or at the front of this one)
         if old is not None and old is not self._in_buf:
             _lib.give_buffer(old)
-        got = keep
-        into = getattr(self._fp, "readinto", None)
-        while got < len(buf):
-            if into is not None:
-                n = into(buf[got:])
-                if not n:
-                    self._in_eof = True
-                    break
-            else:
-                chunk = self._fp.read(len(buf) - got)
-                if not chunk:
-                    self._in_eof = True
-                    break
-                n = len(chunk)
-                buf[got:got + n] = chunk
-            got += n
-        return buf[:got]
+        got, eof = self._file_read_into(buf[keep:])
+        if eof:
+            self._in_eof = True
+        return buf[:keep + got]
 
     def _set_error(self, code, data, ctx):
         msg = ctx.err()
@@ -883,6 +953,7 @@ class _GzipReader:
                         _lib.give_buffer(self._out[0])
                     self._out = _lib.take_window(cap + cap // 4)  # head-room: windows differ a little in size
                 cap = len(self._out[0])
+                self._start_ahead()                      # the file read of the next window runs beside the engine call
                 code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, into=self._out)
                 if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
                     cap = max(cap * 4, ctx.last_needed + 64)
@@ -1020,13 +1091,13 @@ class _GzipReader:
                     self._boff -= back
                     self._pos = target
                     return self._pos
-                if self._is_file:
-                    if self._start is None:
-                        raise _io.UnsupportedOperation("underlying stream is not seekable")
-                    self._fp.seek(self._start)
+                if self._is_file and self._start is None:
+                    raise _io.UnsupportedOperation("underlying stream is not seekable")
                 size = self._size
-                self._reset()
+                self._reset()                                # (waits for a read-ahead that is still using the file)
                 self._size = size
+                if self._is_file:
+                    self._fp.seek(self._start)
             self._skip_to(target)
             return self._pos
 
