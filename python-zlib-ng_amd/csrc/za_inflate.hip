@@ -2040,7 +2040,9 @@ __global__ __launch_bounds__(1024) void za_k_chunk_chain(const uint16_t *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void za_k_chunk_resolve(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
+#define ZA_RESOLVE_THREADS 512
+struct __attribute__((aligned(1))) ZaU2u { uint32_t x, y; };
+__global__ __launch_bounds__(ZA_RESOLVE_THREADS) void za_k_chunk_resolve(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
                                                           const uint16_t *__restrict__ comp, const uint8_t *__restrict__ winbuf,
                                                           uint8_t *__restrict__ out8)
 {
@@ -2051,22 +2053,53 @@ __global__ __launch_bounds__(256) void za_k_chunk_resolve(const uint16_t *__rest
     const uint8_t *wsrc = winbuf + (size_t)g * ZA_WIN;
     const bool first = k == g * ZA_CHUNK_GROUP;
     uint8_t *wdst = first ? w : wg;
-    for (uint32_t j = threadIdx.x * 4; j < ZA_WIN; j += 1024) *(uint32_t *)(wdst + j) = *(const uint32_t *)(wsrc + j);
+    for (uint32_t j = threadIdx.x * 16; j < ZA_WIN; j += 16 * ZA_RESOLVE_THREADS) *(uint4 *)(wdst + j) = *(const uint4 *)(wsrc + j);
     __syncthreads();
     if (!first) {
-        const uint16_t *cm = comp + (size_t)(k - 1) * ZA_WIN;
-        for (uint32_t j = threadIdx.x; j < ZA_WIN; j += 256) {
-            const uint32_t sy = cm[j];
-            w[j] = sy < 256u ? (uint8_t)sy : wg[sy - 256u];
+        const uint16_t *cm = comp + (size_t)(k - 1) * ZA_WIN;      // (64 KiB per chunk: 16-byte aligned)
+        for (uint32_t j = threadIdx.x * 8; j < ZA_WIN; j += 8 * ZA_RESOLVE_THREADS) {
+            const uint4 v = *(const uint4 *)(cm + j);
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+            uint32_t r[2] = {0, 0};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t sy = (q[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+                r[t >> 2] |= (sy < 256u ? sy : (uint32_t)wg[sy - 256u]) << (8 * (t & 3));
+            }
+            *(uint2 *)(w + j) = make_uint2(r[0], r[1]);
         }
         __syncthreads();
     }
+    // The chunk's symbols become bytes, eight per thread and step: one aligned 16-byte load, a look-up in the window only for the
+    // symbols that are markers (few: what a chunk copies from before its start), one 8-byte store.  (One symbol per thread and
+    // step -- a two-byte load, a one-byte store -- made this the longest of the three window kernels: 512 dependent steps per
+    // thread, two workgroups per CU by their LDS.)
     const uint16_t *src = out16 + ch.out_off;
     uint8_t *dst = out8 + ch.out_off;
-    for (uint64_t i = threadIdx.x; i < ch.out_len; i += 256) {
-        const uint32_t sym = src[i];
-        dst[i] = sym < 256u ? (uint8_t)sym : w[(sym - 256u) & (ZA_WIN - 1)];
+    const uint64_t n = ch.out_len;
+    const uint64_t head = min(n, (uint64_t)((8u - (uint32_t)(ch.out_off & 7ull)) & 7u));        // symbols in front of the first 16-byte aligned one
+    if (threadIdx.x < head) { const uint32_t sym = src[threadIdx.x]; dst[threadIdx.x] = sym < 256u ? (uint8_t)sym : w[(sym - 256u) & (ZA_WIN - 1)]; }
+    const uint64_t groups8 = (n - head) >> 3;
+    for (uint64_t i = threadIdx.x; i < groups8; i += ZA_RESOLVE_THREADS) {
+        const uint4 v = *(const uint4 *)(src + head + 8 * i);
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+        uint32_t r[2];
+        if (((v.x | v.y | v.z | v.w) & 0xFF00FF00u) == 0u) {                                      // eight literals: pack the low bytes
+            r[0] = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);
+            r[1] = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u);
+        } else {
+            r[0] = 0; r[1] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t sy = (q[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+                r[t >> 2] |= (sy < 256u ? sy : (uint32_t)w[(sy - 256u) & (ZA_WIN - 1)]) << (8 * (t & 3));
+            }
+        }
+        ZaU2u o; o.x = r[0]; o.y = r[1];
+        *(ZaU2u *)(dst + head + 8 * i) = o;
     }
+    const uint64_t done = head + 8 * groups8;
+    if (done + threadIdx.x < n) { const uint32_t sym = src[done + threadIdx.x]; dst[done + threadIdx.x] = sym < 256u ? (uint8_t)sym : w[(sym - 256u) & (ZA_WIN - 1)]; }
 }
 
 // One workgroup per member: header with the chunk index, deflate bytes from the unit slot, trailer.

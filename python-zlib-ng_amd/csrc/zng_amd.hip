@@ -705,6 +705,22 @@ try {
     const uint32_t wb = n_blocks ? (blocks[0].flags >> 8) & 15u : 0u;
     if (wb != 0 && wb < 9) return fail(c, ZNGAMD_STREAM_ERROR, "window bits must be 9..15");
     r = deflate_host_common(c, in_len, blocks, n_blocks, level, hu, ulen, ucrc, &packed, wb ? (1 << wb) : ZA_WIN, out, out_cap, total);
+    if (r == ZNGAMD_BUF_ERROR && !hu.empty()) {
+        // the packed stream does not fit: because a block outgrew its cap (an overflow, reported like the per-block form does),
+        // or because the caller's buffer is simply too small (ZNGAMD_BUF_ERROR, *total = the size needed)
+        ulen.resize(hu.size());
+        HIPCHK(c, hipMemcpy(ulen.data(), c->st_len.p, hu.size() * 4ull, hipMemcpyDeviceToHost));
+        bool any = false;
+        size_t u2 = 0;
+        for (uint32_t b = 0; b < n_blocks; b++) {
+            uint64_t tot = 0;
+            for (; u2 < hu.size() && hu[u2].block == b; u2++) tot += ulen[u2];
+            crc[b] = 0;
+            out_len[b] = tot >= block_cap ? 0xFFFFFFFFu : (uint32_t)tot;
+            any = any || tot >= block_cap;
+        }
+        if (any) { c->err = "Compressed output exceeds buffer size"; return ZNGAMD_E_OVERFLOW; }
+    }
     if (r) return r;
     int ret = ZNGAMD_OK;
     size_t u = 0;
@@ -1290,7 +1306,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
       hipLaunchKernelGGL(za_k_chunk_compose, dim3(groups), dim3(1024), 0, c->stream, c->out16.p, c->cchunks.p, m, c->ccomp.p);
       hipLaunchKernelGGL(za_k_chunk_chain, dim3(1), dim3(1024), 0, c->stream, c->ccomp.p, m, c->winbuf.p, o.d_dict, o.dict_len);
-      hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(256), 0, c->stream, c->out16.p, c->cchunks.p, c->ccomp.p, c->winbuf.p, d_out); }
+      hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(ZA_RESOLVE_THREADS), 0, c->stream, c->out16.p, c->cchunks.p, c->ccomp.p, c->winbuf.p, d_out); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);

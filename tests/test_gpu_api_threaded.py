@@ -304,3 +304,87 @@ def test_writer_spreads_batches_over_contexts(monkeypatch):
     a = _lib.deflate_blocks_multi(ctxs, data, blocks, 6, 131072 + 13107 + 500)
     b = ctxs[0].deflate_blocks(data, blocks, 6, 131072 + 13107 + 500, joined=True)
     assert a[0] == b[0] and list(a[1]) == list(b[1]) and a[2] == b[2] and list(a[3]) == list(b[3])
+
+
+def test_writer_pieces_of_every_size_class(T):
+    """What write() does with a piece depends on its size: below 32 KiB it is copied under the interpreter lock, from there on
+    (every eighth one, while a batch runs) without it, a piece larger than the current batch limit ends the batch and raises the
+    limit, one of 64 MiB or more goes to the engine as it is -- one stream whatever the mix, and the batches (8 MiB, then twice as
+    much each time) leave no seam."""
+    import zlib
+    from zlib_ng_amd import corpus
+    rng = np.random.default_rng(7)
+    src = corpus.text(96 << 20, seed=3).tobytes()
+    sizes = [1, 100, 32767, 32768, 32769, 131072, (8 << 20) + 1, 3 << 20, 20 << 20, 65 << 20] + [int(x) for x in rng.integers(1, 400000, 60)]
+    rng.shuffle(sizes)
+    out = io.BytesIO()
+    pos, pieces = 0, []
+    with T.open(out, "wb", compresslevel=4, threads=8, block_size=128 * 1024) as f:
+        for sz in sizes:
+            sz = min(sz, len(src) - pos)
+            if sz <= 0:
+                break
+            piece = src[pos:pos + sz] if sz % 3 else memoryview(src)[pos:pos + sz]       # bytes and views alike
+            assert f.write(piece) == sz
+            pos += sz
+    d = zlib.decompressobj(31)
+    got = d.decompress(out.getvalue())
+    assert got == src[:pos] and d.eof
+    assert d.unused_data[:4] == b"\x1f\x8b\x08\x00"             # the trailing empty member of the reference's writer
+
+
+def test_packed_batch_output_equals_the_per_block_form():
+    """zngamd_deflate_blocks_packed (what the writer's batches use: the blocks' outputs back to back, copied straight into the
+    caller's buffer) against zngamd_deflate_blocks (a slot per block): same bytes, lengths and CRCs; into a buffer of the
+    caller's, with a block table made once; an overflowing block is reported the same way."""
+    import zlib
+    from zlib_ng_amd import _lib, corpus
+    ctx = _lib.default_context()
+    data = corpus.mixed(5 << 20, seed=4).tobytes()
+    bs = 96 * 1024 + 7
+    blocks = [(o, min(bs, len(data) - o), min(32768, o), 0) for o in range(0, len(data), bs)]
+    cap = bs + bs // 10 + 500
+    per_block, crcs_a, over_a = ctx.deflate_blocks(data, blocks, 5, cap)
+    packed, crcs_b, over_b, lens = ctx.deflate_blocks(data, blocks, 5, cap, joined=True)
+    assert not over_a and not over_b and crcs_a == crcs_b
+    assert packed == b"".join(per_block) and lens == [len(x) for x in per_block]
+    into = bytearray(len(blocks) * cap)
+    view, crcs_c, over_c, lens_c = ctx.deflate_blocks(data, _lib.block_table(blocks), 5, cap, joined=True, into=into)
+    assert bytes(view) == packed and crcs_c == crcs_a and lens_c == lens and not over_c
+    assert zlib.decompress(packed + b"\x03\x00", -15) == data
+    fold = 0
+    for c, (_, ln, _, _) in zip(crcs_a, blocks):
+        fold = ctx.crc32_combine(fold, c, ln)
+    assert _lib.crc32_combine_many(0, crcs_a, [b[1] for b in blocks]) == fold == zlib.crc32(data)
+    noise = np.random.default_rng(3).bytes(1 << 20)
+    nb = [(o, 65536, 0, 0) for o in range(0, len(noise), 65536)]
+    res, _, over, _ = ctx.deflate_blocks(noise, nb, 6, 65536, joined=True)          # incompressible: every block reaches its cap
+    assert over and res is None
+
+
+def test_reader_read_ahead_and_long_tails(T, Z, monkeypatch, tmp_path):
+    """The next window's bytes are read from the file while the engine decodes this one, into a second buffer behind room for the
+    tail this window leaves over; a tail longer than the room (here the room is made tiny) takes the copying path; seeking
+    back waits for a read that is under way before it moves the file; buffers go back to the pool at close."""
+    from zlib_ng_amd import _lib, corpus
+    data = corpus.text(24 << 20, seed=11).tobytes()
+    path = tmp_path / "a.gz"
+    path.write_bytes(gzip.compress(data[:9 << 20], 6) + gzip.compress(data[9 << 20:], 1))
+    monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(1 << 20))
+    for front in (4 << 20, 4096):
+        monkeypatch.setattr(Z._GzipReader, "_AHEAD_FRONT", front)
+        with T.open(str(path), "rb") as f:
+            assert f.read() == data
+        with open(path, "rb") as fh:
+            r = Z._GzipReader(fh, 1 << 16)
+            assert r.read(1 << 20) == data[:1 << 20]
+            r.seek(5 << 20)
+            assert r.read(100) == data[5 << 20:(5 << 20) + 100]
+            r.seek(10)                                                     # backwards: from the start again, the read-ahead joined first
+            assert r.read(1000) == data[10:1010]
+            assert r.readall() == data[1010:]
+            r.close()
+    before = len(_lib._buffer_pool)
+    with T.open(str(path), "rb") as f:
+        f.read(1 << 20)
+    assert len(_lib._buffer_pool) >= min(before, 1)                        # (closed in the middle of the file: nothing leaks, buffers are kept)
