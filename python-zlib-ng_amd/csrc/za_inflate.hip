@@ -1995,24 +1995,58 @@ __device__ __forceinline__ uint16_t za_tail_sym(const uint16_t *__restrict__ out
 __global__ __launch_bounds__(1024) void za_k_chunk_compose(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
                                                            uint32_t n, uint16_t *__restrict__ comp)
 {
-    __shared__ uint16_t cur[ZA_WIN];                 // 64 KiB: composed map so far, updated in place
+    __shared__ __attribute__((aligned(16))) uint16_t cur[ZA_WIN];     // 64 KiB: composed map so far, updated in place
     const uint32_t tid = threadIdx.x;
     const uint32_t k0 = blockIdx.x * ZA_CHUNK_GROUP;
     const uint32_t k1 = min(n, k0 + ZA_CHUNK_GROUP);
-    for (uint32_t k = k0; k < k1; k++) {
+    // The chunks of a group follow one another (each map is looked up in the one before), so what a step costs is its memory
+    // round trip: every thread takes 32 CONSECUTIVE window positions (four 16-byte loads of the chunk's tail, four 16-byte stores
+    // of the composed map) and has the next chunk's tail on its way while it looks this one's markers up.
+    constexpr uint32_t PER = ZA_WIN / 1024;                           // 32 symbols = 4 x 16 bytes per thread
+    ZaU4u raw[PER / 8], nxt[PER / 8];
+    auto fetch = [&](uint32_t k, ZaU4u *dst) {
         const ZaChunk ch = chunks[k];
-        uint16_t *dst = comp + (size_t)k * ZA_WIN;
-        uint16_t vals[ZA_WIN / 1024];
+        if (ch.out_len >= (uint64_t)ZA_WIN) {
+            const uint16_t *tail = out16 + ch.out_off + (ch.out_len - ZA_WIN) + (uint64_t)tid * PER;
 #pragma unroll
-        for (uint32_t t = 0; t < ZA_WIN / 1024; t++) {
-            uint32_t sy = za_tail_sym(out16, ch, tid + 1024u * t);
-            if (k != k0 && sy >= 256u) sy = cur[sy - 256u];
-            vals[t] = (uint16_t)sy;
+            for (uint32_t t = 0; t < PER / 8; t++) dst[t] = *(const ZaU4u *)(tail + 8u * t);
+        } else {                                                       // a chunk shorter than the window (a short stream's only one)
+            uint32_t w[PER / 2];
+#pragma unroll
+            for (uint32_t t = 0; t < PER; t++) {
+                const uint32_t sy = za_tail_sym(out16, ch, tid * PER + t);
+                if (t & 1u) w[t >> 1] |= sy << 16; else w[t >> 1] = sy;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < PER / 8; t++) { dst[t].x = w[4 * t]; dst[t].y = w[4 * t + 1]; dst[t].z = w[4 * t + 2]; dst[t].w = w[4 * t + 3]; }
+        }
+    };
+    fetch(k0, raw);
+    for (uint32_t k = k0; k < k1; k++) {
+        if (k + 1 < k1) fetch(k + 1, nxt);
+        uint16_t *dst = comp + (size_t)k * ZA_WIN + (size_t)tid * PER;
+        uint4 vals[PER / 8];
+#pragma unroll
+        for (uint32_t t = 0; t < PER / 8; t++) {
+            const uint32_t q[4] = {raw[t].x, raw[t].y, raw[t].z, raw[t].w};
+            uint32_t r[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                uint32_t lo = q[e] & 0xFFFFu, hi = q[e] >> 16;
+                if (k != k0) {
+                    if (lo >= 256u) lo = cur[lo - 256u];
+                    if (hi >= 256u) hi = cur[hi - 256u];
+                }
+                r[e] = lo | (hi << 16);
+            }
+            vals[t] = make_uint4(r[0], r[1], r[2], r[3]);
         }
         __syncthreads();
 #pragma unroll
-        for (uint32_t t = 0; t < ZA_WIN / 1024; t++) { cur[tid + 1024u * t] = vals[t]; dst[tid + 1024u * t] = vals[t]; }
+        for (uint32_t t = 0; t < PER / 8; t++) { *(uint4 *)(cur + tid * PER + 8u * t) = vals[t]; *(uint4 *)(dst + 8u * t) = vals[t]; }
         __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < PER / 8; t++) raw[t] = nxt[t];
     }
 }
 
@@ -2026,17 +2060,36 @@ __global__ __launch_bounds__(1024) void za_k_chunk_chain(const uint16_t *__restr
     const uint32_t groups = (n + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
     for (uint32_t j = tid; j < ZA_WIN; j += 1024) cur[j] = j >= ZA_WIN - dict_len ? dict[j - (ZA_WIN - dict_len)] : (uint8_t)0;
     __syncthreads();
+    // one step per group, each waiting for the one before: the next group's map (64 KiB, 32 consecutive symbols per thread) is on
+    // its way while this one's window is written out
+    constexpr uint32_t PER = ZA_WIN / 1024;
+    uint4 raw[PER / 8], ahead[PER / 8];
+    auto fetch = [&](uint32_t g, uint4 *dst) {
+        const uint16_t *cm = comp + (size_t)((g + 1) * ZA_CHUNK_GROUP - 1) * ZA_WIN + (size_t)tid * PER;
+#pragma unroll
+        for (uint32_t t = 0; t < PER / 8; t++) dst[t] = *(const uint4 *)(cm + 8u * t);
+    };
+    if (groups > 1) fetch(0, raw);
     for (uint32_t g = 0; g < groups; g++) {
+        if (g + 2 < groups) fetch(g + 1, ahead);
         uint8_t *wout = winbuf + (size_t)g * ZA_WIN;
-        for (uint32_t j = tid * 4; j < ZA_WIN; j += 4096) *(uint32_t *)(wout + j) = *(const uint32_t *)(cur + j);
+        for (uint32_t j = tid * 16; j < ZA_WIN; j += 16 * 1024) *(uint4 *)(wout + j) = *(const uint4 *)(cur + j);
         if (g + 1 == groups) break;
-        const uint16_t *cm = comp + (size_t)((g + 1) * ZA_CHUNK_GROUP - 1) * ZA_WIN;
-        for (uint32_t j = tid; j < ZA_WIN; j += 1024) {
-            const uint32_t sy = cm[j];
-            nxt[j] = sy < 256u ? (uint8_t)sy : cur[sy - 256u];
+#pragma unroll
+        for (uint32_t t = 0; t < PER / 8; t++) {
+            const uint32_t q[4] = {raw[t].x, raw[t].y, raw[t].z, raw[t].w};
+            uint32_t r[2] = {0, 0};
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++) {
+                const uint32_t sy = (q[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu;
+                r[e >> 2] |= (sy < 256u ? sy : (uint32_t)cur[sy - 256u]) << (8u * (e & 3u));
+            }
+            *(uint2 *)(nxt + tid * PER + 8u * t) = make_uint2(r[0], r[1]);
         }
         __syncthreads();
-        uint8_t *t = cur; cur = nxt; nxt = t;
+        uint8_t *t2 = cur; cur = nxt; nxt = t2;
+#pragma unroll
+        for (uint32_t t = 0; t < PER / 8; t++) raw[t] = ahead[t];
     }
 }
 
