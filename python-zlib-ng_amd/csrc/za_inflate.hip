@@ -1788,7 +1788,7 @@ __global__ __launch_bounds__(256) void za_k_scan_sync(const uint8_t *__restrict_
 // every wavefront is resident either way and the long sub-sequences, which re-synchronise in fewer passes, are faster.
 // The host picks by the number of chunks (ZNGAMD_CHUNKS_SMALL_FROM in zng_amd.hip).
 struct ZaChunkRes { int32_t status; uint32_t max_back; uint64_t bits; uint64_t out_len; };
-struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t end_bit; };   // absolute bit offsets in the deflate stream
+struct ZaChunk { uint64_t in_bit; uint64_t out_off; uint64_t out_len; uint64_t end_bit; uint64_t src_off; };   // absolute bit offsets in the deflate stream; src_off = where the chunk's 16-bit symbols lie (out_off when they were decoded at their final place)
 
 template <int BITS>
 __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict__ in, uint64_t in_len,
@@ -1816,8 +1816,13 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
 template <int BITS, int Q, int RINGSYMS>       // RINGSYMS symbols of history in LDS; older sources are re-read from the chunk's own output
 __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restrict__ in, uint64_t in_len,
                                                         const ZaChunk *__restrict__ chunks, uint16_t *__restrict__ out16,
-                                                        ZaChunkRes *__restrict__ res, uint64_t first_bit, uint32_t first_hist)
+                                                        ZaChunkRes *__restrict__ res, uint64_t first_bit, uint32_t first_hist,
+                                                        const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0)
 {
+    // Two uses.  After a count pass: a chunk is a run of blocks whose extent and output size are known (out_len, end_bit), its
+    // symbols go to their final place.  Without one (stops = every listed boundary, as the count pass has them): a chunk is ONE
+    // candidate decoded to the next listed boundary or sync point into a scratch area of out_len symbols (src_off) -- sizes and
+    // ends are found out here, and the host places the chunks afterwards.
     __shared__ ZaInfTabs T;
     __shared__ uint16_t win[RINGSYMS];
     __shared__ int scratch[2];
@@ -1828,9 +1833,10 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     uint32_t far = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<2, uint16_t, RINGSYMS, ZaParBufT<BITS, Q>>(in + off, in_len - off, nullptr, 0, out16 + ch.out_off, ch.out_len, T, win,
+        status = za_inflate_serial_core<2, uint16_t, RINGSYMS, ZaParBufT<BITS, Q>>(in + off, in_len - off, nullptr, 0, out16 + ch.src_off, ch.out_len, T, win,
                                                      scratch, P.stage, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
-                                                     ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, false, &far, &chunks[blockIdx.x].end_bit, 1, off * 8ull, &P);
+                                                     ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, stops != nullptr, &far,
+                                                     stops ? stops : &chunks[blockIdx.x].end_bit, stops ? nstops : 1u, off * 8ull, &P);
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = far; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
 
@@ -1989,7 +1995,7 @@ __device__ __forceinline__ uint16_t za_tail_sym(const uint16_t *__restrict__ out
 {
     // symbol at window position j of the window that follows chunk `ch`, in terms of the window before it
     const long long p = (long long)ch.out_len - ZA_WIN + (long long)j;
-    return p < 0 ? (uint16_t)(256u + j + (uint32_t)ch.out_len) : out16[ch.out_off + (uint64_t)p];
+    return p < 0 ? (uint16_t)(256u + j + (uint32_t)ch.out_len) : out16[ch.src_off + (uint64_t)p];
 }
 
 __global__ __launch_bounds__(1024) void za_k_chunk_compose(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
@@ -2007,7 +2013,7 @@ __global__ __launch_bounds__(1024) void za_k_chunk_compose(const uint16_t *__res
     auto fetch = [&](uint32_t k, ZaU4u *dst) {
         const ZaChunk ch = chunks[k];
         if (ch.out_len >= (uint64_t)ZA_WIN) {
-            const uint16_t *tail = out16 + ch.out_off + (ch.out_len - ZA_WIN) + (uint64_t)tid * PER;
+            const uint16_t *tail = out16 + ch.src_off + (ch.out_len - ZA_WIN) + (uint64_t)tid * PER;
 #pragma unroll
             for (uint32_t t = 0; t < PER / 8; t++) dst[t] = *(const ZaU4u *)(tail + 8u * t);
         } else {                                                       // a chunk shorter than the window (a short stream's only one)
@@ -2127,10 +2133,10 @@ __global__ __launch_bounds__(ZA_RESOLVE_THREADS) void za_k_chunk_resolve(const u
     // symbols that are markers (few: what a chunk copies from before its start), one 8-byte store.  (One symbol per thread and
     // step -- a two-byte load, a one-byte store -- made this the longest of the three window kernels: 512 dependent steps per
     // thread, two workgroups per CU by their LDS.)
-    const uint16_t *src = out16 + ch.out_off;
+    const uint16_t *src = out16 + ch.src_off;
     uint8_t *dst = out8 + ch.out_off;
     const uint64_t n = ch.out_len;
-    const uint64_t head = min(n, (uint64_t)((8u - (uint32_t)(ch.out_off & 7ull)) & 7u));        // symbols in front of the first 16-byte aligned one
+    const uint64_t head = min(n, (uint64_t)((8u - (uint32_t)(ch.src_off & 7ull)) & 7u));        // symbols in front of the first 16-byte aligned one
     if (threadIdx.x < head) { const uint32_t sym = src[threadIdx.x]; dst[threadIdx.x] = sym < 256u ? (uint8_t)sym : w[(sym - 256u) & (ZA_WIN - 1)]; }
     const uint64_t groups8 = (n - head) >> 3;
     for (uint64_t i = threadIdx.x; i < groups8; i += ZA_RESOLVE_THREADS) {

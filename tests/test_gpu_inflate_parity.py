@@ -217,7 +217,7 @@ def test_chunk_parallel_inflate_of_sync_flushed_stream(ctx, fastq):
     from oracle import oracle as O
     rng = np.random.default_rng(21)
     data = fastq + fastq[:500000]
-    for step, level in ((100000, 6), (37000, 9), (250000, 1)):
+    for step, level in ((100000, 6), (37000, 9), (250000, 1), (8000, 6)):      # (pieces of 8 000 bytes are too small to be chunks of their own: count pass + merged chunks)
         blob = _sync_flushed_gzip(data, step, level)
         assert gzip.decompress(blob) == data
         ctx.decode_paths(True)
@@ -225,7 +225,8 @@ def test_chunk_parallel_inflate_of_sync_flushed_stream(ctx, fastq):
         code, out, nm = ctx.gunzip(blob, len(data))
         kt = ctx.kernel_times(True); ctx.profiling(False)
         assert (code, nm) == (0, 1) and out == data
-        assert kt["inflate"][1] >= 3 and kt["scan"][1] >= 1, kt          # count, decode, propagate+resolve ran
+        # [count,] decode, propagate + resolve ran: one decoding pass where the sync-delimited pieces are chunks as they are
+        assert kt["inflate"][1] >= (3 if step < 20000 else 2) and kt["scan"][1] >= 1, kt
         assert ctx.decode_paths(True)["chunked"] == 1
     # payload full of `00 00 FF FF` look-alikes: stored blocks (level 0) and compressed
     tricky = (b"\x00\x00\xff\xff" * 50 + rng.bytes(3000)) * 400
