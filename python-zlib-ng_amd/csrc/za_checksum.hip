@@ -12,13 +12,13 @@ __global__ __launch_bounds__(64) void za_k_checksum(const uint8_t *__restrict__ 
                                                     const uint32_t *__restrict__ x8k_table,
                                                     ZaCkPart *__restrict__ parts, int want_adler)
 {
-    __shared__ uint32_t crct[256];
+    __shared__ uint32_t crct[1024];               // slice-by-4 (crc_table: the context's 4 x 256 table)
     const int lane = za_lane();
-    for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
+    for (int i = lane; i < 1024; i += 64) crct[i] = crc_table[i];
     __syncthreads();
     const uint64_t off = (uint64_t)blockIdx.x * ZA_MAX_UNIT;
     const int len = (int)((n - off) > ZA_MAX_UNIT ? ZA_MAX_UNIT : (n - off));
-    const uint32_t c = za_wave_crc32(buf + off, len, crct, x8k_table);
+    const uint32_t c = za_wave_crc32_s4(buf + off, len, crct, x8k_table);
     uint32_t a = 0, b = 0;
     if (want_adler) za_wave_adler(buf + off, len, a, b);
     if (lane == 0) { ZaCkPart p; p.crc = c; p.a = a; p.b = b; p.len = (uint32_t)len; parts[blockIdx.x] = p; }

@@ -295,7 +295,7 @@ static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *c
     HIPCHK(c, c->ck.ensure(nspan));
     {
         ProfScope ps(c, ZNGAMD_K_OTHER);
-        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(64), 0, c->stream, d, n, c->d_crc_table, c->d_x8k, c->ck.p, adler_io ? 1 : 0);
+        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(64), 0, c->stream, d, n, c->d_crc_slice4, c->d_x8k, c->ck.p, adler_io ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     std::vector<ZaCkPart> parts(nspan);
