@@ -654,25 +654,53 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
                         }
                     }
                 }
+                // The others by the whole wave.  The matches that are ready in one round do not read one another (that is what ready
+                // means), so four of them at a time have their first 64 symbols LOADED before any is stored: one trip to memory for
+                // four matches instead of four trips one behind the other (these matches are few, but each cost the wave a full
+                // load-store round trip); what a match has beyond 64 symbols follows in blocks of 64.
                 unsigned long long coop = __ballot(ready && !simple);
                 while (coop) {
-                    const int j = __builtin_ctzll(coop);
-                    coop &= coop - 1ull;
-                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
-                    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
-                    const uint32_t cdist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
-                    const long long dq = (long long)(op + (uint64_t)cd);
-                    const float rd = 1.0f / (float)cdist;
-                    for (uint32_t bs = 0; bs < cl; bs += 64) {
-                        const uint32_t i = bs + (uint32_t)lane;
-                        if (i < cl) {
-                            int k = (int)i;                 // byte i of a self-overlapping match is byte (i mod dist) of its period
-                            if (cdist < cl) {
-                                k = (int)i - (int)cdist * (int)((float)i * rd);
-                                if (k < 0) k += (int)cdist;
-                                if (k >= (int)cdist) k -= (int)cdist;
+                    uint32_t cdv[4], clv[4], cdistv[4];
+                    SymT val[4];
+                    int cnt4 = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        cdv[u] = 0; clv[u] = 0; cdistv[u] = 1; val[u] = 0;
+                        if (coop) {
+                            const int j = __builtin_ctzll(coop);
+                            coop &= coop - 1ull;
+                            cdv[u] = (uint32_t)__builtin_amdgcn_readlane((int)mdst, j);
+                            clv[u] = (uint32_t)__builtin_amdgcn_readlane((int)mlen, j);
+                            cdistv[u] = (uint32_t)__builtin_amdgcn_readlane((int)mdist, j);
+                            cnt4 = u + 1;
+                        }
+                    }
+                    auto src_index = [&](uint32_t i, uint32_t cl, uint32_t cdist) -> int {
+                        int k = (int)i;                     // byte i of a self-overlapping match is byte (i mod dist) of its period
+                        if (cdist < cl) {
+                            k = (int)i - (int)cdist * (int)((float)i * (1.0f / (float)cdist));
+                            if (k < 0) k += (int)cdist;
+                            if (k >= (int)cdist) k -= (int)cdist;
+                        }
+                        return k;
+                    };
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (u < cnt4 && (uint32_t)lane < clv[u]) {
+                            const long long dq = (long long)(op + (uint64_t)cdv[u]);
+                            val[u] = sym_at(dq - (long long)cdistv[u] + src_index((uint32_t)lane, clv[u], cdistv[u]));
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (u < cnt4 && (uint32_t)lane < clv[u]) out[(long long)(op + (uint64_t)cdv[u]) + lane] = val[u];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (u < cnt4 && clv[u] > 64u) {
+                            const long long dq = (long long)(op + (uint64_t)cdv[u]);
+                            for (uint32_t bs = 64; bs < clv[u]; bs += 64) {
+                                const uint32_t i = bs + (uint32_t)lane;
+                                if (i < clv[u]) out[dq + i] = sym_at(dq - (long long)cdistv[u] + src_index(i, clv[u], cdistv[u]));
                             }
-                            out[dq + i] = sym_at(dq - (long long)cdist + k);
                         }
                     }
                 }
