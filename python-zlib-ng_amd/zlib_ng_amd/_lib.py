@@ -4,6 +4,7 @@ There is no fallback: if the library is missing, or no MI355X-class GPU is usabl
 works but the first call that needs the engine raises ``RuntimeError``.
 """
 import ctypes as C
+import mmap as _mmap
 import os
 import sys
 import threading
@@ -299,7 +300,7 @@ _buffer_pool, _buffer_pool_lock = [], threading.Lock()
 
 
 def take_buffer(n):
-    """A bytearray of at least n bytes (contents arbitrary), warm if the pool has one."""
+    """A writable buffer of at least n bytes (contents arbitrary), warm if the pool has one."""
     n = max(int(n), 1)
     with _buffer_pool_lock:
         best = None
@@ -308,17 +309,21 @@ def take_buffer(n):
                 best = i
         if best is not None and len(_buffer_pool[best]) <= 2 * n + (1 << 20):
             return _buffer_pool.pop(best)
-    buf = bytearray(n)
+    # an anonymous private mapping, not a bytearray: bytearray(n) writes n zeros at once -- a page fault per 4 KiB before the request
+    # for huge pages can be made, 100 ms for the 320 MiB of a reader's window -- where the mapping's pages come into being when
+    # they are first written, two MiB at a time
+    buf = _mmap.mmap(-1, n, flags=_mmap.MAP_PRIVATE | _mmap.MAP_ANONYMOUS)
     if n >= _HUGE_MIN:
-        anchor = C.c_char.from_buffer(buf)
-        _advise_huge(C.addressof(anchor), n)
-        del anchor
+        try:
+            buf.madvise(_mmap.MADV_HUGEPAGE)
+        except (AttributeError, OSError, ValueError):
+            pass
     return buf
 
 
 def give_buffer(buf):
     """Hand a buffer from take_buffer() back (nothing may still read or write it)."""
-    if not isinstance(buf, bytearray) or len(buf) < (1 << 20):
+    if not isinstance(buf, (bytearray, _mmap.mmap)) or len(buf) < (1 << 20):
         return
     with _buffer_pool_lock:
         if sum(len(b) for b in _buffer_pool) + len(buf) <= _POOL_MAX_BYTES:
