@@ -388,3 +388,43 @@ def test_reader_read_ahead_and_long_tails(T, Z, monkeypatch, tmp_path):
     with T.open(str(path), "rb") as f:
         f.read(1 << 20)
     assert len(_lib._buffer_pool) >= min(before, 1)                        # (closed in the middle of the file: nothing leaks, buffers are kept)
+
+
+def test_gzip_ng_open_pipelined_writer(tmp_path):
+    """gzip_ng.open compresses through _PipelinedDeflate: batches of 8, 16, 32, 64 MiB on a thread beside the caller, each primed by the
+    32 KiB in front of it -- one deflate stream over one window.  Pieces of every size class, flushes of the three kinds in
+    between (each makes everything written so far readable; a full flush also cuts the history), the CRC folded from the
+    batches, the stdlib as the judge."""
+    import zlib
+    from zlib_ng_amd import corpus, gzip_ng, zlib_ng
+    src = corpus.text(100 << 20, seed=13).tobytes()
+    rng = np.random.default_rng(5)
+    path = tmp_path / "p.gz"
+    pos = 0
+    with gzip_ng.open(str(path), "wb", compresslevel=5) as f:
+        assert isinstance(f.compress, gzip_ng._PipelinedDeflate)
+        for sz in [1, 40000, 131072, (9 << 20) + 3, 131072, 70 << 20, 5, 131072] + [int(x) for x in rng.integers(1, 300000, 40)]:
+            sz = min(sz, len(src) - pos)
+            piece = src[pos:pos + sz] if sz % 2 else memoryview(src)[pos:pos + sz]
+            assert f.write(piece) == sz
+            pos += sz
+            if sz == 5:
+                f.flush()                                             # Z_SYNC_FLUSH: the file is readable up to here
+                d = zlib.decompressobj(31)
+                assert d.decompress(path.read_bytes()) == src[:pos]
+            if sz == 40000:
+                f.flush(zlib_ng.Z_FULL_FLUSH)
+    with gzip.open(str(path), "rb") as g:
+        assert g.read() == src[:pos]
+    raw = path.read_bytes()
+    assert int.from_bytes(raw[-8:-4], "little") == zlib.crc32(src[:pos]) and int.from_bytes(raw[-4:], "little") == pos & 0xFFFFFFFF
+    # the compressor on its own: nothing comes out before a batch is full, everything at the latest with flush(Z_FINISH)
+    c = gzip_ng._PipelinedDeflate(6)
+    parts = [c.compress(src[o:o + 65536]) for o in range(0, 40 << 20, 65536)]      # (the 8 MiB batch comes out when the 16 MiB one goes in)
+    assert parts[0] == b"" and any(parts)
+    parts.append(c.flush())
+    assert zlib.decompress(b"".join(parts), -15) == src[:40 << 20] and c._crc == zlib.crc32(src[:40 << 20])
+    with pytest.raises(ValueError):
+        c.compress(b"more")
+    with pytest.raises(zlib_ng.error):
+        gzip_ng._PipelinedDeflate(10)
