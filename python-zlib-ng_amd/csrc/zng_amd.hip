@@ -607,6 +607,7 @@ static int d2h_payload(zngamd_ctx *c, uint8_t *dst, const uint8_t *src_dev, uint
     if (r) return r;
     if (!c->ev_copy[0]) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_copy[1], hipEventDisableTiming)); }
     const uint64_t np = (n + piece - 1) / piece;
+    double wait_ms = 0, copy_ms = 0;
     for (uint64_t k = 0; k <= np; k++) {
         if (k < np) {
             const uint64_t o = k * piece, ln = std::min(piece, n - o);
@@ -615,10 +616,14 @@ static int d2h_payload(zngamd_ctx *c, uint8_t *dst, const uint8_t *src_dev, uint
         }
         if (k > 0) {
             const uint64_t o = (k - 1) * piece, ln = std::min(piece, n - o);
+            const auto t0 = std::chrono::steady_clock::now();
             HIPCHK(c, hipEventSynchronize(c->ev_copy[(k - 1) & 1]));
+            const auto t1 = std::chrono::steady_clock::now();
             par_memcpy(dst + o, st + ((k - 1) & 1) * piece, ln);
+            if (trace_on()) { wait_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(); }
         }
     }
+    if (trace_on()) fprintf(stderr, "zng_amd trace:   d2h: waiting for the DMA %.3f ms, host copies %.3f ms (%llu pieces)\n", wait_ms, copy_ms, (unsigned long long)np);
     return ZNGAMD_OK;
 }
 
