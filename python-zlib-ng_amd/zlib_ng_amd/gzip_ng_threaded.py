@@ -82,6 +82,7 @@ class _ThreadedGzipReader(io.RawIOBase):
         source, owns = open_as_binary_stream(filename, "rb")
         self.raw, self.closefd = source, owns
         self.fileobj = zlib_ng._GzipReader(source, buffersize=8 * block_size)
+        self.fileobj._decode_ahead = False           # (the pump below is what decodes ahead here)
         self.block_size = block_size
         self.pos = 0
         # (the reference's tests pass a mode string in this position; anything that is not a positive count means 2)

@@ -777,6 +777,7 @@ class _GzipReader:
         self._mtime = 0
         self._lock = _threading.Lock()
         self._size = -1
+        self._decode_ahead = _os.environ.get("ZNGAMD_NO_DECODE_AHEAD") is None     # (gzip_ng_threaded's reader, which has a pump thread of its own, turns it off)
         self._reset()
 
     @property
@@ -786,6 +787,7 @@ class _GzipReader:
         return self._mtime or None
 
     def _reset(self):
+        self._release_windows()  # FIRST: a thread that is decoding or reading ahead works on the state below; it is waited for here
         self._window = max(1 << 16, int(_os.environ.get("ZNGAMD_READ_WINDOW", 64 << 20)))
         self._buf = b""          # decoded, not yet handed out
         self._boff = 0
@@ -796,15 +798,23 @@ class _GzipReader:
         self._error = None       # raised once the buffered good bytes are gone
         self._first = True
         self._state = _lib.GzState()      # where a member larger than the window is being continued
-        self._release_windows()
         self._out = None                  # decoded window (buffer, address); reused, so its pages are faulted in once
         self._spare = []                  # buffers given back by a consumer that took whole windows (_take_window)
         self._in_buf = None               # the compressed window: one buffer, refilled (the engine call is through by then)
         self._ahead = None                # the next window's file bytes being read on a thread of their own (_start_ahead)
+        self._dec_ahead = None            # the next window being decoded on a thread of its own (_start_decode_ahead)
+        self._calls = 0
 
     def _release_windows(self):
         """Window buffers go back to the process-wide pool (_lib.take_buffer): the next reader finds them warm."""
         self._buf = b""
+        if getattr(self, "_dec_ahead", None) is not None:    # a decode-ahead still running: wait, its buffer goes back below
+            t, box = self._dec_ahead
+            self._dec_ahead = None
+            t.join()
+            res = box.get("res")
+            if res is not None and res[1] is not None:
+                _lib.give_buffer(res[1][0])
         if getattr(self, "_ahead", None) is not None:        # a read-ahead still running: wait, drop what it read
             try:
                 ahead = self._join_ahead()
@@ -914,20 +924,22 @@ class _GzipReader:
             self._in_eof = True
         return buf[:keep + got]
 
-    def _set_error(self, code, data, ctx):
+    def _error_for(self, code, data, ctx):
         msg = ctx.err()
         if code == _lib.E_GZ_MAGIC:
             # locate the offending bytes the way the reference reports them
-            self._error = _magic_error(data, ctx) or BadGzipFile("Not a gzipped file (b'??')")
-        elif code in _GZ_ERR:
-            self._error = _GZ_ERR[code](msg)
-        else:
-            self._error = _zerr(code if code in _MSG else _lib.DATA_ERROR, "while decompressing data")
+            return _magic_error(data, ctx) or BadGzipFile("Not a gzipped file (b'??')")
+        if code in _GZ_ERR:
+            return _GZ_ERR[code](msg)
+        return _zerr(code if code in _MSG else _lib.DATA_ERROR, "while decompressing data")
 
-    def _fill(self):
-        """Decode until some output is buffered, the stream ends, or an error is pending."""
+    def _decode_window(self):
+        """The next decoded window -> (bytes view, its buffer, end of stream, pending error).  Works on the decoding side of the
+        state only (input windows, carry, the engine's stream state) and on buffers nobody reads, never on _buf / _boff / _out of
+        the window the consumer is reading: it may run on a thread beside the consumer (_start_decode_ahead)."""
         ctx = _ctx()
-        while not self._done and self._boff >= len(self._buf):
+        pair = None
+        while True:
             data = self._carry if self._in_eof else self._read_window(self._carry)
             self._carry = b""
             if self._first:
@@ -935,50 +947,89 @@ class _GzipReader:
                 if len(data) >= 8:
                     self._mtime = _struct.unpack_from("<I", data, 4)[0]
                 if len(data) >= 2 and data[:2] != b"\x1f\x8b":
-                    self._buf, self._boff, self._done = b"", 0, True
-                    self._error = BadGzipFile(f"Not a gzipped file ({bytes(data[:2])!r})")
-                    return
+                    return b"", pair, True, BadGzipFile(f"Not a gzipped file ({bytes(data[:2])!r})")
             if not data:
-                self._done = True
-                return
+                return b"", pair, True, None
             final = self._in_eof
             isize = _struct.unpack_from("<I", data, len(data) - 4)[0] if (final and len(data) >= 18) else 0
             cap = max(1 << 16, 4 * len(data), min(isize, 1032 * len(data)) + 64)      # (ISIZE is untrusted: bounded by what deflate can expand)
             while True:
-                if self._out is None and self._spare:
-                    self._out = self._spare.pop()        # a window buffer the threaded reader's consumer has finished with
-                if self._out is None or len(self._out[0]) < cap:
-                    self._buf = b""                      # drop the view of the old buffer before replacing it
-                    if self._out is not None:
-                        _lib.give_buffer(self._out[0])
-                    self._out = _lib.take_window(cap + cap // 4)  # head-room: windows differ a little in size
-                cap = len(self._out[0])
+                if pair is None and self._spare:
+                    try:
+                        pair = self._spare.pop()         # a window buffer its consumer has finished with
+                    except IndexError:
+                        pair = None
+                if pair is None or len(pair[0]) < cap:
+                    if pair is not None:
+                        _lib.give_buffer(pair[0])
+                    pair = _lib.take_window(cap + cap // 4)       # head-room: windows differ a little in size
+                cap = len(pair[0])
                 self._start_ahead()                      # the file read of the next window runs beside the engine call
-                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, into=self._out)
+                code, out, nm, used = ctx.gunzip_stream(self._state, data, cap, final, into=pair)
                 if code == _lib.BUF_ERROR and (len(out) >= cap or ctx.last_needed > cap):
                     cap = max(cap * 4, ctx.last_needed + 64)
                     continue
                 break
             if code != _lib.OK:
-                self._buf, self._boff, self._done = out, 0, True
-                self._set_error(code, data, ctx)
-                return
+                return out, pair, True, self._error_for(code, data, ctx)
             if final:
-                self._buf, self._boff = out, 0
+                done = True
                 if 0 < used < len(data):
                     self._carry = bytes(memoryview(data)[used:])   # a continued member ended inside the last window: the rest follows
-                else:
-                    self._done = True
-                if self._boff < len(self._buf) or self._done:
-                    return
+                    done = False
+                if len(out) or done:
+                    return out, pair, done, None
                 continue
             if used == 0:
                 # neither a complete member nor a complete deflate block in the window: take a larger one
                 self._carry = data
                 self._window *= 2
                 continue
-            self._buf, self._boff = out, 0
             self._carry = bytes(memoryview(data)[used:])
+            if len(out):
+                return out, pair, False, None
+
+    def _start_decode_ahead(self):
+        """The window after this one is decoded on a thread of its own while the consumer copies this one out (the engine call,
+        the file read and the copy all release the interpreter lock): gzip_ng.open's reader, which has no pump thread of its
+        own, alternated 13 ms of decoding with 15 ms of copying per window."""
+        if (not self._decode_ahead or not self._is_file or self._dec_ahead is not None or self._closed or self._done
+                or self._error is not None or _sys.is_finalizing()):
+            return
+        box = {}
+
+        def work():
+            try:
+                box["res"] = self._decode_window()
+            except BaseException as exc:                 # raised where the window would have been taken over
+                box["exc"] = exc
+        t = _threading.Thread(target=work, name="zng-amd-decode-ahead")
+        t.start()
+        self._dec_ahead = (t, box)
+
+    def _next_decoded(self):
+        if self._dec_ahead is not None:
+            t, box = self._dec_ahead
+            self._dec_ahead = None
+            t.join()
+            if "exc" in box:
+                raise box["exc"]
+            return box["res"]
+        return self._decode_window()
+
+    def _fill(self):
+        """Decode until some output is buffered, the stream ends, or an error is pending."""
+        while not self._done and self._boff >= len(self._buf):
+            buf, pair, done, err = self._next_decoded()
+            self._buf = b""                              # (drop the view of the window that is finished before its buffer goes back)
+            if self._out is not None and self._out is not pair:
+                self._give_back(self._out)
+            self._out = pair
+            self._buf, self._boff, self._done = buf, 0, done
+            if err is not None:
+                self._error = err
+                self._done = True
+            self._start_decode_ahead()
 
     def _check(self):
         if self._closed:
@@ -999,7 +1050,16 @@ class _GzipReader:
                     raise self._error
                 self._size = self._pos
                 return 0
-            mv[:n] = memoryview(self._buf)[self._boff:self._boff + n]      # one copy, no intermediate bytes object
+            self._calls += 1
+            if (n >= 32768 and (self._calls & 7) == 0 and self._dec_ahead is not None and self._out is not None and not mv.readonly
+                    and len(self._buf) <= len(self._out[0])):
+                # while the next window is being decoded on its thread, every eighth large copy lets go of the interpreter lock
+                # (a foreign call): that thread needs it between its file read and its engine call
+                anchor = _C.c_char.from_buffer(mv)
+                _C.memmove(_C.addressof(anchor), self._out[1].value + self._boff, n)
+                del anchor
+            else:
+                mv[:n] = memoryview(self._buf)[self._boff:self._boff + n]      # one copy, no intermediate bytes object
             self._boff += n
             self._pos += n
             return n
