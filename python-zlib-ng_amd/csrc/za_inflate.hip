@@ -353,11 +353,19 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
-    if (bitpos + 64ull * ZA_PS_MINBITS + 64ull > in_bits || out_cap - op < 256ull) return 0;
-    uint32_t S = (uint32_t)(((in_bits - bitpos - 64ull) >> 6) > (uint64_t)PB::kBits ? (uint64_t)PB::kBits : ((in_bits - bitpos - 64ull) >> 6));
+    // Near the end of the input fewer lanes take part (L of them, sub-sequences of ZA_PS_MINBITS bits) instead of none: the last
+    // 520 bytes of every member went through the sequential rounds, 65 of them (ZA_PS_SHORT_TAIL_LANES: the fewest lanes worth a sweep).
+#ifndef ZA_PS_SHORT_TAIL_LANES
+#define ZA_PS_SHORT_TAIL_LANES 12u
+#endif
+    if (bitpos + (uint64_t)ZA_PS_SHORT_TAIL_LANES * ZA_PS_MINBITS + 64ull > in_bits || out_cap - op < 256ull) return 0;
+    const uint64_t room_bits = in_bits - bitpos - 64ull;
+    uint32_t S = (uint32_t)((room_bits >> 6) > (uint64_t)PB::kBits ? (uint64_t)PB::kBits : (room_bits >> 6));
+    uint32_t L = 64;                                                        // lanes that have a sub-sequence
+    if (S < (uint32_t)ZA_PS_MINBITS) { S = ZA_PS_MINBITS; L = (uint32_t)(room_bits / ZA_PS_MINBITS); }      // ZA_PS_SHORT_TAIL_LANES <= L < 64
     const uint64_t sbyte = (bitpos >> 3) & ~3ull;
     const uint32_t b0 = (uint32_t)(bitpos - sbyte * 8ull);                 // 0..31
-    const uint32_t ndw = ((b0 + 64u * S + 48u) >> 5) + 5u;                  // fits the staging area: a lane reads up to 64 bits ahead
+    const uint32_t ndw = ((b0 + L * S + 48u) >> 5) + 5u;                    // fits the staging area: a lane reads up to 64 bits ahead
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = (uint32_t)lane; i < ndw; i += 64) {
         const uint64_t o = sbyte + 4ull * i;
@@ -527,10 +535,10 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 #endif
     };
 
-    uint32_t start = b0 + (uint32_t)lane * S;
+    uint32_t start = (uint32_t)lane < L ? b0 + (uint32_t)lane * S : ZA_PS_NONE;
     const uint32_t lim = b0 + ((uint32_t)lane + 1u) * S;
     bool dirty = true;
-    int nvalid = 64;
+    int nvalid = (int)L;
     const unsigned long long t0 = ZA_STAT_T();
     int its = 0;
     for (int it = 1;; it++) {
@@ -545,7 +553,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 #endif
             }
         }
-        const uint32_t handed = (uint32_t)__shfl_up((int)(st == 0 ? endp : ZA_PS_NONE), 1, 64);
+        const uint32_t handed = (uint32_t)lane < L ? (uint32_t)__shfl_up((int)(st == 0 ? endp : ZA_PS_NONE), 1, 64) : ZA_PS_NONE;     // (lanes without a sub-sequence stay out)
         const bool ch = lane > 0 && handed != start;
         if (lane > 0) start = handed;
         dirty = ch;
@@ -753,6 +761,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
     int status = ZA_I_OK;
     bool ring_stale = false;       // a parallel sweep wrote `out` only: the LDS ring is refreshed before the next sequential round
     int par_wait = 0;              // sequential rounds to go before the next parallel sweep is tried
+    int short_run = 0;             // sweeps in a row that kept fewer than 16 lanes
     if (hist == 0xFFFFFFFFu) hist = dict_len;
     if (MODE == 0) for (uint32_t i = (uint32_t)lane; i < dict_len; i += 64) if (dict_len - i <= (uint32_t)RING) win[(ZA_WIN - dict_len + i) & (RING - 1)] = (SymT)dict[i];
     // MODE 2: the ring starts out holding the markers of the RING positions before the start
@@ -821,7 +830,17 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                         const int got = za_par_sweep<MODE, SymT, PB>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
                                                                      max_back ? &far : nullptr, eob);
                         ibase = ~0ull;                                   // the staging area was used by the sweep
-                        if (got > 0) { ring_stale = true; if (got < 16) par_wait = 32; continue; }
+                        // A sweep that kept few lanes (the passes had not settled, the queue was full) is followed by another sweep
+                        // at once; only the second such sweep in a row sends the decoder to 32 sequential rounds (data on which the
+                        // sub-sequences do not find their way costs a sweep five times what the same bits cost token by token).
+                        // One that kept few lanes because the block ended in it says nothing about what follows.  Before: 32 rounds
+                        // after every short sweep -- 69 sequential rounds per zlib-written member, 7 % of the kernel.
+                        if (got > 0) {
+                            ring_stale = true;
+                            if (got < 16 && !eob) { if (++short_run >= 2) par_wait = 32; }
+                            else short_run = 0;
+                            continue;
+                        }
                         par_wait = 32;
                     } else par_wait--;
                     if (MODE != 1 && ring_stale) {
