@@ -337,9 +337,12 @@ __device__ unsigned long long za_ps_stat[32];     // 16: rounds of the counting 
 // stream kernel (one wavefront on the whole GPU) takes long sub-sequences, 1024 bits, which re-synchronise in fewer passes;
 // the kernels that run thousands of wavefronts (members, chunks) take 256 bits and a queue of 1024, which leaves room for
 // 9-11 workgroups per CU instead of 4 (chunk decode of 128 MiB: 5-6.6 -> 3.5 ms, 256 MiB of BGZF members: 8.3 -> 5.1 ms).
-template <int BITS, int Q>
+#ifndef ZA_CHUNK_MAXIT
+#define ZA_CHUNK_MAXIT 3            // pass limit of the chunk kernels (sub-sequences of 512 / 1 024 bits settle sooner, and a sweep cut short is followed by another at once: 256 MiB of this engine's stream 4.76 -> 4.24 ms, a zlib stream of 128 MiB 4.09 -> 3.66 ms against the limit of six)
+#endif
+template <int BITS, int Q, int MAXIT = ZA_PS_MAXIT>
 struct ZaParBufT {
-    static constexpr int kBits = BITS, kQ = Q;
+    static constexpr int kBits = BITS, kQ = Q, kMaxIt = MAXIT;
     uint32_t stage[64 * BITS / 32 + 8];   // the sweep's compressed bytes (also the sequential decoder's staging area and the header copy)
     uint32_t qa[Q];                       // position relative to the sweep's first output symbol (17 bits) | (distance - 1) << 17
     uint8_t ql[Q];                        // length - 3          (a counting kernel, MODE 1, never touches the queue: Q = 1)
@@ -559,7 +562,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         dirty = ch;
         const unsigned long long chm = __ballot(ch);
         if (!chm) break;
-        if (it >= ZA_PS_MAXIT) { nvalid = __builtin_ctzll(chm); break; }
+        if (it >= PB::kMaxIt) { nvalid = __builtin_ctzll(chm); break; }
     }
     ZA_STAT_ADD(0, 1); ZA_STAT_ADD(2, its); ZA_STAT_ADD(3, ZA_STAT_T() - t0); ZA_STAT_ADD(13, nvalid);
     // the chain ends at the first lane that did not run to its limit
@@ -1846,13 +1849,13 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
 {
     __shared__ ZaInfTabs T;
     __shared__ int scratch[2];
-    __shared__ ZaParBufT<BITS, 1> PS;
+    __shared__ ZaParBufT<BITS, 1, ZA_CHUNK_MAXIT> PS;
     const uint64_t abit = cands[blockIdx.x];                 // absolute bit offset of a possible block header
     const uint64_t off = abit >> 3;
     uint64_t bits = 0, op = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<1, uint8_t, ZA_WIN, ZaParBufT<BITS, 1>>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, PS.stage,
+        status = za_inflate_serial_core<1, uint8_t, ZA_WIN, ZaParBufT<BITS, 1, ZA_CHUNK_MAXIT>>(in + off, in_len - off, nullptr, 0, nullptr, ZA_COUNT_CAP, T, nullptr, scratch, PS.stage,
                                                     bits, op, (uint32_t)(abit & 7u), nullptr, nullptr,
                                                     whole_streams ? 0u : (abit == first_bit ? first_hist : (uint32_t)ZA_WIN), !whole_streams, nullptr,
                                                     cands, whole_streams ? 0u : ncands, off * 8ull, &PS);
@@ -1873,14 +1876,14 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     __shared__ ZaInfTabs T;
     __shared__ uint16_t win[RINGSYMS];
     __shared__ int scratch[2];
-    __shared__ ZaParBufT<BITS, Q> P;
+    __shared__ ZaParBufT<BITS, Q, ZA_CHUNK_MAXIT> P;
     const ZaChunk ch = chunks[blockIdx.x];
     const uint64_t off = ch.in_bit >> 3;
     uint64_t bits = 0, op = 0;
     uint32_t far = 0;
     int status = ZA_I_DATA;
     if (off <= in_len)
-        status = za_inflate_serial_core<2, uint16_t, RINGSYMS, ZaParBufT<BITS, Q>>(in + off, in_len - off, nullptr, 0, out16 + ch.src_off, ch.out_len, T, win,
+        status = za_inflate_serial_core<2, uint16_t, RINGSYMS, ZaParBufT<BITS, Q, ZA_CHUNK_MAXIT>>(in + off, in_len - off, nullptr, 0, out16 + ch.src_off, ch.out_len, T, win,
                                                      scratch, P.stage, bits, op, (uint32_t)(ch.in_bit & 7u), nullptr, nullptr,
                                                      ch.in_bit == first_bit ? first_hist : (uint32_t)ZA_WIN, stops != nullptr, &far,
                                                      stops ? stops : &chunks[blockIdx.x].end_bit, stops ? nstops : 1u, off * 8ull, &P);
