@@ -837,6 +837,16 @@ struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; }
 // from this many chunks (or block candidates) on, the chunk kernels run in their small-LDS size: more than the 1 024
 // wavefronts the large size keeps resident (256 CUs x 4 workgroups)
 #define ZNGAMD_CHUNKS_SMALL_FROM 1536u
+#define ZNGAMD_CHUNKS_MANY_FROM 4096u          // from here on the chunks outnumber the wavefronts the device holds: the smallest footprint (384-bit sub-sequences, queue of 1 024: 11 per CU) wins -- 1 GiB of this engine's stream 15.2 -> 13.8 ms
+#ifndef ZA_CHUNK_BITS_S
+#define ZA_CHUNK_BITS_S 512          // the marker decoder where chunks are many: bits per sub-sequence, queue entries, symbols of history in LDS
+#endif
+#ifndef ZA_CHUNK_Q_S
+#define ZA_CHUNK_Q_S 1536
+#endif
+#ifndef ZA_CHUNK_RING_S
+#define ZA_CHUNK_RING_S 1024
+#endif
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
                                uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o = ChunkOpts(), ChunkInfo *info = nullptr);
 
@@ -1258,8 +1268,10 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
             HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->cchunks.p, pieces.data(), (size_t)n * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
             { ProfScope ps(c, ZNGAMD_K_INFLATE);
-              if (n >= ZNGAMD_CHUNKS_SMALL_FROM)
-                  hipLaunchKernelGGL((za_k_chunk_decode<512, 1536, 1024>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
+              if (n >= ZNGAMD_CHUNKS_MANY_FROM)
+                  hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
+              else if (n >= ZNGAMD_CHUNKS_SMALL_FROM)
+                  hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
               else
                   hipLaunchKernelGGL((za_k_chunk_decode<1024, 3072, 4096>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n); }
             HIPCHK(c, hipGetLastError());
@@ -1349,8 +1361,10 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, c->cres.ensure(m));
         { ProfScope ps(c, ZNGAMD_K_INFLATE);
-          if (m >= ZNGAMD_CHUNKS_SMALL_FROM)
-              hipLaunchKernelGGL((za_k_chunk_decode<512, 1536, 1024>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
+          if (m >= ZNGAMD_CHUNKS_MANY_FROM)
+              hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
+          else if (m >= ZNGAMD_CHUNKS_SMALL_FROM)
+              hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else
               hipLaunchKernelGGL((za_k_chunk_decode<1024, 3072, 4096>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u); }
         HIPCHK(c, hipGetLastError());
