@@ -1733,11 +1733,14 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
 // entries (11 per CU) is 6 % faster on 8 192 zlib-written members of 128 KiB and 10 % slower on 4 097 BGZF members of 64 KiB
 // (fewer wavefronts than the GPU holds: occupancy is no help, shorter sweeps hurt); 256 entries cost 30 %; kept at 1 024
 // (`profiles/abl_foreign.sh`, `profiles/abl_bgzf.sh`)
+// (r03, after a short sweep stopped costing 32 sequential rounds: a queue of 768 and 512 bytes of history -- the sequential
+// rounds that use the ring are 4 per member now -- leave room for 12 wavefronts per CU instead of 9: 10.96 -> 9.53 ms per GiB;
+// queue 1 024 with the small ring 10.6, queue 512 13.8, 896 entries with 416-bit sub-sequences 9.48)
 #ifndef ZA_MEMBER_RING
-#define ZA_MEMBER_RING 4096
+#define ZA_MEMBER_RING 512
 #endif
 #ifndef ZA_MEMBER_Q
-#define ZA_MEMBER_Q 1024
+#define ZA_MEMBER_Q 768
 #endif
 #ifndef ZA_MEMBER_BITS
 #define ZA_MEMBER_BITS 384             // bits per sub-sequence: 384 is 5 % faster than 256 on zlib-written 128 KiB members (fewer passes per
