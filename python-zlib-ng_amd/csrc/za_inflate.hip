@@ -18,9 +18,13 @@
 #include "za_common.h"
 #include "za_crc.h"
 
+#ifndef ZA_LUT_L_BITS
 #define ZA_LUT_L_BITS 10
+#endif
 #define ZA_IBUF_DW 128             // dwords of bitstream staged in LDS by the sequential decoder
+#ifndef ZA_LUT_D_BITS
 #define ZA_LUT_D_BITS 9
+#endif
 
 // internal status values (host maps them to ZNGAMD_* codes)
 #define ZA_I_OK          0
@@ -32,9 +36,14 @@
 #define ZA_I_CRC       (-104)
 #define ZA_I_LENGTH    (-105)
 
-struct ZaInfTabs {
-    uint16_t lut_l[1 << ZA_LUT_L_BITS];   // (sym<<4)|len, 0 = longer than the LUT or unassigned
-    uint16_t lut_d[1 << ZA_LUT_D_BITS];
+// LB / DB = index bits of the first-level tables (codes longer than that: za_long_decode).  The chunk kernels take 10 / 9 -- the
+// codes this engine writes are at most 10 / 9 bits long --, the members kernel 9 / 8: 1.5 KiB less LDS per wavefront are worth more
+// there (15 per CU instead of 13: 9.42 -> 7.89 ms per GiB of zlib-written members) than the long codes that miss the table cost.
+template <int LB, int DB>
+struct ZaInfTabsT {
+    static constexpr int kLBits = LB, kDBits = DB;
+    uint16_t lut_l[1 << LB];   // (sym<<4)|len, 0 = longer than the LUT or unassigned
+    uint16_t lut_d[1 << DB];
     uint16_t cnt_l[16], cnt_d[16];
     uint16_t fst_l[16], fst_d[16];        // first code of each length (as a number, most significant bit first) and the place of
     uint16_t idx_l[16], idx_d[16];        // its symbol in sym_*: the codes of one length are consecutive (za_long_decode)
@@ -42,6 +51,7 @@ struct ZaInfTabs {
     uint8_t lens[320];
     int status;
 };
+using ZaInfTabs = ZaInfTabsT<ZA_LUT_L_BITS, ZA_LUT_D_BITS>;
 
 struct ZaInfResult {
     int32_t status; uint32_t pad;
@@ -196,7 +206,8 @@ __constant__ uint8_t za_i_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 // Parse a fixed or dynamic block header at `bitpos` (uniform across the wave) and build the decode
 // tables.  Returns ZA_I_OK / ZA_I_DATA / ZA_I_INPUT; advances bitpos past the header.
 #define ZA_HDR_DW 148     // dwords of LDS that hold a whole dynamic header behind its three counts: 57 + 316 * 14 bits, + alignment and look-ahead
-__device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bitpos, int type, ZaInfTabs &T, int *scratch /*2 ints LDS*/,
+template <typename TT>
+__device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bitpos, int type, TT &T, int *scratch /*2 ints LDS*/,
                               uint32_t *hb = nullptr /* ZA_HDR_DW dwords of LDS, or none: the header is then read from memory bit by bit */)
 {
     const int lane = za_lane();
@@ -204,8 +215,8 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         __syncthreads();
         for (int i = lane; i < 320; i += 64)
             T.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : i < 318 ? 5 : 0);
-        za_build_table(T.lens, 288, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
-        za_build_table(T.lens + 288, 30, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
+        za_build_table(T.lens, 288, T.cnt_l, T.sym_l, T.lut_l, TT::kLBits, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
+        za_build_table(T.lens + 288, 30, T.cnt_d, T.sym_d, T.lut_d, TT::kDBits, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
         return ZA_I_OK;
     }
     if (bitpos + 14 > in_bits) return ZA_I_INPUT;
@@ -291,10 +302,10 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
     for (int i = nlen + lane; i < 288; i += 64) T.lens[i] = 0;
     __syncthreads();
     int maxl;
-    st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, ZA_LUT_L_BITS, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
+    st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, TT::kLBits, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
     maxl = scratch[1];
     if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
-    st = za_build_table(T.lens + 288, ndist, T.cnt_d, T.sym_d, T.lut_d, ZA_LUT_D_BITS, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
+    st = za_build_table(T.lens + 288, ndist, T.cnt_d, T.sym_d, T.lut_d, TT::kDBits, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
     maxl = scratch[1];
     if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
     return ZA_I_OK;
@@ -349,9 +360,9 @@ struct ZaParBufT {
 };
 
 // returns the number of lanes whose sub-sequences were decoded (0: nothing done, position untouched)
-template <int MODE, typename SymT, typename PB>
+template <int MODE, typename SymT, typename PB, typename TT>
 __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
-                            SymT *__restrict__ out, uint64_t out_cap, const ZaInfTabs &T, PB *P,
+                            SymT *__restrict__ out, uint64_t out_cap, const TT &T, PB *P,
                             uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob)
 {
     const int lane = za_lane();
@@ -397,8 +408,8 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         w += 2;
         while (bp < lim) {
             if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
-            uint32_t e = T.lut_l[(uint32_t)bb & ((1u << ZA_LUT_L_BITS) - 1u)];
-            if (!e) e = za_long_decode((uint32_t)bb, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, ZA_LUT_L_BITS + 1);
+            uint32_t e = T.lut_l[(uint32_t)bb & ((1u << TT::kLBits) - 1u)];
+            if (!e) e = za_long_decode((uint32_t)bb, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, TT::kLBits + 1);
             if (!e) { s = 2; break; }
             const int sym = (int)(e >> 4);
             uint32_t used = e & 15u;
@@ -416,8 +427,8 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             used += (uint32_t)nx;
             bp += used; bb >>= used; nb -= used;
             if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
-            e = T.lut_d[(uint32_t)bb & ((1u << ZA_LUT_D_BITS) - 1u)];
-            if (!e) e = za_long_decode((uint32_t)bb, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, ZA_LUT_D_BITS + 1);
+            e = T.lut_d[(uint32_t)bb & ((1u << TT::kDBits) - 1u)];
+            if (!e) e = za_long_decode((uint32_t)bb, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, TT::kDBits + 1);
             const int ds = (int)(e >> 4);
             if (!e || ds >= 30) { s = 2; break; }
             used = e & 15u;
@@ -455,7 +466,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             bool l = on;
 #pragma unroll
             for (int i = 0; i < ZA_PS_LITS; i++) {
-                const uint32_t e = T.lut_l[__builtin_amdgcn_ubfe(win, u, ZA_LUT_L_BITS)];
+                const uint32_t e = T.lut_l[__builtin_amdgcn_ubfe(win, u, TT::kLBits)];
                 l = l && (e - 1u) < 0xFFFu && u < room;                     // assigned and a literal ((symbol << 4) | length, symbol < 256) that starts before the limit
                 u += l ? (e & 15u) : 0u;
                 n += l ? 1u : 0u;
@@ -491,8 +502,8 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             // -- the token behind them, whatever it is (a seventh literal, a literal with a long code, end of block, a match)
             const bool tok = u < room;
             const uint32_t m_lo = __builtin_amdgcn_alignbit(hi1, lo1, u2), m_hi = __builtin_amdgcn_alignbit(h21, hi1, u2);
-            uint32_t em = T.lut_l[m_lo & ((1u << ZA_LUT_L_BITS) - 1u)];
-            if (tok && em == 0u) em = za_long_decode(m_lo, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, ZA_LUT_L_BITS + 1);
+            uint32_t em = T.lut_l[m_lo & ((1u << TT::kLBits) - 1u)];
+            if (tok && em == 0u) em = za_long_decode(m_lo, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, TT::kLBits + 1);
             const uint32_t sym = em >> 4, l = em & 15u;
             const bool is_len = tok && sym > 256u && sym <= 285u;
             int nx = 0, dnx = 0;
@@ -500,8 +511,8 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             const uint32_t len = (uint32_t)lbase + __builtin_amdgcn_ubfe(m_lo, l, (uint32_t)nx);
             const uint32_t used = l + (uint32_t)nx;                          // <= 20
             const uint32_t x = __builtin_amdgcn_alignbit(m_hi, m_lo, used);  // the distance code and its extra bits: <= 28 bits
-            uint32_t d = T.lut_d[x & ((1u << ZA_LUT_D_BITS) - 1u)];
-            if (is_len && d == 0u) d = za_long_decode(x, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, ZA_LUT_D_BITS + 1);
+            uint32_t d = T.lut_d[x & ((1u << TT::kDBits) - 1u)];
+            if (is_len && d == 0u) d = za_long_decode(x, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, TT::kDBits + 1);
             const uint32_t ds = d >> 4, dl = d & 15u;
             const bool dist_ok = d != 0u && ds < 30u;
             const int dbase = za_dist_base(dist_ok ? (int)ds : 0, dnx);
@@ -746,11 +757,11 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 #define ZA_I_SYNC 2
 // MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
 // start), RING symbols in LDS; older sources are read back from `out` (written many rounds ago) or are markers.
-template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>>
+template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>, typename TT = ZaInfTabs>
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       SymT *__restrict__ out, uint64_t out_cap,
-                                      ZaInfTabs &T, SymT *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
+                                      TT &T, SymT *win, int *scratch, uint32_t *ibuf, uint64_t &bits_used, uint64_t &out_len,
                                       uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr,
                                       uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr,
                                       const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0, uint64_t abs_bit0 = 0,
@@ -887,7 +898,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     const uint32_t fw = relbit >> 5, fsh = relbit & 31u;
                     const uint64_t flo = ((uint64_t)ibuf[fw + 1] << 32) | ibuf[fw];
                     const uint64_t mine = fsh ? ((flo >> fsh) | ((uint64_t)ibuf[fw + 2] << (64u - fsh))) : flo;
-                    const uint32_t eL = T.lut_l[mine & ((1u << ZA_LUT_L_BITS) - 1u)];
+                    const uint32_t eL = T.lut_l[mine & ((1u << TT::kLBits) - 1u)];
                     const uint32_t l = eL & 15u, sym = eL >> 4;
                     uint32_t nk = (uint32_t)lane + l;            // (kind << 8) | offset of the next token; kind 0 literal
                     uint32_t olen = 1, dist = 0;
@@ -901,7 +912,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                             int len = za_len_base(ls, nx);
                             len += (int)((mine >> l) & ((1u << nx) - 1u));
                             const uint32_t o2 = l + (uint32_t)nx;                        // <= 20
-                            const uint32_t eD = T.lut_d[(mine >> o2) & ((1u << ZA_LUT_D_BITS) - 1u)];
+                            const uint32_t eD = T.lut_d[(mine >> o2) & ((1u << TT::kDBits) - 1u)];
                             const int ds = (int)(eD >> 4);
                             if (eD == 0 || ds >= 30) nk = 0xFFFFu;
                             else {
@@ -1031,13 +1042,13 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                 // speculative decode at bit offset `lane`; LUT only: a code longer than the LUT (rare) is resolved by
                 // the walker when it is really met
                 const uint64_t mine = W >> lane;
-                const uint32_t eL = T.lut_l[mine & ((1u << ZA_LUT_L_BITS) - 1u)];
-                const uint32_t eD = T.lut_d[mine & ((1u << ZA_LUT_D_BITS) - 1u)];
+                const uint32_t eL = T.lut_l[mine & ((1u << TT::kLBits) - 1u)];
+                const uint32_t eD = T.lut_d[mine & ((1u << TT::kDBits) - 1u)];
                 uint32_t o = 0;
                 for (;;) {
                     if (o > 64u - 15u) break;                                        // next code may be cut: new window
                     uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)eL, (int)o);
-                    if (!e) e = za_long_decode((uint32_t)(W >> o), T.cnt_l, T.fst_l, T.idx_l, T.sym_l, ZA_LUT_L_BITS + 1);         // o <= 49: 15 bits are there
+                    if (!e) e = za_long_decode((uint32_t)(W >> o), T.cnt_l, T.fst_l, T.idx_l, T.sym_l, TT::kLBits + 1);         // o <= 49: 15 bits are there
                     if (!e) { status = (bitpos + o + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
                     int sym = (int)(e >> 4);
                     const uint32_t l = e & 15u;
@@ -1057,7 +1068,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     if (o2 > 64u - 15u) break;                                       // distance code may be cut: new window
                     if (nx) len += (int)((W >> (o + l)) & ((1u << nx) - 1u));       // o + l < 64 here
                     uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)eD, (int)o2);
-                    if (!e2) e2 = za_long_decode((uint32_t)(W >> o2), T.cnt_d, T.fst_d, T.idx_d, T.sym_d, ZA_LUT_D_BITS + 1);
+                    if (!e2) e2 = za_long_decode((uint32_t)(W >> o2), T.cnt_d, T.fst_d, T.idx_d, T.sym_d, TT::kDBits + 1);
                     if (!e2) { status = (bitpos + o2 + 15 > in_bits) ? ZA_I_INPUT : ZA_I_DATA; break; }
                     const int ds = (int)(e2 >> 4);
                     if (ds >= 30) { status = ZA_I_DATA; break; }
@@ -1736,6 +1747,12 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
 // (r03, after a short sweep stopped costing 32 sequential rounds: a queue of 768 and 512 bytes of history -- the sequential
 // rounds that use the ring are 4 per member now -- leave room for 12 wavefronts per CU instead of 9: 10.96 -> 9.53 ms per GiB;
 // queue 1 024 with the small ring 10.6, queue 512 13.8, 896 entries with 416-bit sub-sequences 9.48)
+#ifndef ZA_MEMBER_LBITS
+#define ZA_MEMBER_LBITS 9               // index bits of the first-level tables (see ZaInfTabsT): 9 / 8 -> 7.89 ms per GiB, 9 / 7 8.14, 8 / 8 8.02, 8 / 7 8.16, 10 / 8 9.29, 10 / 9 9.42
+#endif
+#ifndef ZA_MEMBER_DBITS
+#define ZA_MEMBER_DBITS 8
+#endif
 #ifndef ZA_MEMBER_RING
 #define ZA_MEMBER_RING 512
 #endif
@@ -1752,7 +1769,7 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial_members(const uint8_t 
                                                                   const uint32_t *__restrict__ x8k_table,
                                                                   int32_t *__restrict__ status_out)
 {
-    __shared__ ZaInfTabs T;
+    __shared__ ZaInfTabsT<ZA_MEMBER_LBITS, ZA_MEMBER_DBITS> T;
     __shared__ uint8_t win[ZA_MEMBER_RING];       // the last bytes of history in LDS; older sources come from the output
     __shared__ int scratch[2];
     __shared__ ZaParBufT<ZA_MEMBER_BITS, ZA_MEMBER_Q> P;
