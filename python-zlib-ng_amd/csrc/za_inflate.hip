@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_count(const uint8_t *__restrict
     if (za_lane() == 0) { ZaChunkRes r; r.status = status; r.max_back = 0; r.bits = off * 8ull + bits; r.out_len = op; res[blockIdx.x] = r; }
 }
 
-template <int BITS, int Q, int RINGSYMS>       // RINGSYMS symbols of history in LDS; older sources are re-read from the chunk's own output
+template <int BITS, int Q, int RINGSYMS, int LB = ZA_LUT_L_BITS, int DB = ZA_LUT_D_BITS>       // RINGSYMS symbols of history in LDS; older sources are re-read from the chunk's own output; LB / DB: index bits of the decode tables
 __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restrict__ in, uint64_t in_len,
                                                         const ZaChunk *__restrict__ chunks, uint16_t *__restrict__ out16,
                                                         ZaChunkRes *__restrict__ res, uint64_t first_bit, uint32_t first_hist,
@@ -1895,7 +1895,7 @@ __global__ __launch_bounds__(64) void za_k_chunk_decode(const uint8_t *__restric
     // symbols go to their final place.  Without one (stops = every listed boundary, as the count pass has them): a chunk is ONE
     // candidate decoded to the next listed boundary or sync point into a scratch area of out_len symbols (src_off) -- sizes and
     // ends are found out here, and the host places the chunks afterwards.
-    __shared__ ZaInfTabs T;
+    __shared__ ZaInfTabsT<LB, DB> T;
     __shared__ uint16_t win[RINGSYMS];
     __shared__ int scratch[2];
     __shared__ ZaParBufT<BITS, Q, ZA_CHUNK_MAXIT> P;

@@ -837,7 +837,7 @@ struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; }
 // from this many chunks (or block candidates) on, the chunk kernels run in their small-LDS size: more than the 1 024
 // wavefronts the large size keeps resident (256 CUs x 4 workgroups)
 #define ZNGAMD_CHUNKS_SMALL_FROM 1536u
-#define ZNGAMD_CHUNKS_MANY_FROM 4096u          // from here on the chunks outnumber the wavefronts the device holds: the smallest footprint (384-bit sub-sequences, queue of 1 024: 11 per CU) wins -- 1 GiB of this engine's stream 15.2 -> 13.8 ms
+#define ZNGAMD_CHUNKS_MANY_FROM 4096u          // from here on the chunks outnumber the wavefronts the device holds: the smallest footprint (384-bit sub-sequences, queue of 1 024, decode tables of 9 / 8 index bits: 12 per CU) wins -- 1 GiB of this engine's stream 15.2 -> 12.4 ms
 #ifndef ZA_CHUNK_BITS_S
 #define ZA_CHUNK_BITS_S 512          // the marker decoder where chunks are many: bits per sub-sequence, queue entries, symbols of history in LDS
 #endif
@@ -1269,7 +1269,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
             HIPCHK(c, hipMemcpyAsync(c->cchunks.p, pieces.data(), (size_t)n * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
             { ProfScope ps(c, ZNGAMD_K_INFLATE);
               if (n >= ZNGAMD_CHUNKS_MANY_FROM)
-                  hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
+                  hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024, 9, 8>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
               else if (n >= ZNGAMD_CHUNKS_SMALL_FROM)
                   hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
               else
@@ -1362,7 +1362,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         HIPCHK(c, c->cres.ensure(m));
         { ProfScope ps(c, ZNGAMD_K_INFLATE);
           if (m >= ZNGAMD_CHUNKS_MANY_FROM)
-              hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
+              hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024, 9, 8>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else if (m >= ZNGAMD_CHUNKS_SMALL_FROM)
               hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else
