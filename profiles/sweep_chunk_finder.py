@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ctx.profiling(True)
     uniq = bytes(corpus.text(64 << 20, seed=5))
     cases = []
-    for mib in (64, 256, 1024):
+    for mib in [int(x) for x in os.environ.get("SWEEP_MIB", "64,256,1024").split(",")]:
         blob = uniq * (mib // 64)
         bio = io.BytesIO()
         with gzip_ng_threaded.open(bio, "wb", compresslevel=6, threads=8, block_size=128 * 1024) as f:

@@ -837,7 +837,9 @@ struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; }
 // from this many chunks (or block candidates) on, the chunk kernels run in their small-LDS size: more than the 1 024
 // wavefronts the large size keeps resident (256 CUs x 4 workgroups)
 #define ZNGAMD_CHUNKS_SMALL_FROM 1536u
-#define ZNGAMD_CHUNKS_MANY_FROM 4096u          // from here on the chunks outnumber the wavefronts the device holds: the smallest footprint (384-bit sub-sequences, queue of 1 024, decode tables of 9 / 8 index bits: 12 per CU) wins -- 1 GiB of this engine's stream 15.2 -> 12.4 ms
+#ifndef ZNGAMD_CHUNKS_MANY_FROM
+#define ZNGAMD_CHUNKS_MANY_FROM 2049u          // more chunks than the middle footprint holds at once (8 per CU x 256): the smallest footprint (384-bit sub-sequences, queue of 1 024, decode tables of 9 / 8 index bits: 12 per CU) wins -- 320 MiB of this engine's stream 7.1 -> 4.9 ms, 1 GiB 15.2 -> 12.4 ms
+#endif
 #ifndef ZA_CHUNK_BITS_S
 #define ZA_CHUNK_BITS_S 512          // the marker decoder where chunks are many: bits per sub-sequence, queue entries, symbols of history in LDS
 #endif
