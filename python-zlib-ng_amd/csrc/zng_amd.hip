@@ -836,7 +836,9 @@ struct ChunkOpts { uint32_t start_bit = 0; const uint8_t *d_dict = nullptr; uint
 struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; };
 // from this many chunks (or block candidates) on, the chunk kernels run in their small-LDS size: more than the 1 024
 // wavefronts the large size keeps resident (256 CUs x 4 workgroups)
-#define ZNGAMD_CHUNKS_SMALL_FROM 1536u
+#ifndef ZNGAMD_CHUNKS_SMALL_FROM
+#define ZNGAMD_CHUNKS_SMALL_FROM 1u             // (r03: with three passes at most and sweeps that follow one another the 512-bit footprint wins at every chunk count -- 512 chunks 3.94 -> 3.38 ms, 1 408 chunks 4.08 -> 3.76 ms; the 1 024-bit one, 4 per CU, stays compiled for comparison: -DZNGAMD_CHUNKS_SMALL_FROM=1536u)
+#endif
 #ifndef ZNGAMD_CHUNKS_MANY_FROM
 #define ZNGAMD_CHUNKS_MANY_FROM 2049u          // more chunks than the middle footprint holds at once (8 per CU x 256): the smallest footprint (384-bit sub-sequences, queue of 1 024, decode tables of 9 / 8 index bits: 12 per CU) wins -- 320 MiB of this engine's stream 7.1 -> 4.9 ms, 1 GiB 15.2 -> 12.4 ms
 #endif
