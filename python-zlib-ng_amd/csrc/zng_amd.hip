@@ -842,6 +842,10 @@ struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; }
 #ifndef ZNGAMD_CHUNKS_MANY_FROM
 #define ZNGAMD_CHUNKS_MANY_FROM 2049u          // more chunks than the middle footprint holds at once (8 per CU x 256): the smallest footprint (384-bit sub-sequences, queue of 1 024, decode tables of 9 / 8 index bits: 12 per CU) wins -- 320 MiB of this engine's stream 7.1 -> 4.9 ms, 1 GiB 15.2 -> 12.4 ms
 #endif
+#ifndef ZA_CHUNK_LB_2P
+#define ZA_CHUNK_LB_2P ZA_LUT_L_BITS     // table index bits of the marker decoder behind a count pass (streams of other writers)
+#define ZA_CHUNK_DB_2P ZA_LUT_D_BITS
+#endif
 #ifndef ZA_CHUNK_BITS_S
 #define ZA_CHUNK_BITS_S 512          // the marker decoder where chunks are many: bits per sub-sequence, queue entries, symbols of history in LDS
 #endif
@@ -1368,7 +1372,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
           if (m >= ZNGAMD_CHUNKS_MANY_FROM)
               hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024, 9, 8>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else if (m >= ZNGAMD_CHUNKS_SMALL_FROM)
-              hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
+              hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S, ZA_CHUNK_LB_2P, ZA_CHUNK_DB_2P>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else
               hipLaunchKernelGGL((za_k_chunk_decode<1024, 3072, 4096>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u); }
         HIPCHK(c, hipGetLastError());
