@@ -8,7 +8,7 @@ L = _lib.load()
 ctx = _lib.default_context()
 names = ["sweeps", "lanes_kept", "sync_passes", "t_sync", "t_emit", "t_resolve", "sweeps_empty", "seq_rounds", "blocks", "t_tables",
          "ring_refills", "out_bytes", "eob_in_sweep", "lanes_exact", "resolve_rounds", "matches",
-         "count_rounds_wave", "count_cycles", "count_matches", "count_runs", "count_rounds_lanes", "join_mismatch", "jm_endp", "jm_cnt", "jm_starts", "jm_lim", "jm_j", "jm_old", "jm_it"]
+         "count_rounds_wave", "count_cycles", "count_matches", "count_runs", "count_rounds_lanes"]
 def stats():
     a = (ctypes.c_ulonglong * 32)()
     assert L.zngamd_debug_ps_stats(a) == 0
@@ -36,6 +36,4 @@ for lvl in (1, 6, 9):
           f"resolve {us('t_resolve')/n:.1f}; tables {us('t_tables')/max(1,s['blocks']):.1f} per block ({s['blocks']/nm:.1f} blocks/member); seq rounds/member {s['seq_rounds']/nm:.1f} | "
           f"counting passes run {s['count_runs']/n:.2f} per sweep, {s['count_rounds_wave']/max(1,s['count_runs']):.1f} rounds each as the wave runs them "
           f"({s['count_rounds_lanes']/max(1,s['count_runs'])/64:.1f} per lane on average over 64), {s['count_cycles']/max(1,s['count_rounds_wave']):.0f} core cycles per round, "
-          f"{s['count_cycles']/max(1,s['count_runs']):.0f} per pass; join mismatches {s['join_mismatch']} (first: endp {s['jm_endp'] >> 32} vs {s['jm_endp'] & 0xFFFFFFFF}, "
-          f"cnt {s['jm_cnt'] >> 40} vs {(s['jm_cnt'] >> 16) & 0xFFFFFF}, st {(s['jm_cnt'] >> 8) & 15} vs {s['jm_cnt'] & 15}; old start {s['jm_starts'] >> 32} new {s['jm_starts'] & 0xFFFFFFFF} lim {s['jm_lim'] >> 32} "
-          f"b at the end {s['jm_lim'] & 0xFFFFFFFF} joined {s['jm_j'] >> 60} ca {(s['jm_j'] >> 30) & 0x3FFFFFFF} cb {s['jm_j'] & 0x3FFFFFFF}; old endp {s['jm_old'] >> 32} cnt {(s['jm_old'] >> 8) & 0xFFFFFF} st {s['jm_old'] & 15} pass {s['jm_it']})")
+          f"{s['count_cycles']/max(1,s['count_runs']):.0f} per pass")
