@@ -840,7 +840,13 @@ struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; }
 #define ZNGAMD_CHUNKS_SMALL_FROM 1u             // (r03: with three passes at most and sweeps that follow one another the 512-bit footprint wins at every chunk count -- 512 chunks 3.94 -> 3.38 ms, 1 408 chunks 4.08 -> 3.76 ms; the 1 024-bit one, 4 per CU, stays compiled for comparison: -DZNGAMD_CHUNKS_SMALL_FROM=1536u)
 #endif
 #ifndef ZNGAMD_CHUNKS_MANY_FROM
-#define ZNGAMD_CHUNKS_MANY_FROM 2049u          // more chunks than the middle footprint holds at once (8 per CU x 256): the smallest footprint (384-bit sub-sequences, queue of 1 024, decode tables of 9 / 8 index bits: 12 per CU) wins -- 320 MiB of this engine's stream 7.1 -> 4.9 ms, 1 GiB 15.2 -> 12.4 ms
+#define ZNGAMD_CHUNKS_MANY_FROM 2049u          // more chunks than the middle footprint holds at once (8 per CU x 256): the smallest footprint (384-bit sub-sequences, queue of 768, 256 symbols of ring, decode tables of 9 / 8 index bits: 16 per CU) wins -- 320 MiB of this engine's stream 7.1 -> 4.9 ms, 1 GiB 15.2 -> 10.4 ms
+#endif
+#ifndef ZA_CHUNK_Q_M
+#define ZA_CHUNK_Q_M 768               // the marker decoder where chunks outnumber the wavefronts: queue entries, symbols of history in LDS (768 / 256: 16 per CU, 1 GiB 12.4 -> 10.4 ms; 768 / 512 11.8, 1 024 / 256 12.1)
+#endif
+#ifndef ZA_CHUNK_RING_M
+#define ZA_CHUNK_RING_M 256
 #endif
 #ifndef ZA_CHUNK_LB_2P
 #define ZA_CHUNK_LB_2P ZA_LUT_L_BITS     // table index bits of the marker decoder behind a count pass (streams of other writers)
@@ -1277,7 +1283,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
             HIPCHK(c, hipMemcpyAsync(c->cchunks.p, pieces.data(), (size_t)n * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
             { ProfScope ps(c, ZNGAMD_K_INFLATE);
               if (n >= ZNGAMD_CHUNKS_MANY_FROM)
-                  hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024, 9, 8>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
+                  hipLaunchKernelGGL((za_k_chunk_decode<384, ZA_CHUNK_Q_M, ZA_CHUNK_RING_M, 9, 8>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
               else if (n >= ZNGAMD_CHUNKS_SMALL_FROM)
                   hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S>), dim3(n), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, c->ccand.p, n);
               else
@@ -1370,7 +1376,7 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         HIPCHK(c, c->cres.ensure(m));
         { ProfScope ps(c, ZNGAMD_K_INFLATE);
           if (m >= ZNGAMD_CHUNKS_MANY_FROM)
-              hipLaunchKernelGGL((za_k_chunk_decode<384, 1024, 1024, 9, 8>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
+              hipLaunchKernelGGL((za_k_chunk_decode<384, ZA_CHUNK_Q_M, ZA_CHUNK_RING_M, 9, 8>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else if (m >= ZNGAMD_CHUNKS_SMALL_FROM)
               hipLaunchKernelGGL((za_k_chunk_decode<ZA_CHUNK_BITS_S, ZA_CHUNK_Q_S, ZA_CHUNK_RING_S, ZA_CHUNK_LB_2P, ZA_CHUNK_DB_2P>), dim3(m), dim3(64), 0, c->stream, d_def, avail, c->cchunks.p, c->out16.p, c->cres.p, (uint64_t)o.start_bit, o.dict_len, (const uint64_t *)nullptr, 0u);
           else

@@ -303,3 +303,27 @@ def test_chunk_parallel_inflate_of_ordinary_gzip(ctx, fastq):
         assert (code == 0) == (ocode == 0), (pos, code, ocode)
         if code == 0:
             assert out == oout
+
+
+def test_chunk_parallel_inflate_with_more_chunks_than_wavefronts():
+    """One stream of 2 640 sync-delimited blocks (330 MiB): more chunks than the middle footprint of the marker decoder holds at
+    once, so the smallest one runs (384-bit sub-sequences, queue of 768, 256 symbols of ring, tables of 9 / 8 index bits) --
+    every byte compared, both through the one-shot call and through a reader whose window takes the stream whole."""
+    import io
+    from zlib_ng_amd import corpus, gzip_ng, gzip_ng_threaded
+    base = corpus.text(66 << 20, seed=23).tobytes()
+    data = base * 5
+    bio = io.BytesIO()
+    with gzip_ng_threaded.open(bio, "wb", compresslevel=6, threads=8, block_size=128 * 1024) as f:
+        f.write(data)
+    blob = bio.getvalue()
+    out = gzip_ng.decompress(blob)
+    assert len(out) == len(data) and out == data
+    del out
+    os.environ["ZNGAMD_READ_WINDOW"] = str(1 << 30)
+    try:
+        with gzip_ng.open(io.BytesIO(blob), "rb") as g:
+            got = g.read()
+    finally:
+        del os.environ["ZNGAMD_READ_WINDOW"]
+    assert got == data
