@@ -9,11 +9,14 @@ Here the data-parallel axis is the GPU, not threads: `threads` is the number of 
 of GPUs one writer uses -- with threads > 1 every batch is cut into contiguous block ranges, one per visible GPU (or per
 entry of ZNGAMD_DEVICES), each range primed by the input in front of it, compressed side by side and written in order
 (`_lib.deflate_blocks_multi`; a process that its launcher bound to one GPU stays on it).
-`write()` cuts and primes blocks exactly as the reference does and puts them on `threads` bounded
-queues in round-robin order; ONE worker thread drains whatever is queued (in the same order), submits
-those blocks to the engine as a single batch (`_ParallelCompress.compress_and_crc_batch`), and writes
-the results in order.  The byte stream has the reference's framing: 10-byte header (with its OS/XFL
-byte order), sync-flushed raw-deflate blocks, `03 00`, CRC32, ISIZE; `flush()` ends the member and
+`write()` cuts and primes blocks exactly as the reference does, but does not hand them over one by one: the bytes are collected in
+a pooled buffer (one copy per byte; every eighth large copy with the interpreter lock released), and a full buffer -- 8 MiB at
+first, twice as much each time, 64 MiB at most -- goes to the engine as ONE batch on a thread of its own
+(`zngamd_deflate_blocks_packed`: the blocks' outputs come back packed, in one piece, into one of two output buffers) while the
+caller fills the second buffer; the file write of a batch runs beside the compression of the next.  The reference's queue
+interface is still there (`input_queues`: what is put on them is drained by one worker thread in round-robin order and
+compressed as a batch, `_ParallelCompress.compress_and_crc_batch`).  The byte stream has the reference's framing: 10-byte
+header (with its OS/XFL byte order), sync-flushed raw-deflate blocks, `03 00`, CRC32, ISIZE; `flush()` ends the member and
 starts a new one; `close()` after the buffered writer's implicit flush leaves a trailing empty member.
 """
 import builtins
