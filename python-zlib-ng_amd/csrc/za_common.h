@@ -71,6 +71,11 @@ __device__ __forceinline__ uint32_t za_hash6(uint32_t lo, uint32_t hi)
     return ((lo * 2654435761u) ^ (hi * 2246822519u)) >> (32 - ZA_HASH_BITS);
 }
 
+// volatile accesses to LDS with the address space spelled out (ds_read / ds_write instead of flat_load / flat_store)
+typedef __attribute__((address_space(3))) volatile uint16_t za_lds_vu16;
+typedef __attribute__((address_space(3))) volatile uint32_t za_lds_vu32;
+typedef __attribute__((address_space(3))) volatile unsigned long long za_lds_vu64;
+
 __device__ __forceinline__ int za_lane() { return (int)(threadIdx.x & 63); }
 
 // wave-wide inclusive scan (64 lanes): DPP row shifts inside the rows of 16 lanes, then the two row broadcasts of gfx9 --

@@ -5,8 +5,8 @@
 // zng_deflateReset + zng_deflateSetDictionary + zng_crc32_z + zng_deflate(Z_SYNC_FLUSH).
 //
 // Pipeline over a batch of units (unit = <=128 KiB of input + <=32 KiB dictionary before it):
-//   k_chains  one wave per unit; u16 head table (64 KiB) in LDS; the 64 positions of a tile are
-//             inserted at once, same-bucket lanes ordered by a ballot bit-slice match-any
+//   k_chains  one wave per run of units; 32-bit head table (32 KiB) in LDS; the 64 positions of a step are
+//             inserted by ONE returning LDS atomic maximum, which also yields every position's link
 //   k_search  one 1024-thread workgroup per unit; chain links of the sliding window staged in a
 //             128 KiB LDS ring; every position searched in parallel
 //   k_parse   one wave per unit, one lane per 2 KiB segment: greedy/lazy selection, symbol
@@ -16,136 +16,57 @@
 //             boundary words merged with atomic OR
 #include "za_common.h"
 #include "za_crc.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // k_chains
 // ------------------------------------------------------------------------------------------------
-// One 256-thread workgroup per unit.  The 13-bit bucket space is split into 4 classes by the top 2 hash
-// bits; wave w owns class w and a private 2048-entry u16 head table (4 x 4 KiB of LDS; with the rings
-// 23 KiB per workgroup: six per CU -- the dense insert is a chain of dependent LDS round trips, and the
-// kernel scales almost linearly with resident waves).  Positions are
-// hashed once, 256 per tile (64 per wave), and handed to the owning wave through a per-class LDS ring in
-// position order (per-wave class counts -> offsets -> ranks: two barriers per tile).  Whenever 64 entries
-// are pending in its ring a wave inserts them as one dense tile: same-bucket lanes are ordered by a
-// bit-slice match-any, so the result is exactly the sequential insertion order.
-#define ZA_CH_WAVES 4
-#define ZA_CH_STAGE 320u                      // pending-entry ring per class: 63 left over + one tile of 256; cursors are kept mod 320
-#define ZA_CH_SUB   (ZA_HASH_BITS - 2)        // bits of the per-wave table index
+// One WAVEFRONT per run of consecutive units, and the whole insert of 64 consecutive positions is ONE LDS instruction:
+// the head table holds 32-bit run-absolute positions, and every lane does a returning atomic maximum of its position into
+// its bucket.  The LDS executes the lanes of an instruction that name one address one after the other, in ascending lane order,
+// so what comes back to a lane is the largest position its bucket held before it: the nearest earlier position of the bucket
+// -- an earlier lane of this very instruction or the table's entry from earlier steps -- which is exactly the sequential
+// insertion order of the spec (oracle stage 1), and the bucket is left with its last position.  That order is not promised
+// anywhere, so it is checked: served in any other order, some lane of a bucket gets back a position that is not below its
+// own, and the step's links are then worked out lane by lane (za_chains_fix; the table itself is right in any order, a
+// maximum does not depend on it).  A wave's LDS operations execute in program order, so the step behind needs no wait: the
+// atomics of consecutive steps go out back to back and their results are used a group of steps later -- no barrier, no hand-over
+// between waves, no ordering of same-bucket lanes by hand, and the links of a step leave as one 128-byte store.
+// (Until round 3 a 256-thread workgroup split the bucket space over four waves, handed every position to the owning wave
+// through LDS rings -- three ballots, eight mbcnt and two barriers per 256 positions -- and ordered the same-bucket lanes of a
+// 64-entry insert with an exchange on a side array: 108 lane-instructions per position, 14.6 ms per 4 GiB.)
+// Positions are 32 bits and absolute in the run, so nothing ages and nothing wraps: a link is valid if it reaches back at most
+// 32 768.  The table is 2^13 x 4 bytes = 32 KiB: five wavefronts per CU, each with a stream of its own.
+#ifndef ZA_CH_GROUP
+#define ZA_CH_GROUP 8
+#endif
+//  ZA_CH_GROUP:                          // steps (of 64 positions) whose loads, atomics and stores are issued together
 
-__device__ __forceinline__ void za_chains_dense(uint16_t *head, const uint32_t *stage, unsigned long long *gmask, uint32_t rd, int m, int pmin,
-                                                uint16_t *__restrict__ prevdist, int dict_len, uint32_t &gen)
+// the links of one step worked out lane by lane (only if the LDS ever served an atomic's lanes out of order)
+__device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t old, bool ins)
 {
+    uint32_t near = 0, pre = 0xFFFFFFFFu;
     const int lane = za_lane();
-    const bool valid = lane < m;
-    uint32_t slot = rd + (uint32_t)lane;              // rd < ZA_CH_STAGE
-    slot -= slot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
-    const uint32_t e = stage[slot];
-    const uint32_t P = e & 0x3FFFFu, h = (e >> 18) & ((1u << ZA_CH_SUB) - 1u);
-    const uint16_t P16 = (uint16_t)(P & 0xFFFFu);
-    // link through the table state left by the earlier tiles
-    const uint32_t hv = head[h];
-    uint32_t d = (P - hv) & 0xFFFFu;
-    if (!(d != 0 && d <= ZA_WIN && (int)(P - d) >= pmin)) d = 0;
-    // Every valid lane stores its LANE NUMBER into its bucket and reads the bucket back: all lanes of one bucket
-    // read the same number (whichever store landed last), so that number names the bucket group with 6 bits.
-    // If every lane reads its own number no two lanes share a bucket and the links above are final.
-    // (volatile: the read-back must come from LDS, where another lane's store may have landed, not from
-    // this lane's own store forwarded by the compiler)
-    volatile uint16_t *vhead = head;
-    if (valid) vhead[h] = (uint16_t)lane;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t rep = valid ? (uint32_t)vhead[h] : (uint32_t)lane;
-    bool last = true;                                // highest lane of my bucket: leaves its position in the table
-    if (__ballot(rep != (uint32_t)lane) != 0ull) {
-        // Some bucket is hit twice in this tile: order its lanes exactly and link later lanes to the nearest earlier one.
-        // Fast way: every lane EXCHANGES its number (tagged with this call's generation, so no word has to be cleared) into a
-        // word named by the group number; what comes back is the lane of its group that the LDS served before it.  If the LDS
-        // serves the lanes of an instruction in ascending order that is the nearest earlier lane, and the word's final value is
-        // the group's last lane.  The order is not promised anywhere, so it is checked: any other order hands some lane a
-        // HIGHER number than its own, and then the careful way below runs instead.
-        uint32_t *g32 = (uint32_t *)gmask;
-        gen++;
-        const uint32_t tag = gen << 8;
-        const uint32_t old = valid ? atomicExch(&g32[rep], tag | (uint32_t)lane) : 0u;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t fin = valid ? ((volatile uint32_t *)g32)[rep] : 0u;
-        const bool has_pred = valid && (old & ~0xFFu) == tag;
-        const uint32_t pl = old & 0xFFu;
-        if (__ballot(has_pred && pl >= (uint32_t)lane) == 0ull) {
-            const uint32_t Pj = __shfl(P, (int)(has_pred ? pl : (uint32_t)lane), 64);
-            if (has_pred) d = P - Pj;
-            last = (fin & 0xFFu) == (uint32_t)lane;
-        } else {
-            // The lanes of a group collect their lane bits in a 64-bit LDS word named by the group number.
-            volatile unsigned long long *vg = gmask;
-            vg[lane] = 0ull;
-            __builtin_amdgcn_wave_barrier();
-            if (valid) atomicOr(&gmask[rep], 1ull << lane);
-            __builtin_amdgcn_wave_barrier();
-            const unsigned long long eq = valid ? vg[rep] : 0ull;
-            const unsigned long long lower = eq & ((1ull << lane) - 1ull);
-            const unsigned long long higher = (eq >> lane) >> 1;
-            const int j = lower ? 63 - __builtin_clzll(lower) : lane;
-            const uint32_t Pj = __shfl(P, j, 64);
-            if (lower) d = P - Pj;                       // nearest earlier position of my bucket inside this tile
-            last = !higher;
-            __builtin_amdgcn_wave_barrier();
-            vg[lane] = 0ull;                             // (no stale bit pattern may look like a tagged lane number later)
+    for (int j = 0; j < 64; j++) {
+        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j), Aj = (uint32_t)__builtin_amdgcn_readlane((int)A, j);
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)old, j);
+        const bool insj = ((__ballot(ins) >> j) & 1ull) != 0ull;
+        if (insj && hj == h) {
+            if (j < lane) near = Aj;               // ascending j: the last one kept is the nearest earlier lane of my bucket
+            pre = oj < pre ? oj : pre;             // the bucket's entry in front of the step: what its first-served lane got back
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (valid && last) vhead[h] = P16;
-    if (valid) prevdist[(int)P - ZA_WIN + dict_len] = (uint16_t)d;
+    return near ? near : pre;
 }
 
-// The head table holds positions as 16 bits, so it must never hold an entry older than 65 535 positions when it is read
-// (the spec knows no aliasing: a bucket's link is the true nearest earlier position or nothing).  Every wave therefore SWEEPS
-// its table every ZA_CH_SWEEP positions: entries older than the window are set to "old" (an age that no lookup accepts and
-// that stays below 65 536 until the next sweep).  The same pass rebases the table when a run moves on to its next unit.
-#define ZA_CH_SWEEP 24576u      // positions between two sweeps
-#define ZA_CH_OLD   36864u      // the age an old entry is given at a sweep: 36864 + 24576 + the insert lag of a tile < 65536
-#define ZA_CH_KEEP  (ZA_WIN + 512u)   // entries up to this age are kept (the inserts lag at most a tile and a group behind a sweep)
-
-// One workgroup per RUN of consecutive units (run_start[r] .. run_start[r + 1]).  Inside a run a unit marked ZA_FLAG_CARRY --
-// its 32 KiB dictionary is the tail of the unit in front of it -- does not insert that dictionary again: the tables are
-// carried over (a quarter of a unit's positions, the same quarter deflateSetDictionary costs the reference's threads for
-// every block).  The links are the same either way: a bucket's link names the nearest earlier position of the bucket, and
-// whether positions in front of the dictionary are known or not changes nothing -- they are out of reach.
-__global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
-                                                                const uint32_t *__restrict__ run_start,
-                                                                uint16_t *__restrict__ prev_ws)
+__global__ __launch_bounds__(64) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                  const uint32_t *__restrict__ run_start,
+                                                  uint16_t *__restrict__ prev_ws)
 {
-    __shared__ uint16_t head_all[ZA_CH_WAVES][1 << ZA_CH_SUB];
-    __shared__ uint32_t ring_all[ZA_CH_WAVES][ZA_CH_STAGE];
-    __shared__ unsigned long long gmask_all[ZA_CH_WAVES][64];   // scratch of the dense insert
-    __shared__ uint32_t cnt[2][ZA_CH_WAVES][ZA_CH_WAVES];    // [tile parity][producer wave][class] entries of a tile
+    __shared__ uint32_t head[1 << ZA_HASH_BITS];      // run-absolute position + 1 of the bucket's last position, 0 = none
     const int lane = za_lane();
-    const uint32_t wave = threadIdx.x >> 6;
-    uint16_t *head = head_all[wave];
-    uint32_t *head32 = (uint32_t *)head;
-    // Two barriers per tile: class counts visible -> every wave places its entries -> rings complete -> consume.
-    uint32_t wrv = 0;          // lane c < 4: entries ever put into class c's ring (every wave keeps the same copy)
-    uint32_t wslot = 0;        // lane c < 4: wrv mod ZA_CH_STAGE
-    uint32_t rd = 0, rslot = 0;   // consumed entries of my class, and that number mod ZA_CH_STAGE
-    uint32_t gen = 0;             // generation tag of the dense insert's exchange words (gmask starts zeroed)
-    gmask_all[wave][lane] = 0ull;
-    uint32_t par = 0;
-    uint32_t psweep = 0;          // position of the last sweep (in the current unit's numbering)
-    // every entry of my table: back by `rebase` positions (a new unit counts from its own start), then "old" if out of reach of `pr`
-    auto sweep = [&](uint32_t pr, uint32_t rebase, bool fresh) {
-        const uint32_t old = (pr - ZA_CH_OLD) & 0xFFFFu;
-        asm volatile("" ::: "memory");                           // (the table is read as u16 elsewhere: no reordering across the sweep)
-        for (int i = lane; i < (1 << ZA_CH_SUB) / 2; i += 64) {
-            uint32_t w = head32[i];
-            uint32_t lo = (w - rebase) & 0xFFFFu, hi = ((w >> 16) - rebase) & 0xFFFFu;
-            if (fresh || ((pr - lo) & 0xFFFFu) > ZA_CH_KEEP) lo = old;
-            if (fresh || ((pr - hi) & 0xFFFFu) > ZA_CH_KEEP) hi = old;
-            head32[i] = lo | (hi << 16);
-        }
-        asm volatile("" ::: "memory");
-        psweep = pr;
-    };
     const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
+    uint32_t goff = 0;                                // positions of the run in front of the current unit
     uint32_t n_prev = 0;
 #pragma unroll 1
     for (uint32_t ui = u0; ui < u1; ui++) {
@@ -158,109 +79,76 @@ __global__ __launch_bounds__(64 * ZA_CH_WAVES) void za_k_chains(const uint8_t *_
 #else
         const bool carry = ui > u0 && (u.flags & ZA_FLAG_CARRY) != 0u;
 #endif
+        if (carry) goff += n_prev;
+        else {
+            // a fresh table: the unit's dictionary is inserted like the unit itself (what deflateSetDictionary does per block)
+            goff = 0;
+            for (int i = lane * 4; i < (1 << ZA_HASH_BITS); i += 256) *(uint4 *)&head[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        n_prev = (uint32_t)n;
         const int total = dict_len + n;
-        const int pmin = ZA_WIN - dict_len;
         // a carried unit starts with the last five positions of the unit in front of it: they had fewer than six bytes left
         // there and have them now (their links go to this unit's own row: that unit's links say "never inserted", which is
         // what a search of THAT unit must see)
         const int first = carry ? dict_len - (ZA_HASH_BYTES - 1) : 0;
-        __syncthreads();                                       // (every wave is through with the unit in front)
-        if (carry) sweep((uint32_t)ZA_WIN, n_prev, false);
-        else sweep((uint32_t)pmin, 0u, true);
-        n_prev = (uint32_t)n;
-        const bool can_load = total >= ZA_HASH_BYTES;          // uniform: the unit + dictionary hold at least one 6-byte context
-        const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available (may be < -dict_len)
-        // A tile is 256 positions: wave w hashes positions [64 w, 64 w + 64) of it -- every position is hashed once.
-        // loads are unconditional from a clamped position (no branch per tile); `valid` masks them later
-        auto load_tile = [&](int tbase) -> uint2 {
-            int p = tbase + 64 * (int)wave + lane - dict_len;
+        const uint32_t abase = goff + (uint32_t)(ZA_WIN - dict_len) + 1u;      // table value of row index i: abase + i
+        if (total < ZA_HASH_BYTES) {                           // (uniform) not one 6-byte context: nothing to insert, every link is 0
+            if (lane >= first && lane < total) prevdist[lane] = 0;
+            continue;
+        }
+        const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available
+        // loads are unconditional from a clamped position (no branch per step); `ins` masks them later
+        auto load_step = [&](int tbase, uint32_t &lo, uint32_t &hi) {
+            int p = tbase + lane - dict_len;
             p = p > pclamp_hi ? pclamp_hi : p;
             p = p < -dict_len ? -dict_len : p;
-            return can_load ? make_uint2(za_ld32(data + p), za_ld16(data + p + 4)) : make_uint2(0u, 0u);
+            lo = za_ld32(data + p); hi = za_ld16(data + p + 4);
         };
-        auto consume = [&](uint32_t upto, bool flush) {
-            while (upto - rd >= 64u) {
-                za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, 64, pmin, prevdist, dict_len, gen);
-                rd += 64u; rslot += 64u; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
-            }
-            if (flush && upto != rd) {
-                za_chains_dense(head, ring_all[wave], gmask_all[wave], rslot, (int)(upto - rd), pmin, prevdist, dict_len, gen);
-                rslot += upto - rd; rslot -= rslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
-                rd = upto;
-            }
-        };
-        auto do_tile = [&](int tbase, const uint2 v) {
-            // ---- the table is swept on time (all four waves at the same tile, each its own table); what is still pending of my
-            // class goes in first -- an entry may wait long for its group of 64 to fill, and it must see the table as it was
-            const uint32_t ptile = (uint32_t)(ZA_WIN + tbase - dict_len);
-            if ((int)(ptile - psweep) >= (int)ZA_CH_SWEEP) {
-                consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), true);
-                sweep(ptile, 0u, false);
-            }
-            // ---- classify: class = top two hash bits; rank = my place among this wave's entries of my class
-            const int i = tbase + 64 * (int)wave + lane, p = i - dict_len;
-            const bool valid = (i >= first) && (i < total) && (p + ZA_HASH_BYTES <= n);
-            const uint32_t h = za_hash6(v.x, v.y);
-            const uint32_t cls = h >> ZA_CH_SUB;
-            const unsigned long long V = __ballot(valid);
-            const unsigned long long B0 = __ballot((cls & 1u) != 0u), B1 = __ballot((cls & 2u) != 0u);
-            const unsigned long long m0 = V & ~B0 & ~B1, m1 = V & B0 & ~B1, m2 = V & ~B0 & B1, m3 = V & B0 & B1;
-            // my place among this wave's entries of my class: the four class masks are wave-uniform (scalar registers), so
-            // four mbcnt pairs and a select are cheaper than building my class's mask per lane
-            auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-            const uint32_t r0 = below(m0), r1 = below(m1), r2 = below(m2), r3 = below(m3);
-            const uint32_t rank = (cls & 2u) ? ((cls & 1u) ? r3 : r2) : ((cls & 1u) ? r1 : r0);
-            if (lane < ZA_CH_WAVES) {
-                const uint32_t c01 = lane == 0 ? (uint32_t)__builtin_popcountll(m0) : (uint32_t)__builtin_popcountll(m1);
-                const uint32_t c23 = lane == 2 ? (uint32_t)__builtin_popcountll(m2) : (uint32_t)__builtin_popcountll(m3);
-                cnt[par][wave][lane] = lane < 2 ? c01 : c23;
-            }
-            __syncthreads();
-            // ---- lane c < 4 adds up class c over the producer waves: where my wave's entries start, and the new cursor
-            uint32_t base = 0;
-            if (lane < ZA_CH_WAVES) {
-                uint32_t before = 0, all = 0;
+        // one group of steps: the NEXT group's bytes are requested first (into the other register set: the loop below is unrolled
+        // twice so that no set is ever copied -- a copy would wait for its loads), then this group's atomics go out back to back,
+        // then their results become links
+        // (a group wholly inside the row -- all but a unit's first and last -- needs no test per lane: `inner`, wave-uniform)
+        auto do_group_as = [&](auto inner_tag, int tbase, const uint32_t (&clo)[ZA_CH_GROUP], const uint32_t (&chi)[ZA_CH_GROUP],
+                               uint32_t (&nlo)[ZA_CH_GROUP], uint32_t (&nhi)[ZA_CH_GROUP]) {
+            constexpr bool inner = decltype(inner_tag)::value;
 #pragma unroll
-                for (uint32_t w = 0; w < ZA_CH_WAVES; w++) {
-                    const uint32_t c = cnt[par][w][lane];
-                    before += w < wave ? c : 0u;
-                    all += c;
-                }
-                base = wslot + before;                         // < 320 + 256
-                wrv += all;
-                wslot += all; wslot -= wslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;
+            for (int g = 0; g < ZA_CH_GROUP; g++) load_step(tbase + 64 * (ZA_CH_GROUP + g), nlo[g], nhi[g]);
+            uint32_t hh[ZA_CH_GROUP], old[ZA_CH_GROUP];
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g++) {
+                const int i = tbase + 64 * g + lane, p = i - dict_len;
+                const bool ins = inner || (i >= first && i < total && p + ZA_HASH_BYTES <= n);
+                hh[g] = za_hash6(clo[g], chi[g]);
+                old[g] = 0u;
+                if (ins) old[g] = atomicMax(&head[hh[g]], abase + (uint32_t)i);
             }
-            par ^= 1u;
-            uint32_t myslot = (uint32_t)__shfl((int)base, (int)cls, 64) + rank;   // < 320 + 192 + 64 (at most three waves in front of mine)
-            myslot -= myslot >= ZA_CH_STAGE ? ZA_CH_STAGE : 0u;                   // one wrap is enough: < 2 * ZA_CH_STAGE
-            if (valid)
-                ring_all[cls][myslot] = (uint32_t)(ZA_WIN + p) | ((h & ((1u << ZA_CH_SUB) - 1u)) << 18);
-            __syncthreads();
-            // ---- consume my class in dense groups of 64, in position order
-            consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), false);
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g++) {
+                const int i = tbase + 64 * g + lane, p = i - dict_len;
+                const bool inrow = inner || (i >= first && i < total);
+                const bool ins = inner || (inrow && p + ZA_HASH_BYTES <= n);
+                const uint32_t A = abase + (uint32_t)i;
+                uint32_t o = old[g];
+                if (__ballot(ins && o >= A) != 0ull) o = za_chains_fix(hh[g], A, o, ins);
+                const uint32_t d = A - o;
+                // positions with fewer than 6 bytes left are never inserted: their link is 0
+                if (inrow) prevdist[i] = (uint16_t)((ins && o != 0u && d <= (uint32_t)ZA_WIN) ? d : 0u);
+            }
         };
-        // four tiles of loads stay in flight ahead of the one being classified
-        const int t0 = carry ? dict_len - 256 : 0;               // (a carried unit: one tile in front of the unit for its five late positions)
-        uint2 va = load_tile(t0), vb = load_tile(t0 + 256), vc = load_tile(t0 + 512), vd = load_tile(t0 + 768);
-        __syncthreads();
-        for (int tbase = t0; tbase < total; tbase += 1024) {
-            do_tile(tbase, va);
-            if (tbase + 256 >= total) break;
-            va = load_tile(tbase + 1024);
-            do_tile(tbase + 256, vb);
-            if (tbase + 512 >= total) break;
-            vb = load_tile(tbase + 1280);
-            do_tile(tbase + 512, vc);
-            if (tbase + 768 >= total) break;
-            vc = load_tile(tbase + 1536);
-            do_tile(tbase + 768, vd);
-            vd = load_tile(tbase + 1792);
-        }
-        consume((uint32_t)__builtin_amdgcn_readlane((int)wrv, (int)wave), true);
-        // positions with fewer than 6 bytes left are never inserted: their link is 0
-        if (wave == 0 && lane < ZA_HASH_BYTES - 1) {
-            const int p = n - 1 - lane;
-            if (p >= -dict_len && (!carry || p >= -(ZA_HASH_BYTES - 1))) prevdist[p + dict_len] = 0;
+        auto do_group = [&](int tbase, const uint32_t (&clo)[ZA_CH_GROUP], const uint32_t (&chi)[ZA_CH_GROUP],
+                            uint32_t (&nlo)[ZA_CH_GROUP], uint32_t (&nhi)[ZA_CH_GROUP]) {
+            if (tbase >= first && tbase + 64 * ZA_CH_GROUP + ZA_HASH_BYTES - 1 <= total) do_group_as(std::true_type{}, tbase, clo, chi, nlo, nhi);
+            else do_group_as(std::false_type{}, tbase, clo, chi, nlo, nhi);
+        };
+        uint32_t alo[ZA_CH_GROUP], ahi[ZA_CH_GROUP], blo[ZA_CH_GROUP], bhi[ZA_CH_GROUP];
+        const int t0 = first & ~63;                             // (steps start at multiples of 64: whole 128-byte lines of links)
+#pragma unroll
+        for (int g = 0; g < ZA_CH_GROUP; g++) load_step(t0 + 64 * g, alo[g], ahi[g]);
+#pragma unroll 1
+        for (int tbase = t0; tbase < total; tbase += 2 * 64 * ZA_CH_GROUP) {
+            do_group(tbase, alo, ahi, blo, bhi);
+            if (tbase + 64 * ZA_CH_GROUP >= total) break;
+            do_group(tbase + 64 * ZA_CH_GROUP, blo, bhi, alo, ahi);
         }
     }
 }
