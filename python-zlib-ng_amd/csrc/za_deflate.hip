@@ -21,37 +21,53 @@
 // ------------------------------------------------------------------------------------------------
 // k_chains
 // ------------------------------------------------------------------------------------------------
-// One WAVEFRONT per run of consecutive units, and the whole insert of 64 consecutive positions is ONE LDS instruction:
-// the head table holds 32-bit run-absolute positions, and every lane does a returning atomic maximum of its position into
-// its bucket.  The LDS executes the lanes of an instruction that name one address one after the other, in ascending lane order,
-// so what comes back to a lane is the largest position its bucket held before it: the nearest earlier position of the bucket
-// -- an earlier lane of this very instruction or the table's entry from earlier steps -- which is exactly the sequential
-// insertion order of the spec (oracle stage 1), and the bucket is left with its last position.  That order is not promised
-// anywhere, so it is checked: served in any other order, some lane of a bucket gets back a position that is not below its
-// own, and the step's links are then worked out lane by lane (za_chains_fix; the table itself is right in any order, a
-// maximum does not depend on it).  A wave's LDS operations execute in program order, so the step behind needs no wait: the
-// atomics of consecutive steps go out back to back and their results are used a group of steps later -- no barrier, no hand-over
-// between waves, no ordering of same-bucket lanes by hand, and the links of a step leave as one 128-byte store.
+// One stream (a run of consecutive units) per workgroup of TWO wavefronts, and the whole insert of 64 consecutive positions
+// is ONE LDS instruction: the head table holds 32-bit run-absolute positions, and every lane does a returning atomic maximum
+// of its position into its bucket.  The LDS executes the lanes of an instruction that name one address one after the other,
+// in ascending lane order, so what comes back to a lane is the largest position its bucket held before it: the nearest
+// earlier position of the bucket -- an earlier lane of this very instruction or the table's entry from earlier steps --
+// which is exactly the sequential insertion order of the spec (oracle stage 1), and the bucket is left with its last
+// position.  That order is not promised anywhere, so it is checked: served in any other order, some lane of a bucket gets
+// back a position that is not below its own, and the step's links are then worked out lane by lane (za_chains_fix; the
+// table itself is right in any order, a maximum does not depend on it).  A wave's LDS operations execute in program order,
+// so the step behind needs no wait: the atomics of consecutive steps go out back to back and their results are used a group
+// of steps later -- no hand-over of positions between owners of bucket classes, no ordering of same-bucket lanes by hand,
+// and the links of a step leave as one 128-byte store.
 // (Until round 3 a 256-thread workgroup split the bucket space over four waves, handed every position to the owning wave
 // through LDS rings -- three ballots, eight mbcnt and two barriers per 256 positions -- and ordered the same-bucket lanes of a
 // 64-entry insert with an exchange on a side array: 108 lane-instructions per position, 14.6 ms per 4 GiB.)
 // Positions are 32 bits and absolute in the run, so nothing ages and nothing wraps: a link is valid if it reaches back at most
-// 32 768.  The table is 2^13 x 4 bytes = 32 KiB: five wavefronts per CU, each with a stream of its own.
-#ifndef ZA_CH_GROUP
-#define ZA_CH_GROUP 8
+// 32 768.  The table is 2^13 x 4 bytes = 32 KiB, which lets four streams share a CU -- one wavefront per SIMD, and a lone
+// wavefront issues an instruction every 6 to 8 cycles (profiles/ubench_occ.hip).  Hence the second wavefront: wave 0 fetches
+// the bytes and hashes them (a group of steps ahead, into a 2 KiB LDS buffer), wave 1 inserts and writes the links; they meet
+// at one barrier per group and each issues half of the instructions.
+// Neither wave talks to memory position by position: 64 lanes fetching 6 bytes each at 64 consecutive byte addresses, and 64
+// two-byte stores per step, kept the kernel waiting for the vector-memory pipe (three such instructions per step: 7.4 ms per
+// 4 GiB whether one wave issued the rest or two).  The bytes of a group arrive as ONE 16-byte load per lane and pass through an
+// LDS ring, from which every lane takes its own six (three aligned dwords, `v_alignbyte`); the links of a group are collected
+// in LDS and leave as one 16-byte store per lane.
+struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };      // 16 bytes at any address
+#define ZA_CH_GROUP 16                         // steps (of 64 positions) per group
+#ifndef ZA_CH_READ
+#define ZA_CH_READ 0                           // 1: a position's bytes as one 8-byte LDS read at its own byte address -- 4.1 -> 9.8 ms
 #endif
-//  ZA_CH_GROUP:                          // steps (of 64 positions) whose loads, atomics and stores are issued together
+// the byte offset of a bucket's table entry out of the full 32-bit product: (x >> 19) << 2 with two full-rate operations
+// (a right shift and an AND; a left shift runs at half rate on this chip, profiles/ubench_issue2.hip)
+#define za_hash6x(lo, hi) (((lo) * 2654435761u) ^ ((hi) * 2246822519u))
+#define ZA_CH_OFFS(x) (((x) >> (32 - ZA_HASH_BITS - 2)) & (((1u << ZA_HASH_BITS) - 1u) << 2))
+#define ZA_CH_CHUNK (64 * ZA_CH_GROUP)         // positions = bytes of a group: 16 per lane
 
-// the links of one step worked out lane by lane (only if the LDS ever served an atomic's lanes out of order)
+// the links of one step worked out lane by lane (only if the LDS ever served an atomic's lanes out of order): what the
+// atomic should have returned
 __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t old, bool ins)
 {
     uint32_t near = 0, pre = 0xFFFFFFFFu;
     const int lane = za_lane();
+    const unsigned long long insm = __ballot(ins);
     for (int j = 0; j < 64; j++) {
         const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j), Aj = (uint32_t)__builtin_amdgcn_readlane((int)A, j);
         const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)old, j);
-        const bool insj = ((__ballot(ins) >> j) & 1ull) != 0ull;
-        if (insj && hj == h) {
+        if (((insm >> j) & 1ull) != 0ull && hj == h) {
             if (j < lane) near = Aj;               // ascending j: the last one kept is the nearest earlier lane of my bucket
             pre = oj < pre ? oj : pre;             // the bucket's entry in front of the step: what its first-served lane got back
         }
@@ -59,20 +75,27 @@ __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t 
     return near ? near : pre;
 }
 
-__global__ __launch_bounds__(64) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
-                                                  const uint32_t *__restrict__ run_start,
-                                                  uint16_t *__restrict__ prev_ws)
+__global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+                                                   const uint32_t *__restrict__ run_start,
+                                                   uint16_t *__restrict__ prev_ws)
 {
-    __shared__ uint32_t head[1 << ZA_HASH_BITS];      // run-absolute position + 1 of the bucket's last position, 0 = none
-    const int lane = za_lane();
+    // the bucket's last position as a run-absolute number that starts ABOVE the window size, 0 = none: `position - entry` is then
+    // a valid link exactly if it is at most 32 768 (an empty bucket gives more), and it is below 1 exactly if the LDS served
+    // the lanes of an atomic out of order (see above)
+    __shared__ uint32_t head[1 << ZA_HASH_BITS];
+    __shared__ uint32_t ring[(2 * ZA_CH_CHUNK + 16) / 4];      // the bytes of two groups (+ the first 16 again behind the end)
+    __shared__ uint16_t hbuf[2][ZA_CH_CHUNK];                  // byte offsets of the buckets (bucket * 4) of a group's positions, two groups;
+                                                               // the inserting wave collects the group's links in the buffer it has read
+    const uint32_t lane = (uint32_t)za_lane();
+    const bool hasher = threadIdx.x < 64;                      // wave 0 fetches and hashes, wave 1 inserts and stores
     const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
     uint32_t goff = 0;                                // positions of the run in front of the current unit
     uint32_t n_prev = 0;
 #pragma unroll 1
     for (uint32_t ui = u0; ui < u1; ui++) {
         const ZaUnit u = units[ui];
-        const uint8_t *data = in + u.in_off;
         const int n = (int)u.in_len, dict_len = (int)u.dict_len;
+        const uint8_t *row = in + u.in_off - dict_len;                 // byte of row index 0 (row index i = position + dictionary length)
         uint16_t *prevdist = prev_ws + (size_t)ui * ZA_PREV_STRIDE;
 #ifdef ZA_ABL_NO_CARRY
         const bool carry = false;
@@ -83,72 +106,148 @@ __global__ __launch_bounds__(64) void za_k_chains(const uint8_t *__restrict__ in
         else {
             // a fresh table: the unit's dictionary is inserted like the unit itself (what deflateSetDictionary does per block)
             goff = 0;
-            for (int i = lane * 4; i < (1 << ZA_HASH_BITS); i += 256) *(uint4 *)&head[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t i = threadIdx.x * 4u; i < (1u << ZA_HASH_BITS); i += 512u) *(uint4 *)&head[i] = make_uint4(0u, 0u, 0u, 0u);
         }
+        __syncthreads();                                       // (the table; and both waves are through with the unit in front)
         n_prev = (uint32_t)n;
         const int total = dict_len + n;
         // a carried unit starts with the last five positions of the unit in front of it: they had fewer than six bytes left
         // there and have them now (their links go to this unit's own row: that unit's links say "never inserted", which is
         // what a search of THAT unit must see)
         const int first = carry ? dict_len - (ZA_HASH_BYTES - 1) : 0;
-        const uint32_t abase = goff + (uint32_t)(ZA_WIN - dict_len) + 1u;      // table value of row index i: abase + i
+        const uint32_t abase = goff + (uint32_t)(2 * ZA_WIN - dict_len) + 1u;     // table value of row index i: abase + i (> 32 768)
         if (total < ZA_HASH_BYTES) {                           // (uniform) not one 6-byte context: nothing to insert, every link is 0
-            if (lane >= first && lane < total) prevdist[lane] = 0;
+            if (!hasher && (int)lane >= first && (int)lane < total) prevdist[lane] = 0;
             continue;
         }
-        const int pclamp_hi = n - ZA_HASH_BYTES;              // last position with 6 bytes available
-        // loads are unconditional from a clamped position (no branch per step); `ins` masks them later
-        auto load_step = [&](int tbase, uint32_t &lo, uint32_t &hi) {
-            int p = tbase + lane - dict_len;
-            p = p > pclamp_hi ? pclamp_hi : p;
-            p = p < -dict_len ? -dict_len : p;
-            lo = za_ld32(data + p); hi = za_ld16(data + p + 4);
+        const int iclamp_hi = total - ZA_HASH_BYTES;          // last row index with 6 bytes available
+        const int t0 = first & ~63;                             // (groups start at multiples of 64: whole lines of links)
+        const int ngroups = (total - t0 + ZA_CH_CHUNK - 1) / ZA_CH_CHUNK;
+        // ---- wave 0.  Chunk c = the ZA_CH_CHUNK bytes from row index t0 + c * ZA_CH_CHUNK, 8 per lane; bytes behind the row's end
+        // are zeros (the positions that would need them are never inserted)
+        auto fetch = [&](int c) -> uint4 {
+            const int cbase = t0 + c * ZA_CH_CHUNK, at = cbase + 16 * (int)lane;
+            if (cbase + ZA_CH_CHUNK <= total) { const ZaU4u v = *(const ZaU4u *)(row + at); return make_uint4(v.x, v.y, v.z, v.w); }      // (uniform) the whole chunk inside the row: no wait here
+            uint32_t r[4] = {0u, 0u, 0u, 0u};                     // the row's last chunk (and the two behind it): byte by byte
+            for (int k = 0; k < 16 && at + k < total; k++) r[k >> 2] |= (uint32_t)row[at + k] << (8 * (k & 3));
+            return make_uint4(r[0], r[1], r[2], r[3]);
         };
-        // one group of steps: the NEXT group's bytes are requested first (into the other register set: the loop below is unrolled
-        // twice so that no set is ever copied -- a copy would wait for its loads), then this group's atomics go out back to back,
-        // then their results become links
-        // (a group wholly inside the row -- all but a unit's first and last -- needs no test per lane: `inner`, wave-uniform)
-        auto do_group_as = [&](auto inner_tag, int tbase, const uint32_t (&clo)[ZA_CH_GROUP], const uint32_t (&chi)[ZA_CH_GROUP],
-                               uint32_t (&nlo)[ZA_CH_GROUP], uint32_t (&nhi)[ZA_CH_GROUP]) {
+        auto stage = [&](int c, uint4 v) {                      // chunk c into its half of the ring
+            *(uint4 *)(ring + (c & 1) * (ZA_CH_CHUNK / 4) + 4 * lane) = v;
+            if ((c & 1) == 0 && lane == 0) *(uint4 *)(ring + 2 * ZA_CH_CHUNK / 4) = v;
+        };
+        auto hash_group = [&](int k, uint16_t *hb) {            // needs chunk k and the head of chunk k + 1 in the ring
+#if ZA_CH_READ == 0
+            const uint32_t *w = ring + (k & 1) * (ZA_CH_CHUNK / 4) + (lane >> 2);
+            const uint32_t sh = lane & 3u;
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g++) {
+                const uint32_t d0 = w[16 * g], d1 = w[16 * g + 1], d2 = w[16 * g + 2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0xFFFFu;
+                hb[64 * g + lane] = (uint16_t)ZA_CH_OFFS(za_hash6x(lo, hi));
+            }
+#else
+            // a position's bytes as ONE 8-byte read at its own byte address (the LDS takes reads at any alignment, and takes its time)
+            const uint8_t *w = (const uint8_t *)ring + (k & 1) * ZA_CH_CHUNK + lane;
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g++) {
+                const uint64_t v = *(const za_u64u *)(w + 64 * g);
+                hb[64 * g + lane] = (uint16_t)ZA_CH_OFFS(za_hash6x((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu));
+            }
+#endif
+        };
+        auto group_inner = [&](int k) -> bool {                 // (uniform) group k lies wholly inside the row: no test per lane, links through LDS
+            const int tbase = t0 + k * ZA_CH_CHUNK;
+            return tbase >= first && tbase + ZA_CH_CHUNK - 1 <= iclamp_hi;
+        };
+        // ---- wave 1: a group's atomics go out back to back, then their results become links (`inner`: the group lies wholly
+        // inside the row -- all but a unit's first and last -- and needs no test per lane; its links leave 16 bytes per lane)
+        auto insert_as = [&](auto inner_tag, int tbase, uint16_t *hb) {
             constexpr bool inner = decltype(inner_tag)::value;
-#pragma unroll
-            for (int g = 0; g < ZA_CH_GROUP; g++) load_step(tbase + 64 * (ZA_CH_GROUP + g), nlo[g], nhi[g]);
+            const uint32_t li = (uint32_t)tbase + lane;                 // my row index in the group's first step
             uint32_t hh[ZA_CH_GROUP], old[ZA_CH_GROUP];
+            const uint32_t A0 = abase + li;
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g++) hh[g] = hb[64 * g + lane];
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) {
-                const int i = tbase + 64 * g + lane, p = i - dict_len;
-                const bool ins = inner || (i >= first && i < total && p + ZA_HASH_BYTES <= n);
-                hh[g] = za_hash6(clo[g], chi[g]);
+                const int i = (int)li + 64 * g;
+                const bool ins = inner || (i >= first && i <= iclamp_hi);
                 old[g] = 0u;
-                if (ins) old[g] = atomicMax(&head[hh[g]], abase + (uint32_t)i);
+#ifdef ZA_ABL_CH_NOATOMIC
+                if (ins) old[g] = *(const uint32_t *)((const uint8_t *)head + hh[g]);       // (timing only)
+#else
+                if (ins) old[g] = atomicMax((uint32_t *)((uint8_t *)head + hh[g]), A0 + 64u * (uint32_t)g);
+#endif
             }
+            int worst = 1;                                             // the smallest `position - entry` of the group: below 1 = served out of order
+            uint32_t dd[ZA_CH_GROUP];
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) {
-                const int i = tbase + 64 * g + lane, p = i - dict_len;
-                const bool inrow = inner || (i >= first && i < total);
-                const bool ins = inner || (inrow && p + ZA_HASH_BYTES <= n);
-                const uint32_t A = abase + (uint32_t)i;
-                uint32_t o = old[g];
-                if (__ballot(ins && o >= A) != 0ull) o = za_chains_fix(hh[g], A, o, ins);
-                const uint32_t d = A - o;
-                // positions with fewer than 6 bytes left are never inserted: their link is 0
-                if (inrow) prevdist[i] = (uint16_t)((ins && o != 0u && d <= (uint32_t)ZA_WIN) ? d : 0u);
+                const int i = (int)li + 64 * g;
+                const bool ins = inner || (i >= first && i <= iclamp_hi);
+                dd[g] = (A0 + 64u * (uint32_t)g) - old[g];
+                const int ds = ins ? (int)dd[g] : 1;
+                worst = ds < worst ? ds : worst;
+            }
+#ifndef ZA_ABL_CH_NOCHECK
+            if (__builtin_expect(__ballot(worst <= 0) != 0ull, 0)) {
+#pragma unroll 1
+                for (int g = 0; g < ZA_CH_GROUP; g++) {
+                    const int i = (int)li + 64 * g;
+                    const bool ins = inner || (i >= first && i <= iclamp_hi);
+                    const uint32_t A = A0 + 64u * (uint32_t)g;
+                    uint32_t hg = hh[0], og = old[0];
+#pragma unroll
+                    for (int q = 1; q < ZA_CH_GROUP; q++) { hg = g == q ? hh[q] : hg; og = g == q ? old[q] : og; }
+                    const uint32_t dfix = A - za_chains_fix(hg >> 2, A, og, ins);
+#pragma unroll
+                    for (int q = 0; q < ZA_CH_GROUP; q++) dd[q] = g == q ? dfix : dd[q];
+                }
+            }
+#endif
+            // positions with fewer than 6 bytes left are never inserted: their link is 0
+            if (inner) {
+                // the links pass through the group's hash buffer (mine until the barrier: its entries are in my registers) and leave
+                // 16 bytes per lane.  (Stored by wave 0 behind the next barrier instead: 4.3 -> 5.0 ms, that wave is the slower one.)
+#pragma unroll
+                for (int g = 0; g < ZA_CH_GROUP; g++) hb[64 * g + lane] = (uint16_t)(dd[g] <= (uint32_t)ZA_WIN ? dd[g] : 0u);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 v0 = *(const uint4 *)&hb[8 * lane], v1 = *(const uint4 *)&hb[512 + 8 * lane];
+#ifndef ZA_ABL_CH_NOSTORE
+                *(uint4 *)(prevdist + tbase + 8 * (int)lane) = v0;      // (rows and groups start at multiples of 128 bytes)
+                *(uint4 *)(prevdist + tbase + 512 + 8 * (int)lane) = v1;
+#endif
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int g = 0; g < ZA_CH_GROUP; g++) {
+                    const int i = (int)li + 64 * g;
+                    const bool inrow = i >= first && i < total;
+                    if (inrow) prevdist[i] = (uint16_t)((i <= iclamp_hi && dd[g] <= (uint32_t)ZA_WIN) ? dd[g] : 0u);
+                }
             }
         };
-        auto do_group = [&](int tbase, const uint32_t (&clo)[ZA_CH_GROUP], const uint32_t (&chi)[ZA_CH_GROUP],
-                            uint32_t (&nlo)[ZA_CH_GROUP], uint32_t (&nhi)[ZA_CH_GROUP]) {
-            if (tbase >= first && tbase + 64 * ZA_CH_GROUP + ZA_HASH_BYTES - 1 <= total) do_group_as(std::true_type{}, tbase, clo, chi, nlo, nhi);
-            else do_group_as(std::false_type{}, tbase, clo, chi, nlo, nhi);
+        auto insert = [&](int k, uint16_t *hb) {
+            const int tbase = t0 + k * ZA_CH_CHUNK;
+            if (group_inner(k)) insert_as(std::true_type{}, tbase, hb);
+            else insert_as(std::false_type{}, tbase, hb);
         };
-        uint32_t alo[ZA_CH_GROUP], ahi[ZA_CH_GROUP], blo[ZA_CH_GROUP], bhi[ZA_CH_GROUP];
-        const int t0 = first & ~63;                             // (steps start at multiples of 64: whole 128-byte lines of links)
-#pragma unroll
-        for (int g = 0; g < ZA_CH_GROUP; g++) load_step(t0 + 64 * g, alo[g], ahi[g]);
+        // iteration k: wave 0 puts chunk k + 1 into the ring, asks for chunk k + 2 and hashes group k; wave 1 inserts group k - 1;
+        // one barrier per iteration (a hash buffer is written again two iterations after it was read; the ring is wave 0's alone)
+        uint4 pend = make_uint4(0u, 0u, 0u, 0u);
+        if (hasher) { stage(0, fetch(0)); pend = fetch(1); }
 #pragma unroll 1
-        for (int tbase = t0; tbase < total; tbase += 2 * 64 * ZA_CH_GROUP) {
-            do_group(tbase, alo, ahi, blo, bhi);
-            if (tbase + 64 * ZA_CH_GROUP >= total) break;
-            do_group(tbase + 64 * ZA_CH_GROUP, blo, bhi, alo, ahi);
+        for (int k = 0; k <= ngroups; k++) {
+            if (hasher) {
+                if (k < ngroups) {
+                    stage(k + 1, pend);
+                    pend = fetch(k + 2);
+                    hash_group(k, hbuf[k & 1]);
+                }
+            } else if (k >= 1) insert(k - 1, hbuf[(k - 1) & 1]);
+            __syncthreads();
         }
     }
 }
@@ -411,7 +510,6 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #define ZA_PROW (ZA_PCH + 1)          // carried entry + chunk (odd stride)
 #define ZA_BLEN(b) (((b) >> 16) & 0xFFu)      // length - 3 of a `best` entry, 0 = no match
 
-struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };
 
 __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ units,
                                                  const uint32_t *__restrict__ best_ws, uint32_t *__restrict__ tok_ws,

@@ -72,7 +72,7 @@ struct zngamd_ctx {
     std::vector<ZaUnit> last_hu;                 // the units of the last deflate call as the kernels saw them (zngamd_debug_fetch)
     std::vector<ZaUnit> plan_in; std::vector<uint32_t> plan_runs; uint32_t plan_ch = 0;     // the unit table the device holds was planned from this one: a caller that compresses batch after batch of the same shape pays for the planning once
     std::vector<zngamd_block> blocks_in; std::vector<ZaUnit> blocks_hu; uint64_t blocks_len = 0;
-    uint32_t chain_slots = 1280;                 // chain-kernel wavefronts the device holds at once: CUs x 5 (32 KiB of LDS each)
+    uint32_t chain_slots = 1024;                 // chain-kernel workgroups the device holds at once: CUs x 4 (34 KiB of LDS each)
     uint32_t chain_run = 0;                      // ZNGAMD_CHAIN_RUN: fixed run length of the chain kernel (0 = sized to the device)
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
@@ -153,7 +153,7 @@ try {
     c->stream = c->own_stream;
     if (const char *e = getenv("ZNGAMD_CHUNK_UNITS")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chunk_units = (uint32_t)v; }
     if (const char *e = getenv("ZNGAMD_CHAIN_RUN")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chain_run = (uint32_t)v; }
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->chain_slots = (uint32_t)cus * 5u; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->chain_slots = (uint32_t)cus * 4u; }
     // tables: CRC-32 byte table and x^(8*2048*k) mod P
     uint32_t tab[256], x8k[64];
     for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); tab[i] = v; }
@@ -472,7 +472,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         run_pos += nruns + 1;
         if (level > 0) {
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
-              hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(64), 0, c->stream, d_in, du, d_runs, c->prev.p); }
+              hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(128), 0, c->stream, d_in, du, d_runs, c->prev.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
               if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
               else hipLaunchKernelGGL(za_k_search<false>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L); }
