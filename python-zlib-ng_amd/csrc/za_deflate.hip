@@ -279,6 +279,26 @@ __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t 
 // cycles: two or four positions of a thread searched at once, their chain walks interleaved by hand, 6.82 -> 6.80 / 7.13 ms per
 // GiB; a candidate's 16 bytes as ONE unaligned ds_read_b128 -- the LDS takes wide reads at any byte address -- 9.4 ms; as three
 // aligned ds_read_b64 and a select per dword 7.57 ms.)
+// the match of `len` bytes between the window positions qb and P, extended to its true length (at most maxlen): 8 bytes per round,
+// each side from three aligned dwords (the ring's mirrored pad covers the overrun); most matches end in the first round
+__device__ __forceinline__ int za_search_extend(const uint32_t *win32, uint32_t qb, uint32_t P, int len, int maxlen)
+{
+    for (;;) {
+        const uint32_t o = (uint32_t)len;
+        const uint32_t is = (qb + o) & (ZA_BYTES - 1), ws = is >> 2, ip = (P + o) & (ZA_BYTES - 1), wp = ip >> 2;
+        const uint32_t s0 = win32[ws], s1 = win32[ws + 1], s2 = win32[ws + 2], p0 = win32[wp], p1 = win32[wp + 1], p2 = win32[wp + 2];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(s1, s0, is & 3u) ^ __builtin_amdgcn_alignbyte(p1, p0, ip & 3u);
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(s2, s1, is & 3u) ^ __builtin_amdgcn_alignbyte(p2, p1, ip & 3u);
+        uint32_t g0, g1;
+        asm("v_ffbl_b32 %0, %2\n\tv_ffbl_b32 %1, %3\n\tv_add_u32_e64 %1, %1, 32 clamp\n\tv_min_u32_e32 %0, %0, %1"
+            : "=&v"(g0), "=&v"(g1) : "v"(a0), "v"(a1));
+        const int nb = (int)min(g0 >> 3, 8u);
+        len += nb;
+        if (nb < 8 || len >= maxlen) break;
+    }
+    return len < maxlen ? len : maxlen;
+}
+
 // FULL: candidates are compared in full (levels with cap 258); otherwise on 16 bytes, winner extended afterwards
 template <bool FULL>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
@@ -434,11 +454,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                         (best_len < 16 || (uint8_t)za_lds_ld32(win32, q + (uint32_t)best_len) == (uint8_t)za_lds_ld32(win32, P + (uint32_t)best_len))) {
                         // levels that compare in full: at least 16 equal bytes -- finish the compare the long way (a candidate that
                         // differs at the byte behind the best length so far cannot beat it: zlib's quick reject, one LDS read)
-                        while (len < maxlen) {
-                            const uint32_t x = za_lds_ld32(win32, q + (uint32_t)len) ^ za_lds_ld32(win32, P + (uint32_t)len);
-                            if (x) { len += (int)(__builtin_ctz(x) >> 3); break; }
-                            len += 4;
-                        }
+                        len = za_search_extend(win32, q, P, len, maxlen);       // (8 bytes per round; 4 per round until round 4)
                     }
                     if (FULL) len = len < cap ? len : cap;
                     const bool better = len > best_len;
@@ -448,22 +464,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 }
                 if (!FULL && best_len == cap && cap < maxlen) {
                     // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
-                    const uint32_t qb = P - (uint32_t)best_dist;
-                    for (;;) {                                   // 8 bytes per round; most winners end in the first
-                        const uint32_t o = (uint32_t)best_len;
-                        // eight bytes of each side from three aligned dwords (the ring's mirrored pad covers the overrun)
-                        const uint32_t is = (qb + o) & (ZA_BYTES - 1), ws = is >> 2, ip = (P + o) & (ZA_BYTES - 1), wp = ip >> 2;
-                        const uint32_t s0 = win32[ws], s1 = win32[ws + 1], s2 = win32[ws + 2], p0 = win32[wp], p1 = win32[wp + 1], p2 = win32[wp + 2];
-                        const uint32_t a0 = __builtin_amdgcn_alignbyte(s1, s0, is & 3u) ^ __builtin_amdgcn_alignbyte(p1, p0, ip & 3u);
-                        const uint32_t a1 = __builtin_amdgcn_alignbyte(s2, s1, is & 3u) ^ __builtin_amdgcn_alignbyte(p2, p1, ip & 3u);
-                        uint32_t g0, g1;
-                        asm("v_ffbl_b32 %0, %2\n\tv_ffbl_b32 %1, %3\n\tv_add_u32_e64 %1, %1, 32 clamp\n\tv_min_u32_e32 %0, %0, %1"
-                            : "=&v"(g0), "=&v"(g1) : "v"(a0), "v"(a1));
-                        const int nb = (int)min(g0 >> 3, 8u);
-                        best_len += nb;
-                        if (nb < 8 || best_len >= maxlen) break;
-                    }
-                    best_len = best_len < maxlen ? best_len : maxlen;
+                    best_len = za_search_extend(win32, P - (uint32_t)best_dist, P, best_len, maxlen);
                 }
                 if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
                     result = ((uint32_t)(best_len - 3) << 16) | (uint32_t)best_dist;
