@@ -407,6 +407,89 @@ def main():
                    "frac": round(fbytes / (min(f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(fbytes)}
         del d_for, d_tile, d_ft
 
+    # ---- what the drop-in writer writes, decoded: the compress leg's OWN gathered stream (one raw deflate stream of dict-chained,
+    # sync-flushed 128 KiB blocks: gzip_ng_threaded.py:299-338 -- what gzip_ng_threaded.open(..., "rb") and zlib_ng.decompress get
+    # for every file this product or the reference writes) through the chunk-parallel decoder; outside the timed region ----
+    chained = None
+    if rank == 0 and blo == 0 and not args.no_foreign:
+        d_comp[comp_bytes:comp_bytes + 66] = 0
+        d_comp[comp_bytes] = 3                                   # empty final block
+        vlen, vused = C.c_uint64(0), C.c_uint64(0)
+        c_wall, c_kern = [], []
+        for it in range(3):
+            d_out.zero_()
+            torch.cuda.synchronize()             # (torch's stream and the engine's are not ordered with each other)
+            ctx.profiling(True); ctx.kernel_times(reset=True)
+            t = time.perf_counter()
+            rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
+            c_wall.append((time.perf_counter() - t) * 1e3)
+            c_kern.append(sum(v[0] for v in ctx.kernel_times(reset=True).values()))
+            ctx.profiling(False)
+            assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
+        assert torch.equal(d_out[:size], d_in[:size]), "chained stream: output differs"
+        cbytes = comp_bytes + size
+        cms = min(c_wall)
+        chained = {"bound": "hbm", "kernel": "za_k_chunk_decode + za_k_chunk_compose / _chain / _resolve (+ za_k_scan_sync)",
+                   "stream": f"the compress leg's own output: ONE raw deflate stream, {nblocks} dict-chained blocks of 128 KiB ending in sync flushes",
+                   "ms": round(cms, 3), "kernel_ms": round(min(c_kern), 3),
+                   "decompress_MBps": round(size / (cms * 1e-3) / 1e6, 1),
+                   "achieved": round(cbytes / (cms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(cbytes),
+                   "note": "ms = the whole device-resident call (its host-side planning between the kernels included), best of 3"}
+
+    # ---- BGZF: standard 'BC' members (at most 65 280 bytes of input each, FEXTRA subfield BC = member size - 1) written by the
+    # system zlib, one wavefront per member; outside the timed region ----
+    bgzf = None
+    if rank == 0 and not args.no_foreign and size % uniq == 0:
+        import struct
+        from concurrent.futures import ThreadPoolExecutor
+        hv = memoryview(host)
+        BG = 65280
+        nbg = (uniq + BG - 1) // BG
+
+        def bmember(b):
+            piece = hv[b * BG:min(uniq, (b + 1) * BG)]
+            co = zlib.compressobj(args.level, zlib.DEFLATED, -15)
+            raw = co.compress(piece) + co.flush()
+            bsize = 18 + len(raw) + 8 - 1
+            return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + raw +
+                    struct.pack("<II", zlib.crc32(piece), len(piece)))
+        with ThreadPoolExecutor(host_cores()) as ex:
+            mem = list(ex.map(bmember, range(nbg)))
+        tile = b"".join(mem)
+        tl = len(tile)
+        d_tile = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
+        d_bg = torch.empty(reps * tl + 64, dtype=torch.uint8, device=dev)
+        d_bg[:reps * tl].view(reps, tl)[:] = d_tile
+        d_bg[reps * tl:] = 0
+        nmem = reps * nbg
+        bt = (_lib.Member * nmem)()
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in mem])])
+        for m in range(nmem):
+            r_, b = divmod(m, nbg)
+            ilen = min(uniq, (b + 1) * BG) - b * BG
+            bt[m] = _lib.Member(r_ * tl + int(offs[b]) + 18, len(mem[b]) - 26, r_ * uniq + b * BG, ilen, 0, 0, 0)
+        d_bt = torch.frombuffer(bytearray(bytes(bt)), dtype=torch.uint8).to(dev)
+        d_bstat = torch.empty(nmem, dtype=torch.int32, device=dev)
+        d_out.zero_()
+        torch.cuda.synchronize()
+        b_ms = []
+        for it in range(2):
+            ctx.profiling(True); ctx.kernel_times(reset=True)
+            chk(L.zngamd_gzip_inflate_plain_members_dev(h, ptr(d_bg), reps * tl, ptr(d_bt), nmem, ptr(d_out), size, ptr(d_bstat)),
+                "gzip_inflate_plain_members_dev (BGZF)")
+            b_ms.append(ctx.kernel_times(reset=True)["inflate"][0])
+            ctx.profiling(False)
+        assert int((d_bstat != 0).sum().item()) == 0, "BGZF members: errors"
+        assert torch.equal(d_out[:size], d_in[:size]), "BGZF members: output differs"
+        bbytes = reps * tl + size
+        bgzf = {"bound": "hbm", "kernel": "za_k_inflate_serial_members", "members": nmem,
+                "writer": "system zlib " + zlib.ZLIB_RUNTIME_VERSION + f" level {args.level}, BGZF members ('BC' subfield) of 65 280 bytes",
+                "ms": round(min(b_ms), 3), "decompress_MBps": round(size / (min(b_ms) * 1e-3) / 1e6, 1),
+                "achieved": round(bbytes / (min(b_ms) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(bbytes / (min(b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(bbytes)}
+        del d_bg, d_tile, d_bt, d_bstat
+
     # ---- per-leg numbers -----------------------------------------------------------------------------
     steps = args.steps
     deflate_ms = sum(kt[k][0] for k in ("chains", "search", "parse", "plan", "pack", "gather")) / steps
@@ -414,7 +497,7 @@ def main():
     # The roofline of the step's dominant LEG: deflate = the kernels chains + search + parse + plan + pack + gather
     # together move N_in + C_out algorithmic bytes per unit -- no single one of them can be credited with those bytes -- so the
     # leg is priced as one: algorithmic bytes of one launch set (the whole shard) / the sum of its kernels' average launch times.
-    # (`roofline_dominant_kernel` prices the longest single kernel with the bytes its own role makes it move.)
+    # (`dominant_kernel` names the longest single kernel, with the bytes its own role makes it move and its instruction issue.)
     legs = {"deflate": deflate_ms, "inflate": inflate_ms}
     dom_leg = max(legs, key=legs.get)
     dom = max(("chains", "search", "parse", "plan", "pack", "inflate"), key=lambda k: kt[k][0])
@@ -442,11 +525,12 @@ def main():
     own = {"chains": 1.0 + 2.0, "search": 2.0 + 1.0 + 4.0, "parse": 4.0 + 0.8, "pack": 1.6 + comp_bytes / size, "plan": 0.02,
            "inflate": (ms_len.value + size) / size}
     dom_bytes = own[dom] * size / launches_per_step
-    roofline_dom = {"bound": "hbm", "kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
+    # the longest single kernel: NOT a roofline fraction of the path (its bytes are intermediates) -- the bytes its own role makes it
+    # move, and, since it is bound by instruction issue, its vector instructions against the chip's issue rate (`valu`, below)
+    roofline_dom = {"kernel": "za_k_" + ("inflate_members" if dom == "inflate" else dom),
                     "avg_launch_ms": round(avg_ms, 4), "own_bytes_per_launch": int(dom_bytes),
-                    "achieved": round(dom_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "bytes this kernel's own role makes it read and write (links, entries, tokens included), by design"}
+                    "own_bytes_GBps": round(dom_bytes / (avg_ms * 1e-3) / 1e9, 2),
+                    "note": "bytes this kernel's own role makes it read and write (links, entries, tokens included), by design; no fraction of a roofline"}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic_step, traffic_src, pmc_per_unit = {}, None, {}
     if os.path.exists(pmc):
@@ -466,6 +550,15 @@ def main():
             per_unit = pj.get(roofline_dom["kernel"])
             if per_unit:
                 roofline_dom["traffic"] = int(per_unit * nblocks / launches_per_step)
+            # bound "valu": vector wave-instructions per unit from the SQ pass of the same build; peak = one wave-instruction per
+            # SIMD every 4 cycles (what all but add / logic / right shift issue at on gfx950: profiles/ubench_issue2.hip) at 2.4 GHz
+            vi = (pj.get("valu_wave_insts_per_unit") or {}).get(roofline_dom["kernel"])
+            if vi:
+                peak_g = 1024 * 2.4 / 4.0
+                ach = vi * nblocks / launches_per_step / (avg_ms * 1e-3) / 1e9
+                roofline_dom["valu"] = {"bound": "valu", "lane_instructions_per_input_byte": round(vi * 64 / BLOCK, 1),
+                                        "achieved": round(ach, 1), "peak": round(peak_g, 1), "unit": "G wave-instructions/s",
+                                        "frac": round(ach / peak_g, 3)}
         except Exception:
             pass
 
@@ -486,7 +579,7 @@ def main():
         "ratio": round(size / comp_bytes, 4),
         "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kt.items() if v[1]},
         "roofline": roofline,
-        "roofline_dominant_kernel": roofline_dom,
+        "dominant_kernel": roofline_dom,
         "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains+search+parse+plan+pack+gather",
                                       "achieved": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
@@ -552,6 +645,12 @@ def main():
             out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
     if foreign is not None:
         out["roofline_inflate_foreign"] = foreign
+    if chained is not None:
+        out["roofline_inflate_chained"] = chained
+    if bgzf is not None:
+        if pmc_per_unit.get("za_k_inflate_serial_members_bgzf"):
+            bgzf["traffic"] = int(pmc_per_unit["za_k_inflate_serial_members_bgzf"] * bgzf["members"])
+        out["roofline_inflate_bgzf"] = bgzf
     # ---- the drop-in API over host buffers (PCIe, Python call overhead and fresh result objects included): NEVER `value`,
     # outside the timed region, rank 0 at N = 1 only.  One-shot calls on 256 MiB of the same text; the reference's own streaming
     # benchmark (benchmark_scripts/gzipwrite128kblocks.py:6-12, gzipread128kblocks.py:5-9): a gzip file written and read back

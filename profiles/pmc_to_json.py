@@ -29,5 +29,9 @@ for k, c in sorted(per.items()):
         out[k] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / units)
         out[k + "_fetch_raw"] = int(c["FETCH_SIZE"] * 1024 / units)
         out[k + "_write"] = int(c["WRITE_SIZE"] * 1024 / units)
+# vector wave-instructions per unit (SQ pass of the same build): bench.py's `dominant_kernel.valu` view
+valu = {k: round(c["SQ_INSTS_VALU"] / units, 1) for k, c in sorted(per.items()) if c.get("SQ_INSTS_VALU", 0) > 1e6}
+if valu:
+    out["valu_wave_insts_per_unit"] = valu
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
