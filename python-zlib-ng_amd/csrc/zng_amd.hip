@@ -863,6 +863,8 @@ struct ChunkInfo { bool cut = false; bool ended = false; uint64_t end_bit = 0; }
 #endif
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
                                uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o = ChunkOpts(), ChunkInfo *info = nullptr);
+static int inflate_chunked_once(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
+                                uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o, ChunkInfo *info);
 
 int zngamd_inflate_raw(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *in_used, uint32_t *crc, uint32_t *adler)
@@ -1189,8 +1191,45 @@ static int chunk_bail(int why)
 // Options: the stream may start at a bit offset inside the first byte with up to 32 KiB of history (a stream resumed at
 // a block header), and with allow_cut a stream that runs past the end of the buffer is decoded up to its last complete
 // block (info->cut, info->end_bit = where the next block header starts; *in_used = that bit's byte).
+// A long stream goes through the pipeline in BATCHES of compressed input (ZNGAMD_CHUNK_BATCH_MIB, 512 MiB): every batch is a
+// stream resumed at a block header with the 32 KiB in front of it as its history (the options above), cut in front of its last,
+// incomplete piece -- so the scratch area of the one-pass marker decode (12 bytes per compressed byte) is bounded by the batch,
+// not by the stream: 4 GiB of text asked for 18 GiB of it and went through the count pass instead (7.8 of 38 ms), a 16 GiB
+// stream would not have fitted a busy GPU at all.
 static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
                                uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o, ChunkInfo *info)
+{
+    static const uint64_t batch = [] { const char *e = getenv("ZNGAMD_CHUNK_BATCH_MIB"); long v = e ? atol(e) : 512; return (uint64_t)(v < 16 ? 16 : v > 8192 ? 8192 : v) << 20; }();
+    ChunkInfo dummy; if (!info) info = &dummy;
+    if (avail <= batch + batch / 4) return inflate_chunked_once(c, d_def, avail, d_out, out_room, out_len, in_used, o, info);
+    uint64_t pos_bit = o.start_bit, acc = 0;
+    const uint8_t *dict = o.d_dict; uint32_t dict_len = o.dict_len;
+    for (int b = 0;; b++) {
+        const uint64_t byte0 = pos_bit >> 3;
+        const bool lastb = avail - byte0 <= batch + batch / 4;
+        ChunkOpts bo; bo.start_bit = (uint32_t)(pos_bit & 7ull); bo.d_dict = dict; bo.dict_len = dict_len; bo.allow_cut = lastb ? o.allow_cut : true;
+        ChunkInfo bi; uint64_t bl = 0, bu = 0;
+        const int r = inflate_chunked_once(c, d_def + byte0, lastb ? avail - byte0 : batch, d_out + acc, out_room - acc, &bl, &bu, bo, &bi);
+        if (r == ZNGAMD_BUF_ERROR) { *out_len = acc + bl; *info = bi; return r; }
+        if (r < 0) return r;
+        if (r != 0 || (!lastb && !bi.ended && (bl == 0 || acc + bl < (uint64_t)ZA_WIN))) {
+            // a batch this path does not take (or one that made no headway): the whole stream the old way, as one
+            if (b == 0 && r != 0) { *info = bi; }
+            return inflate_chunked_once(c, d_def, avail, d_out, out_room, out_len, in_used, o, info);
+        }
+        acc += bl;
+        if (lastb || bi.ended) {
+            *out_len = acc; *in_used = byte0 + bu;
+            info->cut = bi.cut; info->ended = bi.ended; info->end_bit = byte0 * 8ull + bi.end_bit;
+            return 0;
+        }
+        pos_bit = byte0 * 8ull + bi.end_bit;
+        dict = d_out + acc - ZA_WIN; dict_len = ZA_WIN;               // (acc >= 32 KiB: checked above)
+    }
+}
+
+static int inflate_chunked_once(zngamd_ctx *c, const uint8_t *d_def, uint64_t avail, uint8_t *d_out, uint64_t out_room,
+                                uint64_t *out_len, uint64_t *in_used, const ChunkOpts &o, ChunkInfo *info)
 {
     ChunkInfo dummy; if (!info) info = &dummy;
     *info = ChunkInfo();
@@ -1276,9 +1315,12 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
             pieces[i] = pc;
             sc += (pc.out_len + 7) & ~7ull;                            // (16-byte aligned symbol areas)
         }
-        if (sc * 2 <= (16ull << 30)) {
+        // (no room for the scratch area on this device right now: not an error -- the two passes below need a sixth of it)
+        bool scratch_ok = sc * 2 <= (16ull << 30);
+        if (scratch_ok && c->out16.ensure(sc + 64) != hipSuccess) { (void)hipGetLastError(); scratch_ok = false; }
+        if (scratch_ok) {
             phase("  marker decode (one pass)");
-            HIPCHK(c, c->out16.ensure(sc + 64)); HIPCHK(c, c->cchunks.ensure(n)); HIPCHK(c, c->cres.ensure(n));
+            HIPCHK(c, c->cchunks.ensure(n)); HIPCHK(c, c->cres.ensure(n));
             HIPCHK(c, hipMemcpyAsync(c->ccand.p, cand.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->cchunks.p, pieces.data(), (size_t)n * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
             { ProfScope ps(c, ZNGAMD_K_INFLATE);

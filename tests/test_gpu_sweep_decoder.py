@@ -10,6 +10,8 @@ import zlib
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -214,3 +216,37 @@ def test_many_chunks_take_the_small_kernel_size(Z, fastq):
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
         z = co.compress(small) + co.flush()
         assert Z.decompress(z, -15) == small
+
+
+def test_long_stream_goes_through_the_chunk_pipeline_in_batches():
+    """A stream longer than one batch of the chunk pipeline (ZNGAMD_CHUNK_BATCH_MIB, 16 MiB here instead of 512) is decoded batch
+    by batch, every batch resumed at a block header with the 32 KiB in front of it as its history: a block-parallel writer's
+    stream (sync points: one decoding pass) and an ordinary gzip file (bit-level block finder, two passes), both against the
+    system zlib.  In a child process: the batch size is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import gzip, os, sys, zlib
+sys.path.insert(0, os.path.join(%r, "python-zlib-ng_amd"))
+from zlib_ng_amd import corpus, zlib_ng, _lib
+data = corpus.text(96 << 20, seed=11).tobytes()
+ours = zlib_ng.compress(data, 6, 31)                    # dict-chained 128 KiB blocks ending in sync flushes
+assert len(ours) > (24 << 20)
+ctx = _lib.default_context(); ctx.decode_paths(reset=True)
+assert zlib_ng.decompress(ours, 31) == data
+assert ctx.decode_paths()["chunked"] >= 1
+plain = gzip.compress(data[:64 << 20], 6, mtime=0)      # one ordinary member
+assert len(plain) > (20 << 20)
+assert zlib_ng.decompress(plain, 31) == data[:64 << 20]
+bad = bytearray(ours); bad[len(bad) // 2] ^= 0x10         # damage inside a later batch: an error, not a hang or wrong bytes
+try:
+    out = zlib_ng.decompress(bytes(bad), 31)
+    assert out != data
+    raise SystemExit("damaged stream decoded without an error")
+except zlib_ng.error:
+    pass
+print("ok")
+''' % (ROOT,)
+    env = dict(os.environ, ZNGAMD_CHUNK_BATCH_MIB="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-2000:])
