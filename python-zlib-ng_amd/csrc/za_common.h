@@ -64,6 +64,8 @@ typedef uint64_t __attribute__((aligned(1))) za_u64u;
 __device__ __forceinline__ uint32_t za_ld32(const uint8_t *p) { return *(const za_u32u *)p; }
 __device__ __forceinline__ uint64_t za_ld64(const uint8_t *p) { return *(const za_u64u *)p; }
 typedef uint16_t __attribute__((aligned(1))) za_u16u;
+struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };      // 16 bytes at any address
+struct __attribute__((aligned(1))) ZaU2u { uint32_t x, y; };
 __device__ __forceinline__ uint32_t za_ld16(const uint8_t *p) { return *(const za_u16u *)p; }
 // bucket of a 6-byte context: lo = bytes 0..3, hi = bytes 4..5
 __device__ __forceinline__ uint32_t za_hash6(uint32_t lo, uint32_t hi)

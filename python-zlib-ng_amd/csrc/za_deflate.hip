@@ -46,7 +46,6 @@
 // 4 GiB whether one wave issued the rest or two).  The bytes of a group arrive as ONE 16-byte load per lane and pass through an
 // LDS ring, from which every lane takes its own six (three aligned dwords, `v_alignbyte`); the links of a group are collected
 // in LDS and leave as one 16-byte store per lane.
-struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };      // 16 bytes at any address
 #define ZA_CH_GROUP 16                         // steps (of 64 positions) per group
 #ifndef ZA_CH_READ
 #define ZA_CH_READ 0                           // 1: a position's bytes as one 8-byte LDS read at its own byte address -- 4.1 -> 9.8 ms

@@ -651,11 +651,29 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             // short non-overlapping matches whose source is real output are copied by their own lane, 16 bytes per batch
             const uint32_t nbytes = mlen * (uint32_t)sizeof(SymT);
             const bool simple = has && mdist >= mlen && nbytes <= 64u && adst >= (uint64_t)mdist;
+            const bool wide = (adst + (uint64_t)mlen) * sizeof(SymT) + 16ull <= out_cap * sizeof(SymT);      // (a 16-byte load behind the source stays inside the buffer)
             while (pending) {
                 const bool ready = !done && (pending & deps) == 0ull;
                 if (ready && simple) {
                     uint8_t *o = (uint8_t *)(out + adst);
                     const uint8_t *sp = (const uint8_t *)(out + (adst - (uint64_t)mdist));
+                    // 16 bytes per load and store (64 lanes at 64 unrelated addresses: what an instruction costs the memory pipe is its
+                    // lanes, not its bytes); a load may reach past the source's end into bytes of no meaning (never past the buffer:
+                    // the source ends at or below the destination, which has `wide` bytes of room)
+                    if (wide) {
+                        for (uint32_t i = 0; i < nbytes; i += 16) {
+                            const uint32_t rem = nbytes - i;
+                            ZaU4u v = *(const ZaU4u *)(sp + i);
+                            uint8_t *q = o + i;
+                            if (rem >= 16u) *(ZaU4u *)q = v;
+                            else {
+                                if (rem & 8u) { ZaU2u t; t.x = v.x; t.y = v.y; *(ZaU2u *)q = t; q += 8; v.x = v.z; v.y = v.w; }
+                                if (rem & 4u) { *(za_u32u *)q = v.x; q += 4; v.x = v.y; }
+                                if (rem & 2u) { *(za_u16u *)q = (uint16_t)v.x; q += 2; v.x >>= 16; }
+                                if (rem & 1u) *q = (uint8_t)v.x;
+                            }
+                        }
+                    } else
                     for (uint32_t i = 0; i < nbytes; i += 16) {
                         const uint32_t rem = nbytes - i;
                         uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
@@ -2172,7 +2190,6 @@ __global__ __launch_bounds__(1024) void za_k_chunk_chain(const uint16_t *__restr
 }
 
 #define ZA_RESOLVE_THREADS 512
-struct __attribute__((aligned(1))) ZaU2u { uint32_t x, y; };
 __global__ __launch_bounds__(ZA_RESOLVE_THREADS) void za_k_chunk_resolve(const uint16_t *__restrict__ out16, const ZaChunk *__restrict__ chunks,
                                                           const uint16_t *__restrict__ comp, const uint8_t *__restrict__ winbuf,
                                                           uint8_t *__restrict__ out8)
