@@ -42,6 +42,7 @@
 template <int LB, int DB>
 struct ZaInfTabsT {
     static constexpr int kLBits = LB, kDBits = DB;
+    static_assert(LB >= 7 && DB >= 7 && LB <= 15 && DB <= 15, "za_long_decode answers for the lengths 8..15 only: a first-level table must hold every code of up to 7 bits");
     uint16_t lut_l[1 << LB];   // (sym<<4)|len, 0 = longer than the LUT or unassigned
     uint16_t lut_d[1 << DB];
     uint16_t cnt_l[16], cnt_d[16];

@@ -435,6 +435,9 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     const bool same_plan = c->plan_ch == ch && c->plan_in.size() == hu.size() && c->last_hu.size() == hu.size() &&
                            memcmp(c->plan_in.data(), hu.data(), hu.size() * sizeof(ZaUnit)) == 0;
     if (!same_plan) {
+        // (the kept plan describes device tables that are about to be overwritten: should an upload fail half way, a later call
+        // with the old shape must not find it valid)
+        c->plan_in.clear(); c->plan_ch = 0; c->last_hu.clear();
         std::vector<ZaUnit> hv(hu);
         std::vector<uint32_t> run_start;
         for (uint32_t c0 = 0; c0 < n; c0 += ch) {
@@ -576,19 +579,26 @@ static int host_stage(zngamd_ctx *c, size_t bytes, uint8_t **p)
 static void par_memcpy(uint8_t *dst, const uint8_t *src, size_t n)
 {
     const size_t piece = 4u << 20;
+    static const long env_threads = [] { const char *e = getenv("ZNGAMD_COPY_THREADS"); return e ? atol(e) : 0L; }();      // (read once, not per piece)
     unsigned hw = std::thread::hardware_concurrency();
     size_t t = std::min<size_t>(std::min<size_t>(hw ? hw / 2 : 4, 8), n / piece);
-    if (const char *e = getenv("ZNGAMD_COPY_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) t = std::min<size_t>((size_t)v, std::max<size_t>(n / (1u << 20), 1)); }
+    if (env_threads >= 1 && env_threads <= 64) t = std::min<size_t>((size_t)env_threads, std::max<size_t>(n / (1u << 20), 1));
     if (t <= 1) { memcpy(dst, src, n); return; }
     const size_t step = ((n / t) + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
     th.reserve(t);
+    size_t started_to = step;                                  // bytes [0, started_to) have a copier (this thread takes the first piece)
     for (size_t i = 1; i < t; i++) {
         const size_t o = i * step;
         if (o >= n) break;
-        th.emplace_back([=] { memcpy(dst + o, src + o, std::min(step, n - o)); });
+        // a thread that cannot be started (EAGAIN under a pids limit) must not unwind through the joinable ones -- that is
+        // std::terminate(), the host process gone: whatever has no copier yet is copied here
+        try { th.emplace_back([=] { memcpy(dst + o, src + o, std::min(step, n - o)); }); }
+        catch (...) { break; }
+        started_to = std::min(n, o + step);
     }
     memcpy(dst, src, std::min(step, n));
+    if (started_to < n) memcpy(dst + started_to, src + started_to, n - started_to);
     for (auto &x : th) x.join();
 }
 
@@ -1260,7 +1270,7 @@ static int inflate_chunked_once(zngamd_ctx *c, const uint8_t *d_def, uint64_t av
     // A stream written block-parallel (the reference's threaded writer, pigz, this engine) has a sync point every block: when
     // no stretch of more than 2 MiB is without one, those are boundaries enough and the bit-level header finder (a pass over
     // every bit offset of the stream, about as dear as the decode itself) is not run.
-    static const uint32_t dense_min = getenv("ZNGAMD_DENSE_MIN") ? (uint32_t)atol(getenv("ZNGAMD_DENSE_MIN")) : 8u;
+    static const uint32_t dense_min = [] { const long v = getenv("ZNGAMD_DENSE_MIN") ? atol(getenv("ZNGAMD_DENSE_MIN")) : 8; return (uint32_t)(v < 1 ? 1 : v); }();
     bool dense = cnt[0] >= dense_min;
     if (dense) {
         std::sort(cand.begin(), cand.end());
@@ -1390,7 +1400,7 @@ static int inflate_chunked_once(zngamd_ctx *c, const uint8_t *d_def, uint64_t av
             i = (size_t)(it - cand.begin());
         }
     }
-    static const uint64_t chunk_div = getenv("ZNGAMD_CHUNK_DIV") ? (uint64_t)atol(getenv("ZNGAMD_CHUNK_DIV")) : 4096u;
+    static const uint64_t chunk_div = [] { const long v = getenv("ZNGAMD_CHUNK_DIV") ? atol(getenv("ZNGAMD_CHUNK_DIV")) : 4096; return (uint64_t)(v < 1 ? 1 : v); }();
     const uint64_t target = std::max<uint64_t>(32u << 10, acc / chunk_div);
     for (size_t b = 0; b < blocks.size();) {
         ZaChunk cur = blocks[b++];

@@ -777,7 +777,16 @@ class _GzipReader:
         self._mtime = 0
         self._lock = _threading.Lock()
         self._size = -1
-        self._decode_ahead = _os.environ.get("ZNGAMD_NO_DECODE_AHEAD") is None     # (gzip_ng_threaded's reader, which has a pump thread of its own, turns it off)
+        self._decode_ahead = _os.environ.get("ZNGAMD_NO_DECODE_AHEAD") is None     # (gzip_ng_threaded's reader, which has a pump thread of its own, turns it off; ZNGAMD_NO_DECODE_AHEAD=1 does it for every reader)
+        # Reading and decoding ahead touch `fp` from a thread of their own and ask for whole windows: only for sources that can be
+        # sought (regular files, BytesIO) -- on a pipe or a socket a consumer that stops early would wait in close() for a window
+        # that may never come, and a caller that goes on using its file object would meet a second reader.
+        self._bulk_ok = False
+        if self._is_file and self._start is not None:
+            try:
+                self._bulk_ok = bool(fp.seekable())
+            except (AttributeError, OSError, ValueError):
+                self._bulk_ok = False
         self._reset()
 
     @property
@@ -803,6 +812,7 @@ class _GzipReader:
         self._in_buf = None               # the compressed window: one buffer, refilled (the engine call is through by then)
         self._ahead = None                # the next window's file bytes being read on a thread of their own (_start_ahead)
         self._dec_ahead = None            # the next window being decoded on a thread of its own (_start_decode_ahead)
+        self._windows_taken = 0           # decoded windows the consumer has taken: decoding ahead starts with the second
         self._calls = 0
 
     def _release_windows(self):
@@ -854,7 +864,7 @@ class _GzipReader:
     def _start_ahead(self):
         """Read the next window's bytes from the file on a thread of its own while the engine decodes this one (both release
         the interpreter lock): into a second buffer, behind room for the tail this window will leave over."""
-        if not self._is_file or self._in_eof or self._ahead is not None or self._closed or _sys.is_finalizing():
+        if not self._bulk_ok or self._in_eof or self._ahead is not None or self._closed or _sys.is_finalizing():
             return
         front, want = self._AHEAD_FRONT, self._window
         buf = _lib.take_buffer(front + want)
@@ -993,8 +1003,10 @@ class _GzipReader:
         """The window after this one is decoded on a thread of its own while the consumer copies this one out (the engine call,
         the file read and the copy all release the interpreter lock): gzip_ng.open's reader, which has no pump thread of its
         own, alternated 13 ms of decoding with 15 ms of copying per window."""
-        if (not self._decode_ahead or not self._is_file or self._dec_ahead is not None or self._closed or self._done
-                or self._error is not None or _sys.is_finalizing()):
+        # (only once the consumer has come back for a second window: a reader that wants the first bytes of a file does not
+        # pay for the decode of a window it never asks for)
+        if (not self._decode_ahead or not self._bulk_ok or self._windows_taken < 2 or self._dec_ahead is not None or self._closed
+                or self._done or self._error is not None or _sys.is_finalizing()):
             return
         box = {}
 
@@ -1029,6 +1041,7 @@ class _GzipReader:
             if err is not None:
                 self._error = err
                 self._done = True
+            self._windows_taken += 1
             self._start_decode_ahead()
 
     def _check(self):

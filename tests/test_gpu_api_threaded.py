@@ -462,3 +462,46 @@ def test_reader_rewinds_while_decoding_ahead(Z, monkeypatch, tmp_path):
         g.seek(100)
         assert g.read(50) == data[100:150]
         assert g.read() == data[150:]
+
+
+def test_reader_leaves_a_source_that_cannot_be_sought_alone(Z, monkeypatch):
+    """Reading and decoding ahead run on threads of their own and ask the source for whole windows: a pipe, a socket or any
+    object that cannot be sought gets neither (a consumer that stops early would wait in close() for a window that may never
+    come, and the caller's file object would have a second reader) -- and a file that can be sought is decoded ahead only once
+    the consumer has come back for a second window."""
+    import io
+    import threading
+    from zlib_ng_amd import corpus
+
+    class Pipe(io.RawIOBase):                                    # reads like a file, cannot be sought
+        def __init__(self, b):
+            self._b = io.BytesIO(b)
+
+        def readable(self):
+            return True
+
+        def seekable(self):
+            return False
+
+        def readinto(self, buf):
+            return self._b.readinto(buf)
+
+    data = corpus.text(6 << 20, seed=23).tobytes()
+    blob = gzip.compress(data, 6)
+    monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(1 << 18))
+    names = lambda: {t.name for t in threading.enumerate() if t.name.startswith("zng-amd-")}
+    r = Z._GzipReader(Pipe(blob), 1 << 16)
+    assert not r._bulk_ok
+    got = b""
+    while len(got) < (3 << 20):
+        got += r.read(70000)
+        assert not names(), names()
+    assert got == data[:len(got)]
+    r.close()
+    r = Z._GzipReader(io.BytesIO(blob), 1 << 16)
+    assert r._bulk_ok
+    first = r.read(1000)
+    assert first == data[:1000] and "zng-amd-decode-ahead" not in names()        # the first window alone: nothing decoded ahead
+    assert first + r.readall() == data
+    r.close()
+    assert not names()
