@@ -306,10 +306,17 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                                                                  const uint16_t *__restrict__ prev_ws,
                                                                  uint32_t *__restrict__ best_ws, ZaLevel L)
 {
-    __shared__ uint16_t ring[ZA_RING];
-    __shared__ uint32_t win32[ZA_BYTES / 4 + 8];
-    uint8_t *win8 = (uint8_t *)win32;
+    // One block of LDS with the byte window FIRST: a candidate's LDS address is then its position's low 16 bits (no base to add),
+    // and the link ring is walked with byte addresses that have its base in them (no shift and no add per step).  A link of
+    // 0xFFFF in the ring = end of the chain (what the chain kernel writes as 0): the walk's "too far" test ends it, one compare
+    // instead of two per step.  (8 % fewer vector instructions per step, 1.5 % of the kernel's time: the candidates' LDS reads --
+    // five dwords at a random address, 26 LDS cycles per wave -- weigh as much as the instructions.)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ZA_BYTES + 32 + 2 * ZA_RING];
+    uint32_t *win32 = (uint32_t *)lds;
+    uint16_t *ring = (uint16_t *)(lds + ZA_BYTES + 32);
+    constexpr uint32_t RING_B0 = ZA_BYTES + 32, RING_BYTES = 2 * ZA_RING;      // the ring's byte range in the block
     const int tid = (int)threadIdx.x;
+    auto link_in = [](uint16_t v) -> uint16_t { return v ? v : (uint16_t)0xFFFFu; };
     // One workgroup per RUN of consecutive units -- the chain kernel's runs.  Behind the head of a run every unit's dictionary
     // is the tail of the unit in front of it, and the window of that unit is still in the rings: the walk goes on where it
     // stood instead of staging 32 KiB of links and bytes again with all sixteen waves waiting.  `goff` = the run's positions
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     if (carried && tid < ZA_HASH_BYTES - 1)
         // the last five positions of the unit in front: never inserted there (their links in the ring say so), inserted by
         // this unit's chain pass (its own row)
-        ring[(goff + (uint32_t)(ZA_WIN - (ZA_HASH_BYTES - 1) + tid)) % ZA_RING] = prevdist[dict_len - (ZA_HASH_BYTES - 1) + tid];
+        ring[(goff + (uint32_t)(ZA_WIN - (ZA_HASH_BYTES - 1) + tid)) % ZA_RING] = link_in(prevdist[dict_len - (ZA_HASH_BYTES - 1) + tid]);
     auto load_bytes = [&](int p) -> uint32_t {          // dword of input at p (a multiple of 4), zero outside the unit
         if (p >= -dict_len && (long long)p + 4 <= readable) return za_ld32(data + p);
         uint32_t v = 0;                                   // edges: before the dictionary start or past the caller's buffer
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     {
         int need_links = ZA_SEARCH_TILE < n ? ZA_SEARCH_TILE : n;
         for (int p = links_loaded + tid; p < need_links; p += ZA_SEARCH_THREADS)
-            ring[(goff + (uint32_t)(ZA_WIN + p)) % ZA_RING] = prevdist[p + dict_len];
+            ring[(goff + (uint32_t)(ZA_WIN + p)) % ZA_RING] = link_in(prevdist[p + dict_len]);
         links_loaded = need_links;
         int need_bytes = ZA_SEARCH_TILE + ZA_LOOKAHEAD;
         if (need_bytes > n) need_bytes = n;
@@ -397,8 +404,9 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 nb[k] = p < need_bytes ? load_bytes(p) : 0u;
             }
         }
+        uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;      // ring slot of my position, moved on by 1 024 per round
 #pragma unroll 1
-        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
             if (p >= n) continue;
             int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
@@ -422,19 +430,20 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 const int nice = L.nice < cap ? L.nice : cap;
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
                 uint32_t q = P;
-                int qs = (int)(P % ZA_RING);                                 // ring slot of q, kept incrementally
-                uint32_t d = ring[qs];
+                uint32_t qb = RING_B0 + 2u * slot;                           // LDS byte address of q's link, kept incrementally
+                uint32_t d = *(const uint16_t *)(lds + qb);
                 int depth = L.chain;
                 while (depth-- > 0) {
                     q -= d;
-                    qs -= (int)d;
-                    qs += qs < 0 ? ZA_RING : 0;
+                    qb -= 2u * d;
+                    qb += qb < RING_B0 ? RING_BYTES : 0u;
                     const int dist = (int)(P - q);
-                    if (d == 0 || dist > L.max_dist) break;
+                    if (dist > L.max_dist) break;                            // (also the end of the chain: a link of 0xFFFF)
                     // one LDS round trip per chain step: next link + 5 aligned dwords of the candidate
-                    d = ring[qs];
-                    const uint32_t idx = q & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
-                    const uint32_t c0 = win32[w], c1 = win32[w + 1], c2 = win32[w + 2], c3 = win32[w + 3], c4 = win32[w + 4];
+                    d = *(const uint16_t *)(lds + qb);
+                    const uint32_t sh = q & 3u;
+                    const uint32_t *cw = (const uint32_t *)(lds + (q & (uint32_t)(ZA_BYTES - 4)));
+                    const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
                     uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0;
                     uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
                     uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2;
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int p = links_loaded + tid + k * ZA_SEARCH_THREADS;
-            if (p < need_links) ring[(goff + (uint32_t)(ZA_WIN + p)) % ZA_RING] = nl[k];
+            if (p < need_links) ring[(goff + (uint32_t)(ZA_WIN + p)) % ZA_RING] = link_in(nl[k]);
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {

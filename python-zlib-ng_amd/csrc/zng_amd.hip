@@ -2113,13 +2113,18 @@ try {
         HIPCHKM(m, hipMemcpyAsync(dst + my_off, d_local, sizes[m->rank], hipMemcpyDeviceToDevice, m->stream));
     if (m->world > 1) {
         NCCLCHK(m, m->api->GroupStart());
-        for (int r = 0; r < m->world; r++) {
+        // (a call that fails inside the group must not leave the group open: it is closed first, then the first error is reported)
+        ncclResult_t bad = ncclSuccess;
+        const char *what = "";
+        for (int r = 0; r < m->world && bad == ncclSuccess; r++) {
             if (r != m->rank) {
-                if (sizes[m->rank]) NCCLCHK(m, m->api->Send(d_local, sizes[m->rank], ncclUint8, r, m->comm, m->stream));
-                if (sizes[r]) NCCLCHK(m, m->api->Recv(dst + offs[(size_t)r], sizes[r], ncclUint8, r, m->comm, m->stream));
+                if (sizes[m->rank]) { bad = m->api->Send(d_local, sizes[m->rank], ncclUint8, r, m->comm, m->stream); what = "ncclSend"; }
+                if (bad == ncclSuccess && sizes[r]) { bad = m->api->Recv(dst + offs[(size_t)r], sizes[r], ncclUint8, r, m->comm, m->stream); what = "ncclRecv"; }
             }
         }
-        NCCLCHK(m, m->api->GroupEnd());
+        const ncclResult_t ended = m->api->GroupEnd();
+        if (bad != ncclSuccess) { m->err = std::string(what) + ": " + m->api->GetErrorString(bad); return ZNGAMD_E_HIP; }
+        NCCLCHK(m, ended);
     }
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
