@@ -56,6 +56,23 @@
 #define ZA_CH_OFFS(x) (((x) >> (32 - ZA_HASH_BITS - 2)) & (((1u << ZA_HASH_BITS) - 1u) << 2))
 #define ZA_CH_CHUNK (64 * ZA_CH_GROUP)         // positions = bytes of a group: 16 per lane
 
+// A 16-byte load whose wait is written by hand.  The compiler's own waits were the chain kernel's whole time: it staged a chunk
+// behind `s_waitcnt vmcnt(0)` -- every load in flight, the one issued a moment ago included, because it had shuffled that load's
+// registers -- so an iteration lasted as long as a trip to memory whatever the waves did in it.  Issued through an asm statement
+// a load is invisible to that bookkeeping: the destination must not be touched before za_wait_loads names it (nothing else of
+// the wave's loop is a vector-memory operation, so `newer` = the loads issued after the one that is needed), and every load
+// must have been waited for before its registers can be anything else's (za_wait_loads(0) over all sets at the end).
+typedef uint32_t za_v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void za_issue_load16(za_v4u32 &dst, const uint8_t *addr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int NEWER>
+__device__ __forceinline__ void za_wait_loads(za_v4u32 &a, za_v4u32 &b, za_v4u32 &c, za_v4u32 &d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(NEWER) : "memory");
+}
+
 // the links of one step worked out lane by lane (only if the LDS ever served an atomic's lanes out of order): what the
 // atomic should have returned
 __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t old, bool ins)
@@ -119,19 +136,51 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
             if (!hasher && (int)lane >= first && (int)lane < total) prevdist[lane] = 0;
             continue;
         }
+        if (total < 16) {
+            // (uniform) a row shorter than one 16-byte load -- a stream of 6 .. 15 bytes without a dictionary, nothing carried: lane i
+            // of the inserting wave takes row index i and looks at the lanes below it (the table is left alone: nothing follows it)
+            if (!hasher) {
+                uint32_t h = 0xFFFFFFFFu;
+                const bool ins = (int)lane >= first && (int)lane <= total - ZA_HASH_BYTES;
+                if (ins) h = za_hash6(za_ld32(row + lane), za_ld16(row + lane + 4));
+                uint32_t d = 0;
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
+                    if (ins && j < (int)lane && hj == h) d = lane - (uint32_t)j;
+                }
+                if ((int)lane >= first && (int)lane < total) prevdist[lane] = (uint16_t)d;
+            }
+            continue;
+        }
         const int iclamp_hi = total - ZA_HASH_BYTES;          // last row index with 6 bytes available
         const int t0 = first & ~63;                             // (groups start at multiples of 64: whole lines of links)
         const int ngroups = (total - t0 + ZA_CH_CHUNK - 1) / ZA_CH_CHUNK;
         // ---- wave 0.  Chunk c = the ZA_CH_CHUNK bytes from row index t0 + c * ZA_CH_CHUNK, 8 per lane; bytes behind the row's end
         // are zeros (the positions that would need them are never inserted)
-        auto fetch = [&](int c) -> uint4 {
-            const int cbase = t0 + c * ZA_CH_CHUNK, at = cbase + 16 * (int)lane;
-            if (cbase + ZA_CH_CHUNK <= total) { const ZaU4u v = *(const ZaU4u *)(row + at); return make_uint4(v.x, v.y, v.z, v.w); }      // (uniform) the whole chunk inside the row: no wait here
-            uint32_t r[4] = {0u, 0u, 0u, 0u};                     // the row's last chunk (and the two behind it): byte by byte
-            for (int k = 0; k < 16 && at + k < total; k++) r[k >> 2] |= (uint32_t)row[at + k] << (8 * (k & 3));
-            return make_uint4(r[0], r[1], r[2], r[3]);
+        // (every fetch is ONE plain 16-byte load -- behind the row's end from a place moved back into the row, put right when
+        // the chunk is staged)
+        const int last16 = total - 16;                              // last row index a 16-byte load may start at (total >= 16 here)
+        auto fetch = [&](int c, za_v4u32 &dst) {
+            int at = t0 + c * ZA_CH_CHUNK + 16 * (int)lane;
+            at = at > last16 ? last16 : at;
+            za_issue_load16(dst, row + at);
         };
         auto stage = [&](int c, uint4 v) {                      // chunk c into its half of the ring
+            const int cbase = t0 + c * ZA_CH_CHUNK;
+            if (cbase + ZA_CH_CHUNK > total) {                  // (uniform) the row's last chunk and those behind it: zeros behind the row's end
+                const int at = cbase + 16 * (int)lane;
+                const int delta = at > last16 ? at - last16 : 0;    // the load started this many bytes in front of my place
+                const uint32_t w[8] = {v.x, v.y, v.z, v.w, 0u, 0u, 0u, 0u};
+                uint32_t r[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { lo = (i + (delta >> 2)) == j ? w[j] : lo; hi = (i + (delta >> 2) + 1) == j ? w[j] : hi; }
+                    r[i] = delta >= 16 ? 0u : __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)delta & 3u);
+                }
+                v = make_uint4(r[0], r[1], r[2], r[3]);
+            }
             *(uint4 *)(ring + (c & 1) * (ZA_CH_CHUNK / 4) + 4 * lane) = v;
             if ((c & 1) == 0 && lane == 0) *(uint4 *)(ring + 2 * ZA_CH_CHUNK / 4) = v;
         };
@@ -235,18 +284,49 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
         };
         // iteration k: wave 0 puts chunk k + 1 into the ring, asks for chunk k + 2 and hashes group k; wave 1 inserts group k - 1;
         // one barrier per iteration (a hash buffer is written again two iterations after it was read; the ring is wave 0's alone)
-        uint4 pend = make_uint4(0u, 0u, 0u, 0u);
-        if (hasher) { stage(0, fetch(0)); pend = fetch(1); }
-#pragma unroll 1
-        for (int k = 0; k <= ngroups; k++) {
-            if (hasher) {
+        // The two waves run loops of their own and meet at one barrier per iteration (as many in either loop).  Wave 0 asks for the
+        // bytes FOUR groups ahead -- chunk c travels in register set c & 3, the loop is unrolled four times so that no set is ever
+        // copied -- and its loop holds no other memory operation, so the wait in front of a chunk's staging is for that chunk alone:
+        // with the inserting wave's stores in the same loop the compiler waited for EVERY load in flight, the one just issued
+        // included, and an iteration lasted as long as a trip to memory whatever the two waves did in it (a stream had one
+        // 1 KiB load in flight, a CU four).
+        auto wg_barrier = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        if (hasher) {
+            za_v4u32 p0 = {0u, 0u, 0u, 0u}, p1 = p0, p2 = p0, p3 = p0;
+            fetch(0, p0);
+            za_wait_loads<0>(p0, p1, p2, p3);
+            stage(0, make_uint4(p0.x, p0.y, p0.z, p0.w));
+            fetch(1, p1); fetch(2, p2); fetch(3, p3); fetch(4, p0);
+            auto iteration = [&](int k, za_v4u32 &pend) {        // pend: chunk k + 1 on arrival (the oldest of four in flight), chunk k + 5 on return
                 if (k < ngroups) {
-                    stage(k + 1, pend);
-                    pend = fetch(k + 2);
+                    za_wait_loads<3>(p0, p1, p2, p3);
+                    stage(k + 1, make_uint4(pend.x, pend.y, pend.z, pend.w));
+                    fetch(k + 5, pend);
                     hash_group(k, hbuf[k & 1]);
                 }
-            } else if (k >= 1) insert(k - 1, hbuf[(k - 1) & 1]);
-            __syncthreads();
+                wg_barrier();
+            };
+#pragma unroll 1
+            for (int k = 0; k <= ngroups; k += 4) {
+                iteration(k, p1);
+                if (k + 1 > ngroups) break;
+                iteration(k + 1, p2);
+                if (k + 2 > ngroups) break;
+                iteration(k + 2, p3);
+                if (k + 3 > ngroups) break;
+                iteration(k + 3, p0);
+            }
+            za_wait_loads<0>(p0, p1, p2, p3);                    // (the chunks asked for behind the row's end: their registers are free only now)
+        } else {
+#pragma unroll 1
+            for (int k = 0; k <= ngroups; k++) {
+                if (k >= 1) insert(k - 1, hbuf[(k - 1) & 1]);
+                wg_barrier();
+            }
         }
     }
 }
