@@ -189,7 +189,6 @@ def main():
         blocks[b] = _lib.Block(HALO + b * BLOCK, BLOCK, 32768 if (b or blo) else 0, 0, 0)
     n_units = L.zngamd_count_units(blocks, nblocks)
     assert n_units == nblocks
-    d_slots = torch.empty(n_units * _lib.SLOT_STRIDE, dtype=torch.uint8, device=dev)
     d_ulen = torch.empty(n_units, dtype=torch.int32, device=dev)
     d_ucrc = torch.empty(n_units, dtype=torch.int32, device=dev)
     d_comp = torch.empty(size // 2 + (64 << 20), dtype=torch.uint8, device=dev)   # text compresses ~3x
@@ -215,11 +214,10 @@ def main():
     gathered = {}
 
     def step():
-        # (1) compress + gather (+ exchange of the slices)
-        chk(L.zngamd_deflate_blocks_dev(h, ptr(d_buf), HALO + size, blocks, nblocks, args.level, ptr(d_slots), ptr(d_ulen),
-                                        ptr(d_ucrc), None), "deflate_blocks_dev")
-        chk(L.zngamd_gather_dev(h, ptr(d_slots), ptr(d_ulen), n_units, ptr(d_comp), 0, d_comp.numel(), None,
-                                C.byref(comp_total)), "gather_dev")
+        # (1) compress straight into the one contiguous stream: every unit's size is known before it is packed, so the packer
+        #     writes at the unit's final byte offset (no slots, no gather) (+ exchange of the slices)
+        chk(L.zngamd_deflate_blocks_packed_dev(h, ptr(d_buf), HALO + size, blocks, nblocks, args.level, ptr(d_comp), d_comp.numel() - 64,
+                                               ptr(d_ulen), ptr(d_ucrc), None, C.byref(comp_total)), "deflate_blocks_packed_dev")
         if exchange:
             # CRC-32 of my range from the per-block values (the writer thread's fold, gzip_ng_threaded.py:394), then the layout of
             # the one stream: 24 bytes per rank over RCCL
@@ -507,7 +505,7 @@ def main():
     if dom_leg == "deflate":
         leg_kernels = ("chains", "search", "parse", "plan", "pack", "gather")
         leg_bytes = size + comp_bytes
-        leg_name = "deflate pipeline: za_k_chains + za_k_search + za_k_parse + za_k_plan + za_k_pack + za_k_gather"
+        leg_name = "deflate pipeline: za_k_chains + za_k_search + za_k_parse + za_k_plan + za_k_offsets + za_k_pack (packed: no gather)"
     else:
         leg_kernels = ("scan", "inflate")
         leg_bytes = size + ms_len.value
@@ -542,6 +540,8 @@ def main():
             for k in ("chains", "search", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
                 if pj.get("za_k_" + k):
                     traffic_step[k] = int(pj["za_k_" + k] * nblocks)
+                elif k == "gather":    # packed deflate: what is left under this timer is za_k_offsets (4 B read + 8 B written per unit: below the counters' floor)
+                    traffic_step[k] = int(pj.get("za_k_offsets", 12) * nblocks)
             names = {"scan": "scan_members", "inflate": "inflate_members"}
             tr = [traffic_step.get(names.get(k, k)) for k in leg_kernels]
             if all(t is not None for t in tr if True) and any(tr):
@@ -570,7 +570,7 @@ def main():
         "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"one stream of {total_size >> 20} MiB seeded Zipf-word text ({uniq >> 20} MiB distinct, tiled), {size >> 20} MiB per GPU "
-                               f"(contiguous block ranges, 32 KiB halo), 128 KiB blocks, level {args.level}: dict-chained deflate + gather"
+                               f"(contiguous block ranges, 32 KiB halo), 128 KiB blocks, level {args.level}: dict-chained deflate packed at final offsets"
                                f"{' + RCCL exchange of the slices (zngamd_comm_*: layout all-gather, grouped send/recv)' if exchange_stream else ' + layout exchange (sizes) over RCCL' if exchange else ''}, then two-pass inflate of "
                                f"{nblocks} independent gzip members written by this engine ('ZA' chunk index, flat dynamic headers)",
                    "block": BLOCK, "level": args.level, "bytes_per_gpu": size},
@@ -580,7 +580,7 @@ def main():
         "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kt.items() if v[1]},
         "roofline": roofline,
         "dominant_kernel": roofline_dom,
-        "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains+search+parse+plan+pack+gather",
+        "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains+search+parse+plan+offsets+pack",
                                       "achieved": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
         "device_memory_in_use_GB": round((total_b - free_b) / 1e9, 1),

@@ -125,6 +125,16 @@ int zngamd_deflate_blocks_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len
                               const zngamd_block *blocks, uint32_t n_blocks, int level,
                               void *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc,
                               uint32_t *h_unit_block);
+/* The same blocks straight into ONE contiguous stream at d_out (what zngamd_deflate_blocks_dev + zngamd_gather_dev leave at
+ * d_dst, without the slots and without the copy: every unit's exact size is known before it is packed, a prefix sum places it).
+ * Per unit: d_unit_len, d_unit_crc and (optional) d_unit_off = its byte offset in the stream; *total_bytes (host) = the
+ * stream's size.  ZNGAMD_BUF_ERROR with *total_bytes = the size needed when out_cap is too small.  Replaces, for a batch of
+ * blocks, the copies of ParallelCompress_compress_and_crc's results (reference src/zlib_ng/zlib_ngmodule.c:1765-1777) and the
+ * in-order concatenation of the writer thread (src/zlib_ng/gzip_ng_threaded.py:382-398). */
+int zngamd_deflate_blocks_packed_dev(zngamd_ctx *ctx, const void *d_in, uint64_t in_len,
+                                     const zngamd_block *blocks, uint32_t n_blocks, int level,
+                                     void *d_out, uint64_t out_cap, uint32_t *d_unit_len, uint32_t *d_unit_crc,
+                                     uint64_t *d_unit_off, uint64_t *total_bytes);
 /* Packs unit slots back to back at d_dst + dst_base; returns the total in *total_bytes (host).
  * d_unit_off (device, n_units x u64, may be NULL) receives each unit's byte offset. */
 int zngamd_gather_dev(zngamd_ctx *ctx, const void *d_slots, const uint32_t *d_unit_len, uint32_t n_units,

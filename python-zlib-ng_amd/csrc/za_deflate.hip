@@ -941,9 +941,15 @@ struct ZaBitW {
 
 __constant__ uint8_t za_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// Packed mode (hdr_ws != nullptr): the unit's final place is not known yet -- the header goes to a buffer of its own (ZA_HDR_STRIDE
+// bytes per unit) and the unit's EXACT compressed size to unit_len (header + histogram x (code length + extra bits) + end of
+// block + marker: everything that decides it is here), so that one prefix sum gives every unit its offset in the stream and the
+// packer writes it there -- no slots, no gather pass.
+#define ZA_HDR_STRIDE 640u      // bytes of header buffer per unit: the longest dynamic header is 3 + 14 + 57 + 316 x 14 bits = 563 bytes
 __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units, const uint32_t *__restrict__ hist_ws,
                                                 uint32_t *__restrict__ code_ws, ZaPlan *__restrict__ plan_ws,
-                                                uint8_t *__restrict__ out, uint32_t out_stride, int level)
+                                                uint8_t *__restrict__ out, uint32_t out_stride, int level,
+                                                uint8_t *__restrict__ hdr_ws, uint32_t *__restrict__ unit_len)
 {
     __shared__ ZaPlanLds S;
     const ZaUnit u = units[blockIdx.x];
@@ -954,7 +960,13 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
     ZaPlan plan; plan.btype = 0; plan.header_bits = 0; plan.pad0 = plan.pad1 = 0;
     uint32_t *code_out = code_ws + (size_t)blockIdx.x * ZA_CODE_STRIDE;
     if (n == 0 || level == 0) {
-        if (lane == 0) plan_ws[blockIdx.x] = plan;
+        if (lane == 0) {
+            plan_ws[blockIdx.x] = plan;
+            if (unit_len) {
+                const uint32_t nchunks = ((uint32_t)n + 65534u) / 65535u;
+                unit_len[blockIdx.x] = n == 0 ? (final ? 2u : 5u) : (uint32_t)n + 5u * nchunks + (final ? 0u : 5u);
+            }
+        }
         return;
     }
     const uint32_t *hist = hist_ws + (size_t)blockIdx.x * ZA_HIST_STRIDE;
@@ -1059,10 +1071,17 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
             za_canon_serial(S.lens + 288, 30, S.codes + 288);
         }
         plan.btype = (uint32_t)btype;
+        if (unit_len) {
+            // the unit's size, exactly: what the packer will write (it checks)
+            const unsigned long long bits = btype == 2 ? cost_dyn : cost_fix;       // header + tokens + end of block
+            const unsigned long long endbit = bits + (final ? 0ull : 3ull);
+            unit_len[blockIdx.x] = btype == 0 ? (uint32_t)n + 5u * (uint32_t)nchunks + (final ? 0u : 5u)
+                                              : (uint32_t)((endbit + 7ull) >> 3) + (final ? 0u : 4u);
+        }
         if (btype != 0) {
             ZaBitW w;
-            w.out = (uint32_t *)(out + (size_t)blockIdx.x * out_stride);
-            w.cap_words = out_stride / 4; w.w = 0; w.acc = 0; w.nb = 0; w.ovf = false;
+            w.out = hdr_ws ? (uint32_t *)(hdr_ws + (size_t)blockIdx.x * ZA_HDR_STRIDE) : (uint32_t *)(out + (size_t)blockIdx.x * out_stride);
+            w.cap_words = hdr_ws ? ZA_HDR_STRIDE / 4 : out_stride / 4; w.w = 0; w.acc = 0; w.nb = 0; w.ovf = false;
             w.put((uint32_t)final | ((uint32_t)btype << 1), 3);
             if (btype == 2 && flat) {
                 // flat form: the code-length code is the 4-bit code of the symbols 0..15 (code(s) = s), no run lengths
@@ -1103,13 +1122,18 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
 // per step, places from a wave prefix sum over their bit lengths, bits ORed into an LDS ring, complete dwords stored 64 at a time.
 #define ZA_PK_RING 256  // dwords of the packer's output ring (a power of two; a group of 64 token words fills at most 96)
 
+// Packed mode (dst_off != nullptr): the unit is written at out + dst_off[unit], any byte address, its size as the plan kernel
+// worked it out (out_len on entry; a different size is ZA_ST_SIZE); the stream's first and last dword are shared with the units
+// beside it and written byte by byte.  out_stride is then the room behind the unit's place: the end of the destination.
+#define ZA_ST_SIZE 2u           // (packed mode) the packer's size differs from the planned one
 __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
                                                 const uint32_t *__restrict__ tok_ws, const uint32_t *__restrict__ segtok_ws,
                                                 const uint32_t *__restrict__ code_ws, const ZaPlan *__restrict__ plan_ws,
                                                 uint32_t *__restrict__ segbits_ws, uint32_t *__restrict__ cidx_ws,
                                                 uint8_t *__restrict__ out,
                                                 uint32_t out_stride, uint32_t *__restrict__ out_len,
-                                                uint32_t *__restrict__ status)
+                                                uint32_t *__restrict__ status,
+                                                const uint64_t *__restrict__ dst_off, uint64_t dst_cap, const uint8_t *__restrict__ hdr_ws)
 {
     __shared__ uint32_t codes[ZA_CODE_STRIDE];
     __shared__ uint32_t ring[ZA_PK_RING];            // the open dwords of the unit's bit stream
@@ -1119,9 +1143,19 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     const int lane = za_lane();
     const bool final = (u.flags & ZA_FLAG_FINAL) != 0;
     const ZaPlan plan = plan_ws[blockIdx.x];
-    uint8_t *slot = out + (size_t)blockIdx.x * out_stride;
-    uint32_t *slot32 = (uint32_t *)slot;
-    const uint32_t cap_words = out_stride / 4;
+    const bool packed = dst_off != nullptr;
+    const uint64_t my_off = packed ? dst_off[blockIdx.x] : 0ull;
+    const uint32_t planned = packed ? out_len[blockIdx.x] : 0u;
+    if (packed) {
+        // the planned size must fit the destination: nothing is written otherwise
+        out_stride = my_off + (uint64_t)planned <= dst_cap ? planned : 0u;
+        if (planned && !out_stride) { if (lane == 0) { out_len[blockIdx.x] = 0u; status[blockIdx.x] = ZA_ST_OVERFLOW; } return; }
+    }
+    uint8_t *slot = packed ? out + my_off : out + (size_t)blockIdx.x * out_stride;
+    // the bit stream is built in dwords of an ALIGNED base: a unit at an odd byte address starts at bit 8 * (address & 3) of dword 0
+    const uint32_t b0 = packed ? (uint32_t)((uintptr_t)slot & 3u) : 0u, bit0 = 8u * b0;
+    uint32_t *slot32 = (uint32_t *)(slot - b0);
+    const uint32_t cap_words = packed ? (b0 + out_stride + 3u) / 4u : out_stride / 4;
     uint32_t *segbits = segbits_ws + (size_t)blockIdx.x * ZA_SEGB_STRIDE;
     uint32_t *cidx = cidx_ws + (size_t)blockIdx.x * ZA_CIDX_STRIDE;       // chunk index of indexed members (oracle: chunk_idx)
     const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
@@ -1167,7 +1201,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
         }
         for (int i = lane; i < ZA_SEGB_STRIDE; i += 64) segbits[i] = 0;
         for (int i = lane; i < ZA_CIDX_STRIDE; i += 64) cidx[i] = 0;
-        if (lane == 0) { out_len[blockIdx.x] = ovf ? 0u : total_bytes; status[blockIdx.x] = ovf ? ZA_ST_OVERFLOW : 0u; }
+        if (lane == 0) { out_len[blockIdx.x] = ovf ? 0u : total_bytes; status[blockIdx.x] = ovf ? ZA_ST_OVERFLOW : (packed && total_bytes != planned) ? ZA_ST_SIZE : 0u; }
         return;
     }
 
@@ -1182,10 +1216,11 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     // lane writing single dwords into lines of its own (the packer's 45 KB of output cost 365 KB of memory writes that way).
     const uint32_t *tok_unit = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE;
     const uint32_t mycnt = lane < nseg ? segtok_ws[(size_t)blockIdx.x * ZA_MAX_SEGS + lane] : 0u;
-    uint32_t bitpos = plan.header_bits;            // (wave-uniform) bits of the stream so far
+    uint32_t bitpos = packed ? bit0 : plan.header_bits;      // (wave-uniform) bits of the stream so far, counted from bit 0 of slot32
     uint32_t wbase = bitpos >> 5;                  // the first dword that is still open; ring slot = dword index mod ZA_PK_RING
-    if ((bitpos & 31u) && lane == 0) ring[wbase & (ZA_PK_RING - 1)] = wbase < cap_words ? slot32[wbase] : 0u;     // the header's last, partial dword (plan kernel)
+    if (!packed && (bitpos & 31u) && lane == 0) ring[wbase & (ZA_PK_RING - 1)] = wbase < cap_words ? slot32[wbase] : 0u;     // the header's last, partial dword (plan kernel)
     __syncthreads();
+    const uint32_t end_byte = b0 + planned;        // (packed) first byte behind the unit, counted from slot32
     // `v` (at most 37 bits... 48 with a fixed block's longer codes) of `nb` bits from every lane, in lane order, behind `bitpos`
     auto emit = [&](uint64_t v, uint32_t nb) {
         const uint32_t incl = za_wave_incl_scan(nb);
@@ -1207,15 +1242,30 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             const uint32_t d = wbase + i;
             const uint32_t val = ring[d & (ZA_PK_RING - 1)];
             ring[d & (ZA_PK_RING - 1)] = 0;
-            if (d < cap_words) slot32[d] = val; else ovf = true;
+            if (d >= cap_words) ovf = true;
+            else if (packed && (d == 0u ? b0 != 0u : 4u * d + 4u > end_byte)) {
+                // a dword shared with the unit in front (its low bytes) or behind (its high bytes): my bytes only
+                for (uint32_t k = d == 0u ? b0 : 0u; k < 4u && 4u * d + k < end_byte; k++) ((uint8_t *)slot32)[4u * d + k] = (uint8_t)(val >> (8u * k));
+            } else slot32[d] = val;
         }
         wbase += nw;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    if (packed) {
+        // the header, from its buffer: 64 dwords per step through the same ring (the last one cut to what is left)
+        const uint32_t *hw = (const uint32_t *)(hdr_ws + (size_t)blockIdx.x * ZA_HDR_STRIDE);
+        for (uint32_t base = 0; base < plan.header_bits; base += 64u * 32u) {
+            const uint32_t at = base + 32u * (uint32_t)lane;
+            const uint32_t nb = at < plan.header_bits ? (plan.header_bits - at < 32u ? plan.header_bits - at : 32u) : 0u;
+            uint32_t v = nb ? hw[at >> 5] : 0u;
+            if (nb < 32u) v &= (1u << nb) - 1u;
+            emit((uint64_t)v, nb);
+        }
+    }
     for (int sg = 0; sg < nseg; sg++) {
         const uint32_t cnt = (uint32_t)__shfl((int)mycnt, sg, 64);
-        if (lane == 0) { segbits[sg] = bitpos; cidx[sg] = bitpos; }      // (index entries: the codec forces a token boundary at every segment start)
+        if (lane == 0) { segbits[sg] = bitpos - bit0; cidx[sg] = bitpos - bit0; }      // (index entries: the codec forces a token boundary at every segment start)
         const uint32_t *tk = tok_unit + ((size_t)sg << ZA_SEG_SHIFT);
         uint32_t tnext = (uint32_t)lane < cnt ? tk[lane] : 0u;
         for (uint32_t g = 0; g < cnt; g += 64) {
@@ -1239,7 +1289,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
             emit(has ? (uint64_t)a | ((uint64_t)b << an) : 0ull, has ? an + bn : 0u);
         }
     }
-    const uint32_t end_all = bitpos;                              // bit offset of the end-of-block code
+    const uint32_t end_all = bitpos - bit0;                       // bit offset of the end-of-block code
     for (int i = lane; i <= ZA_MAX_SEGS; i += 64) if (i >= nseg) segbits[i] = end_all;
     if (lane == 0) { segbits[ZA_MAX_SEGS] = end_all; cidx[nseg] = end_all; }
     // tail: EOB, then final padding or the sync-flush marker (empty stored block): one more group with a single word
@@ -1254,14 +1304,22 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
         total_bytes = padded >> 3;
         if (!final) { v |= 0xFFFF0000ull << nb; nb += 32; total_bytes += 4; }      // LEN = 0, NLEN = 0xFFFF
         emit(lane == 0 ? v : 0ull, lane == 0 ? nb : 0u);
-        // the last, partial dword
-        if ((bitpos & 31u) && lane == 0) { if (wbase < cap_words) slot32[wbase] = ring[wbase & (ZA_PK_RING - 1)]; else ovf = true; }
+        // the last, partial dword (packed: my bytes of it)
+        if ((bitpos & 31u) && lane == 0) {
+            if (wbase >= cap_words) ovf = true;
+            else if (!packed) slot32[wbase] = ring[wbase & (ZA_PK_RING - 1)];
+            else {
+                const uint32_t val = ring[wbase & (ZA_PK_RING - 1)];
+                for (uint32_t k = wbase == 0u ? b0 : 0u; k < 4u && 4u * wbase + k < end_byte; k++) ((uint8_t *)slot32)[4u * wbase + k] = (uint8_t)(val >> (8u * k));
+            }
+        }
         if (total_bytes > out_stride) ovf = true;
     }
     const unsigned long long anyovf = __ballot(ovf);
     if (lane == 0) {
+        const bool wrong = packed && !anyovf && total_bytes != planned;
         out_len[blockIdx.x] = anyovf ? 0u : total_bytes;
-        status[blockIdx.x] = anyovf ? ZA_ST_OVERFLOW : 0u;
+        status[blockIdx.x] = anyovf ? ZA_ST_OVERFLOW : wrong ? ZA_ST_SIZE : 0u;
     }
 }
 
@@ -1291,8 +1349,10 @@ __global__ __launch_bounds__(256) void za_k_gather(const uint8_t *__restrict__ s
 // units != nullptr: indexed members -- every unit also takes 4 bytes of index per 256 bytes of its input
 __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict__ out_len, uint32_t n, uint32_t extra,
                                                      uint64_t base, uint64_t *__restrict__ dst_off,
-                                                     uint64_t *__restrict__ total, const ZaUnit *__restrict__ units)
+                                                     uint64_t *__restrict__ total, const ZaUnit *__restrict__ units,
+                                                     const uint64_t *__restrict__ d_base = nullptr)      // (+ *d_base: the total of the launches in front)
 {
+    if (d_base) base += *d_base;
     auto ext = [&](uint32_t i) -> unsigned long long {
         return (unsigned long long)extra + (units ? 4ull * ((units[i].in_len + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT) : 0ull);
     };
@@ -1307,7 +1367,7 @@ __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict_
     if (tid == 0) {
         unsigned long long run = base;
         for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-        *total = run - base;
+        *total = d_base ? run : run - base;
     }
     __syncthreads();
     unsigned long long run = part[tid];

@@ -75,7 +75,7 @@ struct zngamd_ctx {
     uint32_t chain_slots = 1024;                 // chain-kernel workgroups the device holds at once: CUs x 4 (34 KiB of LDS each)
     uint32_t chain_run = 0;                      // ZNGAMD_CHAIN_RUN: fixed run length of the chain kernel (0 = sized to the device)
     // staging
-    DevBuf<uint8_t> st_in, st_out, st_slots, st_aux; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
+    DevBuf<uint8_t> st_in, st_out, st_slots, st_aux, hdr; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
     DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
     DevBuf<ZaCkPart> ck; DevBuf<uint32_t> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
@@ -411,8 +411,11 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
 }
 
 // launch the five deflate kernels over all units (in chunks that bound the workspace)
+// `packed` set: no slots -- the plan kernel sizes every unit exactly, a prefix sum places it, the packer writes it there
+struct PackedDst { uint8_t *d_dst = nullptr; uint64_t cap = 0; uint64_t *d_unit_off = nullptr; };
 static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const std::vector<ZaUnit> &hu, int level,
-                             uint8_t *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc, int max_dist = ZA_WIN)
+                             uint8_t *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc, int max_dist = ZA_WIN,
+                             const PackedDst *packed = nullptr)
 {
     if (level == -1) level = 6;
     if (level < 0 || level > 9) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
@@ -427,6 +430,14 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     }
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
     HIPCHK(c, c->codes.ensure((size_t)ch * ZA_CODE_STRIDE)); HIPCHK(c, c->plan.ensure(ch));
+    uint64_t *d_run_total = (uint64_t *)((uint8_t *)c->d_small + 224);      // (packed) bytes of the launches so far
+    uint64_t *d_offs = nullptr;
+    if (packed) {
+        HIPCHK(c, c->hdr.ensure((size_t)ch * ZA_HDR_STRIDE));
+        d_offs = packed->d_unit_off;
+        if (!d_offs) { HIPCHK(c, c->st_off.ensure(n)); d_offs = c->st_off.p; }
+        HIPCHK(c, hipMemsetAsync(d_run_total, 0, 8, c->stream));
+    }
     // Runs of the chain kernel: one workgroup walks a run of consecutive units and carries its tables from unit to unit where
     // the next unit's dictionary is the tail of the one before (ZA_FLAG_CARRY); a run costs its first unit's dictionary
     // again, so longer runs save more (a quarter of the positions at most) -- but workgroups are handed out in order, and a
@@ -486,13 +497,26 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             ProfScope ps(c, ZNGAMD_K_PARSE);
             hipLaunchKernelGGL(za_k_unit_crc, dim3(m), dim3(64), 0, c->stream, d_in, du, d_unit_crc + c0, c->d_crc_table, c->d_x8k);
         }
+        if (packed) {
+            { ProfScope ps(c, ZNGAMD_K_PLAN);
+              hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
+                                 (uint8_t *)nullptr, 0u, level, c->hdr.p, d_unit_len + c0); }
+            { ProfScope ps(c, ZNGAMD_K_GATHER);          // (what is left of the gather: the prefix sum)
+              hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(1024), 0, c->stream, d_unit_len + c0, m, 0u, 0ull, d_offs + c0, d_run_total,
+                                 (const ZaUnit *)nullptr, (const uint64_t *)d_run_total); }
+            { ProfScope ps(c, ZNGAMD_K_PACK);
+              hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok.p, c->segtok.p, c->codes.p, c->plan.p,
+                                 c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, c->cidx.p + (size_t)c0 * ZA_CIDX_STRIDE, packed->d_dst,
+                                 0u, d_unit_len + c0, c->status.p + c0, (const uint64_t *)(d_offs + c0), packed->cap, (const uint8_t *)c->hdr.p); }
+        } else {
         { ProfScope ps(c, ZNGAMD_K_PLAN);
           hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
-                             d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE, (uint32_t)ZNGAMD_SLOT_STRIDE, level); }
+                             d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE, (uint32_t)ZNGAMD_SLOT_STRIDE, level, (uint8_t *)nullptr, (uint32_t *)nullptr); }
         { ProfScope ps(c, ZNGAMD_K_PACK);
           hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok.p, c->segtok.p, c->codes.p, c->plan.p,
                              c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, c->cidx.p + (size_t)c0 * ZA_CIDX_STRIDE, d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE,
-                             (uint32_t)ZNGAMD_SLOT_STRIDE, d_unit_len + c0, c->status.p + c0); }
+                             (uint32_t)ZNGAMD_SLOT_STRIDE, d_unit_len + c0, c->status.p + c0, (const uint64_t *)nullptr, 0ull, (const uint8_t *)nullptr); }
+        }
         HIPCHK(c, hipGetLastError());
     }
     c->last_units = n; c->last_single_chunk = (n <= ch);
@@ -520,6 +544,41 @@ try {
     if (r) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
+
+// The blocks' compressed bytes back to back at d_out (no slots, no gather pass): *total_bytes and, per unit, its size, CRC-32 and
+// (optional) offset.  ZNGAMD_BUF_ERROR with *total_bytes = the size needed when out_cap is too small (units that did not fit are
+// not written); ZNGAMD_E_OVERFLOW never (a unit has no cap of its own here).
+int zngamd_deflate_blocks_packed_dev(zngamd_ctx *c, const void *d_in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                                     int level, void *d_out, uint64_t out_cap, uint32_t *d_unit_len, uint32_t *d_unit_crc,
+                                     uint64_t *d_unit_off, uint64_t *total_bytes)
+try {
+    if (!c || (!blocks && n_blocks) || !d_out || !d_unit_len || !d_unit_crc || !total_bytes) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    int r = ZNGAMD_OK;
+    if (!(n_blocks && c->blocks_in.size() == n_blocks && c->blocks_len == in_len &&
+          memcmp(c->blocks_in.data(), blocks, (size_t)n_blocks * sizeof(zngamd_block)) == 0)) {
+        c->blocks_in.clear();
+        r = build_units(c, blocks, n_blocks, in_len, c->blocks_hu);
+        if (r) return r;
+        c->blocks_in.assign(blocks, blocks + n_blocks); c->blocks_len = in_len;
+    }
+    const std::vector<ZaUnit> &hu = c->blocks_hu;
+    *total_bytes = 0;
+    if (hu.empty()) return ZNGAMD_OK;
+    PackedDst pd; pd.d_dst = (uint8_t *)d_out; pd.cap = out_cap; pd.d_unit_off = d_unit_off;
+    r = deflate_units_dev(c, (const uint8_t *)d_in, in_len, hu, level, nullptr, d_unit_len, d_unit_crc, ZA_WIN, &pd);
+    if (r) return r;
+    const uint64_t *d_run_total = (const uint64_t *)((const uint8_t *)c->d_small + 224);
+    std::vector<uint32_t> st(hu.size());
+    HIPCHK(c, hipMemcpyAsync(total_bytes, d_run_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, st.size() * 4ull, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (*total_bytes > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "destination too small");
+    // a unit whose packed size is not the planned one would have shifted everything behind it: never expected, always checked
+    for (uint32_t v : st) if (v) return fail(c, ZNGAMD_E_HIP, "packed deflate: a unit's size differs from its plan");
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 

@@ -32,7 +32,7 @@ SYMBOLS = [
     "zngamd_device_count", "zngamd_ctx_create", "zngamd_ctx_destroy", "zngamd_last_error", "zngamd_version",
     "zngamd_set_stream", "zngamd_sync", "zngamd_dmalloc", "zngamd_dfree", "zngamd_h2d", "zngamd_d2h",
     "zngamd_crc32", "zngamd_adler32", "zngamd_crc32_dev", "zngamd_crc32_combine", "zngamd_crc32_combine_many", "zngamd_level_ok",
-    "zngamd_deflate_blocks", "zngamd_deflate_blocks_packed", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_gather_dev",
+    "zngamd_deflate_blocks", "zngamd_deflate_blocks_packed", "zngamd_count_units", "zngamd_deflate_blocks_dev", "zngamd_deflate_blocks_packed_dev", "zngamd_gather_dev",
     "zngamd_deflate_stream", "zngamd_inflate_raw", "zngamd_inflate_resume", "zngamd_gzip_scan_dev", "zngamd_gzip_inflate_members_dev",
     "zngamd_gzip_inflate_plain_members_dev", "zngamd_inflate_raw_dev", "zngamd_compare_dev", "zngamd_crc32_fold_dev",
     "zngamd_stream_deflate_init", "zngamd_stream_deflate", "zngamd_stream_deflate_set_dictionary", "zngamd_stream_deflate_copy", "zngamd_stream_pending", "zngamd_stream_inflate_ahead",
@@ -105,6 +105,8 @@ def load():
         L.zngamd_count_units.restype = C.c_uint32
         L.zngamd_deflate_blocks_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
                                                 vp, vp, vp, u32p]
+        L.zngamd_deflate_blocks_packed_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int, vp, C.c_uint64, vp, vp, vp,
+                                                       C.POINTER(C.c_uint64)]
         L.zngamd_gather_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint64, vp,
                                         C.POINTER(C.c_uint64)]
         L.zngamd_deflate_stream.argtypes = [vp, u8p, C.c_uint64, C.c_int, C.c_int, u8p, C.c_uint64,

@@ -177,3 +177,54 @@ def test_chain_tables_carried_across_units_equal_the_oracle(monkeypatch):
                 dv.free()
         d_in.free()
         del ctx
+
+
+def test_packed_deflate_equals_slots_and_gather(ctx):
+    """zngamd_deflate_blocks_packed_dev (every unit's size known before it is packed, a prefix sum places it, the packer writes at
+    any byte address) leaves exactly the stream that zngamd_deflate_blocks_dev + zngamd_gather_dev leave -- blocks of odd sizes,
+    stored and fixed blocks, an empty block, a FINAL last block, every level; the system zlib decodes it."""
+    from zlib_ng_amd import _lib, corpus
+    L, h = ctx.L, ctx.h
+    rng = np.random.default_rng(5)
+    text = corpus.text(1 << 20, seed=9).tobytes()
+    data = (text[:300001] + rng.bytes(70001) + bytes(50000) + text[300001:700003] + b"ab" + rng.bytes(5) + text[700003:900000])
+    sizes = [131072, 1, 99999, 131071, 0, 7, 65536, 40000, 131072, 3, 70001, 131072]
+    cuts, off = [], 0
+    for sz in sizes:
+        cuts.append((off, sz)); off += sz
+    while off < len(data):
+        sz = min(131072, len(data) - off); cuts.append((off, sz)); off += sz
+    nb = len(cuts)
+    d_in = Dev(ctx, len(data) + 64); d_in.put(data + bytes(64))
+    for level in (0, 1, 4, 6, 9):
+        for final_last in (False, True):
+            blocks = (_lib.Block * nb)()
+            for b, (o, n) in enumerate(cuts):
+                blocks[b] = _lib.Block(o, n, min(o, 32768), _lib.FLAG_FINAL if (final_last and b == nb - 1) else 0, 0)
+            nu = L.zngamd_count_units(blocks, nb)
+            d_slots, d_len, d_crc = Dev(ctx, nu * _lib.SLOT_STRIDE), Dev(ctx, nu * 4), Dev(ctx, nu * 4)
+            assert L.zngamd_deflate_blocks_dev(h, d_in.p, len(data), blocks, nb, level, d_slots.p, d_len.p, d_crc.p, None) == 0, ctx.err()
+            d_dst = Dev(ctx, len(data) + nu * 64 + 64)
+            total = C.c_uint64(0)
+            assert L.zngamd_gather_dev(h, d_slots.p, d_len.p, nu, d_dst.p, 0, d_dst.n, None, C.byref(total)) == 0, ctx.err()
+            want = d_dst.get(total.value).tobytes()
+            want_len, want_crc = d_len.get(dtype=np.uint32).copy(), d_crc.get(dtype=np.uint32).copy()
+            d_pk, d_len2, d_crc2, d_off = Dev(ctx, len(data) + nu * 64 + 64), Dev(ctx, nu * 4), Dev(ctx, nu * 4), Dev(ctx, nu * 8)
+            total2 = C.c_uint64(0)
+            assert L.zngamd_deflate_blocks_packed_dev(h, d_in.p, len(data), blocks, nb, level, d_pk.p, d_pk.n, d_len2.p, d_crc2.p, d_off.p,
+                                                      C.byref(total2)) == 0, ctx.err()
+            assert total2.value == total.value, (level, final_last)
+            assert np.array_equal(d_len2.get(dtype=np.uint32), want_len) and np.array_equal(d_crc2.get(dtype=np.uint32), want_crc)
+            offs = d_off.get(dtype=np.uint64)
+            assert np.array_equal(offs, np.concatenate([[0], np.cumsum(want_len.astype(np.uint64))[:-1]]))
+            got = d_pk.get(total2.value).tobytes()
+            assert got == want, (level, final_last, next(i for i in range(len(want)) if got[i] != want[i]))
+            tail = b"" if final_last else b"\x03\x00"
+            assert zlib.decompress(got + tail, -15) == data
+            # too small a destination: the size needed, nothing else
+            small = C.c_uint64(0)
+            assert L.zngamd_deflate_blocks_packed_dev(h, d_in.p, len(data), blocks, nb, level, d_pk.p, total.value - 1, d_len2.p, d_crc2.p, None,
+                                                      C.byref(small)) == _lib.BUF_ERROR and small.value == total.value
+            for d in (d_slots, d_len, d_crc, d_dst, d_pk, d_len2, d_crc2, d_off):
+                d.free()
+    d_in.free()
