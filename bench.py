@@ -682,8 +682,8 @@ def main():
         # here (the 256 MiB four times over), the file written once outside the timing and checked with the system zlib
         STREAM_REPS = 4
 
-        def w128(dst):
-            with gzip_ng_threaded.open(dst, "wb", compresslevel=args.level, threads=8, block_size=CALL) as f:
+        def w128(dst, members=False):
+            with gzip_ng_threaded.open(dst, "wb", compresslevel=args.level, threads=8, block_size=CALL, indexed_members=members) as f:
                 for _ in range(STREAM_REPS):
                     for o in range(0, api_n, CALL):
                         f.write(mvb[o:o + CALL])
@@ -716,6 +716,17 @@ def main():
             assert got == STREAM_REPS * api_n
         r128()
         t_r = best_of(r128, 2)
+        # the same writer with indexed_members=True: independent members with this engine's chunk index, read back by the same reader
+        # (one wavefront per member instead of the chunk pipeline); a gzip file for the system zlib as well
+        w128(gz_path, True)
+        with open(gz_path, "rb") as fh:
+            assert fh.read(4) == b"\x1f\x8b\x08\x04"
+        import gzip as _gz
+        with _gz.open(gz_path, "rb") as fh:
+            assert fh.read(api_n) == blob, "member writer: output differs"
+        t_mw = best_of(lambda: w128(os.devnull, True), 3)
+        r128()
+        t_mr = best_of(r128, 2)
         # ... and through gzip_ng.open, which is what those two scripts open (one window over the whole stream; the engine's batches
         # run beside the caller): the same 1 GiB to os.devnull, and read back from the file gzip_ng.open wrote
         from zlib_ng_amd import gzip_ng
@@ -745,11 +756,13 @@ def main():
         os.rmdir(tmpdir)
         out["api"] = {"compress_MBps": round(api_n / t_c / 1e6, 1), "decompress_MBps": round(api_n / t_d / 1e6, 1),
                       "threaded_write_MBps": round(STREAM_REPS * api_n / t_w / 1e6, 1), "threaded_read_MBps": round(STREAM_REPS * api_n / t_r / 1e6, 1),
+                      "threaded_members_write_MBps": round(STREAM_REPS * api_n / t_mw / 1e6, 1), "threaded_members_read_MBps": round(STREAM_REPS * api_n / t_mr / 1e6, 1),
                       "open_write_MBps": round(STREAM_REPS * api_n / t_ow / 1e6, 1), "open_read_MBps": round(STREAM_REPS * api_n / t_or / 1e6, 1),
                       "note": f"host buffers, PCIe and fresh result objects included; {api_n >> 20} MiB of the same text, level {args.level}: zlib_ng.compress / "
                               "decompress (gzip container) one-shot; gzip_ng_threaded.open(threads=8, block_size=128 KiB) in 128 KiB calls as the reference's own "
                               f"benchmark scripts do it: {STREAM_REPS * api_n >> 20} MiB written to os.devnull, the same stream read back from a temporary file "
-                              "(open_*: the same through gzip_ng.open, which is what the scripts themselves open); best of 2-3"}
+                              "(open_*: the same through gzip_ng.open, which is what the scripts themselves open; threaded_members_*: the threaded writer with "
+                              "indexed_members=True and the same reader on its file); best of 2-3"}
         del blob, comp_blob
     if rank == 0:
         sys.stdout.flush()

@@ -37,9 +37,14 @@ _UNLOCKED_COPY_FROM = 32 * 1024          # pieces from this size on are copied w
 
 
 def open(filename, mode="rb", compresslevel=gzip_ng._COMPRESS_LEVEL_TRADEOFF, encoding=None, errors=None,
-         newline=None, *, threads=1, block_size=1024 * 1024):
+         newline=None, *, threads=1, block_size=1024 * 1024, indexed_members=None):
     """Like gzip.open for streamed reading / writing (no seeking).  threads == 0 defers to gzip_ng.open,
-    threads < 0 uses the CPU count (gzip_ng_threaded.py:22-75)."""
+    threads < 0 uses the CPU count (gzip_ng_threaded.py:22-75).
+
+    indexed_members (an addition; writing only; None = the environment's ZNGAMD_WRITER_MEMBERS, off when unset): the file is
+    written as independent gzip members of at most 128 KiB with this engine's chunk index in their FEXTRA field -- still a
+    gzip file for every gzip reader (RFC 1952 members, as bgzip writes them), and the format this engine's reader decodes
+    with one wavefront per member instead of through the chunk pipeline.  Off, the byte stream is the reference's."""
     if threads == 0:
         return gzip_ng.open(filename, mode, compresslevel, encoding, errors, newline)
     if threads < 0:
@@ -59,7 +64,7 @@ def open(filename, mode="rb", compresslevel=gzip_ng._COMPRESS_LEVEL_TRADEOFF, en
         # the writer without being copied here first -- io.BufferedWriter hands on what is longer than its buffer as it is.
         stream = FlushableBufferedWriter(
             _ThreadedGzipWriter(filename, mode.replace("t", "b"), block_size=block_size, level=compresslevel,
-                                threads=threads),
+                                threads=threads, indexed_members=indexed_members),
             buffer_size=max(io.DEFAULT_BUFFER_SIZE, min(block_size, 1 << 16) - 1))
     return io.TextIOWrapper(stream, encoding, errors, newline) if "t" in mode else stream
 
@@ -208,8 +213,13 @@ class _ThreadedGzipWriter(io.RawIOBase):
     onto one engine batch per drain."""
 
     def __init__(self, filename, mode="wb", level=zlib_ng.Z_DEFAULT_COMPRESSION, threads=1, queue_size=1,
-                 block_size=1024 * 1024):
+                 block_size=1024 * 1024, indexed_members=None):
         self._closed = True           # so that __del__/__exit__ are harmless if __init__ fails
+        if indexed_members is None:
+            indexed_members = os.environ.get("ZNGAMD_WRITER_MEMBERS", "0") not in ("", "0")
+        self._members = bool(indexed_members)
+        self._member_size = max(1, min(block_size, 128 * 1024))
+        self._members_written = 0                    # bytes of members written so far
         if "t" in mode or "r" in mode:
             raise ValueError("Only binary writing is supported")
         if "b" not in mode:
@@ -268,6 +278,8 @@ class _ThreadedGzipWriter(io.RawIOBase):
             raise ValueError("I/O operation on closed file")
 
     def _write_gzip_header(self):
+        if self._members:                            # every member brings its own header
+            return
         # gzip_ng_threaded.py:269-284: note the order of the last two bytes (OS, then XFL)
         xfl = 2 if self.level == zlib_ng.Z_BEST_COMPRESSION else 4 if self.level == zlib_ng.Z_BEST_SPEED else 0
         self.raw.write(struct.pack("BBBBIBB", 0x1f, 0x8b, 8, 0, 0, 0xff, xfl))
@@ -351,18 +363,21 @@ class _ThreadedGzipWriter(io.RawIOBase):
                 if self.exception:
                     raise self.exception
             R, bs, buf = DEFLATE_WINDOW_SIZE, self.block_size, self._small
-            tail = memoryview(self.previous_block)[-R:]
-            t = tail.nbytes
-            buf[R - t:R] = tail
-            view = memoryview(buf)[R - t:R + n]
-            key = (t, n, bs)
-            if key != self._table_key:
-                blocks = [(t + o, min(bs, n - o), min(R, t + o), 0) for o in range(0, n, bs)]
-                self._table_key, self._table = key, (blocks, _lib.block_table(blocks))
-            blocks, table = self._table
+            if self._members:                        # independent members: no history in front, no block table
+                view, blocks, table = memoryview(buf)[R:R + n], None, None
+            else:
+                tail = memoryview(self.previous_block)[-R:]
+                t = tail.nbytes
+                buf[R - t:R] = tail
+                view = memoryview(buf)[R - t:R + n]
+                key = (t, n, bs)
+                if key != self._table_key:
+                    blocks = [(t + o, min(bs, n - o), min(R, t + o), 0) for o in range(0, n, bs)]
+                    self._table_key, self._table = key, (blocks, _lib.block_table(blocks))
+                blocks, table = self._table
+                last = n - ((n - 1) // bs) * bs
+                self.previous_block = bytes(buf[R + n - last:R + n])
             self._size += n
-            last = n - ((n - 1) // bs) * bs
-            self.previous_block = bytes(buf[R + n - last:R + n])
             if wait or sys.is_finalizing():
                 self._emit(view, blocks, table)
             else:
@@ -399,6 +414,12 @@ class _ThreadedGzipWriter(io.RawIOBase):
         with self.lock:
             if self.exception:
                 raise self.exception
+        if self._members:
+            step = 256 << 20
+            for lo in range(0, nbytes, step):
+                self._emit(view[lo:min(nbytes, lo + step)], None)
+            self._size += nbytes
+            return nbytes
         tail = bytes(memoryview(self.previous_block)[-DEFLATE_WINDOW_SIZE:])
         bs = self.block_size
         emit = self._emit
@@ -425,6 +446,17 @@ class _ThreadedGzipWriter(io.RawIOBase):
 
     def _emit(self, buf, blocks, table=None):
         """One engine batch (spread over the writer's GPUs) and the write of its output."""
+        if self._members:
+            # indexed members (zngamd_gzip_members): header, chunk index, FINAL deflate block, CRC32 and ISIZE per member, in one piece
+            packed = self._contexts()[0].gzip_members(buf, self._member_size, self.level)
+            self._members_written += len(packed)
+            self._settle_write()
+            if sys.is_finalizing():
+                self.raw.write(packed)
+                return
+            self._write_thread = threading.Thread(target=self._write_later, args=(packed,), name="zng-amd-writer-io")
+            self._write_thread.start()
+            return
         cap = self.block_size + max(self.block_size // 10, 500)
         turn = self._packed_turn
         self._packed_turn = turn ^ 1
@@ -470,12 +502,19 @@ class _ThreadedGzipWriter(io.RawIOBase):
                 self.exception = exc
             raise exc
 
-    def _end_gzip_stream(self):
+    def _end_gzip_stream(self, closing=False):
         self._check_closed()
         self._flush_small()
         self._settle_write()
         for q in self.input_queues:
             q.join()
+        if self._members:
+            if closing and not self._members_written:   # nothing was ever written: an empty member makes it a gzip file
+                self.raw.write(struct.pack("BBBBIBB", 0x1f, 0x8b, 8, 0, 0, 0, 0xff) + b"\x03\x00" + bytes(8))
+                self._members_written = 20
+            self._crc = self._size = 0
+            self.raw.flush()
+            return
         # empty final block, then CRC32 and ISIZE (gzip_ng_threaded.py:332-338)
         self.raw.write(b"\x03\x00" + struct.pack("<II", self._crc, self._size & 0xFFFFFFFF))
         self._crc = 0
@@ -489,7 +528,7 @@ class _ThreadedGzipWriter(io.RawIOBase):
     def close(self):
         if self._closed:
             return
-        self._end_gzip_stream()
+        self._end_gzip_stream(closing=True)
         self.stop()
         if self.exception:
             self.raw.close()
@@ -550,7 +589,13 @@ class _ThreadedGzipWriter(io.RawIOBase):
                 origins.append(q)
                 self._drain_index += 1
             try:
-                results = compressor.compress_and_crc_batch(batch)
+                if self._members:
+                    joined = b"".join(bytes(d) for d, _ in batch)
+                    out = self._contexts()[0].gzip_members(joined, self._member_size, self.level)
+                    self._members_written += len(out)
+                    results = [(out, 0)] + [(b"", 0)] * (len(batch) - 1)
+                else:
+                    results = compressor.compress_and_crc_batch(batch)
             except Exception as exc:
                 for q in origins:
                     q.task_done()

@@ -505,3 +505,40 @@ def test_reader_leaves_a_source_that_cannot_be_sought_alone(Z, monkeypatch):
     assert first + r.readall() == data
     r.close()
     assert not names()
+
+
+def test_writer_of_indexed_members(T, tmp_path, monkeypatch):
+    """indexed_members=True (or ZNGAMD_WRITER_MEMBERS=1): the writer leaves independent gzip members of at most 128 KiB carrying
+    this engine's chunk index -- a gzip file for the standard library, and the members this engine's reader decodes with one
+    wavefront each (the decoder's `indexed` path, not the chunk pipeline)."""
+    import gzip as std_gzip
+    from zlib_ng_amd import _lib, corpus
+    data = corpus.text(5 * (1 << 20) + 4321, seed=21).tobytes()
+    target = tmp_path / "members.gz"
+    with T.open(target, "wb", compresslevel=6, threads=2, block_size=128 * 1024, indexed_members=True) as f:
+        for o in range(0, 3 << 20, 100000):                     # small writes, collected
+            f.write(data[o:min(o + 100000, 3 << 20)])
+        f.flush()                                               # (a flush in the middle ends nothing but the batch)
+        f.write(data[3 << 20:])
+    raw = target.read_bytes()
+    assert raw[:4] == b"\x1f\x8b\x08\x04"                       # FEXTRA: the index
+    assert std_gzip.decompress(raw) == data
+    n_members = -(-(3 << 20) // (128 * 1024)) + -(-(len(data) - (3 << 20)) // (128 * 1024))     # (no trailing empty member)
+    ctx = _lib.default_context()
+    ctx.decode_paths(reset=True)
+    with T.open(target, "rb", threads=1) as f:
+        assert f.read() == data
+    counts = ctx.decode_paths(reset=True)
+    assert counts["indexed"] == n_members and counts["chunked"] == 0 and counts["sequential"] == 0, counts
+    # one big write, the environment switch, and an empty file
+    monkeypatch.setenv("ZNGAMD_WRITER_MEMBERS", "1")
+    with T.open(target, "wb", threads=1) as f:
+        f.write(data)
+    assert std_gzip.decompress(target.read_bytes()) == data and target.read_bytes()[3] == 4
+    with T.open(target, "wb", threads=1) as f:
+        pass
+    assert std_gzip.decompress(target.read_bytes()) == b""
+    monkeypatch.delenv("ZNGAMD_WRITER_MEMBERS")
+    with T.open(target, "wb", threads=1) as f:                  # off: the reference's framing
+        f.write(data[:100000])
+    assert target.read_bytes()[3] == 0 and std_gzip.decompress(target.read_bytes()) == data[:100000]
