@@ -705,32 +705,47 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
     { PhaseClock pc(nullptr, "build_units"); r = build_units(c, blocks, n_blocks, in_len, hu); }
     if (r) return r;
     const uint32_t n = (uint32_t)hu.size();
-    HIPCHK(c, c->st_slots.ensure((size_t)n * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(n)); HIPCHK(c, c->st_crc.ensure(n));
+    HIPCHK(c, c->st_len.ensure(n)); HIPCHK(c, c->st_crc.ensure(n));
+    // Packed: every unit's size is planned before it is packed and the packer writes at its final offset (no slots, no gather).
+    // A unit is never larger than its stored form: its bytes + 5 per stored chunk of 65 535 + an empty stored block behind it.
+    uint64_t bound = 64;
+    for (const ZaUnit &u : hu) bound += (uint64_t)u.in_len + 32u;
+    HIPCHK(c, c->st_out.ensure(bound));
+    PackedDst pd; pd.d_dst = c->st_out.p; pd.cap = bound; pd.d_unit_off = nullptr;
     { PhaseClock pc(c, "deflate kernels");
-      r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p, max_dist); }
+      r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, nullptr, c->st_len.p, c->st_crc.p, max_dist, &pd); }
     if (r) return r;
-    // upper bound of the packed size without a round trip: every unit fits its slot
-    HIPCHK(c, c->st_out.ensure((size_t)n * ZNGAMD_SLOT_STRIDE));
-    uint64_t total = 0;
-    { PhaseClock pc(c, "gather");
-      r = gather_dev(c, c->st_slots.p, c->st_len.p, n, 0, c->st_out.p, 0, (uint64_t)n * ZNGAMD_SLOT_STRIDE, nullptr, &total, true); }
-    if (r) return r;
-    // one-shot callers take the packed stream straight into their buffer (no intermediate copy)
     const bool direct = direct_out != nullptr;
-    if (direct) { *direct_len = total; if (total > direct_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
     ulen.resize(n); ucrc.resize(n);
-    uint8_t *stage = nullptr;
-    if (!direct) { int rs = host_stage(c, total, &stage); if (rs) return rs; *packed = stage; }
     std::vector<uint32_t> st(n);
-    PhaseClock pc(c, "results to the host");
-    HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-    if (total && !direct) HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, total, hipMemcpyDeviceToHost, c->stream));
-    if (total && direct) { const int rc_ = d2h_payload(c, direct_out, c->st_out.p, total); if (rc_) return rc_; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    const uint64_t *d_run_total = (const uint64_t *)((const uint8_t *)c->d_small + 224);
+    // One round trip for the sizes, and for a small result the bytes as well (its upper bound travels: the size is not known yet)
+    const uint64_t EAGER = 512u << 10;
+    uint8_t *stage = nullptr;
+    const bool eager = bound <= EAGER;
+    if (eager) { int rs = host_stage(c, bound, &stage); if (rs) return rs; }
+    {
+        PhaseClock pc(c, "results to the host");
+        HIPCHK(c, hipMemcpyAsync(&total, d_run_total, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
+        if (eager) HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, bound, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     prof_collect(c);
-    for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_OVERFLOW, "unit overflowed its slot");
+    for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_HIP, "packed deflate: a unit's size differs from its plan");
+    if (total > bound) return fail(c, ZNGAMD_E_HIP, "packed deflate: stream larger than its bound");
+    // one-shot callers take the packed stream straight into their buffer (no intermediate copy)
+    if (direct) { *direct_len = total; if (total > direct_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+    if (eager) {
+        if (direct) memcpy(direct_out, stage, total); else *packed = stage;
+        return ZNGAMD_OK;
+    }
+    if (!direct) { int rs = host_stage(c, total, &stage); if (rs) return rs; *packed = stage; }
+    if (total && !direct) { HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, total, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    if (total && direct) { const int rc_ = d2h_payload(c, direct_out, c->st_out.p, total); if (rc_) return rc_; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return ZNGAMD_OK;
 }
 
