@@ -343,6 +343,15 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
 #define ZA_RING           40960            // chain-link ring: window 32768 + two tiles
 #define ZA_BYTES          65536            // byte ring (power of two)
 #define ZA_LOOKAHEAD      272              // bytes staged beyond the tile: max match 258 + wide compares
+// Levels that compare in full walk 8-16 chain steps, and most positions are done long before the last one (text at level 9:
+// 7.8 steps on average, 31 % of the positions take all 16): a wave walks ZA_WL_STEPS steps at a time, and the positions that
+// are not done yet go to a work list of the wave's own in LDS (two dwords each), from which the wave takes 64 at a time as
+// soon as it holds that many -- the later steps run on full waves.  At most 63 entries wait when 64 more arrive.
+#ifndef ZA_WL_STEPS
+#define ZA_WL_STEPS       4
+#endif
+#define ZA_WL_ENTRIES     127
+#define ZA_WL_BYTES       (16 * ZA_WL_ENTRIES * 8)
 
 // byte-aligned dword of the byte ring at absolute position `addr` (the ring has mirrored pad dwords behind its end)
 __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t addr)
@@ -362,7 +371,7 @@ __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t 
 // each side from three aligned dwords (the ring's mirrored pad covers the overrun); most matches end in the first round
 __device__ __forceinline__ int za_search_extend(const uint32_t *win32, uint32_t qb, uint32_t P, int len, int maxlen)
 {
-    for (;;) {
+    {   // first round: 8 bytes (most matches end here)
         const uint32_t o = (uint32_t)len;
         const uint32_t is = (qb + o) & (ZA_BYTES - 1), ws = is >> 2, ip = (P + o) & (ZA_BYTES - 1), wp = ip >> 2;
         const uint32_t s0 = win32[ws], s1 = win32[ws + 1], s2 = win32[ws + 2], p0 = win32[wp], p1 = win32[wp + 1], p2 = win32[wp + 2];
@@ -373,7 +382,25 @@ __device__ __forceinline__ int za_search_extend(const uint32_t *win32, uint32_t 
             : "=&v"(g0), "=&v"(g1) : "v"(a0), "v"(a1));
         const int nb = (int)min(g0 >> 3, 8u);
         len += nb;
-        if (nb < 8 || len >= maxlen) break;
+        if (nb < 8 || len >= maxlen) return len < maxlen ? len : maxlen;
+    }
+    for (;;) {   // a long match: 16 bytes per round (five aligned dwords a side)
+        const uint32_t o = (uint32_t)len;
+        const uint32_t is = (qb + o) & (ZA_BYTES - 1), ws = is >> 2, ip = (P + o) & (ZA_BYTES - 1), wp = ip >> 2;
+        const uint32_t s0 = win32[ws], s1 = win32[ws + 1], s2 = win32[ws + 2], s3 = win32[ws + 3], s4 = win32[ws + 4];
+        const uint32_t p0 = win32[wp], p1 = win32[wp + 1], p2 = win32[wp + 2], p3 = win32[wp + 3], p4 = win32[wp + 4];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(s1, s0, is & 3u) ^ __builtin_amdgcn_alignbyte(p1, p0, ip & 3u);
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(s2, s1, is & 3u) ^ __builtin_amdgcn_alignbyte(p2, p1, ip & 3u);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(s3, s2, is & 3u) ^ __builtin_amdgcn_alignbyte(p3, p2, ip & 3u);
+        const uint32_t a3 = __builtin_amdgcn_alignbyte(s4, s3, is & 3u) ^ __builtin_amdgcn_alignbyte(p4, p3, ip & 3u);
+        uint32_t g0, g1, g2, g3;
+        asm("v_ffbl_b32 %0, %4\n\tv_ffbl_b32 %1, %5\n\tv_ffbl_b32 %2, %6\n\tv_ffbl_b32 %3, %7\n\t"
+            "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
+            "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
+            : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(96u));
+        const int nb = (int)min(g0 >> 3, 16u);
+        len += nb;
+        if (nb < 16 || len >= maxlen) break;
     }
     return len < maxlen ? len : maxlen;
 }
@@ -391,7 +418,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     // 0xFFFF in the ring = end of the chain (what the chain kernel writes as 0): the walk's "too far" test ends it, one compare
     // instead of two per step.  (8 % fewer vector instructions per step, 1.5 % of the kernel's time: the candidates' LDS reads --
     // five dwords at a random address, 26 LDS cycles per wave -- weigh as much as the instructions.)
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ZA_BYTES + 32 + 2 * ZA_RING];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ZA_BYTES + 32 + 2 * ZA_RING + (FULL ? ZA_WL_BYTES : 0)];
     uint32_t *win32 = (uint32_t *)lds;
     uint16_t *ring = (uint16_t *)(lds + ZA_BYTES + 32);
     constexpr uint32_t RING_B0 = ZA_BYTES + 32, RING_BYTES = 2 * ZA_RING;      // the ring's byte range in the block
@@ -484,6 +511,137 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 nb[k] = p < need_bytes ? load_bytes(p) : 0u;
             }
         }
+        if constexpr (FULL) {
+        // ---- levels 7-9: ZA_WL_STEPS chain steps per visit, the unfinished positions through the wave's work list
+        const int lane = tid & 63;
+        uint32_t *wl = (uint32_t *)(lds + ZA_BYTES + 32 + 2 * ZA_RING) + (tid >> 6) * (2 * ZA_WL_ENTRIES);
+        uint32_t wl_n = 0;                                                 // entries on my wave's list (the same in every lane)
+        // one visit: up to ZA_WL_STEPS more steps of the walk of position P; true = not done yet
+        auto visit = [&](uint32_t P, uint32_t me0, uint32_t me1, uint32_t me2, uint32_t me3, int maxlen, int cap, int nice,
+                         uint32_t &q, uint32_t &qb, uint32_t &d, int &best_len, int &best_dist, int &depth) -> bool {
+            bool alive = depth > 0;
+            int steps = ZA_WL_STEPS;
+            while (alive && steps-- > 0) {
+                depth--;
+                q -= d;
+                qb -= 2u * d;
+                qb += qb < RING_B0 ? RING_BYTES : 0u;
+                const int dist = (int)(P - q);
+                if (dist > L.max_dist) { alive = false; break; }            // (also the end of the chain: a link of 0xFFFF)
+                d = *(const uint16_t *)(lds + qb);
+                const uint32_t sh = q & 3u;
+                const uint32_t *cw = (const uint32_t *)(lds + (q & (uint32_t)(ZA_BYTES - 4)));
+                const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
+                uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0;
+                uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
+                uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2;
+                uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
+                uint32_t fbit, f1, f2, f3;
+                asm("v_ffbl_b32 %0, %4\n\tv_ffbl_b32 %1, %5\n\tv_ffbl_b32 %2, %6\n\tv_ffbl_b32 %3, %7\n\t"
+                    "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
+                    "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
+                    : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));
+                int len = (int)min(fbit >> 3, 16u);
+                if (len == 16 && cap > 16 && best_len < cap &&
+                    (best_len < 16 || (uint8_t)za_lds_ld32(win32, q + (uint32_t)best_len) == (uint8_t)za_lds_ld32(win32, P + (uint32_t)best_len)))
+                    len = za_search_extend(win32, q, P, len, maxlen);
+                len = len < cap ? len : cap;
+                const bool better = len > best_len;
+                best_len = better ? len : best_len;
+                best_dist = better ? dist : best_dist;
+                alive = best_len < nice && depth > 0;
+            }
+            return alive;
+        };
+        auto my16 = [&](uint32_t P, uint32_t &me0, uint32_t &me1, uint32_t &me2, uint32_t &me3) {
+            const uint32_t idx = P & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
+            const uint32_t m0 = win32[w], m1 = win32[w + 1], m2 = win32[w + 2], m3 = win32[w + 3], m4 = win32[w + 4];
+            me0 = __builtin_amdgcn_alignbyte(m1, m0, sh); me1 = __builtin_amdgcn_alignbyte(m2, m1, sh);
+            me2 = __builtin_amdgcn_alignbyte(m3, m2, sh); me3 = __builtin_amdgcn_alignbyte(m4, m3, sh);
+        };
+        auto finish = [&](int p, uint32_t me0, int best_len, int best_dist) {
+            uint32_t result = 0;
+            if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
+                result = ((uint32_t)(best_len - 3) << 16) | (uint32_t)best_dist;
+            best[p] = __builtin_amdgcn_perm(me0, result, 0x04020100u);
+        };
+        // the unfinished walks of this visit go to the list: position in the tile | best length << 12 | steps left << 21, and
+        // how far back the walk stands | best distance << 16
+        auto push = [&](bool alive, int p, uint32_t P, uint32_t q, int best_len, int best_dist, int depth) {
+            const unsigned long long m = __ballot(alive);
+            if (alive) {
+                const uint32_t at = wl_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                wl[2 * at] = (uint32_t)(p - base) | ((uint32_t)best_len << 12) | ((uint32_t)depth << 21);
+                wl[2 * at + 1] = (P - q) | ((uint32_t)best_dist << 16);
+            }
+            wl_n += (uint32_t)__builtin_popcountll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // other lanes read these entries (one wave: only the compiler must keep the order)
+            __builtin_amdgcn_wave_barrier();
+        };
+        // the last nb entries of the list (nb <= 64) get their next visit
+        auto batch = [&](uint32_t nb) {
+            wl_n -= nb;
+            const bool has = (uint32_t)lane < nb;
+            uint32_t e0 = 0, e1 = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (has) { e0 = wl[2 * (wl_n + lane)]; e1 = wl[2 * (wl_n + lane) + 1]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the pushes below may land on the slots just read)
+            __builtin_amdgcn_wave_barrier();
+            bool alive = false;
+            int p = 0, best_len = 0, best_dist = 0, depth = 0;
+            uint32_t P = 0, q = 0;
+            if (has) {
+                p = base + (int)(e0 & 0xFFFu);
+                best_len = (int)((e0 >> 12) & 0x1FFu); depth = (int)(e0 >> 21); best_dist = (int)(e1 >> 16);
+                P = goff + (uint32_t)(ZA_WIN + p);
+                q = P - (e1 & 0xFFFFu);
+                int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
+                if (seg_end > n) seg_end = n;
+                int maxlen = seg_end - p;
+                if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
+                const int cap = L.cap < maxlen ? L.cap : maxlen, nice = L.nice < cap ? L.nice : cap;
+                uint32_t me0, me1, me2, me3;
+                my16(P, me0, me1, me2, me3);
+                const uint32_t sq = q % ZA_RING;
+                uint32_t qb = RING_B0 + 2u * sq;
+                uint32_t d = *(const uint16_t *)(lds + qb);
+                alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
+                if (!alive) finish(p, me0, best_len, best_dist);
+            }
+            push(alive, p, P, q, best_len, best_dist, depth);
+        };
+        uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;
+#pragma unroll 1
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
+            const int p = base + k * ZA_SEARCH_THREADS + tid;
+            bool alive = false;
+            const uint32_t P = goff + (uint32_t)(ZA_WIN + p);
+            uint32_t q = P;
+            int best_len = ZA_MIN_MATCH - 1, best_dist = 0, depth = L.chain;
+            if (p < n) {
+                int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
+                if (seg_end > n) seg_end = n;
+                int maxlen = seg_end - p;
+                if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
+                uint32_t me0, me1, me2, me3;
+                my16(P, me0, me1, me2, me3);
+                if (maxlen >= ZA_MIN_MATCH) {
+                    const int cap = L.cap < maxlen ? L.cap : maxlen, nice = L.nice < cap ? L.nice : cap;
+                    uint32_t qb = RING_B0 + 2u * slot;
+                    uint32_t d = *(const uint16_t *)(lds + qb);
+                    alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
+                }
+                if (!alive) finish(p, me0, best_len, best_dist);
+            }
+            push(alive, p, P, q, best_len, best_dist, depth);
+            while (__builtin_amdgcn_readfirstlane((int)wl_n) >= 64) batch(64u);
+        }
+        for (;;) {                                                         // what is left of the tile's walks
+            const uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl_n);
+            if (left == 0) break;
+            batch(left < 64u ? left : 64u);
+        }
+        } else {
         uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;      // ring slot of my position, moved on by 1 024 per round
 #pragma unroll 1
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
@@ -562,6 +720,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #else
             best[p] = __builtin_amdgcn_perm(me0, result, 0x04020100u);       // byte 3 = my byte (byte 0 of me0), bytes 0..2 = result
 #endif
+        }
         }
         // ---- put the next tile into the rings.  No barrier is needed in front of these stores: they land at least
         // 65536-4096-272-32768 byte slots / 40960-4096-32768 link slots behind any walk of this tile that is still
