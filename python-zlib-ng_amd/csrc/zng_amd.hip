@@ -27,7 +27,7 @@ static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants
 // level is >= zlib 1.2.11's at the same level on the text / FASTQ / mixed corpora
 static const ZaLevel ZA_LEVELS[10] = {
     {0, 0, 0, ZA_WIN, 0}, {1, 8, 0, ZA_WIN, 16}, {2, 8, 0, ZA_WIN, 16}, {3, 16, 0, ZA_WIN, 16}, {2, 16, 8, ZA_WIN, 16}, {2, 32, 16, ZA_WIN, 16},
-    {3, 32, 16, ZA_WIN, 16}, {8, 32, 16, ZA_WIN, 258}, {12, 64, 16, ZA_WIN, 258}, {16, 128, 128, ZA_WIN, 258}};
+    {3, 32, 16, ZA_WIN, 16}, {8, 32, 16, ZA_WIN, 258}, {10, 64, 16, ZA_WIN, 258}, {12, 128, 128, ZA_WIN, 258}};
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;
