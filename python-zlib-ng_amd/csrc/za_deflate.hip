@@ -956,6 +956,7 @@ struct ZaPlanLds {
     uint8_t cl_lens[19];
     uint16_t cl_codes[19];
     int m;
+    int btype;
 };
 
 // rank-sort the non-zero symbols by (freq, index); all lanes take part.  Result in S.key[0..m).
@@ -1028,6 +1029,119 @@ __device__ void za_lengths_serial(ZaPlanLds &S, int nsym, int limit, uint8_t *le
     int idx = 0;
     for (int l = limit; l >= 1; l--)
         for (int k = 0; k < cnt[l] && idx < m; k++) lens[S.key[idx++] & 511u] = (uint8_t)l;
+}
+
+// The same lengths with the wave: only the two-queue merge that builds the tree (phase 1 of Moffat-Katajainen) is a chain of
+// dependent steps, and it stays on lane 0 -- with the heads of its two queues kept in registers and the next two leaves fetched
+// ahead, so that a step waits for one LDS round trip at most instead of four.  Everything behind it is done by all lanes: the
+// depths of the internal nodes by pointer jumping (depth += depth of the parent, parent = the parent's parent: nine rounds at
+// most for 285 nodes) instead of a walk down the array, the leaves per depth from the internal nodes per depth (a level holds
+// twice the internal nodes of the level above it: leaves = 2 x inner[d - 1] - inner[d]) instead of the third pass, the lengths
+// by rank.  S.cltok and S.clf are scratch here (the header is built later).  125 -> 50 us for the literal/length tree of a text
+// unit: the latency of every batch too small to fill the device, and of every small call.
+__device__ void za_lengths_wave(ZaPlanLds &S, int nsym, int limit, uint8_t *lens)
+{
+    const int lane = za_lane();
+    __syncthreads();
+    const int m = S.m;
+    for (int i = lane; i < nsym; i += 64) lens[i] = 0;
+    __syncthreads();
+    if (m == 0) return;
+    if (m == 1) { if (lane == 0) lens[S.key[0] & 511u] = 1; __syncthreads(); return; }
+    uint32_t *A = S.A;
+    uint16_t *dep = S.cltok;                                   // depth of internal node i
+    for (int i = lane; i < m; i += 64) A[i] = S.key[i] >> 9;
+    __syncthreads();
+    if (lane == 0) {
+        const uint32_t NONE = 0xFFFFFFFFu;                     // (no frequency and no sum of frequencies is that large)
+        const uint32_t a0 = A[0] + A[1];
+        A[0] = a0;
+        int root = 0, leaf = 2;
+        uint32_t wr = a0;                                      // weight of the internal node at the head of its queue (valid while root < next)
+        uint32_t fl = leaf < m ? A[leaf] : NONE, fl1 = leaf + 1 < m ? A[leaf + 1] : NONE;      // the next two leaves
+        for (int next = 1; next < m - 1; next++) {
+            uint32_t w;
+            // (the first pick always finds an internal node: the one the step in front made)
+            if (fl == NONE || wr < fl) { w = wr; A[root] = (uint32_t)next; root++; wr = root < next ? A[root] : NONE; }
+            else { w = fl; leaf++; fl = fl1; fl1 = leaf + 1 < m ? A[leaf + 1] : NONE; }
+            if (fl == NONE || (root < next && wr < fl)) { w += wr; A[root] = (uint32_t)next; root++; wr = root < next ? A[root] : NONE; }
+            else { w += fl; leaf++; fl = fl1; fl1 = leaf + 1 < m ? A[leaf + 1] : NONE; }
+            A[next] = w;
+            if (root == next) wr = w;                          // the queue was empty: the new node is its head
+        }
+    }
+    __syncthreads();
+    // internal nodes 0 .. m - 2, node m - 2 the root; A[i] = parent of node i
+    const int ninner = m - 1, top = m - 2;
+    int pi[5], di[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int i = lane + 64 * k;
+        pi[k] = top; di[k] = 0;
+        if (i < top) { pi[k] = (int)A[i]; di[k] = 1; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int i = lane + 64 * k; if (i < ninner) { A[i] = (uint32_t)pi[k]; dep[i] = (uint16_t)di[k]; } }
+    for (int round = 0; round < 10; round++) {
+        __syncthreads();
+        int np[5], nd[5];
+        bool open = false;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = lane + 64 * k;
+            np[k] = pi[k]; nd[k] = di[k];
+            if (i < ninner) { np[k] = (int)A[pi[k]]; nd[k] = di[k] + (int)dep[pi[k]]; open = open || np[k] != top; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = lane + 64 * k;
+            pi[k] = np[k]; di[k] = nd[k];
+            if (i < ninner) { A[i] = (uint32_t)np[k]; dep[i] = (uint16_t)nd[k]; }
+        }
+        if (__ballot(open) == 0ull) break;
+    }
+    __syncthreads();
+    // internal nodes per depth (in A, which is free now), then leaves per depth
+    for (int i = lane; i < 288; i += 64) A[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int i = lane + 64 * k; if (i < ninner) atomicAdd(&A[di[k]], 1u); }
+    __syncthreads();
+    uint32_t deep = 0, beyond = 0;                             // leaves at depth >= limit / > limit
+    for (int d = lane + 1; d < 288; d += 64) {
+        const uint32_t nl = 2u * A[d - 1] - A[d];
+        if (d < limit) S.clf[d] = nl;
+        deep += d >= limit ? nl : 0u;
+        beyond += d > limit ? nl : 0u;
+    }
+    for (int x = 32; x >= 1; x >>= 1) { deep += __shfl_xor(deep, x, 64); beyond += __shfl_xor(beyond, x, 64); }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t *cnt = S.clf;                                 // cnt[1 .. limit]
+        cnt[limit] = deep;
+        if (beyond) {
+            uint32_t total = 0;
+            for (int i = 1; i <= limit; i++) total += cnt[i] << (limit - i);
+            // every step removes one unit of the Kraft sum; the guard only bounds a corrupted state
+            for (int guard = 0; total != (1u << limit) && guard < (1 << 17); guard++) {
+                cnt[limit]--;
+                for (int i = limit - 1; i > 0; i--)
+                    if (cnt[i]) { cnt[i]--; cnt[i + 1] += 2; break; }
+                total--;
+            }
+        }
+    }
+    __syncthreads();
+    // lengths by rank: the rarest symbols take the longest codes
+    for (int r = lane; r < m; r += 64) {
+        uint32_t acc = 0;
+        int len = 1;
+        for (int l = limit; l >= 1; l--) { acc += S.clf[l]; if ((uint32_t)r < acc) { len = l; break; } }
+        lens[S.key[r] & 511u] = (uint8_t)len;
+    }
+    __syncthreads();
 }
 
 // lane 0 only: canonical codes, bit-reversed for LSB-first emission
@@ -1140,12 +1254,12 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
     __syncthreads();
     // lit/len tree
     za_sort_syms(S, S.freq, 286);
-    if (lane == 0) za_lengths_serial(S, 286, ZA_LIMIT_L, S.lens);
-    __syncthreads();
+    za_lengths_wave(S, 286, ZA_LIMIT_L, S.lens);
     if (lane < 2) S.lens[286 + lane] = 0;
     // distance tree
     za_sort_syms(S, S.freq + 288, 30);
-    if (lane == 0) { za_lengths_serial(S, 30, ZA_LIMIT_D, S.lens + 288); S.lens[318] = S.lens[319] = 0; }
+    za_lengths_wave(S, 30, ZA_LIMIT_D, S.lens + 288);
+    if (lane < 2) S.lens[318 + lane] = 0;
     __syncthreads();
 
     // canonical codes and the exact data costs: by all lanes (lane 0 alone walked 600 symbols through LDS, one round trip each)
@@ -1166,11 +1280,22 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         cost_df += f * (uint32_t)(5 + ex);
     }
     for (int d = 32; d >= 1; d >>= 1) { cost_dd += __shfl_xor(cost_dd, d, 64); cost_df += __shfl_xor(cost_df, d, 64); }
+    // the code-length sequence of the header: hlit literal/length lengths, then hdist distance lengths (copied by all lanes)
+    int hlit, hdist;
+    {
+        unsigned long long nz[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int i = lane + 64 * k; nz[k] = __ballot(i < 286 && S.lens[i] != 0); }
+        hlit = 257;
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (nz[k]) { const int t = 64 * k + 64 - __builtin_clzll(nz[k]); hlit = t > hlit ? t : hlit; }
+        const unsigned long long nzd = __ballot(lane < 30 && S.lens[288 + lane] != 0);
+        hdist = nzd ? 64 - __builtin_clzll(nzd) : 1;
+        for (int i = lane; i < hlit; i += 64) S.seq[i] = S.lens[i];
+        if (lane < hdist) S.seq[hlit + lane] = S.lens[288 + lane];
+        __syncthreads();
+    }
     if (lane == 0) {
-        int hlit = 286; while (hlit > 257 && S.lens[hlit - 1] == 0) hlit--;
-        int hdist = 30; while (hdist > 1 && S.lens[288 + hdist - 1] == 0) hdist--;
-        for (int i = 0; i < hlit; i++) S.seq[i] = S.lens[i];
-        for (int i = 0; i < hdist; i++) S.seq[hlit + i] = S.lens[288 + i];
         // run-length encode the code lengths (tokens: sym | extra<<8)
         const int nseq = hlit + hdist;
         int nt = 0, i = 0;
@@ -1219,16 +1344,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         unsigned long long bestc = cost_dyn; int btype = 2;
         if (cost_fix <= bestc) { bestc = cost_fix; btype = 1; }
         if (cost_sto <= bestc) { bestc = cost_sto; btype = 0; }
-        if (btype == 1) {
-            int s = 0;
-            for (; s < 144; s++) S.lens[s] = 8;
-            for (; s < 256; s++) S.lens[s] = 9;
-            for (; s < 280; s++) S.lens[s] = 7;
-            for (; s < 288; s++) S.lens[s] = 8;
-            for (s = 0; s < 32; s++) S.lens[288 + s] = 5;
-            za_canon_serial(S.lens, 288, S.codes);
-            za_canon_serial(S.lens + 288, 30, S.codes + 288);
-        }
+        S.btype = btype;                                       // (a fixed block's code table is filled in by all lanes below)
         plan.btype = (uint32_t)btype;
         if (unit_len) {
             // the unit's size, exactly: what the packer will write (it checks)
@@ -1271,6 +1387,21 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         plan_ws[blockIdx.x] = plan;
     }
     __syncthreads();
+    if (S.btype == 1) {
+        // the fixed code (RFC 1951 3.2.6), bit-reversed for LSB-first emission: lane 0 alone walked 600 LDS round trips for it,
+        // and the smallest inputs -- whose latency is this kernel's -- are the ones that take fixed blocks
+        for (int i = lane; i < 320; i += 64) {
+            uint32_t len = 0, code = 0;
+            if (i < 144) { len = 8; code = 0x30u + (uint32_t)i; }
+            else if (i < 256) { len = 9; code = 0x190u + (uint32_t)(i - 144); }
+            else if (i < 280) { len = 7; code = (uint32_t)(i - 256); }
+            else if (i < 288) { len = 8; code = 0xC0u + (uint32_t)(i - 280); }
+            else { len = 5; code = (uint32_t)(i - 288); }            // 288 .. 319: distance codes 0 .. 31
+            S.lens[i] = (uint8_t)len;
+            S.codes[i] = i < 318 ? (uint16_t)(__brev(code) >> (32u - len)) : (uint16_t)0;
+        }
+        __syncthreads();
+    }
     for (int i = lane; i < 320; i += 64) code_out[i] = (uint32_t)S.codes[i] | ((uint32_t)S.lens[i] << 16);
 }
 

@@ -286,21 +286,28 @@ uint32_t zngamd_crc32_combine_many(uint32_t crc, const uint32_t *crcs, const uin
 }
 
 // run the checksum kernel over a device buffer and fold the per-span partials
-static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *crc_io, uint32_t *adler_io)
+// In two halves, so that a caller with kernels of its own to run can put them between the two and wait once: checksum_launch
+// enqueues the kernel and the copy of its partial results, checksum_fold (behind a synchronisation of the stream) folds them.
+static int checksum_launch(zngamd_ctx *c, const uint8_t *d, uint64_t n, bool want_adler, std::vector<ZaCkPart> &parts)
 {
+    parts.clear();
     if (n == 0) return ZNGAMD_OK;
-    PhaseClock pc(c, "checksum of a device buffer");
     const uint64_t nspan = (n + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT;
     if (nspan > 0x7FFFFFFFull) return fail(c, ZNGAMD_E_ARG, "buffer too large");
     HIPCHK(c, c->ck.ensure(nspan));
     {
         ProfScope ps(c, ZNGAMD_K_OTHER);
-        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(64), 0, c->stream, d, n, c->d_crc_slice4, c->d_x8k, c->ck.p, adler_io ? 1 : 0);
+        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(64), 0, c->stream, d, n, c->d_crc_slice4, c->d_x8k, c->ck.p, want_adler ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
-    std::vector<ZaCkPart> parts(nspan);
+    parts.resize(nspan);
     HIPCHK(c, hipMemcpyAsync(parts.data(), c->ck.p, nspan * sizeof(ZaCkPart), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZNGAMD_OK;
+}
+
+static void checksum_fold(const std::vector<ZaCkPart> &parts, uint32_t *crc_io, uint32_t *adler_io)
+{
+    const uint64_t nspan = parts.size();
     if (crc_io) {
         // all spans but the last are ZA_MAX_UNIT long: one multiplier, x^(8 * ZA_MAX_UNIT) mod P, serves them (2 048 spans of a
         // 256 MiB result cost 0.6 ms when each call worked its multiplier out again)
@@ -321,6 +328,17 @@ static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *c
         }
         *adler_io = (uint32_t)((B << 16) | A);
     }
+}
+
+static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *crc_io, uint32_t *adler_io)
+{
+    if (n == 0) return ZNGAMD_OK;
+    PhaseClock pc(c, "checksum of a device buffer");
+    std::vector<ZaCkPart> parts;
+    const int r = checksum_launch(c, d, n, adler_io != nullptr, parts);
+    if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    checksum_fold(parts, crc_io, adler_io);
     return ZNGAMD_OK;
 }
 
@@ -841,10 +859,13 @@ try {
     zngamd_block B; B.off = 0; B.len = (uint32_t)in_len; B.dict_len = 0; B.flags = ZNGAMD_FLAG_FINAL; B.reserved = 0;
     std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; const uint8_t *packed = nullptr;
     if (window_bits < 9 || window_bits > 15) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    // the zlib container's Adler-32: its kernel goes out in front of the deflate kernels and is waited for with them
+    std::vector<ZaCkPart> ck_parts;
+    if (adler) { r = checksum_launch(c, c->st_in.p, in_len, true, ck_parts); if (r) return r; }
     r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, &packed, 1 << window_bits, out, out_cap, out_len);
-    if (r) return r;
+    if (r) { (void)hipStreamSynchronize(c->stream); return r; }       // (ck_parts is a local the copy may still be writing)
     if (crc) { uint32_t v = 0; for (size_t u = 0; u < hu.size(); u++) v = u ? zngamd_crc32_combine(v, ucrc[u], hu[u].in_len) : ucrc[u]; *crc = v; }
-    if (adler) { uint32_t a = 1; r = checksum_dev(c, c->st_in.p, in_len, nullptr, &a); if (r) return r; *adler = a; }
+    if (adler) { uint32_t a = 1; checksum_fold(ck_parts, nullptr, &a); *adler = a; }
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 
