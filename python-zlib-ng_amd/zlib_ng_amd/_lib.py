@@ -579,13 +579,26 @@ class Context:
             return r, memoryview(out)[:n], nm.value, used.value
         return r, _take(out, n), nm.value, used.value
 
-    def gzip_members(self, data, block_size, level):
+    @staticmethod
+    def gzip_members_room(n, block_size):
+        """Bytes that always hold the members of n bytes of input."""
+        nb = max(1, (n + block_size - 1) // max(block_size, 1))
+        return n + n // 16 + nb * 2800 + 64         # index: 4 bytes per 256 bytes of input; flat headers; stored worst case
+
+    def gzip_members(self, data, block_size, level, into=None):
+        """One indexed gzip member per block_size bytes of `data`; into = a buffer of the caller's with gzip_members_room()
+        bytes (warm memory: a fresh result object costs a page fault per 4 KiB): the result is then a view of it."""
         p, keep = _addr(data)
         n = memoryview(data).nbytes
-        nb = max(1, (n + block_size - 1) // max(block_size, 1))
-        cap = n + n // 16 + nb * 2800 + 64          # index: 4 bytes per 256 bytes of input; flat headers; stored worst case
-        out = _Out(cap)
+        cap = self.gzip_members_room(n, block_size)
         ol = C.c_uint64(0)
+        if into is not None and len(into) >= cap:
+            anchor = C.c_char.from_buffer(into)
+            r = self.L.zngamd_gzip_members(self.h, p, n, block_size, level, C.cast(C.addressof(anchor), C.c_void_p), len(into), C.byref(ol))
+            del anchor
+            self._chk(r)
+            return memoryview(into)[:ol.value]
+        out = _Out(cap)
         self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, out.addr(), cap, C.byref(ol)))
         return out.take(ol.value)
 

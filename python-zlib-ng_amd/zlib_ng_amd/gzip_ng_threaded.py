@@ -448,9 +448,19 @@ class _ThreadedGzipWriter(io.RawIOBase):
         """One engine batch (spread over the writer's GPUs) and the write of its output."""
         if self._members:
             # indexed members (zngamd_gzip_members): header, chunk index, FINAL deflate block, CRC32 and ISIZE per member, in one piece
-            packed = self._contexts()[0].gzip_members(buf, self._member_size, self.level)
+            ctx = self._contexts()[0]
+            turn = self._packed_turn
+            self._packed_turn = turn ^ 1
+            need = ctx.gzip_members_room(memoryview(buf).nbytes, self._member_size)
+            into = self._packed[turn]
+            if into is None or len(into) < need:                     # (the file write of the batch before last, which used it, is through)
+                _lib.give_buffer(into)
+                into = self._packed[turn] = _lib.take_buffer(need)
+            packed = ctx.gzip_members(buf, self._member_size, self.level, into=into)
             self._members_written += len(packed)
             self._settle_write()
+            if not isinstance(self.raw, (io.FileIO, io.BufferedWriter, io.BufferedRandom, io.BytesIO)):
+                packed = bytes(packed)               # an object of the caller's: it may keep what it is given
             if sys.is_finalizing():
                 self.raw.write(packed)
                 return
