@@ -443,7 +443,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     const uint32_t ch = std::min(n, c->chunk_units);
     HIPCHK(c, c->units.ensure(n)); HIPCHK(c, c->segbits.ensure((size_t)n * ZA_SEGB_STRIDE)); HIPCHK(c, c->cidx.ensure((size_t)n * ZA_CIDX_STRIDE)); HIPCHK(c, c->status.ensure(n));
     if (level > 0) {
-        HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
+        HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE + 8)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
         HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
     }
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
