@@ -42,7 +42,7 @@ extern "C" {
 #define ZA_MAX_UNIT   131072    /* one codec unit = at most 64 segments             */
 #define ZA_MAX_SEGS   64
 #define ZA_WIN        32768
-#define ZA_HASH_BITS  13
+#define ZA_HASH_BITS  14
 #define ZA_MIN_MATCH  4
 #define ZA_HASH_BYTES 6         /* bytes hashed into a chain bucket */
 #define ZA_MAX_MATCH  258

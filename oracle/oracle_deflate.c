@@ -32,8 +32,8 @@ typedef struct { int chain, nice, lazy, cap; } za_level;
  * wins ties, the walk ends at min(nice, cap) equal bytes); the winner is then extended to its true length.
  * 16 on the fast levels (one 16-byte compare per candidate on the GPU), 258 = compare in full. */
 static const za_level LEVELS[10] = {
-    {0, 0, 0, 0}, {1, 8, 0, 16}, {2, 8, 0, 16}, {3, 16, 0, 16}, {2, 16, 8, 16}, {2, 32, 16, 16},
-    {3, 32, 16, 16}, {8, 32, 16, 258}, {10, 64, 16, 258}, {12, 128, 128, 258}
+    {0, 0, 0, 0}, {1, 8, 0, 16}, {2, 8, 0, 16}, {3, 16, 0, 16}, {2, 16, 8, 16}, {2, 32, 8, 16},
+    {2, 32, 16, 16}, {6, 32, 16, 258}, {8, 64, 16, 258}, {12, 128, 128, 258}
 };
 
 /* test-only: forced token-boundary granularity (default ZA_SEG) */

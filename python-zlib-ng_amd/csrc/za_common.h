@@ -12,7 +12,9 @@
 #define ZA_MAX_UNIT   131072
 #define ZA_MAX_SEGS   64
 #define ZA_WIN        32768
-#define ZA_HASH_BITS  13
+#ifndef ZA_HASH_BITS
+#define ZA_HASH_BITS  14
+#endif
 #define ZA_MIN_MATCH  4
 #define ZA_HASH_BYTES 6
 #define ZA_MAX_MATCH  258

@@ -91,7 +91,7 @@ __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t 
     return near ? near : pre;
 }
 
-__global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
+__global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
                                                    const uint32_t *__restrict__ run_start,
                                                    uint16_t *__restrict__ prev_ws)
 {
@@ -100,10 +100,17 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
     // the lanes of an atomic out of order (see above)
     __shared__ uint32_t head[1 << ZA_HASH_BITS];
     __shared__ uint32_t ring[(2 * ZA_CH_CHUNK + 16) / 4];      // the bytes of two groups (+ the first 16 again behind the end)
-    __shared__ uint16_t hbuf[2][ZA_CH_CHUNK];                  // byte offsets of the buckets (bucket * 4) of a group's positions, two groups;
-                                                               // the inserting wave collects the group's links in the buffer it has read
+    __shared__ uint16_t hbuf[2][ZA_CH_CHUNK];                  // byte offsets of the buckets (bucket * 4) of a group's positions, two groups
+    __shared__ uint32_t obuf[2][ZA_CH_CHUNK];                  // what the atomics returned for a group (the links' raw form), two groups; the
+                                                               // storing wave turns a group into links in place
     const uint32_t lane = (uint32_t)za_lane();
-    const bool hasher = threadIdx.x < 64;                      // wave 0 fetches and hashes, wave 1 inserts and stores
+    // FOUR wavefronts per stream, a pipeline of three stages with one barrier per tick (a group of 1 024 positions per tick):
+    // waves 0 and 1 hash group t (wave 0 also stages the bytes of group t + 1: it takes the second half of the group, which is
+    // the half that needs them; wave 1 the first), wave 2 issues the atomics of group t - 1 (and checks their order), wave 3 turns
+    // what they returned for group t - 2 into links and stores them.  The kernel is bound by the instructions a CU issues, and a
+    // wave issues one every eight cycles or so whatever shares its SIMD: with a table of 64 KiB only two streams fit a CU, and
+    // two waves per stream would leave its SIMDs half idle.
+    const uint32_t role = threadIdx.x >> 6;
     const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
     uint32_t goff = 0;                                // positions of the run in front of the current unit
     uint32_t n_prev = 0;
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
         else {
             // a fresh table: the unit's dictionary is inserted like the unit itself (what deflateSetDictionary does per block)
             goff = 0;
-            for (uint32_t i = threadIdx.x * 4u; i < (1u << ZA_HASH_BITS); i += 512u) *(uint4 *)&head[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t i = threadIdx.x * 4u; i < (1u << ZA_HASH_BITS); i += 1024u) *(uint4 *)&head[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        __syncthreads();                                       // (the table; and both waves are through with the unit in front)
+        __syncthreads();                                       // (the table; and all waves are through with the unit in front)
         n_prev = (uint32_t)n;
         const int total = dict_len + n;
         // a carried unit starts with the last five positions of the unit in front of it: they had fewer than six bytes left
@@ -133,13 +140,13 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
         const int first = carry ? dict_len - (ZA_HASH_BYTES - 1) : 0;
         const uint32_t abase = goff + (uint32_t)(2 * ZA_WIN - dict_len) + 1u;     // table value of row index i: abase + i (> 32 768)
         if (total < ZA_HASH_BYTES) {                           // (uniform) not one 6-byte context: nothing to insert, every link is 0
-            if (!hasher && (int)lane >= first && (int)lane < total) prevdist[lane] = 0;
+            if (role == 2u && (int)lane >= first && (int)lane < total) prevdist[lane] = 0;
             continue;
         }
         if (total < 16) {
             // (uniform) a row shorter than one 16-byte load -- a stream of 6 .. 15 bytes without a dictionary, nothing carried: lane i
             // of the inserting wave takes row index i and looks at the lanes below it (the table is left alone: nothing follows it)
-            if (!hasher) {
+            if (role == 2u) {
                 uint32_t h = 0xFFFFFFFFu;
                 const bool ins = (int)lane >= first && (int)lane <= total - ZA_HASH_BYTES;
                 if (ins) h = za_hash6(za_ld32(row + lane), za_ld16(row + lane + 4));
@@ -184,33 +191,26 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
             *(uint4 *)(ring + (c & 1) * (ZA_CH_CHUNK / 4) + 4 * lane) = v;
             if ((c & 1) == 0 && lane == 0) *(uint4 *)(ring + 2 * ZA_CH_CHUNK / 4) = v;
         };
-        auto hash_group = [&](int k, uint16_t *hb) {            // needs chunk k and the head of chunk k + 1 in the ring
-#if ZA_CH_READ == 0
+        // half a group's positions hashed (steps g0 .. g0 + 7): needs chunk k and, for the second half, the head of chunk k + 1
+        auto hash_half = [&](int k, int g0, uint16_t *hb) {
             const uint32_t *w = ring + (k & 1) * (ZA_CH_CHUNK / 4) + (lane >> 2);
             const uint32_t sh = lane & 3u;
 #pragma unroll
-            for (int g = 0; g < ZA_CH_GROUP; g++) {
-                const uint32_t d0 = w[16 * g], d1 = w[16 * g + 1], d2 = w[16 * g + 2];
+            for (int g = 0; g < ZA_CH_GROUP / 2; g++) {
+                const int gg = g0 + g;
+                const uint32_t d0 = w[16 * gg], d1 = w[16 * gg + 1], d2 = w[16 * gg + 2];
                 const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0xFFFFu;
-                hb[64 * g + lane] = (uint16_t)ZA_CH_OFFS(za_hash6x(lo, hi));
+                hb[64 * gg + lane] = (uint16_t)ZA_CH_OFFS(za_hash6x(lo, hi));
             }
-#else
-            // a position's bytes as ONE 8-byte read at its own byte address (the LDS takes reads at any alignment, and takes its time)
-            const uint8_t *w = (const uint8_t *)ring + (k & 1) * ZA_CH_CHUNK + lane;
-#pragma unroll
-            for (int g = 0; g < ZA_CH_GROUP; g++) {
-                const uint64_t v = *(const za_u64u *)(w + 64 * g);
-                hb[64 * g + lane] = (uint16_t)ZA_CH_OFFS(za_hash6x((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu));
-            }
-#endif
         };
-        auto group_inner = [&](int k) -> bool {                 // (uniform) group k lies wholly inside the row: no test per lane, links through LDS
+        auto group_inner = [&](int k) -> bool {                 // (uniform) group k lies wholly inside the row: no test per lane
             const int tbase = t0 + k * ZA_CH_CHUNK;
             return tbase >= first && tbase + ZA_CH_CHUNK - 1 <= iclamp_hi;
         };
-        // ---- wave 1: a group's atomics go out back to back, then their results become links (`inner`: the group lies wholly
-        // inside the row -- all but a unit's first and last -- and needs no test per lane; its links leave 16 bytes per lane)
-        auto insert_as = [&](auto inner_tag, int tbase, uint16_t *hb) {
+        // wave 2: a group's atomics go out back to back; what they return goes to the storing wave as it is (`inner`: the group
+        // lies wholly inside the row -- all but a unit's first and last -- and needs no test per lane).  Only the order check is
+        // made here, where the buckets still are in registers: a lane served out of order got back a position at or above its own
+        auto insert_as = [&](auto inner_tag, int tbase, const uint16_t *hb, uint32_t *ob) {
             constexpr bool inner = decltype(inner_tag)::value;
             const uint32_t li = (uint32_t)tbase + lane;                 // my row index in the group's first step
             uint32_t hh[ZA_CH_GROUP], old[ZA_CH_GROUP];
@@ -228,18 +228,11 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
                 if (ins) old[g] = atomicMax((uint32_t *)((uint8_t *)head + hh[g]), A0 + 64u * (uint32_t)g);
 #endif
             }
-            int worst = 1;                                             // the smallest `position - entry` of the group: below 1 = served out of order
-            uint32_t dd[ZA_CH_GROUP];
+            uint32_t top = 0;                                          // bit 31 set: some step got back an entry at or above its own position
 #pragma unroll
-            for (int g = 0; g < ZA_CH_GROUP; g++) {
-                const int i = (int)li + 64 * g;
-                const bool ins = inner || (i >= first && i <= iclamp_hi);
-                dd[g] = (A0 + 64u * (uint32_t)g) - old[g];
-                const int ds = ins ? (int)dd[g] : 1;
-                worst = ds < worst ? ds : worst;
-            }
+            for (int g = 0; g < ZA_CH_GROUP; g++) top |= (A0 + 64u * (uint32_t)g - old[g] - 1u);
 #ifndef ZA_ABL_CH_NOCHECK
-            if (__builtin_expect(__ballot(worst <= 0) != 0ull, 0)) {
+            if (__builtin_expect(__ballot((int)top < 0) != 0ull, 0)) {
 #pragma unroll 1
                 for (int g = 0; g < ZA_CH_GROUP; g++) {
                     const int i = (int)li + 64 * g;
@@ -248,83 +241,103 @@ __global__ __launch_bounds__(128) void za_k_chains(const uint8_t *__restrict__ i
                     uint32_t hg = hh[0], og = old[0];
 #pragma unroll
                     for (int q = 1; q < ZA_CH_GROUP; q++) { hg = g == q ? hh[q] : hg; og = g == q ? old[q] : og; }
-                    const uint32_t dfix = A - za_chains_fix(hg >> 2, A, og, ins);
+                    const uint32_t ofix = za_chains_fix(hg >> 2, A, og, ins);
 #pragma unroll
-                    for (int q = 0; q < ZA_CH_GROUP; q++) dd[q] = g == q ? dfix : dd[q];
+                    for (int q = 0; q < ZA_CH_GROUP; q++) old[q] = g == q ? ofix : old[q];
                 }
             }
 #endif
-            // positions with fewer than 6 bytes left are never inserted: their link is 0
-            if (inner) {
-                // the links pass through the group's hash buffer (mine until the barrier: its entries are in my registers) and leave
-                // 16 bytes per lane.  (Stored by wave 0 behind the next barrier instead: 4.3 -> 5.0 ms, that wave is the slower one.)
 #pragma unroll
-                for (int g = 0; g < ZA_CH_GROUP; g++) hb[64 * g + lane] = (uint16_t)(dd[g] <= (uint32_t)ZA_WIN ? dd[g] : 0u);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int g = 0; g < ZA_CH_GROUP; g++) ob[64 * g + lane] = old[g];
+        };
+        // wave 3: what the atomics returned becomes links (position - entry if that is at most 32 768; positions with fewer than 6
+        // bytes left were never inserted: 0), which leave 16 bytes per lane twice where the group lies wholly inside the row (rows
+        // and groups start at multiples of 128 bytes)
+        auto store_links = [&](int k, uint32_t *ob) {
+            const int tbase = t0 + k * ZA_CH_CHUNK;
+            const uint32_t A0 = abase + (uint32_t)tbase + lane;
+            uint32_t dd[ZA_CH_GROUP];
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g++) dd[g] = A0 + 64u * (uint32_t)g - ob[64 * g + lane];
+            if (group_inner(k)) {
+                uint16_t *lb = (uint16_t *)ob;                              // the links take the front half of the group's own buffer
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const uint4 v0 = *(const uint4 *)&hb[8 * lane], v1 = *(const uint4 *)&hb[512 + 8 * lane];
+#pragma unroll
+                for (int g = 0; g < ZA_CH_GROUP; g++) lb[64 * g + lane] = (uint16_t)(dd[g] <= (uint32_t)ZA_WIN ? dd[g] : 0u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 v0 = *(const uint4 *)&lb[8 * lane], v1 = *(const uint4 *)&lb[512 + 8 * lane];
 #ifndef ZA_ABL_CH_NOSTORE
-                *(uint4 *)(prevdist + tbase + 8 * (int)lane) = v0;      // (rows and groups start at multiples of 128 bytes)
+                *(uint4 *)(prevdist + tbase + 8 * (int)lane) = v0;
                 *(uint4 *)(prevdist + tbase + 512 + 8 * (int)lane) = v1;
 #endif
-                __builtin_amdgcn_wave_barrier();
             } else {
 #pragma unroll
                 for (int g = 0; g < ZA_CH_GROUP; g++) {
-                    const int i = (int)li + 64 * g;
-                    const bool inrow = i >= first && i < total;
-                    if (inrow) prevdist[i] = (uint16_t)((i <= iclamp_hi && dd[g] <= (uint32_t)ZA_WIN) ? dd[g] : 0u);
+                    const int i = tbase + (int)lane + 64 * g;
+                    if (i >= first && i < total) prevdist[i] = (uint16_t)((i <= iclamp_hi && dd[g] <= (uint32_t)ZA_WIN) ? dd[g] : 0u);
                 }
             }
         };
-        auto insert = [&](int k, uint16_t *hb) {
-            const int tbase = t0 + k * ZA_CH_CHUNK;
-            if (group_inner(k)) insert_as(std::true_type{}, tbase, hb);
-            else insert_as(std::false_type{}, tbase, hb);
-        };
-        // iteration k: wave 0 puts chunk k + 1 into the ring, asks for chunk k + 2 and hashes group k; wave 1 inserts group k - 1;
-        // one barrier per iteration (a hash buffer is written again two iterations after it was read; the ring is wave 0's alone)
-        // The two waves run loops of their own and meet at one barrier per iteration (as many in either loop).  Wave 0 asks for the
-        // bytes FOUR groups ahead -- chunk c travels in register set c & 3, the loop is unrolled four times so that no set is ever
-        // copied -- and its loop holds no other memory operation, so the wait in front of a chunk's staging is for that chunk alone:
-        // with the inserting wave's stores in the same loop the compiler waited for EVERY load in flight, the one just issued
-        // included, and an iteration lasted as long as a trip to memory whatever the two waves did in it (a stream had one
-        // 1 KiB load in flight, a CU four).
         auto wg_barrier = [] {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
-        if (hasher) {
+        // Ticks t = 0 .. ngroups + 1, one barrier behind each (and one behind wave 0's prologue).  Wave 0 asks for the bytes FOUR
+        // groups ahead -- chunk c travels in register set c & 3, its loop is unrolled four times so that no set is ever copied --
+        // and its loop holds no other memory operation, so the wait in front of a chunk's staging is for that chunk alone.
+        if (role == 0u) {
             za_v4u32 p0 = {0u, 0u, 0u, 0u}, p1 = p0, p2 = p0, p3 = p0;
             fetch(0, p0);
             za_wait_loads<0>(p0, p1, p2, p3);
             stage(0, make_uint4(p0.x, p0.y, p0.z, p0.w));
             fetch(1, p1); fetch(2, p2); fetch(3, p3); fetch(4, p0);
-            auto iteration = [&](int k, za_v4u32 &pend) {        // pend: chunk k + 1 on arrival (the oldest of four in flight), chunk k + 5 on return
-                if (k < ngroups) {
+            wg_barrier();
+            auto tick = [&](int t, za_v4u32 &pend) {             // pend: chunk t + 1 on arrival (the oldest of four in flight), chunk t + 5 on return
+                if (t < ngroups) {
                     za_wait_loads<3>(p0, p1, p2, p3);
-                    stage(k + 1, make_uint4(pend.x, pend.y, pend.z, pend.w));
-                    fetch(k + 5, pend);
-                    hash_group(k, hbuf[k & 1]);
+                    stage(t + 1, make_uint4(pend.x, pend.y, pend.z, pend.w));
+                    fetch(t + 5, pend);
+                    hash_half(t, ZA_CH_GROUP / 2, hbuf[t & 1]);
                 }
                 wg_barrier();
             };
 #pragma unroll 1
-            for (int k = 0; k <= ngroups; k += 4) {
-                iteration(k, p1);
-                if (k + 1 > ngroups) break;
-                iteration(k + 1, p2);
-                if (k + 2 > ngroups) break;
-                iteration(k + 2, p3);
-                if (k + 3 > ngroups) break;
-                iteration(k + 3, p0);
+            for (int t = 0; t <= ngroups + 1; t += 4) {
+                tick(t, p1);
+                if (t + 1 > ngroups + 1) break;
+                tick(t + 1, p2);
+                if (t + 2 > ngroups + 1) break;
+                tick(t + 2, p3);
+                if (t + 3 > ngroups + 1) break;
+                tick(t + 3, p0);
             }
             za_wait_loads<0>(p0, p1, p2, p3);                    // (the chunks asked for behind the row's end: their registers are free only now)
-        } else {
+        } else if (role == 1u) {
+            wg_barrier();
 #pragma unroll 1
-            for (int k = 0; k <= ngroups; k++) {
-                if (k >= 1) insert(k - 1, hbuf[(k - 1) & 1]);
+            for (int t = 0; t <= ngroups + 1; t++) {
+                if (t < ngroups) hash_half(t, 0, hbuf[t & 1]);
+                wg_barrier();
+            }
+        } else if (role == 2u) {
+            wg_barrier();
+#pragma unroll 1
+            for (int t = 0; t <= ngroups + 1; t++) {
+                if (t >= 1 && t - 1 < ngroups) {
+                    const int k = t - 1, tbase = t0 + k * ZA_CH_CHUNK;
+                    if (group_inner(k)) insert_as(std::true_type{}, tbase, hbuf[k & 1], obuf[k & 1]);
+                    else insert_as(std::false_type{}, tbase, hbuf[k & 1], obuf[k & 1]);
+                }
+                wg_barrier();
+            }
+        } else {
+            wg_barrier();
+#pragma unroll 1
+            for (int t = 0; t <= ngroups + 1; t++) {
+                if (t >= 2) store_links(t - 2, obuf[(t - 2) & 1]);
                 wg_barrier();
             }
         }

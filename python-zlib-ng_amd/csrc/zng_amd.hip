@@ -25,9 +25,10 @@ static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants
 
 // (max_chain, nice_length, max_lazy) per level -- DESIGN.md 3.6: calibrated so that the ratio at each
 // level is >= zlib 1.2.11's at the same level on the text / FASTQ / mixed corpora
+#define ZA_CH_STREAMS_PER_CU (ZA_HASH_BITS >= 14 ? 2u : 3u)     // what the chain kernel's LDS (table + 14 KiB) lets a CU hold
 static const ZaLevel ZA_LEVELS[10] = {
-    {0, 0, 0, ZA_WIN, 0}, {1, 8, 0, ZA_WIN, 16}, {2, 8, 0, ZA_WIN, 16}, {3, 16, 0, ZA_WIN, 16}, {2, 16, 8, ZA_WIN, 16}, {2, 32, 16, ZA_WIN, 16},
-    {3, 32, 16, ZA_WIN, 16}, {8, 32, 16, ZA_WIN, 258}, {10, 64, 16, ZA_WIN, 258}, {12, 128, 128, ZA_WIN, 258}};
+    {0, 0, 0, ZA_WIN, 0}, {1, 8, 0, ZA_WIN, 16}, {2, 8, 0, ZA_WIN, 16}, {3, 16, 0, ZA_WIN, 16}, {2, 16, 8, ZA_WIN, 16}, {2, 32, 8, ZA_WIN, 16},
+    {2, 32, 16, ZA_WIN, 16}, {6, 32, 16, ZA_WIN, 258}, {8, 64, 16, ZA_WIN, 258}, {12, 128, 128, ZA_WIN, 258}};
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;
@@ -153,7 +154,7 @@ try {
     c->stream = c->own_stream;
     if (const char *e = getenv("ZNGAMD_CHUNK_UNITS")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chunk_units = (uint32_t)v; }
     if (const char *e = getenv("ZNGAMD_CHAIN_RUN")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) c->chain_run = (uint32_t)v; }
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->chain_slots = (uint32_t)cus * 4u; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->chain_slots = (uint32_t)cus * ZA_CH_STREAMS_PER_CU; }
     // tables: CRC-32 byte table and x^(8*2048*k) mod P
     uint32_t tab[256], x8k[64];
     for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1) ? (0xEDB88320u ^ (v >> 1)) : (v >> 1); tab[i] = v; }
@@ -504,7 +505,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         run_pos += nruns + 1;
         if (level > 0) {
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
-              hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(128), 0, c->stream, d_in, du, d_runs, c->prev.p); }
+              hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
               if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
               else hipLaunchKernelGGL(za_k_search<false>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L); }
