@@ -10,7 +10,7 @@
  * this file byte for byte, stage by stage.
  *
  *   stage 1  hash chains        prevdist[p] = distance to the nearest earlier position whose
- *                               6-byte hash lands in the same 13-bit bucket, if within 32 768
+ *                               6-byte hash lands in the same 14-bit bucket, if within 32 768
  *   stage 2  match search       best[p] = longest match among the first `chain` chain entries,
  *                               nearest wins ties, truncated at the 2 KiB segment end
  *   stage 3  parse              per 2 KiB segment, greedy (levels 1-3) or one-step lazy (4-9)

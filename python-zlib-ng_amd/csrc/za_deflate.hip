@@ -21,8 +21,8 @@
 // ------------------------------------------------------------------------------------------------
 // k_chains
 // ------------------------------------------------------------------------------------------------
-// One stream (a run of consecutive units) per workgroup of TWO wavefronts, and the whole insert of 64 consecutive positions
-// is ONE LDS instruction: the head table holds 32-bit run-absolute positions, and every lane does a returning atomic maximum
+// One stream (a run of consecutive units) per workgroup, and the whole insert of 64 consecutive positions is ONE LDS
+// instruction: the head table holds 32-bit run-absolute positions, and every lane does a returning atomic maximum
 // of its position into its bucket.  The LDS executes the lanes of an instruction that name one address one after the other,
 // in ascending lane order, so what comes back to a lane is the largest position its bucket held before it: the nearest
 // earlier position of the bucket -- an earlier lane of this very instruction or the table's entry from earlier steps --
@@ -31,21 +31,22 @@
 // back a position that is not below its own, and the step's links are then worked out lane by lane (za_chains_fix; the
 // table itself is right in any order, a maximum does not depend on it).  A wave's LDS operations execute in program order,
 // so the step behind needs no wait: the atomics of consecutive steps go out back to back and their results are used a group
-// of steps later -- no hand-over of positions between owners of bucket classes, no ordering of same-bucket lanes by hand,
-// and the links of a step leave as one 128-byte store.
+// of steps later -- no hand-over of positions between owners of bucket classes, no ordering of same-bucket lanes by hand.
 // (Until round 3 a 256-thread workgroup split the bucket space over four waves, handed every position to the owning wave
 // through LDS rings -- three ballots, eight mbcnt and two barriers per 256 positions -- and ordered the same-bucket lanes of a
 // 64-entry insert with an exchange on a side array: 108 lane-instructions per position, 14.6 ms per 4 GiB.)
 // Positions are 32 bits and absolute in the run, so nothing ages and nothing wraps: a link is valid if it reaches back at most
-// 32 768.  The table is 2^13 x 4 bytes = 32 KiB, which lets four streams share a CU -- one wavefront per SIMD, and a lone
-// wavefront issues an instruction every 6 to 8 cycles (profiles/ubench_occ.hip).  Hence the second wavefront: wave 0 fetches
-// the bytes and hashes them (a group of steps ahead, into a 2 KiB LDS buffer), wave 1 inserts and writes the links; they meet
-// at one barrier per group and each issues half of the instructions.
-// Neither wave talks to memory position by position: 64 lanes fetching 6 bytes each at 64 consecutive byte addresses, and 64
+// 32 768.  The table is 2^14 x 4 bytes = 64 KiB: two streams per CU.  A wave issues an instruction every eight cycles or so
+// however many others share its SIMD (profiles/ubench_occ.hip), so a stream is dealt to FOUR waves, a pipeline with one barrier
+// per group of 1 024 positions (see the kernel): two hash, one issues the atomics, one makes the links and stores them.  (With
+// a 32 KiB table and four streams per CU two waves per stream did as well -- the kernel is bound by the instructions a CU can
+// issue, about 510 per group however they are dealt: 3.7 ms per 4 GiB with 13 bits and two waves, 4.2 with four; with 14 bits
+// 6.7 with two waves and 4.8 with four.)
+// No wave talks to memory position by position: 64 lanes fetching 6 bytes each at 64 consecutive byte addresses, and 64
 // two-byte stores per step, kept the kernel waiting for the vector-memory pipe (three such instructions per step: 7.4 ms per
 // 4 GiB whether one wave issued the rest or two).  The bytes of a group arrive as ONE 16-byte load per lane and pass through an
 // LDS ring, from which every lane takes its own six (three aligned dwords, `v_alignbyte`); the links of a group are collected
-// in LDS and leave as one 16-byte store per lane.
+// in LDS and leave as two 16-byte stores per lane.
 #define ZA_CH_GROUP 16                         // steps (of 64 positions) per group
 #ifndef ZA_CH_READ
 #define ZA_CH_READ 0                           // 1: a position's bytes as one 8-byte LDS read at its own byte address -- 4.1 -> 9.8 ms
