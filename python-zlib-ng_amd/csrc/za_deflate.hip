@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
     // a valid link exactly if it is at most 32 768 (an empty bucket gives more), and it is below 1 exactly if the LDS served
     // the lanes of an atomic out of order (see above)
     __shared__ uint32_t head[1 << ZA_HASH_BITS];
-    __shared__ uint32_t ring[(2 * ZA_CH_CHUNK + 16) / 4];      // the bytes of two groups (+ the first 16 again behind the end)
-    __shared__ uint16_t hbuf[2][ZA_CH_CHUNK];                  // byte offsets of the buckets (bucket * 4) of a group's positions, two groups
-    __shared__ uint32_t obuf[2][ZA_CH_CHUNK];                  // what the atomics returned for a group (the links' raw form), two groups; the
+    __shared__ __attribute__((aligned(16))) uint32_t ring[(2 * ZA_CH_CHUNK + 16) / 4];      // the bytes of two groups (+ the first 16 again behind the end)
+    __shared__ __attribute__((aligned(16))) uint16_t hbuf[2][ZA_CH_CHUNK];                  // byte offsets of the buckets (bucket * 4) of a group's positions, two groups
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[2][ZA_CH_CHUNK];                  // what the atomics returned for a group (the links' raw form), two groups; the
                                                                // storing wave turns a group into links in place
     const uint32_t lane = (uint32_t)za_lane();
     // FOUR wavefronts per stream, a pipeline of three stages with one barrier per tick (a group of 1 024 positions per tick):
@@ -192,16 +192,24 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
             *(uint4 *)(ring + (c & 1) * (ZA_CH_CHUNK / 4) + 4 * lane) = v;
             if ((c & 1) == 0 && lane == 0) *(uint4 *)(ring + 2 * ZA_CH_CHUNK / 4) = v;
         };
-        // half a group's positions hashed (steps g0 .. g0 + 7): needs chunk k and, for the second half, the head of chunk k + 1
+        // half a group's positions hashed (steps g0 .. g0 + 7: 512 positions): needs chunk k and, for the second half, the head of
+        // chunk k + 1.  A lane takes FOUR consecutive positions at a time out of one set of three aligned dwords (the four byte
+        // offsets are constants: the first needs no alignment at all) and leaves their four bucket offsets as one 8-byte store --
+        // three reads and one write per four positions instead of per position (a quarter fewer instructions in this stage).
         auto hash_half = [&](int k, int g0, uint16_t *hb) {
-            const uint32_t *w = ring + (k & 1) * (ZA_CH_CHUNK / 4) + (lane >> 2);
-            const uint32_t sh = lane & 3u;
+#ifdef ZA_ABL_CH_NOHASH
+            return;
+#endif
+            const uint32_t *w = ring + (k & 1) * (ZA_CH_CHUNK / 4) + 16 * g0 + lane;     // dword of position 64 g0 + 4 lane
+            uint16_t *o = hb + 64 * g0 + 4 * lane;
 #pragma unroll
-            for (int g = 0; g < ZA_CH_GROUP / 2; g++) {
-                const int gg = g0 + g;
-                const uint32_t d0 = w[16 * gg], d1 = w[16 * gg + 1], d2 = w[16 * gg + 2];
-                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0xFFFFu;
-                hb[64 * gg + lane] = (uint16_t)ZA_CH_OFFS(za_hash6x(lo, hi));
+            for (int j = 0; j < ZA_CH_GROUP / 8; j++) {                                   // positions 64 g0 + 256 j + 4 lane + {0, 1, 2, 3}
+                const uint32_t d0 = w[64 * j], d1 = w[64 * j + 1], d2 = w[64 * j + 2];
+                const uint32_t h0 = ZA_CH_OFFS(za_hash6x(d0, d1 & 0xFFFFu));
+                const uint32_t h1 = ZA_CH_OFFS(za_hash6x(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1) & 0xFFFFu));
+                const uint32_t h2 = ZA_CH_OFFS(za_hash6x(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2) & 0xFFFFu));
+                const uint32_t h3 = ZA_CH_OFFS(za_hash6x(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3) & 0xFFFFu));
+                *(uint2 *)(o + 256 * j) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
             }
         };
         auto group_inner = [&](int k) -> bool {                 // (uniform) group k lies wholly inside the row: no test per lane
