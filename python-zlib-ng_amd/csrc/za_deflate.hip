@@ -48,9 +48,6 @@
 // LDS ring, from which every lane takes its own six (three aligned dwords, `v_alignbyte`); the links of a group are collected
 // in LDS and leave as two 16-byte stores per lane.
 #define ZA_CH_GROUP 16                         // steps (of 64 positions) per group
-#ifndef ZA_CH_READ
-#define ZA_CH_READ 0                           // 1: a position's bytes as one 8-byte LDS read at its own byte address -- 4.1 -> 9.8 ms
-#endif
 // the byte offset of a bucket's table entry out of the full 32-bit product: (x >> 19) << 2 with two full-rate operations
 // (a right shift and an AND; a left shift runs at half rate on this chip, profiles/ubench_issue2.hip)
 #define za_hash6x(lo, hi) (((lo) * 2654435761u) ^ ((hi) * 2246822519u))

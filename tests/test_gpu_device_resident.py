@@ -38,7 +38,7 @@ def test_device_resident_round_trip(ctx):
     data = corpus.text(40 * B + 12345, seed=8).tobytes()           # 41 blocks, the last one short
     nb = (len(data) + B - 1) // B
     d_in = Dev(ctx, len(data) + 64); d_in.put(data + bytes(64))
-    for level in (1, 6, 8, 9):      # (8 and 9: the work-list search, ten and twelve chain steps in visits of four)
+    for level in (1, 6, 8, 9):      # (8 and 9: the work-list search, eight and twelve chain steps in visits of four)
         blocks = (_lib.Block * nb)()
         for b in range(nb):
             blocks[b] = _lib.Block(b * B, min(B, len(data) - b * B), 32768 if b else 0, 0, 0)
@@ -154,7 +154,7 @@ def test_chain_tables_carried_across_units_equal_the_oracle(monkeypatch):
         nb = len(blocks_py)
         blocks = (_lib.Block * nb)(*[_lib.Block(o, s, d, 0, 0) for o, s, d in blocks_py])
         nu = L.zngamd_count_units(blocks, nb)
-        for level in (1, 6, 8, 9):      # (8 and 9: the work-list search, ten and twelve chain steps in visits of four)
+        for level in (1, 6, 8, 9):      # (8 and 9: the work-list search, eight and twelve chain steps in visits of four)
             d_slots, d_len, d_crc = Dev(ctx, nu * _lib.SLOT_STRIDE), Dev(ctx, nu * 4), Dev(ctx, nu * 4)
             ublock = (C.c_uint32 * nu)()
             assert L.zngamd_deflate_blocks_dev(h, d_in.p, total, blocks, nb, level, d_slots.p, d_len.p, d_crc.p, ublock) == 0, ctx.err()
