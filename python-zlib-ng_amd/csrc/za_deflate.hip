@@ -425,7 +425,8 @@ __device__ __forceinline__ int za_search_extend(const uint32_t *win32, uint32_t 
 }
 
 // FULL: candidates are compared in full (levels with cap 258); otherwise on 16 bytes, winner extended afterwards
-template <bool FULL>
+// STEPS: the chain steps of the level as a constant (1 .. 3: the walk is unrolled, no loop counter, no loop) or 0 = L.chain
+template <bool FULL, int STEPS = 0>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                  const ZaUnit *__restrict__ units,
                                                                  const uint32_t *__restrict__ run_start,
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                          uint32_t &q, uint32_t &qb, uint32_t &d, int &best_len, int &best_dist, int &depth) -> bool {
             bool alive = depth > 0;
             int steps = ZA_WL_STEPS;
+#pragma unroll
             while (alive && steps-- > 0) {
                 depth--;
                 q -= d;
@@ -710,7 +712,8 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 uint32_t q = P;
                 uint32_t qb = RING_B0 + 2u * slot;                           // LDS byte address of q's link, kept incrementally
                 uint32_t d = *(const uint16_t *)(lds + qb);
-                int depth = L.chain;
+                int depth = STEPS > 0 ? STEPS : L.chain;
+#pragma unroll
                 while (depth-- > 0) {
                     q -= d;
                     qb -= 2u * d;

@@ -508,6 +508,9 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
               hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
               if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
+              else if (L.chain == 1) hipLaunchKernelGGL((za_k_search<false, 1>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
+              else if (L.chain == 2) hipLaunchKernelGGL((za_k_search<false, 2>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
+              else if (L.chain == 3) hipLaunchKernelGGL((za_k_search<false, 3>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
               else hipLaunchKernelGGL(za_k_search<false>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L); }
             { ProfScope ps(c, ZNGAMD_K_PARSE);
               hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
