@@ -1677,13 +1677,16 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
     uint64_t pos = 0, op = 0, last_member_bytes = 0;
     uint32_t members = 0;
     int ret = ZNGAMD_OK;
+    bool prefix_done = false;                        // the fast path for indexed members took the front of the buffer
     // fast path: the whole stream is indexed members -> two-pass scheme
     {
         uint64_t doff; bool za; uint32_t hl;
         if (in_len >= ZA_MEMBER_FIXED + 8 && parse_gzip_header(in, in_len, 0, &doff, &za, &hl) == ZNGAMD_OK && za) {
             std::vector<ZaMember> hm; uint64_t total = 0;
             uint64_t covered = 0;
-            if (scan_members_dev(c, c->st_in.p, in_len, hm, &total, partial, &covered) == ZNGAMD_OK) {
+            // (a run of indexed members at the front is enough: what follows them -- members of another writer appended to the
+            // file -- goes to the member loop below)
+            if (scan_members_dev(c, c->st_in.p, in_len, hm, &total, true, &covered) == ZNGAMD_OK) {
                 if (total > out_cap) { *out_len = total; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
                 HIPCHK(c, c->members.ensure(hm.size())); HIPCHK(c, c->mstatus.ensure(hm.size()));
                 HIPCHK(c, hipMemcpyAsync(c->members.p, hm.data(), hm.size() * sizeof(ZaMember), hipMemcpyHostToDevice, c->stream));
@@ -1695,13 +1698,18 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
                 prof_collect(c);
                 bool all_ok = true;
                 for (size_t i = 0; i < st.size(); i++) if (st[i] != ZA_I_OK) { all_ok = false; break; }
-                if (all_ok) {
+                if (all_ok && (covered == in_len || partial)) {
                     if (total) { const int rc_ = d2h_payload(c, out, c->st_out.p, total); if (rc_) return rc_; }
                     *out_len = total;
                     if (n_members) *n_members = (uint32_t)hm.size();
                     c->paths[ZNGAMD_PATH_INDEXED] += hm.size();
                     *in_consumed = covered;          // == in_len unless partial
                     return ZNGAMD_OK;
+                }
+                if (all_ok) {                        // the indexed members are a prefix of the buffer: their bytes stay where they are
+                    c->paths[ZNGAMD_PATH_INDEXED] += hm.size();
+                    op = total; members = (uint32_t)hm.size(); pos = covered;
+                    prefix_done = true;
                 }
                 // anything unexpected (foreign 'ZA' field, stored blocks, corruption): the sequential
                 // reader below decides, member by member
@@ -1710,7 +1718,7 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
     }
     // second fast path: BGZF-style members ('B','C' subfield = block size - 1).  The member table comes from a
     // header hop over the host copy; all members are then decoded in one launch, one wavefront each.
-    {
+    if (!prefix_done) {
         std::vector<ZaMember> hm; uint64_t total = 0;
         uint64_t covered = 0;
         if (hop_bgzf(in, in_len, hm, &total, partial, &covered) && hm.size() > 1) {
@@ -1743,7 +1751,7 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
         }
     }
     // third fast path: a run of small ordinary members at the front (see hop_plain_members); the loop below continues behind it
-    {
+    if (!prefix_done) {
         std::vector<ZaMember> hm; std::vector<uint64_t> hpos; uint64_t total = 0, covered = 0;
         r = hop_plain_members(c, in, in_len, hm, hpos, &total, &covered);
         if (r) return r;

@@ -327,3 +327,20 @@ def test_chunk_parallel_inflate_with_more_chunks_than_wavefronts():
     finally:
         del os.environ["ZNGAMD_READ_WINDOW"]
     assert got == data
+
+
+def test_indexed_members_followed_by_other_members(ctx):
+    """A file that starts with indexed members and goes on with members of another writer (appended later, `cat a.gz b.gz`):
+    the indexed run is decoded by the member decoder, what follows by the member loop -- one result, the right order."""
+    import gzip
+    from zlib_ng_amd import corpus, gzip_ng
+    data = corpus.text(1500000, seed=31).tobytes()
+    head = ctx.gzip_members(data[:1000000], 131072, 6)
+    tail_plain = gzip.compress(data[1000000:1300000], 6, mtime=0)
+    tail_indexed = ctx.gzip_members(data[1300000:], 131072, 6)
+    blob = bytes(head) + tail_plain + bytes(tail_indexed)
+    ctx.decode_paths(True)
+    assert gzip_ng.decompress(blob) == data
+    paths = ctx.decode_paths(True)
+    assert paths["indexed"] == 8 and paths["chunked"] + paths["sequential"] + paths["bgzf"] >= 3, paths
+    assert gzip.decompress(blob) == data
