@@ -646,10 +646,20 @@ def main():
     if foreign is not None:
         out["roofline_inflate_foreign"] = foreign
     if chained is not None:
+        # HBM bytes of the chunk pipeline's kernels for one decode of the stream: the counter passes give every kernel's average
+        # launch (per unit of the launch size they were taken at); a decode launches each of them once per batch of compressed input
+        # (ZNGAMD_CHUNK_BATCH_MIB, 512 by default), so average x batches = the kernel's share of one decode
+        ck = ("za_k_scan_sync", "za_k_chunk_decode", "za_k_chunk_compose", "za_k_chunk_chain", "za_k_chunk_resolve")
+        if all(pmc_per_unit.get(k) for k in ck) and pmc_per_unit.get("units_per_launch") == nblocks:      # (the shape the passes were taken at)
+            batch = int(os.environ.get("ZNGAMD_CHUNK_BATCH_MIB", "512")) << 20
+            nbatch = max(1, -(-comp_bytes // batch))
+            chained["traffic"] = int(sum(pmc_per_unit[k] for k in ck) * nblocks * nbatch)
+            chained["traffic_source"] = traffic_src + f"; {nbatch} batches per decode"
         out["roofline_inflate_chained"] = chained
     if bgzf is not None:
-        if pmc_per_unit.get("za_k_inflate_serial_members_bgzf"):
-            bgzf["traffic"] = int(pmc_per_unit["za_k_inflate_serial_members_bgzf"] * bgzf["members"])
+        if pmc_per_unit.get("za_k_inflate_serial_members"):
+            # (the counter passes average this kernel's launches over the foreign-member and the BGZF leg: both decode the same text)
+            bgzf["traffic"] = int(pmc_per_unit["za_k_inflate_serial_members"] * nblocks)
         out["roofline_inflate_bgzf"] = bgzf
     # ---- the drop-in API over host buffers (PCIe, Python call overhead and fresh result objects included): NEVER `value`,
     # outside the timed region, rank 0 at N = 1 only.  One-shot calls on 256 MiB of the same text; the reference's own streaming
