@@ -10,6 +10,7 @@ by construction); the data-parallel writer is gzip_ng_threaded.
 import ctypes
 import gzip
 import io
+import os
 import struct
 import sys
 import threading
@@ -49,6 +50,16 @@ def open(filename, mode="rb", compresslevel=_COMPRESS_LEVEL_TRADEOFF, encoding=N
             if val is not None:
                 raise ValueError(f"Argument '{name}' not supported in binary mode")
     raw_mode = mode.replace("t", "")
+    if ("w" in raw_mode or "a" in raw_mode or "x" in raw_mode) and os.environ.get("ZNGAMD_WRITER_MEMBERS", "0") not in ("", "0"):
+        # an addition (off unless the environment asks for it): the file as independent indexed members -- written by the block
+        # writer of gzip_ng_threaded, which has that format; still a gzip file for every reader, and the members this engine's
+        # own reader decodes with one wavefront each
+        from . import gzip_ng_threaded
+        wmode = raw_mode if "b" in raw_mode else raw_mode + "b"
+        fobj = gzip_ng_threaded.FlushableBufferedWriter(
+            gzip_ng_threaded._ThreadedGzipWriter(filename, wmode, level=compresslevel, threads=1, block_size=128 * 1024, indexed_members=True),
+            buffer_size=(1 << 16) - 1)
+        return io.TextIOWrapper(fobj, encoding, errors, newline) if text else fobj
     if _is_pathlike(filename):
         fobj = GzipNGFile(filename, raw_mode, compresslevel)
     elif hasattr(filename, "read") or hasattr(filename, "write"):

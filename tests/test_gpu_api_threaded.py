@@ -542,3 +542,29 @@ def test_writer_of_indexed_members(T, tmp_path, monkeypatch):
     with T.open(target, "wb", threads=1) as f:                  # off: the reference's framing
         f.write(data[:100000])
     assert target.read_bytes()[3] == 0 and std_gzip.decompress(target.read_bytes()) == data[:100000]
+
+
+def test_gzip_ng_open_writes_members_when_the_environment_asks(tmp_path, monkeypatch):
+    """ZNGAMD_WRITER_MEMBERS=1 also reaches gzip_ng.open(..., "w?"): the file is independent indexed members (binary and text
+    mode), any gzip reader reads it; without the variable the writer is GzipNGFile as ever."""
+    import gzip as std_gzip
+    from zlib_ng_amd import corpus, gzip_ng
+    data = corpus.text(700000, seed=41).tobytes()
+    target = tmp_path / "m.gz"
+    monkeypatch.setenv("ZNGAMD_WRITER_MEMBERS", "1")
+    with gzip_ng.open(target, "wb", compresslevel=6) as f:
+        assert not isinstance(f, gzip_ng.GzipNGFile)
+        for o in range(0, len(data), 50000):
+            f.write(data[o:o + 50000])
+    raw = target.read_bytes()
+    assert raw[3] == 4 and std_gzip.decompress(raw) == data
+    with gzip_ng.open(target, "rb") as f:
+        assert f.read() == data
+    with gzip_ng.open(target, "wt", encoding="utf-8") as f:
+        f.write("zeile eins\nzeile zwei\n")
+    assert std_gzip.decompress(target.read_bytes()) == b"zeile eins\nzeile zwei\n"
+    monkeypatch.delenv("ZNGAMD_WRITER_MEMBERS")
+    with gzip_ng.open(target, "wb") as f:
+        assert isinstance(f, gzip_ng.GzipNGFile)
+        f.write(data[:1000])
+    assert target.read_bytes()[3] != 4 and std_gzip.decompress(target.read_bytes()) == data[:1000]
