@@ -43,10 +43,13 @@ extern "C" {
 #define ZA_MAX_SEGS   64
 #define ZA_WIN        32768
 #define ZA_HASH_BITS  14
-#define ZA_MIN_MATCH  4
-#define ZA_HASH_BYTES 6         /* bytes hashed into a chain bucket */
+#define ZA_MIN_MATCH  3
+#define ZA_HASH_BYTES_A 5       /* context bytes of link table A (chains), B and C (nearest occurrence only) */
+#define ZA_HASH_BYTES_B 3
+#define ZA_HASH_BYTES_C 12
 #define ZA_MAX_MATCH  258
-#define ZA_TOO_FAR    4096      /* a minimum-length match farther than this is dropped */
+#define ZA_DP_WEAK_DIST 256     /* cost statistics: a 3-byte match farther back than this counts as literals */
+#define ZA_DP_SUB      4         /* the dynamic programme also tries the 4 next shorter lengths of a position's match */
 
 #define ZA_FLAG_FINAL 1         /* last block gets BFINAL=1, no sync-flush marker    */
 #define ZA_FLAG_FLATHDR 2       /* dynamic header in its flat form: the code-length code is the fixed 4-bit code of
@@ -77,8 +80,8 @@ uint32_t za_o_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
  * deflate(Z_SYNC_FLUSH).  Returns compressed size or a negative ZA_* code (ZA_BUF_ERROR when
  * `cap` is too small).  Optional debug outputs may be NULL. */
 typedef struct {
-    uint16_t *prevdist;   /* [dict_len + n]  chain links (stage 1)                  */
-    uint32_t *best;       /* [n]  len<<16 | dist, 0 = none (stage 2)                 */
+    uint16_t *prevdist;   /* [dict_len + n]  links of table A (stage 1)             */
+    uint32_t *best;       /* [n]  len<<16 | dist, 0 = none (stage 2, before the dynamic programme) */
     uint32_t *tokens;     /* [n]  tokens at segment slots seg*ZA_SEG (stage 3)       */
     uint32_t *seg_ntok;   /* [ZA_MAX_SEGS]                                           */
     uint32_t *hist;       /* [320] 0..285 lit/len, 288..317 dist (stage 3)           */
@@ -89,6 +92,10 @@ typedef struct {
     uint32_t *chunk_idx;  /* [ZA_MAX_CHUNKS+1] entry c: bit offset (23 bits) of the first token that starts at
                              or behind output byte c*256, | (that token's start - c*256) << 23;
                              entry nchunk = offset of EOB (stage 5; Huffman blocks only)  */
+    uint16_t *linkB;      /* [dict_len + n]  links of table B (stage 1)             */
+    uint16_t *linkC;      /* [dict_len + n]  links of table C (stage 1; levels that use it) */
+    uint32_t *best_dp;    /* [n]  the entries as the dynamic programme leaves them (stage 3a; = best on levels 1-3) */
+    uint32_t *dp_cost;    /* [258] the unit's cost table in quarter bits: [0..255] literals, [256] match base (stage 3a) */
 } za_o_debug;
 
 long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int flags,

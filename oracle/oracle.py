@@ -42,7 +42,8 @@ def build(force=False):
 class _Debug(C.Structure):
     _fields_ = [("prevdist", C.c_void_p), ("best", C.c_void_p), ("tokens", C.c_void_p),
                 ("seg_ntok", C.c_void_p), ("hist", C.c_void_p), ("lens", C.c_void_p),
-                ("seg_bits", C.c_void_p), ("btype", C.c_void_p), ("chunk_idx", C.c_void_p)]
+                ("seg_bits", C.c_void_p), ("btype", C.c_void_p), ("chunk_idx", C.c_void_p),
+                ("linkB", C.c_void_p), ("linkC", C.c_void_p), ("best_dp", C.c_void_p), ("dp_cost", C.c_void_p)]
 
 
 _lib = None
@@ -114,9 +115,12 @@ def deflate_unit(data, zdict=b"", level=6, flags=0, debug=False, cap=None):
                     tokens=np.zeros(max(nseg * SEG, 1), np.uint32),
                     seg_ntok=np.zeros(MAX_SEGS, np.uint32), hist=np.zeros(320, np.uint32),
                     lens=np.zeros(320, np.uint8), seg_bits=np.zeros(MAX_SEGS + 1, np.uint32),
-                    btype=np.zeros(1, np.int32), chunk_idx=np.zeros(MAX_CHUNKS + 1, np.uint32))
+                    btype=np.zeros(1, np.int32), chunk_idx=np.zeros(MAX_CHUNKS + 1, np.uint32),
+                    linkB=np.zeros(dl + n, np.uint16), linkC=np.zeros(dl + n, np.uint16),
+                    best_dp=np.zeros(max(n, 1), np.uint32), dp_cost=np.zeros(258, np.uint32))
         dbg = _Debug(*[arrs[k].ctypes.data for k in
-                       ("prevdist", "best", "tokens", "seg_ntok", "hist", "lens", "seg_bits", "btype", "chunk_idx")])
+                       ("prevdist", "best", "tokens", "seg_ntok", "hist", "lens", "seg_bits", "btype", "chunk_idx",
+                        "linkB", "linkC", "best_dp", "dp_cost")])
     r = lib().za_o_deflate_unit(buf.ctypes.data + dl, dl, n, level, flags, out.ctypes.data, cap,
                                 C.byref(crc), C.byref(dbg) if dbg is not None else None)
     if r < 0:
@@ -124,6 +128,7 @@ def deflate_unit(data, zdict=b"", level=6, flags=0, debug=False, cap=None):
     res = out[:r].tobytes()
     if debug:
         arrs["best"] = arrs["best"][:n]
+        arrs["best_dp"] = arrs["best_dp"][:n]
         arrs["btype"] = int(arrs["btype"][0])
         return res, crc.value, arrs
     return res, crc.value

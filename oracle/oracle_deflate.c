@@ -9,11 +9,14 @@
  * python-zlib-ng_amd/csrc/ are an independent implementation of the same five stages and must match
  * this file byte for byte, stage by stage.
  *
- *   stage 1  hash chains        prevdist[p] = distance to the nearest earlier position whose
- *                               6-byte hash lands in the same 14-bit bucket, if within 32 768
- *   stage 2  match search       best[p] = longest match among the first `chain` chain entries,
- *                               nearest wins ties, truncated at the 2 KiB segment end
- *   stage 3  parse              per 2 KiB segment, greedy (levels 1-3) or one-step lazy (4-9)
+ *   stage 1  link tables        link[p] = distance to the nearest earlier position whose context hashes into the same
+ *                               14-bit bucket, if within 32 768: table A over 5-byte contexts (walked as a chain),
+ *                               tables B (3 bytes) and C (12 bytes) as one candidate each
+ *   stage 2  match search       best[p] = longest match among the first `chain` entries of chain A and the
+ *                               candidates of B and C, nearest wins ties, truncated at the 2 KiB segment end
+ *   stage 3a dynamic programme  (levels 4-9) per 2 KiB segment, backwards: literal or match (or the match shortened by
+ *                               up to 4) by estimated bit costs; rewrites best[]
+ *   stage 3  parse              per 2 KiB segment, greedy over best[]
  *   stage 4  entropy plan       histograms -> length-limited canonical Huffman (Moffat-Katajainen
  *                               in-place lengths + count-based limiting), stored/fixed/dynamic pick
  *   stage 5  bit packing        header, tokens, EOB, then sync-flush marker or final padding
@@ -24,16 +27,21 @@
 #include <pthread.h>
 #include <time.h>
 
-typedef struct { int chain, nice, lazy, cap; } za_level;
-/* (max_chain, nice_length, max_lazy) per level.  Calibrated for this codec (every position is
- * searched and a whole 128 KiB unit shares one Huffman block), so that the ratio at each level is at
- * least that of zlib 1.2.11 at the same level on the text / FASTQ / mixed corpora. */
-/* cap: candidates are compared on their first `cap` bytes only while the chain is walked (longest wins, nearest
- * wins ties, the walk ends at min(nice, cap) equal bytes); the winner is then extended to its true length.
- * 16 on the fast levels (one 16-byte compare per candidate on the GPU), 258 = compare in full. */
+typedef struct { int chain, nice, cap, use_c, dp, too_far3, too_far4; } za_level;
+/* Level table.  Three link tables: A = chains over 5-byte contexts, walked `chain` steps; B = the nearest
+ * earlier position with the same 3-byte context (one candidate, every level); C = the nearest earlier position with the same 12-byte
+ * context (one candidate, levels 6-9: "skip ahead in chain A to the first long match").  Levels 1-3 take the longest candidate
+ * greedily; levels 4-9 choose literals / matches per 2 KiB segment by a backward dynamic programme over estimated bit costs (dp).
+ * cap: candidates are compared on their first `cap` bytes only (longest wins, nearest wins ties); the winner is then extended to
+ * its true length.  16 on the fast levels (one 16-byte compare per candidate on the GPU), 258 = compare in full, and only those
+ * levels stop a walk early at `nice` equal bytes.  too_far3 / too_far4: a match of 3 / 4 bytes farther back than this is dropped.
+ * Calibrated against zlib 1.2.11 at the same level on held-out real files (Python sources, C headers, ELF) as well as the synthetic
+ * corpora: tests/test_oracle_ratio_heldout.py. */
 static const za_level LEVELS[10] = {
-    {0, 0, 0, 0}, {1, 8, 0, 16}, {2, 8, 0, 16}, {3, 16, 0, 16}, {2, 16, 8, 16}, {2, 32, 8, 16},
-    {2, 32, 16, 16}, {6, 32, 16, 258}, {8, 64, 16, 258}, {12, 128, 128, 258}
+    {0, 0, 0, 0, 0, 0, 0},
+    {1, 16, 16, 0, 0, 256, 4096}, {2, 16, 16, 0, 0, 256, 4096}, {3, 16, 16, 0, 0, 256, 4096},
+    {1, 16, 16, 0, 1, 4096, 32768}, {2, 16, 16, 0, 1, 4096, 32768}, {2, 16, 16, 1, 1, 4096, 32768},
+    {4, 32, 258, 1, 1, 4096, 32768}, {8, 64, 258, 1, 1, 4096, 32768}, {12, 128, 258, 1, 1, 4096, 32768}
 };
 
 /* test-only: forced token-boundary granularity (default ZA_SEG) */
@@ -41,36 +49,49 @@ static int g_cut = ZA_SEG;
 void za_o_set_cut(int cut) { g_cut = cut; }
 
 /* test-only override of the level table (parameter studies); chain <= 0 switches it off */
-static za_level g_override = {0, 0, 0, 258};
-void za_o_override_level(int chain, int nice, int lazy) { g_override.chain = chain; g_override.nice = nice; g_override.lazy = lazy; }
-void za_o_override_cap(int cap) { g_override.cap = cap; }
+static za_level g_override = {0, 0, 258, 1, 1, 4096, 32768};
+void za_o_override_level(int chain, int nice, int cap, int use_c, int dp, int too_far3, int too_far4)
+{
+    g_override = (za_level){ chain, nice, cap, use_c, dp, too_far3, too_far4 };
+}
 
 static inline uint32_t ld32(const uint8_t *p)
 {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
-/* bucket of the 6 bytes at p: chains over 6-byte contexts carry far fewer junk candidates than 4-byte
- * ones, so a few steps find what 4-byte chains need 16+ steps for */
-static inline uint32_t hash6(const uint8_t *p)
+/* buckets of the three link tables (all ZA_HASH_BITS wide): A over 5 bytes, B over 3, C over 12 */
+#define ZA_K1 2654435761u
+#define ZA_K2 2246822519u
+#define ZA_K3 3266489917u
+static const int za_hash_bytes[3] = { ZA_HASH_BYTES_A, ZA_HASH_BYTES_B, ZA_HASH_BYTES_C };
+static inline uint32_t hash_of(const uint8_t *p, int table)
 {
-    uint32_t lo = ld32(p), hi = (uint32_t)p[4] | ((uint32_t)p[5] << 8);
-    return ((lo * 2654435761u) ^ (hi * 2246822519u)) >> (32 - ZA_HASH_BITS);
+    uint32_t x;
+    if (table == 0) x = (ld32(p) * ZA_K1) ^ ((uint32_t)p[4] * ZA_K2);
+    else if (table == 1) x = ld32(p) * (ZA_K1 << 8);                 /* the product's top bits depend on bytes 0..2 only */
+    else {
+        x = (ld32(p) * ZA_K1) ^ (ld32(p + 4) * ZA_K2);
+        x = ((x ^ (x >> 15)) * ZA_K2) ^ (ld32(p + 8) * ZA_K3);
+    }
+    return x >> (32 - ZA_HASH_BITS);
 }
 
 /* ---------------- stage 1 ---------------- */
-static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *prevdist)
+static void stage1_chains(const uint8_t *data, int dict_len, int n, int table, uint16_t *prevdist)
 {
     /* head[h] = the nearest earlier position of bucket h, or none.  No 16-bit wrap-around: a bucket's link is the true
      * nearest earlier position of the bucket if that lies within 32 768 and not in front of the dictionary, else none --
      * so the links of a position do not depend on whether positions further back than its window were ever seen (what lets
-     * the chain kernel carry its tables from one unit of a stream to the next instead of inserting the dictionary again). */
+     * the chain kernel carry its tables from one unit of a stream to the next instead of inserting the dictionary again).
+     * A position with fewer bytes left in the unit than the table's context is not inserted. */
     static __thread int32_t head[1 << ZA_HASH_BITS];
+    const int hb = za_hash_bytes[table];
     for (int i = 0; i < (1 << ZA_HASH_BITS); i++) head[i] = -1;
     for (int p = -dict_len; p < n; p++) {
         int i = p + dict_len;
-        if (p + ZA_HASH_BYTES > n) { prevdist[i] = 0; continue; }
+        if (p + hb > n) { prevdist[i] = 0; continue; }
         int32_t P = ZA_WIN + p;
-        uint32_t h = hash6(data + p);
+        uint32_t h = hash_of(data + p, table);
         int32_t q = head[h];
         int32_t d = q >= 0 ? P - q : 0;
         prevdist[i] = (uint16_t)((d >= 1 && d <= ZA_WIN) ? d : 0);
@@ -79,8 +100,17 @@ static void stage1_chains(const uint8_t *data, int dict_len, int n, uint16_t *pr
 }
 
 /* ---------------- stage 2 ---------------- */
-static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const uint16_t *prevdist,
-                              int p, const za_level *L, int max_dist)
+/* one candidate at distance `dist`: its first `cap` bytes against the position's; longer wins, nearer wins ties */
+static inline void try_candidate(const uint8_t *data, int p, int dist, int cap, int *best_len, int *best_dist)
+{
+    const uint8_t *q = data + p - dist;
+    int len = 0;
+    while (len < cap && q[len] == data[p + len]) len++;
+    if (len > *best_len || (len == *best_len && dist < *best_dist)) { *best_len = len; *best_dist = dist; }
+}
+
+static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const uint16_t *linkA, const uint16_t *linkB,
+                              const uint16_t *linkC, int p, const za_level *L, int max_dist)
 {
     int seg_end = (p / g_cut + 1) * g_cut;          /* g_cut == ZA_SEG except in parameter studies */
     if (seg_end > n) seg_end = n;
@@ -91,27 +121,31 @@ static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const ui
     const int nice = L->nice < cap ? L->nice : cap;
     int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
     int q = p, depth = L->chain;
-    while (depth-- > 0) {
-        int d = prevdist[q + dict_len];
+    while (depth-- > 0) {                                     /* table A: a walk */
+        int d = linkA[q + dict_len];
         if (d == 0) break;
         q -= d;
         int dist = p - q;
         if (dist > max_dist) break;
-        if (data[q + best_len] != data[p + best_len]) continue;
-        int len = 0;
-        while (len < cap && data[q + len] == data[p + len]) len++;
-        if (len > best_len) {
-            best_len = len; best_dist = dist;
-            if (len >= nice) break;
-        }
+        try_candidate(data, p, dist, cap, &best_len, &best_dist);
+        if (best_len >= nice) break;
+    }
+    /* tables B and C: the position's own link, one candidate each (the levels that compare in full skip them behind a nice match) */
+    for (int t = 1; t <= (L->use_c ? 2 : 1); t++) {
+        int d = (t == 1 ? linkB : linkC)[p + dict_len];
+        if (d == 0 || d > max_dist) continue;
+        if (L->cap > 16 && best_len >= nice) break;
+        try_candidate(data, p, d, cap, &best_len, &best_dist);
     }
     if (best_len < ZA_MIN_MATCH) return 0;
     if (best_len == cap)                                      /* the winner's true length */
         while (best_len < maxlen && data[p - best_dist + best_len] == data[p + best_len]) best_len++;
-    if (best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR) return 0;
+    if (best_len == 3 && best_dist > L->too_far3) return 0;
+    if (best_len == 4 && best_dist > L->too_far4) return 0;
     return ((uint32_t)best_len << 16) | (uint32_t)best_dist;
 }
 
+/* ---------------- symbol maps ---------------- */
 /* ---------------- symbol maps ---------------- */
 static const uint16_t len_base[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
 static const uint8_t  len_extra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -129,6 +163,76 @@ static int dist_code(int dist)   /* 0..29 */
     int c = 29;
     while (dist_base[c] > dist) c--;
     return c;
+}
+
+/* ---------------- stage 3a: dynamic programme ---------------- */
+/* 4 * log2(a / b) in whole quarter bits, a >= b >= 1, a < 2^22 */
+static int ilog4(uint32_t a, uint32_t b)
+{
+    uint32_t q = (a << 8) / b;                       /* the ratio with 8 fractional bits, >= 256 */
+    int lg = 0;
+    while ((q >> lg) >= 512u) lg++;
+    uint32_t t = q >> lg;                             /* 256 .. 511 */
+    return 4 * lg + (t >= 304u) + (t >= 362u) + (t >= 431u);     /* 256 * 2^(1/4), 2^(2/4), 2^(3/4) */
+}
+
+/* Bit costs in quarter bits, estimated from the search results of the unit alone (no pass over tokens exists yet).  A position
+ * is "literal-like" if it has no match, or only a 3-byte match farther back than ZA_DP_WEAK_DIST (such a match costs about what
+ * its three literals cost; on data whose every position has one -- a small alphabet at random -- counting them as matches would
+ * price literals out of the parse altogether):
+ *   U  = literal-like positions, hU[b] = their bytes: the literals to come are mostly these;
+ *   NM = other positions whose length is not one less than the length in front of them: "a new match starts here", the
+ *        number of match tokens to come;
+ *   a literal b costs log2(T / h'[b]) + log2((U + NM) / U) (h' = 16 hU + 1 + U / 64: unseen bytes are dear, not impossible),
+ *   a match costs 3 bits of length code + log2((U + NM) / NM) + its extra bits + 5 bits of distance code + its extra bits. */
+static void dp_costs(const uint8_t *data, int n, const uint32_t *best, uint32_t *cost /* [258] */)
+{
+    uint32_t h[256], U = 0, NM = 0, T = 0;
+    memset(h, 0, sizeof h);
+    for (int p = 0; p < n; p++) {
+        uint32_t len = best[p] >> 16, lp = p ? best[p - 1] >> 16 : 0;
+        if (len == 0 || (len == 3 && (best[p] & 0xFFFF) > ZA_DP_WEAK_DIST)) { h[data[p]]++; U++; }
+        else if (len + 1 != lp) NM++;
+    }
+    for (int b = 0; b < 256; b++) { h[b] = 16 * h[b] + 1 + (U >> 6); T += h[b]; }
+    int lbias = ilog4(U + NM, U ? U : 1), mbias = ilog4(U + NM, NM ? NM : 1);
+    if (lbias > 24) lbias = 24;
+    if (mbias > 24) mbias = 24;
+    for (int b = 0; b < 256; b++) {
+        int c = ilog4(T, h[b]) + lbias;
+        cost[b] = (uint32_t)(c < 12 ? 12 : c > 52 ? 52 : c);
+    }
+    cost[256] = (uint32_t)(12 + mbias + 20);          /* length code + distance code */
+    cost[257] = 0;
+}
+
+static void stage3a_dp(const uint8_t *data, int n, uint32_t *best, const za_level *L, uint32_t *cost_out)
+{
+    uint32_t cost[258];
+    static __thread uint32_t acc[ZA_SEG + 1];
+    dp_costs(data, n, best, cost);
+    if (cost_out) memcpy(cost_out, cost, sizeof cost);
+    for (int s0 = 0; s0 < n; s0 += ZA_SEG) {
+        int e = s0 + ZA_SEG > n ? n : s0 + ZA_SEG;
+        acc[e - s0] = 0;
+        for (int p = e - 1; p >= s0; p--) {
+            uint32_t c = cost[data[p]] + acc[p + 1 - s0];
+            int choice = 0;                                    /* 0 = literal */
+            int len = (int)(best[p] >> 16), dist = (int)(best[p] & 0xFFFF);
+            if (len) {
+                uint32_t mc0 = cost[256] + 4u * dist_extra[dist_code(dist)];
+                int lo = len - ZA_DP_SUB < ZA_MIN_MATCH ? ZA_MIN_MATCH : len - ZA_DP_SUB;
+                for (int l = len; l >= lo; l--) {             /* the longest first: it keeps a tie */
+                    if (l == 3 && dist > L->too_far3) break;
+                    if (l == 4 && dist > L->too_far4) break;
+                    uint32_t mc = mc0 + 4u * len_extra[len_code(l)] + acc[p + l - s0];
+                    if (mc < c) { c = mc; choice = l; }
+                }
+            }
+            acc[p - s0] = c;
+            best[p] = choice ? ((uint32_t)choice << 16) | (uint32_t)dist : 0u;
+        }
+    }
 }
 
 /* ---------------- stage 4 helpers ---------------- */
@@ -282,7 +386,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
     uint8_t lens[320];
     uint16_t codes[320];
     uint32_t *tokens = NULL, *best = NULL;
-    uint16_t *prevdist = NULL;
+    uint16_t *prevdist = NULL, *linkB = NULL, *linkC = NULL;
     uint32_t seg_ntok[ZA_MAX_SEGS];
     uint32_t seg_bits[ZA_MAX_SEGS + 1];
     uint32_t chunk_idx[ZA_MAX_CHUNKS + 1];
@@ -297,11 +401,25 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
 
     if (!use_stored) {
         prevdist = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(dict_len + n));
+        linkB = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(dict_len + n));
+        linkC = (uint16_t *)calloc((size_t)(dict_len + n), sizeof(uint16_t));
         best = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
         tokens = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
-        if (!prevdist || !best || !tokens) { free(prevdist); free(best); free(tokens); return ZA_MEM_ERROR; }
-        stage1_chains(data, dict_len, n, prevdist);
-        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, p, L, g_max_dist);
+        if (!prevdist || !linkB || !linkC || !best || !tokens) { free(prevdist); free(linkB); free(linkC); free(best); free(tokens); return ZA_MEM_ERROR; }
+        stage1_chains(data, dict_len, n, 0, prevdist);
+        stage1_chains(data, dict_len, n, 1, linkB);
+        if (L->use_c) stage1_chains(data, dict_len, n, 2, linkC);
+        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, linkB, linkC, p, L, g_max_dist);
+        if (dbg) {
+            if (dbg->prevdist) memcpy(dbg->prevdist, prevdist, sizeof(uint16_t) * (size_t)(dict_len + n));
+            if (dbg->linkB) memcpy(dbg->linkB, linkB, sizeof(uint16_t) * (size_t)(dict_len + n));
+            if (dbg->linkC) memcpy(dbg->linkC, linkC, sizeof(uint16_t) * (size_t)(dict_len + n));
+            if (dbg->best) memcpy(dbg->best, best, sizeof(uint32_t) * (size_t)n);
+        }
+        /* stage 3a (levels 4-9): the dynamic programme rewrites the entries -- a position it makes a literal loses its match, a
+         * match it shortens gets the shorter length -- so that the greedy walk of stage 3 follows its choices */
+        if (L->dp) stage3a_dp(data, n, best, L, dbg ? dbg->dp_cost : NULL);
+        if (dbg && dbg->best_dp) memcpy(dbg->best_dp, best, sizeof(uint32_t) * (size_t)n);
         /* stage 3: parse every segment on its own */
         for (int s = 0; s < nseg; s++) {
             int p = s * ZA_SEG, end = p + ZA_SEG;
@@ -312,10 +430,6 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
                 uint32_t b = best[p];
                 int len = (int)(b >> 16);
                 if (len >= ZA_MIN_MATCH) {
-                    if (L->lazy && len < L->lazy && p + 1 < end && (int)(best[p + 1] >> 16) > len) {
-                        t[nt++] = data[p]; hist[data[p]]++; p++;
-                        continue;
-                    }
                     int dist = (int)(b & 0xFFFF);
                     /* a match token carries its symbols: bit 31, length code << 26, length extra << 21, distance
                      * code << 16, distance extra (the packer needs no symbol arithmetic) */
@@ -342,8 +456,6 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         }
         hist[256] = 1;
         if (dbg) {
-            if (dbg->prevdist) memcpy(dbg->prevdist, prevdist, sizeof(uint16_t) * (size_t)(dict_len + n));
-            if (dbg->best) memcpy(dbg->best, best, sizeof(uint32_t) * (size_t)n);
             if (dbg->tokens) memcpy(dbg->tokens, tokens, sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
             if (dbg->seg_ntok) memcpy(dbg->seg_ntok, seg_ntok, sizeof seg_ntok);
             if (dbg->hist) memcpy(dbg->hist, hist, sizeof hist);
@@ -485,7 +597,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
     else { putbits(&w, 0, 3); flushbyte(&w); putbits(&w, 0, 16); putbits(&w, 0xFFFF, 16); }
     if (dbg && dbg->seg_bits) memcpy(dbg->seg_bits, seg_bits, sizeof seg_bits);
     if (dbg && dbg->chunk_idx) memcpy(dbg->chunk_idx, chunk_idx, sizeof chunk_idx);
-    free(prevdist); free(best); free(tokens);
+    free(prevdist); free(linkB); free(linkC); free(best); free(tokens);
     return w.overflow ? ZA_BUF_ERROR : (long)w.pos;
 }
 

@@ -79,3 +79,44 @@ def mixed(nbytes, seed=5):
     soup = ops[rng.choice(len(ops), size=part, p=np.array([12, 11, 10, 9, 8, 8, 8, 7, 7, 7, 7, 6]) / 100)]
     rnd = np.frombuffer(rng.bytes(nbytes - 6 * part), np.uint8)
     return np.concatenate([t, x, f, walk[:part], sparse, soup, rnd])
+
+
+def heldout(max_bytes=4 << 20):
+    """Held-out real files for the ratio gates (tests/test_oracle_ratio_heldout.py, bench.py `ratio_heldout`): data the level
+    table was NOT designed on a generator for.  Assembled at run time from files any box with Python has; a corpus whose
+    files are missing is left out.  -> {name: bytes}, each at most max_bytes."""
+    import glob
+    import os
+    import sys
+    import sysconfig
+
+    def cat(paths):
+        out, size = [], 0
+        for f in paths:
+            try:
+                with open(f, "rb") as fh:
+                    b = fh.read(max_bytes - size)
+            except OSError:
+                continue
+            out.append(b)
+            size += len(b)
+            if size >= max_bytes:
+                break
+        return b"".join(out)
+
+    res = {}
+    py = cat(sorted(glob.glob(os.path.join(sysconfig.get_path("stdlib"), "*.py"))))
+    if len(py) >= 1 << 20:
+        res["python_sources"] = py
+    exe = cat([os.path.realpath(sys.executable)])
+    if len(exe) >= 1 << 20:
+        res["python_elf"] = exe
+    for cand in ("/usr/lib/x86_64-linux-gnu/libc.so.6", "/lib/x86_64-linux-gnu/libc.so.6", "/lib64/libc.so.6",
+                 "/usr/lib64/libc.so.6", "/usr/lib/libc.so.6"):
+        if os.path.isfile(cand):
+            res["libc_elf"] = cat([cand])
+            break
+    hdr = cat(sorted(glob.glob("/usr/include/**/*.h", recursive=True)))
+    if len(hdr) >= 1 << 20:
+        res["c_headers"] = hdr
+    return res
