@@ -369,7 +369,8 @@ int zngamd_comm_max_f64(zngamd_comm *comm, double *value);
 #define ZNGAMD_K_SCAN   6
 #define ZNGAMD_K_INFLATE 7
 #define ZNGAMD_K_OTHER  8
-#define ZNGAMD_K_COUNT  9
+#define ZNGAMD_K_OPTPARSE 9     /* the dynamic programme between search and parse (levels 4-9) */
+#define ZNGAMD_K_COUNT  10
 int zngamd_profiling(zngamd_ctx *ctx, int on);
 /* accumulated milliseconds and launch counts per kernel class since the last reset */
 int zngamd_kernel_times(zngamd_ctx *ctx, double *ms /*[ZNGAMD_K_COUNT]*/, uint64_t *launches /*[ZNGAMD_K_COUNT]*/, int reset);
@@ -384,8 +385,11 @@ int zngamd_kernel_times(zngamd_ctx *ctx, double *ms /*[ZNGAMD_K_COUNT]*/, uint64
 int zngamd_decode_paths(zngamd_ctx *ctx, uint64_t *members /*[ZNGAMD_PATH_COUNT]*/, int reset);
 
 /* ---- debugging aid for the parity tests: copy a stage's intermediate of unit `u` of the last
- * deflate call to the host.  what: 0 prevdist(u16) 1 best(u32) 2 tokens(u32) 3 seg_ntok(u32)
- * 4 hist(u32) 5 codes(u32) 6 seg_bits(u32) 7 plan(4 x u32) */
+ * deflate call to the host.  what: 0 links of table A (u16) 1 best(u32, as the parse kernel read it: behind the dynamic
+ * programme on levels 4-9) 2 tokens(u32) 3 seg_ntok(u32) 4 hist(u32) 5 codes(u32) 6 seg_bits(u32) 7 plan(4 x u32)
+ * 8 chunk index(u32) 9 / 10 links of tables B / C (u16) 11 best as the search left it (u32) 12 the dynamic programme's cost
+ * table (258 x u32); 11 and 12 exist only after zngamd_debug_keep(ctx, 1) (a copy of 4 bytes per input byte per call) */
+int zngamd_debug_keep(zngamd_ctx *ctx, int on);
 int zngamd_debug_fetch(zngamd_ctx *ctx, int what, uint32_t unit, void *host_dst, size_t bytes);
 
 #ifdef __cplusplus

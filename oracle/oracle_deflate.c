@@ -223,8 +223,7 @@ static void stage3a_dp(const uint8_t *data, int n, uint32_t *best, const za_leve
                 uint32_t mc0 = cost[256] + 4u * dist_extra[dist_code(dist)];
                 int lo = len - ZA_DP_SUB < ZA_MIN_MATCH ? ZA_MIN_MATCH : len - ZA_DP_SUB;
                 for (int l = len; l >= lo; l--) {             /* the longest first: it keeps a tie */
-                    if (l == 3 && dist > L->too_far3) break;
-                    if (l == 4 && dist > L->too_far4) break;
+                    if (l == 3 && dist > L->too_far3) break;          /* (what the search would have dropped) */
                     uint32_t mc = mc0 + 4u * len_extra[len_code(l)] + acc[p + l - s0];
                     if (mc < c) { c = mc; choice = l; }
                 }

@@ -15,10 +15,20 @@
 #ifndef ZA_HASH_BITS
 #define ZA_HASH_BITS  14
 #endif
-#define ZA_MIN_MATCH  4
-#define ZA_HASH_BYTES 6
+#define ZA_MIN_MATCH  3
+// three link tables: A = chains over 5-byte contexts, B / C = the nearest earlier 3- / 12-byte context
+#define ZA_TABLE_A 0
+#define ZA_TABLE_B 1
+#define ZA_TABLE_C 2
+#define ZA_HASH_BYTES_A 5
+#define ZA_HASH_BYTES_B 3
+#define ZA_HASH_BYTES_C 12
 #define ZA_MAX_MATCH  258
-#define ZA_TOO_FAR    4096
+#define ZA_DP_SUB     4         // the dynamic programme also tries the 4 next shorter lengths of a position's match
+#define ZA_DP_WEAK_DIST 256     // cost statistics: a 3-byte match farther back than this counts as literals
+// a `best` entry: distance - 1 (bits 0..14) | length (bits 15..23: 0 = no match, else 3..258) | the position's own byte << 24
+#define ZA_ELEN(e)  (((e) >> 15) & 0x1FFu)
+#define ZA_EDIST(e) (((e) & 0x7FFFu) + 1u)
 
 #define ZA_FLAG_FINAL 1u
 #define ZA_FLAG_FLATHDR 2u      // dynamic header in its flat form (4-bit code lengths at fixed offsets): indexed members
@@ -57,8 +67,10 @@ struct ZaPlan {
     uint32_t pad0, pad1;
 };
 
-// cap: bytes compared per candidate while the chain is walked (16 or 258); the winner is extended afterwards
-struct ZaLevel { int chain, nice, lazy, max_dist, cap; };
+// chain: steps of the walk over table A; cap: bytes compared per candidate (16 or 258; the winner is extended afterwards);
+// use_c: table C's candidate too; dp: the dynamic programme (stage 3a) between search and parse;
+// too_far3 / too_far4: a match of 3 / 4 bytes farther back than this is dropped
+struct ZaLevel { int chain, nice, max_dist, cap, use_c, dp, too_far3, too_far4; };
 
 typedef uint32_t __attribute__((aligned(1))) za_u32u;
 typedef uint64_t __attribute__((aligned(1))) za_u64u;
@@ -69,11 +81,20 @@ typedef uint16_t __attribute__((aligned(1))) za_u16u;
 struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };      // 16 bytes at any address
 struct __attribute__((aligned(1))) ZaU2u { uint32_t x, y; };
 __device__ __forceinline__ uint32_t za_ld16(const uint8_t *p) { return *(const za_u16u *)p; }
-// bucket of a 6-byte context: lo = bytes 0..3, hi = bytes 4..5
-__device__ __forceinline__ uint32_t za_hash6(uint32_t lo, uint32_t hi)
+// the full 32-bit hash of a table's context out of its little-endian dwords w0 = bytes 0..3, w1 = bytes 4..7, w2 = bytes 8..11
+// (the bucket is its top ZA_HASH_BITS bits; bytes behind the context do not matter: A masks byte 4 out of w1, B's product has
+// its multiplier shifted so that byte 3 cannot reach the top bits)
+#define ZA_K1 2654435761u
+#define ZA_K2 2246822519u
+#define ZA_K3 3266489917u
+template <int TABLE> __device__ __forceinline__ uint32_t za_hash_x(uint32_t w0, uint32_t w1, uint32_t w2)
 {
-    return ((lo * 2654435761u) ^ (hi * 2246822519u)) >> (32 - ZA_HASH_BITS);
+    if (TABLE == ZA_TABLE_A) return (w0 * ZA_K1) ^ ((w1 & 0xFFu) * ZA_K2);
+    if (TABLE == ZA_TABLE_B) return w0 * (ZA_K1 << 8);
+    uint32_t x = (w0 * ZA_K1) ^ (w1 * ZA_K2);
+    return ((x ^ (x >> 15)) * ZA_K2) ^ (w2 * ZA_K3);
 }
+template <int TABLE> struct ZaTableBytes { static constexpr int value = TABLE == ZA_TABLE_A ? ZA_HASH_BYTES_A : TABLE == ZA_TABLE_B ? ZA_HASH_BYTES_B : ZA_HASH_BYTES_C; };
 
 // volatile accesses to LDS with the address space spelled out (ds_read / ds_write instead of flat_load / flat_store)
 typedef __attribute__((address_space(3))) volatile uint16_t za_lds_vu16;

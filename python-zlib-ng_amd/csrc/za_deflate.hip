@@ -9,7 +9,9 @@
 //             inserted by ONE returning LDS atomic maximum, which also yields every position's link
 //   k_search  one 1024-thread workgroup per unit; chain links of the sliding window staged in a
 //             128 KiB LDS ring; every position searched in parallel
-//   k_parse   one wave per unit, one lane per 2 KiB segment: greedy/lazy selection, symbol
+//   k_optparse (levels 4-9) one wave per unit, one lane per 2 KiB segment: backward dynamic programme over estimated bit
+//             costs, rewrites the search results so that the greedy parse follows its choices
+//   k_parse   one wave per unit, one lane per 2 KiB segment: greedy selection, symbol
 //             histogram with LDS atomics, CRC-32 per segment folded with GF(2) products
 //   k_plan    one wave per unit: length-limited canonical Huffman, block-type choice, header bits
 //   k_pack    one wave per unit, one lane per segment: bit lengths -> wave prefix sum -> packing,
@@ -50,7 +52,6 @@
 #define ZA_CH_GROUP 16                         // steps (of 64 positions) per group
 // the byte offset of a bucket's table entry out of the full 32-bit product: (x >> 19) << 2 with two full-rate operations
 // (a right shift and an AND; a left shift runs at half rate on this chip, profiles/ubench_issue2.hip)
-#define za_hash6x(lo, hi) (((lo) * 2654435761u) ^ ((hi) * 2246822519u))
 #define ZA_CH_OFFS(x) (((x) >> (32 - ZA_HASH_BITS - 2)) & (((1u << ZA_HASH_BITS) - 1u) << 2))
 #define ZA_CH_CHUNK (64 * ZA_CH_GROUP)         // positions = bytes of a group: 16 per lane
 
@@ -89,6 +90,8 @@ __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t 
     return near ? near : pre;
 }
 
+// TABLE: which of the three link tables (za_common.h): the context's length and hash are all that differs
+template <int TABLE>
 __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
                                                    const uint32_t *__restrict__ run_start,
                                                    uint16_t *__restrict__ prev_ws)
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
     __shared__ __attribute__((aligned(16))) uint16_t hbuf[2][ZA_CH_CHUNK];                  // byte offsets of the buckets (bucket * 4) of a group's positions, two groups
     __shared__ __attribute__((aligned(16))) uint32_t obuf[2][ZA_CH_CHUNK];                  // what the atomics returned for a group (the links' raw form), two groups; the
                                                                // storing wave turns a group into links in place
+    constexpr int HB = ZaTableBytes<TABLE>::value;               // bytes of a context: a position with fewer left in its unit is not inserted
     const uint32_t lane = (uint32_t)za_lane();
     // FOUR wavefronts per stream, a pipeline of three stages with one barrier per tick (a group of 1 024 positions per tick):
     // waves 0 and 1 hash group t (wave 0 also stages the bytes of group t + 1: it takes the second half of the group, which is
@@ -132,22 +136,22 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
         __syncthreads();                                       // (the table; and all waves are through with the unit in front)
         n_prev = (uint32_t)n;
         const int total = dict_len + n;
-        // a carried unit starts with the last five positions of the unit in front of it: they had fewer than six bytes left
+        // a carried unit starts with the last HB - 1 positions of the unit in front of it: they had fewer than HB bytes left
         // there and have them now (their links go to this unit's own row: that unit's links say "never inserted", which is
         // what a search of THAT unit must see)
-        const int first = carry ? dict_len - (ZA_HASH_BYTES - 1) : 0;
+        const int first = carry ? dict_len - (HB - 1) : 0;
         const uint32_t abase = goff + (uint32_t)(2 * ZA_WIN - dict_len) + 1u;     // table value of row index i: abase + i (> 32 768)
-        if (total < ZA_HASH_BYTES) {                           // (uniform) not one 6-byte context: nothing to insert, every link is 0
+        if (total < HB) {                           // (uniform) not one whole context: nothing to insert, every link is 0
             if (role == 2u && (int)lane >= first && (int)lane < total) prevdist[lane] = 0;
             continue;
         }
         if (total < 16) {
-            // (uniform) a row shorter than one 16-byte load -- a stream of 6 .. 15 bytes without a dictionary, nothing carried: lane i
+            // (uniform) a row shorter than one 16-byte load -- a stream of up to 15 bytes without a dictionary, nothing carried: lane i
             // of the inserting wave takes row index i and looks at the lanes below it (the table is left alone: nothing follows it)
             if (role == 2u) {
                 uint32_t h = 0xFFFFFFFFu;
-                const bool ins = (int)lane >= first && (int)lane <= total - ZA_HASH_BYTES;
-                if (ins) h = za_hash6(za_ld32(row + lane), za_ld16(row + lane + 4));
+                const bool ins = (int)lane >= first && (int)lane <= total - HB;
+                if (ins) h = za_hash_x<TABLE>(za_ld32(row + lane), HB > 4 ? za_ld32(row + lane + 4) : 0u, HB > 8 ? za_ld32(row + lane + 8) : 0u) >> (32 - ZA_HASH_BITS);     // (the input has 8 readable bytes of slack; what lies behind the context does not reach the bucket)
                 uint32_t d = 0;
                 for (int j = 0; j < 16; j++) {
                     const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
             }
             continue;
         }
-        const int iclamp_hi = total - ZA_HASH_BYTES;          // last row index with 6 bytes available
+        const int iclamp_hi = total - HB;          // last row index with a whole context available
         const int t0 = first & ~63;                             // (groups start at multiples of 64: whole lines of links)
         const int ngroups = (total - t0 + ZA_CH_CHUNK - 1) / ZA_CH_CHUNK;
         // ---- wave 0.  Chunk c = the ZA_CH_CHUNK bytes from row index t0 + c * ZA_CH_CHUNK, 8 per lane; bytes behind the row's end
@@ -201,12 +205,24 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
             uint16_t *o = hb + 64 * g0 + 4 * lane;
 #pragma unroll
             for (int j = 0; j < ZA_CH_GROUP / 8; j++) {                                   // positions 64 g0 + 256 j + 4 lane + {0, 1, 2, 3}
-                const uint32_t d0 = w[64 * j], d1 = w[64 * j + 1], d2 = w[64 * j + 2];
-                const uint32_t h0 = ZA_CH_OFFS(za_hash6x(d0, d1 & 0xFFFFu));
-                const uint32_t h1 = ZA_CH_OFFS(za_hash6x(__builtin_amdgcn_alignbyte(d1, d0, 1), __builtin_amdgcn_alignbyte(d2, d1, 1) & 0xFFFFu));
-                const uint32_t h2 = ZA_CH_OFFS(za_hash6x(__builtin_amdgcn_alignbyte(d1, d0, 2), __builtin_amdgcn_alignbyte(d2, d1, 2) & 0xFFFFu));
-                const uint32_t h3 = ZA_CH_OFFS(za_hash6x(__builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 3) & 0xFFFFu));
-                *(uint2 *)(o + 256 * j) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                const uint32_t d0 = w[64 * j], d1 = w[64 * j + 1];
+                uint32_t hh[4];
+                if constexpr (TABLE == ZA_TABLE_A) {                                      // bytes 0..3 and byte 4 of each position
+                    hh[0] = za_hash_x<TABLE>(d0, d1, 0u);
+#pragma unroll
+                    for (int q = 1; q < 4; q++) hh[q] = za_hash_x<TABLE>(__builtin_amdgcn_alignbyte(d1, d0, q), d1 >> (8 * q), 0u);
+                } else if constexpr (TABLE == ZA_TABLE_B) {
+                    hh[0] = za_hash_x<TABLE>(d0, 0u, 0u);
+#pragma unroll
+                    for (int q = 1; q < 4; q++) hh[q] = za_hash_x<TABLE>(__builtin_amdgcn_alignbyte(d1, d0, q), 0u, 0u);
+                } else {
+                    const uint32_t d2 = w[64 * j + 2], d3 = w[64 * j + 3];
+                    hh[0] = za_hash_x<TABLE>(d0, d1, d2);
+#pragma unroll
+                    for (int q = 1; q < 4; q++)
+                        hh[q] = za_hash_x<TABLE>(__builtin_amdgcn_alignbyte(d1, d0, q), __builtin_amdgcn_alignbyte(d2, d1, q), __builtin_amdgcn_alignbyte(d3, d2, q));
+                }
+                *(uint2 *)(o + 256 * j) = make_uint2(ZA_CH_OFFS(hh[0]) | (ZA_CH_OFFS(hh[1]) << 16), ZA_CH_OFFS(hh[2]) | (ZA_CH_OFFS(hh[3]) << 16));
             }
         };
         auto group_inner = [&](int k) -> bool {                 // (uniform) group k lies wholly inside the row: no test per lane
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) ob[64 * g + lane] = old[g];
         };
-        // wave 3: what the atomics returned becomes links (position - entry if that is at most 32 768; positions with fewer than 6
+        // wave 3: what the atomics returned becomes links (position - entry if that is at most 32 768; positions with fewer than HB
         // bytes left were never inserted: 0), which leave 16 bytes per lane twice where the group lies wholly inside the row (rows
         // and groups start at multiples of 128 bytes)
         auto store_links = [&](int k, uint32_t *ob) {
@@ -379,7 +395,7 @@ __device__ __forceinline__ uint32_t za_lds_ld32(const uint32_t *win32, uint32_t 
     return __builtin_amdgcn_alignbyte(win32[w + 1], win32[w], idx & 3u);     // win32 has 4 mirrored pad dwords
 }
 
-// `best` entry of a position: distance (bits 0..15) | length - 3 (bits 16..23, 0: no match) | the position's own byte << 24 --
+// `best` entry of a position: distance - 1 (bits 0..14) | length (bits 15..23, 0: no match) | the position's own byte << 24 --
 // the parse kernel then needs nothing but these entries (no second pass over the input)
 
 // (Measured this round and dropped -- the kernel is bound by its instruction count, neither by LDS latency nor by LDS bank
@@ -426,11 +442,17 @@ __device__ __forceinline__ int za_search_extend(const uint32_t *win32, uint32_t 
 
 // FULL: candidates are compared in full (levels with cap 258); otherwise on 16 bytes, winner extended afterwards
 // STEPS: the chain steps of the level as a constant (1 .. 3: the walk is unrolled, no loop counter, no loop) or 0 = L.chain
-template <bool FULL, int STEPS = 0>
+// USEC: table C's candidate is tried too (levels 6-9)
+// Candidates of a position: the first L.chain entries of its chain in table A (a walk through the link ring in LDS), then its own
+// link in table B and in table C (the nearest earlier 3- / 12-byte context: one global 2-byte load each, no walk).  Longest wins,
+// nearest wins ties; the levels that compare in full stop at L.nice equal bytes.
+template <bool FULL, int STEPS = 0, bool USEC = false>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                  const ZaUnit *__restrict__ units,
                                                                  const uint32_t *__restrict__ run_start,
                                                                  const uint16_t *__restrict__ prev_ws,
+                                                                 const uint16_t *__restrict__ linkb_ws,
+                                                                 const uint16_t *__restrict__ linkc_ws,
                                                                  uint32_t *__restrict__ best_ws, ZaLevel L)
 {
     // One block of LDS with the byte window FIRST: a candidate's LDS address is then its position's low 16 bits (no base to add),
@@ -467,6 +489,8 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     const uint8_t *data = in + u.in_off;
     const int n = (int)u.in_len, dict_len = (int)u.dict_len;
     const uint16_t *prevdist = prev_ws + (size_t)ui * ZA_PREV_STRIDE;     // index p + dict_len
+    const uint16_t *linkb = linkb_ws + (size_t)ui * ZA_PREV_STRIDE + dict_len;      // index p (own positions only: no walk through these)
+    const uint16_t *linkc = linkc_ws + (size_t)ui * ZA_PREV_STRIDE + dict_len;
     const bool carried = ui > u0;           // (the host cuts a run wherever a unit's dictionary is not the tail of its predecessor)
     uint32_t *best = best_ws + (size_t)ui * ZA_BEST_STRIDE;
     // bytes that may be read starting at data[0] without leaving the caller's buffer
@@ -474,10 +498,10 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     goff = carried ? goff + (uint32_t)n_prev : 0u;
     int links_loaded = carried ? 0 : -dict_len;                        // positions p < links_loaded have their chain link in the ring
     int bytes_loaded = carried ? carry_bytes - n_prev : (-dict_len) & ~3;   // positions p < bytes_loaded have their byte in the byte ring (aligned dwords)
-    if (carried && tid < ZA_HASH_BYTES - 1)
-        // the last five positions of the unit in front: never inserted there (their links in the ring say so), inserted by
+    if (carried && tid < ZA_HASH_BYTES_A - 1)
+        // the last four positions of the unit in front: never inserted there (their links in the ring say so), inserted by
         // this unit's chain pass (its own row)
-        ring[(goff + (uint32_t)(ZA_WIN - (ZA_HASH_BYTES - 1) + tid)) % ZA_RING] = link_in(prevdist[dict_len - (ZA_HASH_BYTES - 1) + tid]);
+        ring[(goff + (uint32_t)(ZA_WIN - (ZA_HASH_BYTES_A - 1) + tid)) % ZA_RING] = link_in(prevdist[dict_len - (ZA_HASH_BYTES_A - 1) + tid]);
     auto load_quad = [&](int p, int limit) -> uint2 {    // links of positions p .. p + 3 (what lies at and behind `limit` is not used)
         // (one plain predicated load: a branch with narrower loads in it makes the compiler wait for every load in flight at the
         // join.  The last group of a unit reads up to three entries past its links: inside the row, or the workspace's slack)
@@ -601,10 +625,36 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             me0 = __builtin_amdgcn_alignbyte(m1, m0, sh); me1 = __builtin_amdgcn_alignbyte(m2, m1, sh);
             me2 = __builtin_amdgcn_alignbyte(m3, m2, sh); me3 = __builtin_amdgcn_alignbyte(m4, m3, sh);
         };
-        auto finish = [&](int p, uint32_t me0, int best_len, int best_dist) {
+        // a walk is over: the position's own links in tables B and C (one candidate each, compared in full; skipped behind a nice
+        // match), the drop rules, the entry
+        auto finish = [&](int p, uint32_t P, uint32_t me0, uint32_t me1, uint32_t me2, uint32_t me3, int maxlen, int cap, int nice,
+                          int best_len, int best_dist) {
+#pragma unroll
+            for (int t = 0; t < (USEC ? 2 : 1); t++) {
+                const int dl = maxlen >= ZA_MIN_MATCH ? (int)(t == 0 ? linkb : linkc)[p] : 0;
+                if (dl != 0 && dl <= L.max_dist && best_len < nice) {
+                    const uint32_t q = P - (uint32_t)dl;
+                    const uint32_t sh = q & 3u;
+                    const uint32_t *cw = (const uint32_t *)(lds + (q & (uint32_t)(ZA_BYTES - 4)));
+                    const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0, x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2, x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
+                    uint32_t fbit, f1, f2, f3;
+                    asm("v_ffbl_b32 %0, %4\n\tv_ffbl_b32 %1, %5\n\tv_ffbl_b32 %2, %6\n\tv_ffbl_b32 %3, %7\n\t"
+                        "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
+                        "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
+                        : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));
+                    int len = (int)min(fbit >> 3, 16u);
+                    if (len == 16 && cap > 16) len = za_search_extend(win32, q, P, len, maxlen);     // (no quick reject: a tie with a nearer candidate counts)
+                    len = len < cap ? len : cap;
+                    const bool better = len > best_len || (len == best_len && dl < best_dist);
+                    best_len = better ? len : best_len;
+                    best_dist = better ? dl : best_dist;
+                }
+            }
             uint32_t result = 0;
-            if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
-                result = ((uint32_t)(best_len - 3) << 16) | (uint32_t)best_dist;
+            if (best_len >= ZA_MIN_MATCH && !(best_len == 3 && best_dist > L.too_far3) && !(best_len == 4 && best_dist > L.too_far4))
+                result = ((uint32_t)best_len << 15) | (uint32_t)(best_dist - 1);
             best[p] = __builtin_amdgcn_perm(me0, result, 0x04020100u);
         };
         // the unfinished walks of this visit go to the list: position in the tile | best length << 12 | steps left << 21, and
@@ -648,7 +698,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 uint32_t qb = RING_B0 + 2u * sq;
                 uint32_t d = *(const uint16_t *)(lds + qb);
                 alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
-                if (!alive) finish(p, me0, best_len, best_dist);
+                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist);
             }
             push(alive, p, P, q, best_len, best_dist, depth);
         };
@@ -667,13 +717,13 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
                 uint32_t me0, me1, me2, me3;
                 my16(P, me0, me1, me2, me3);
+                const int cap = L.cap < maxlen ? L.cap : maxlen, nice = L.nice < cap ? L.nice : cap;
                 if (maxlen >= ZA_MIN_MATCH) {
-                    const int cap = L.cap < maxlen ? L.cap : maxlen, nice = L.nice < cap ? L.nice : cap;
                     uint32_t qb = RING_B0 + 2u * slot;
                     uint32_t d = *(const uint16_t *)(lds + qb);
                     alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
                 }
-                if (!alive) finish(p, me0, best_len, best_dist);
+                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist);
             }
             push(alive, p, P, q, best_len, best_dist, depth);
             while (__builtin_amdgcn_readfirstlane((int)wl_n) >= 64) batch(64u);
@@ -685,10 +735,18 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         }
         } else {
         uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;      // ring slot of my position, moved on by 1 024 per round
+        // my four positions' own links in tables B and C (issued at the tile's start, used behind the walks)
+        uint32_t lkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], lkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
+#pragma unroll
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
+            const int p = base + k * ZA_SEARCH_THREADS + tid;
+            lkb[k] = p < n ? (uint32_t)linkb[p] : 0u;
+            lkc[k] = USEC && p < n ? (uint32_t)linkc[p] : 0u;
+        }
 #ifndef ZA_SEARCH_KUNROLL
 #define ZA_SEARCH_KUNROLL 4              // the four positions of a thread per tile as straight code (18.9 against 19.4 ms per 4 GiB at level 6)
 #endif
-#pragma unroll ZA_SEARCH_KUNROLL
+#pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
             if (p >= n) continue;
@@ -696,7 +754,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             if (seg_end > n) seg_end = n;
             int maxlen = seg_end - p;
             if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
-            // the result: distance (bits 0..15) | length - 3 (bits 16..23); the position's own byte travels in the top byte
+            // the result: distance - 1 (bits 0..14) | length (bits 15..23); the position's own byte travels in the top byte
             uint32_t result = 0;
             const uint32_t P = goff + (uint32_t)(ZA_WIN + p);
             // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
@@ -754,12 +812,33 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     best_dist = better ? dist : best_dist;
                     if (best_len >= nice) break;
                 }
+                // tables B and C: one candidate each, the same branch-free 16-byte compare (no link: the position against itself,
+                // masked out); a tie goes to the nearer one
+#pragma unroll
+                for (int t = 0; t < (USEC ? 2 : 1); t++) {
+                    const uint32_t dl = t == 0 ? lkb[k] : lkc[k];
+                    const uint32_t q2 = P - dl;
+                    const uint32_t sh = q2 & 3u;
+                    const uint32_t *cw = (const uint32_t *)(lds + (q2 & (uint32_t)(ZA_BYTES - 4)));
+                    const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0, x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2, x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
+                    uint32_t fbit, f1, f2, f3;
+                    asm("v_ffbl_b32 %0, %4\n\tv_ffbl_b32 %1, %5\n\tv_ffbl_b32 %2, %6\n\tv_ffbl_b32 %3, %7\n\t"
+                        "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
+                        "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
+                        : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));
+                    const int len = (int)min(fbit >> 3, (uint32_t)cap);
+                    const bool better = dl != 0u && (int)dl <= L.max_dist && (len > best_len || (len == best_len && (int)dl < best_dist));
+                    best_len = better ? len : best_len;
+                    best_dist = better ? (int)dl : best_dist;
+                }
                 if (!FULL && best_len == cap && cap < maxlen) {
                     // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
                     best_len = za_search_extend(win32, P - (uint32_t)best_dist, P, best_len, maxlen);
                 }
-                if (best_len >= ZA_MIN_MATCH && !(best_len == ZA_MIN_MATCH && best_dist > ZA_TOO_FAR))
-                    result = ((uint32_t)(best_len - 3) << 16) | (uint32_t)best_dist;
+                if (best_len >= ZA_MIN_MATCH && !(best_len == 3 && best_dist > L.too_far3) && !(best_len == 4 && best_dist > L.too_far4))
+                    result = ((uint32_t)best_len << 15) | (uint32_t)(best_dist - 1);
             }
 #ifdef ZA_ABL_SEARCH_NOLIT
             best[p] = result;                                                 // (timing only: the parse then sees zero bytes)
@@ -785,6 +864,190 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_optparse : stage 3a, the dynamic programme of levels 4-9
+// ------------------------------------------------------------------------------------------------
+// One wave per unit, one lane per 2 KiB segment, like the parse kernel it feeds.  Going BACKWARDS through its segment a lane
+// works out, for every position p, the cheapest way to code everything from p to the segment's end: acc[p] = min(literal +
+// acc[p + 1], match of l bytes + acc[p + l]) over the position's match and its ZA_DP_SUB next shorter lengths, in estimated
+// quarter bits.  The choice is written back INTO the `best` entry (no match / the chosen length), so that the greedy walk of
+// the parse kernel is the programme's parse.
+//   costs      worked out first, from the unit's entries alone (oracle dp_costs): a coalesced pass of the whole
+//              wave over the entries -- bytes of the literal-like positions (LDS atomics), their count U, the count NM of
+//              positions where a new match starts -- then 256 literal costs and one match base cost, integer logarithms in
+//              quarter bits, by all lanes;
+//   acc[]      a lane needs acc[p + 1 .. p + 258]: a ring of 264 16-bit slots per lane in LDS (costs are kept modulo 2^16 --
+//              two entries at most 258 positions apart differ by less than 2^15 -- and compared through signed differences), its
+//              first eight slots mirrored behind its end so that the five values a step reads never wrap; lane stride odd in
+//              dwords: the lanes stand at the same slot most of the time, and that is conflict-free;
+//   entries    staged through LDS rows in chunks of 32 positions, loaded and stored TRANSPOSED like the parse kernel's (eight
+//              lanes move the eight 16-byte pieces of one segment's row), last chunk first.
+#define ZA_PCH 32                     // positions of a chunk of entries (this kernel's and the parse kernel's)
+#define ZA_PROW (ZA_PCH + 1)          // dwords of a lane's LDS row: (parse: the carried entry +) the chunk; an odd stride
+#define ZA_DP_RING   264
+#define ZA_DP_RSTRIDE 274         // u16 per lane: ring + 8 mirrored slots, rounded to an odd number of dwords (137)
+#define ZA_DP_COSTS  258          // per unit: [0..255] literal costs, [256] match base, [257] 0
+
+// 4 * log2(a / b) in whole quarter bits, a >= b >= 1, a < 2^22
+__device__ __forceinline__ int za_ilog4(uint32_t a, uint32_t b)
+{
+    const uint32_t q = (a << 8) / b;                  // >= 256
+    const int lg = 23 - (int)__builtin_clz(q);
+    const uint32_t t = q >> lg;                       // 256 .. 511
+    return 4 * lg + (t >= 304u ? 1 : 0) + (t >= 362u ? 1 : 0) + (t >= 431u ? 1 : 0);
+}
+
+__global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ units, uint32_t *__restrict__ best_ws,
+                                                    uint32_t *__restrict__ cost_out /* debug: ZA_DP_COSTS per unit, or null */, ZaLevel L)
+{
+    __shared__ uint32_t costt[ZA_DP_COSTS + 6];
+    __shared__ uint8_t lxt[ZA_MAX_MATCH + 6];                     // 4 * extra bits of a length
+    __shared__ __attribute__((aligned(16))) uint16_t ring[64 * ZA_DP_RSTRIDE];
+    __shared__ uint32_t rowb[64 * ZA_PROW];
+    uint32_t *hist = (uint32_t *)ring;                            // (statistics first: the ring is not in use yet)
+    const ZaUnit u = units[blockIdx.x];
+    const int n = (int)u.in_len;
+    const int lane = za_lane();
+    const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
+    if (n == 0) return;
+    // ---- the unit's cost table
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    for (int l = lane; l <= ZA_MAX_MATCH + 5; l += 64) {
+        int lc, ln = 0, le;
+        if (l >= 3 && l <= ZA_MAX_MATCH) za_len_sym(l, lc, ln, le);
+        lxt[l] = (uint8_t)(4 * ln);
+    }
+    __syncthreads();
+    uint32_t U = 0, NM = 0;
+    {
+        uint32_t carry_len = 0;                                    // length field of the position in front of this round's first
+        for (int base = 0; base < n; base += 256) {
+            const int i0 = base + 4 * lane;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 < n) v = *(const uint4 *)(best + i0);           // (rows are 16-byte aligned; what lies behind n is not looked at)
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+            uint32_t lp = (uint32_t)__shfl_up((int)ZA_ELEN(v.w), 1, 64);
+            if (lane == 0) lp = carry_len;
+            carry_len = (uint32_t)__builtin_amdgcn_readlane((int)ZA_ELEN(v.w), 63);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t len = ZA_ELEN(e[k]);
+                if (i0 + k < n) {
+                    if (len == 0u || (len == 3u && ZA_EDIST(e[k]) > (uint32_t)ZA_DP_WEAK_DIST)) { atomicAdd(&hist[e[k] >> 24], 1u); U++; }
+                    else if (len + 1u != lp) NM++;
+                }
+                lp = len;
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { U += (uint32_t)__shfl_xor((int)U, d, 64); NM += (uint32_t)__shfl_xor((int)NM, d, 64); }
+    __syncthreads();
+    uint32_t hh[4], T = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { hh[k] = 16u * hist[lane + 64 * k] + 1u + (U >> 6); T += hh[k]; }
+    for (int d = 32; d >= 1; d >>= 1) T += (uint32_t)__shfl_xor((int)T, d, 64);
+    {
+        int lbias = za_ilog4(U + NM, U ? U : 1u), mbias = za_ilog4(U + NM, NM ? NM : 1u);
+        lbias = lbias > 24 ? 24 : lbias;
+        mbias = mbias > 24 ? 24 : mbias;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = za_ilog4(T, hh[k]) + lbias;
+            costt[lane + 64 * k] = (uint32_t)(c < 12 ? 12 : c > 52 ? 52 : c);
+        }
+        if (lane == 0) { costt[256] = (uint32_t)(12 + mbias + 20); costt[257] = 0u; }
+    }
+    __syncthreads();
+    if (cost_out) for (int i = lane; i < ZA_DP_COSTS; i += 64) cost_out[(size_t)blockIdx.x * ZA_DP_COSTS + i] = costt[i];
+    __syncthreads();                                               // (the statistics' counters lie in the ring)
+
+    // ---- the programme, last chunk first
+    const int s0 = lane << ZA_SEG_SHIFT;
+    int s1 = s0 + ZA_SEG;
+    if (s1 > n) s1 = n;
+    const bool active = lane < nseg;
+    uint32_t *myb = rowb + lane * ZA_PROW;
+    uint16_t *myr = ring + lane * ZA_DP_RSTRIDE;
+    const uint32_t mbase = costt[256];
+    int slot = active ? (s1 - s0) % ZA_DP_RING : 0;                // slot of position s1: acc = 0
+    if (active) { myr[slot] = 0; if (slot < 8) myr[slot + ZA_DP_RING] = 0; }
+    int acc_next = 0;                                              // acc[p + 1], the whole number (at most 2 048 x 52)
+    uint4 pb[8];
+    auto prefetch = [&](int c) {
+        const int rel = c * ZA_PCH;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + rel + 4 * (lane & 7);
+            pb[j] = make_uint4(0, 0, 0, 0);
+            if (c >= 0 && sg < nseg && off < n) pb[j] = *(const uint4 *)(best + off);
+        }
+    };
+    const int nch = ((n < ZA_SEG ? n : ZA_SEG) + ZA_PCH - 1) / ZA_PCH;      // chunks of the longest segment
+    prefetch(nch - 1);
+#pragma unroll 1
+    for (int c = nch - 1; c >= 0; c--) {
+        const int cb = s0 + c * ZA_PCH;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t *r = rowb + (8 * j + (lane >> 3)) * ZA_PROW + 4 * (lane & 7);
+            r[0] = pb[j].x; r[1] = pb[j].y; r[2] = pb[j].z; r[3] = pb[j].w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        prefetch(c - 1);
+        int ce = cb + ZA_PCH;
+        if (ce > s1) ce = s1;
+        if (active && cb < s1) {
+#pragma unroll 1
+            for (int p = ce - 1; p >= cb; p--) {
+                slot = slot ? slot - 1 : ZA_DP_RING - 1;
+                const uint32_t e = myb[p - cb];
+                const uint32_t len = ZA_ELEN(e), dm1 = e & 0x7FFFu;
+                int c_best = (int)costt[e >> 24];                  // the literal, relative to acc[p + 1]
+                uint32_t choice = 0;
+                if (len != 0u) {
+                    int de = 30 - (int)__builtin_clz(dm1 | 1u);    // extra bits of the distance: 0 for distances 1 .. 4
+                    de = de < 0 ? 0 : de;
+                    const int mc0 = (int)mbase + 4 * de;
+                    const uint32_t l0 = len > 7u ? len - (uint32_t)ZA_DP_SUB : 3u;       // the shortest length tried
+                    int st = slot + (int)l0;
+                    st = st >= ZA_DP_RING ? st - ZA_DP_RING : st;
+                    uint32_t a[ZA_DP_SUB + 1], x[ZA_DP_SUB + 1];
+#pragma unroll
+                    for (int k = 0; k <= ZA_DP_SUB; k++) { a[k] = myr[st + k]; x[k] = lxt[l0 + (uint32_t)k]; }
+                    const bool far3 = dm1 >= (uint32_t)L.too_far3;                       // a 3-byte match that far back is no candidate
+#pragma unroll
+                    for (int k = ZA_DP_SUB; k >= 0; k--) {                                // the longest first: it keeps a tie
+                        const uint32_t l = l0 + (uint32_t)k;
+                        const int rel = (int)(int16_t)(uint16_t)(a[k] - (uint32_t)acc_next);
+                        const int mc = mc0 + (int)x[k] + rel;
+                        const bool ok = l <= len && !(l == 3u && far3) && mc < c_best;
+                        c_best = ok ? mc : c_best;
+                        choice = ok ? l : choice;
+                    }
+                }
+                acc_next += c_best;
+                myr[slot] = (uint16_t)acc_next;
+                if (slot < 8) myr[slot + ZA_DP_RING] = (uint16_t)acc_next;
+                myb[p - cb] = choice ? ((e & 0xFF007FFFu) | (choice << 15)) : (e & 0xFF000000u);
+            }
+        }
+        // ---- the chunk's entries go back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + c * ZA_PCH + 4 * (lane & 7);
+            const uint32_t *r = rowb + sg * ZA_PROW + 4 * (lane & 7);
+            if (sg < nseg && off < n) *(uint4 *)(best + off) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_parse  (+ histogram + CRC-32)
 // ------------------------------------------------------------------------------------------------
 // One wave per unit, one lane per 2 KiB segment.  Each lane walks its own stream of `best` entries -- which carry the
@@ -795,10 +1058,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 // instruction = 64 memory requests, and the kernel was bound by the request rate of L2, not by bytes or instructions) --
 // eight lanes fetch the eight 16-byte pieces of one segment's 128-byte row, so an instruction touches eight whole lines,
 // and the pieces are written to the owning lane's LDS row.  A row keeps the previous chunk's last entry in front of the
-// chunk (slot 0): the token at a chunk's last position needs best[p + 1] (lazy rule) and is decided one chunk later.
-#define ZA_PCH 32
-#define ZA_PROW (ZA_PCH + 1)          // carried entry + chunk (odd stride)
-#define ZA_BLEN(b) (((b) >> 16) & 0xFFu)      // length - 3 of a `best` entry, 0 = no match
+// chunk (slot 0): the token at a chunk's last position looks at best[p + 1] (literals share token words) and is decided one chunk later.
 
 
 __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ units,
@@ -826,7 +1086,6 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
     const bool active = lane < nseg;
     const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     uint32_t *myb = rowb + lane * ZA_PROW;
-    const uint32_t lazyf = L.lazy > 3 ? (uint32_t)(L.lazy - 3) : 0u;       // the lazy limit in the entries' length field
 
     uint4 pb[8];                   // piece lane & 7 of the `best` rows of segments 8 j + (lane >> 3)
     auto prefetch = [&](int c) {
@@ -895,23 +1154,23 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
                 };
                 while (p < lim) {
                     const uint32_t b = myb[p - cb + 1], bn = myb[p - cb + 2], e2 = myb[p - cb + 3];
-                    const uint32_t lf = ZA_BLEN(b), nlf = ZA_BLEN(bn);
-                    const bool deferred = lazyf && lf < lazyf && p + 1 < s1 && nlf > lf;
-                    const bool is_match = lf != 0u && !deferred;
-                    const int len = (int)lf + 3;
+                    // (greedy over the entries: on levels 4-9 the dynamic programme has rewritten them so that this IS its parse)
+                    const uint32_t lf = ZA_ELEN(b), nlf = ZA_ELEN(bn);
+                    const bool is_match = lf != 0u;
+                    const int len = (int)lf;
                     const uint32_t lit = b >> 24;
-                    const int dist = is_match ? (int)(b & 0xFFFFu) : 1;
+                    const int dist = is_match ? (int)ZA_EDIST(b) : 1;
                     int lc, ln, le, dc, dn, de;
                     za_len_sym(is_match ? len : 3, lc, ln, le);
                     za_dist_sym(dist, dc, dn, de);
                     // a match token carries its symbols (length code << 26, extra << 21, distance code << 16, extra): the
-                    // packer, which is VALU-bound, needs no symbol arithmetic.  A literal at a position without any match (length
-                    // field 0: a literal whatever the lazy rule says) takes up to two more such positions into its token word --
+                    // packer, which is VALU-bound, needs no symbol arithmetic.  A literal (a position without a match: length
+                    // field 0) takes up to two more such positions into its token word --
                     // bytes in bits 0..23, count - 1 in bits 24..25 -- as far as this chunk's entries reach: most tokens of
                     // text are literals, 3.8 in a row, and fewer token words are fewer stores here and fewer loads in the packer.
                     // (Their entries were read together with this position's: one LDS round trip per round.)
                     const bool c1 = lf == 0u && p + 1 < ce && nlf == 0u;
-                    const bool c2 = c1 && p + 2 < ce && ZA_BLEN(e2) == 0u;
+                    const bool c2 = c1 && p + 2 < ce && ZA_ELEN(e2) == 0u;
                     const uint32_t l1 = bn >> 24, l2 = e2 >> 24;
                     const uint32_t t = is_match ? (0x80000000u | ((uint32_t)lc << 26) | ((uint32_t)le << 21) | ((uint32_t)dc << 16) | (uint32_t)de)
                                                 : lit | (c1 ? l1 << 8 : 0u) | (c2 ? l2 << 16 : 0u) | (((c1 ? 1u : 0u) + (c2 ? 1u : 0u)) << 24);

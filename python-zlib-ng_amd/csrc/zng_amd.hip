@@ -23,12 +23,14 @@ static_assert(sizeof(zngamd_member) == sizeof(ZaMember), "member layout");
 static_assert(ZNGAMD_SLOT_STRIDE % 4 == 0 && ZNGAMD_SLOT_STRIDE >= ZA_MAX_UNIT + 32, "slot stride");
 static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants");
 
-// (max_chain, nice_length, max_lazy) per level -- DESIGN.md 3.6: calibrated so that the ratio at each
-// level is >= zlib 1.2.11's at the same level on the text / FASTQ / mixed corpora
+// the level table (the same numbers as the oracle's): chain steps over table A, nice, cap, table C, dynamic programme,
+// too_far3, too_far4.  Within 2 % of zlib 1.2.11 at the same level on held-out real files, at least zlib on the synthetic corpora.
 #define ZA_CH_STREAMS_PER_CU (ZA_HASH_BITS >= 14 ? 2u : 3u)     // what the chain kernel's LDS (table + 14 KiB) lets a CU hold
 static const ZaLevel ZA_LEVELS[10] = {
-    {0, 0, 0, ZA_WIN, 0}, {1, 8, 0, ZA_WIN, 16}, {2, 8, 0, ZA_WIN, 16}, {3, 16, 0, ZA_WIN, 16}, {2, 16, 8, ZA_WIN, 16}, {2, 32, 8, ZA_WIN, 16},
-    {2, 32, 16, ZA_WIN, 16}, {6, 32, 16, ZA_WIN, 258}, {8, 64, 16, ZA_WIN, 258}, {12, 128, 128, ZA_WIN, 258}};
+    {0, 0, ZA_WIN, 0, 0, 0, 0, 0},
+    {1, 16, ZA_WIN, 16, 0, 0, 256, 4096}, {2, 16, ZA_WIN, 16, 0, 0, 256, 4096}, {3, 16, ZA_WIN, 16, 0, 0, 256, 4096},
+    {1, 16, ZA_WIN, 16, 0, 1, 4096, 32768}, {2, 16, ZA_WIN, 16, 0, 1, 4096, 32768}, {2, 16, ZA_WIN, 16, 1, 1, 4096, 32768},
+    {4, 32, ZA_WIN, 258, 1, 1, 4096, 32768}, {8, 64, ZA_WIN, 258, 1, 1, 4096, 32768}, {12, 128, ZA_WIN, 258, 1, 1, 4096, 32768}};
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t cap = 0;
@@ -66,7 +68,8 @@ struct zngamd_ctx {
     uint32_t *d_crc_slice4 = nullptr;                                         // CRC slice-by-4 table of za_k_inflate_members
     // deflate workspaces (per chunk of units)
     uint32_t chunk_units = 32768;                // units per launch: 1.4 MiB of workspace each (46 GB at 4 GiB of input); fewer, fuller launches
-    DevBuf<uint16_t> prev; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
+    DevBuf<uint16_t> prev, linkb, linkc; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
+    bool debug_keep = false; DevBuf<uint32_t> best_keep, dpcost;     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
     // per call
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status, runs;
     uint32_t last_units = 0; bool last_single_chunk = false;
@@ -197,7 +200,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    c->prev.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
+    c->prev.release(); c->linkb.release(); c->linkc.release(); c->best_keep.release(); c->dpcost.release(); c->hdr.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
     c->plan.release(); c->units.release(); c->segbits.release(); c->cidx.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
@@ -445,6 +448,9 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     HIPCHK(c, c->units.ensure(n)); HIPCHK(c, c->segbits.ensure((size_t)n * ZA_SEGB_STRIDE)); HIPCHK(c, c->cidx.ensure((size_t)n * ZA_CIDX_STRIDE)); HIPCHK(c, c->status.ensure(n));
     if (level > 0) {
         HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE + 8)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
+        HIPCHK(c, c->linkb.ensure((size_t)ch * ZA_PREV_STRIDE + 8));
+        if (ZA_LEVELS[level].use_c) HIPCHK(c, c->linkc.ensure((size_t)ch * ZA_PREV_STRIDE + 8));
+        if (c->debug_keep) { HIPCHK(c, c->best_keep.ensure((size_t)ch * ZA_BEST_STRIDE)); HIPCHK(c, c->dpcost.ensure((size_t)ch * ZA_DP_COSTS)); }
         HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
     }
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
@@ -505,13 +511,24 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         run_pos += nruns + 1;
         if (level > 0) {
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
-              hipLaunchKernelGGL(za_k_chains, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p); }
+              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_A>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p);
+              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_B>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkb.p);
+              if (L.use_c) hipLaunchKernelGGL(za_k_chains<ZA_TABLE_C>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkc.p); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
-              if (L.cap > 16) hipLaunchKernelGGL(za_k_search<true>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
-              else if (L.chain == 1) hipLaunchKernelGGL((za_k_search<false, 1>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
-              else if (L.chain == 2) hipLaunchKernelGGL((za_k_search<false, 2>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
-              else if (L.chain == 3) hipLaunchKernelGGL((za_k_search<false, 3>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L);
-              else hipLaunchKernelGGL(za_k_search<false>, dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, c->prev.p, c->best.p, L); }
+#define ZA_LAUNCH_SEARCH(...) hipLaunchKernelGGL((za_k_search<__VA_ARGS__>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, \
+                                                 c->prev.p, c->linkb.p, L.use_c ? c->linkc.p : c->linkb.p, c->best.p, L)
+              if (L.cap > 16) { if (L.use_c) ZA_LAUNCH_SEARCH(true, 0, true); else ZA_LAUNCH_SEARCH(true, 0, false); }
+              else if (L.chain == 1) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 1, true); else ZA_LAUNCH_SEARCH(false, 1, false); }
+              else if (L.chain == 2) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 2, true); else ZA_LAUNCH_SEARCH(false, 2, false); }
+              else if (L.chain == 3) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 3, true); else ZA_LAUNCH_SEARCH(false, 3, false); }
+              else { if (L.use_c) ZA_LAUNCH_SEARCH(false, 0, true); else ZA_LAUNCH_SEARCH(false, 0, false); }
+#undef ZA_LAUNCH_SEARCH
+            }
+            if (L.dp) {
+                if (c->debug_keep) HIPCHK(c, hipMemcpyAsync(c->best_keep.p, c->best.p, (size_t)m * ZA_BEST_STRIDE * 4, hipMemcpyDeviceToDevice, c->stream));
+                ProfScope ps(c, ZNGAMD_K_OPTPARSE);
+                hipLaunchKernelGGL(za_k_optparse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->debug_keep ? c->dpcost.p : (uint32_t *)nullptr, L);
+            }
             { ProfScope ps(c, ZNGAMD_K_PARSE);
               hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
                                  d_unit_crc + c0, c->d_crc_table, c->d_x8k, L); }
@@ -873,6 +890,14 @@ try {
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 
+int zngamd_debug_keep(zngamd_ctx *c, int on)
+{
+    if (!c) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->debug_keep = on != 0;
+    return ZNGAMD_OK;
+}
+
 int zngamd_debug_fetch(zngamd_ctx *c, int what, uint32_t unit, void *dst, size_t bytes)
 try {
     if (!c || !dst) return ZNGAMD_E_ARG;
@@ -889,23 +914,29 @@ try {
     case 6: src = c->segbits.p + (size_t)unit * ZA_SEGB_STRIDE; lim = ZA_SEGB_STRIDE * 4ull; break;
     case 7: src = c->plan.p + unit; lim = sizeof(ZaPlan); break;
     case 8: src = c->cidx.p + (size_t)unit * ZA_CIDX_STRIDE; lim = ZA_CIDX_STRIDE * 4ull; break;
+    case 9: src = c->linkb.p ? c->linkb.p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
+    case 10: src = c->linkc.p ? c->linkc.p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
+    case 11: src = c->best_keep.p ? c->best_keep.p + (size_t)unit * ZA_BEST_STRIDE : nullptr; lim = ZA_BEST_STRIDE * 4ull; break;
+    case 12: src = c->dpcost.p ? c->dpcost.p + (size_t)unit * ZA_DP_COSTS : nullptr; lim = ZA_DP_COSTS * 4ull; break;
     default: return fail(c, ZNGAMD_E_ARG, "unknown stage");
     }
     if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
     HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-    if (what == 0 && unit < c->last_hu.size() && (c->last_hu[unit].flags & ZA_FLAG_CARRY) && !(c->last_hu[unit].flags & ZA_FLAG_RUNHEAD) && unit > 0) {
+    if ((what == 0 || what == 9 || what == 10) && unit < c->last_hu.size() && (c->last_hu[unit].flags & ZA_FLAG_CARRY) && !(c->last_hu[unit].flags & ZA_FLAG_RUNHEAD) && unit > 0) {
         // a unit whose chain tables were carried over: the links of its dictionary are the links of the last 32 KiB of the unit in
-        // front of it (that unit's row) -- all but the last five, which this unit inserted itself; links that reach in front of
-        // the dictionary are "no link" for this unit
+        // front of it (that unit's row) -- all but the last few (context length - 1), which this unit inserted itself; links that
+        // reach in front of the dictionary are "no link" for this unit
         const ZaUnit &u = c->last_hu[unit], &pv = c->last_hu[unit - 1];
-        const size_t nd = std::min<size_t>(bytes / 2, u.dict_len - (ZA_HASH_BYTES - 1));
+        const uint16_t *tab = what == 0 ? c->prev.p : what == 9 ? c->linkb.p : c->linkc.p;
+        const size_t late = (what == 0 ? ZA_HASH_BYTES_A : what == 9 ? ZA_HASH_BYTES_B : ZA_HASH_BYTES_C) - 1;
+        const size_t nd = std::min<size_t>(bytes / 2, u.dict_len - late);
         uint16_t *d16 = (uint16_t *)dst;
-        HIPCHK(c, hipMemcpy(d16, c->prev.p + (size_t)(unit - 1) * ZA_PREV_STRIDE + pv.dict_len + pv.in_len - u.dict_len, nd * 2, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(d16, tab + (size_t)(unit - 1) * ZA_PREV_STRIDE + pv.dict_len + pv.in_len - u.dict_len, nd * 2, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < nd; i++) if (d16[i] > i) d16[i] = 0;
     }
-    if (what == 1) {     // the kernels' entry (distance | (length - 3) << 16 | the position's byte << 24) in the documented form len << 16 | dist
+    if (what == 1 || what == 11) {     // the kernels' entry (distance - 1 | length << 15 | the position's byte << 24) in the documented form len << 16 | dist
         uint32_t *e = (uint32_t *)dst;
-        for (size_t i = 0; i < bytes / 4; i++) { const uint32_t lf = (e[i] >> 16) & 0xFFu; e[i] = lf ? ((lf + 3u) << 16) | (e[i] & 0xFFFFu) : 0u; }
+        for (size_t i = 0; i < bytes / 4; i++) { const uint32_t lf = ZA_ELEN(e[i]); e[i] = lf ? (lf << 16) | ZA_EDIST(e[i]) : 0u; }
     }
     return ZNGAMD_OK;
 } ZA_ABI_GUARD

@@ -25,7 +25,7 @@ CHUNK_SHIFT = 11
 UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
-K_NAMES = ["chains", "search", "parse", "plan", "pack", "gather", "scan", "inflate", "other"]
+K_NAMES = ["chains", "search", "parse", "plan", "pack", "gather", "scan", "inflate", "other", "optparse"]
 
 # every symbol include/zng_amd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -41,7 +41,7 @@ SYMBOLS = [
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch",
+    "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch", "zngamd_debug_keep",
 ]
 
 
@@ -138,6 +138,7 @@ def load():
         L.zngamd_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_decode_paths.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
+        L.zngamd_debug_keep.argtypes = [vp, C.c_int]
         _lib = L
         return L
 
@@ -498,6 +499,9 @@ class Context:
             C.memmove(base + total, t, len(t))
             total += len(t)
         return out.take(total), crc.value, ad.value
+
+    def debug_keep(self, on=True):
+        self._chk(self.L.zngamd_debug_keep(self.h, 1 if on else 0))
 
     def debug_fetch(self, what, unit, nbytes):
         b = C.create_string_buffer(nbytes)

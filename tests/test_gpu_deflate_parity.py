@@ -28,14 +28,24 @@ def _stage_compare(ctx, O, data, zdict, level, flags):
     from zlib_ng_amd import _lib
     buf = zdict + data
     exp, exp_crc, dbg = O.deflate_unit(data, zdict, level, flags, debug=True)
+    ctx.debug_keep(True)
     got, crcs, ovf = ctx.deflate_blocks(buf, [(len(zdict), len(data), len(zdict), flags)], level, len(data) + 1024)
+    ctx.debug_keep(False)
     n, dl = len(data), len(zdict)
     lv = 6 if level == -1 else level
     if n and lv > 0:
         prev = np.frombuffer(ctx.debug_fetch(0, 0, 2 * (dl + n)), np.uint16)
         assert np.array_equal(prev, dbg["prevdist"]), f"stage1 chains differ at {np.flatnonzero(prev != dbg['prevdist'])[:5]}"
+        for what, key in ((9, "linkB"), (10, "linkC")) if lv >= 6 else ((9, "linkB"),):
+            lk = np.frombuffer(ctx.debug_fetch(what, 0, 2 * (dl + n)), np.uint16)
+            assert np.array_equal(lk, dbg[key]), f"stage1 {key} differs at {np.flatnonzero(lk != dbg[key])[:5]}"
+        if lv >= 4:      # the dynamic programme rewrites the entries: the search's own results are the kept copy
+            pre = np.frombuffer(ctx.debug_fetch(11, 0, 4 * n), np.uint32)
+            assert np.array_equal(pre, dbg["best"]), f"stage2 search differs at {np.flatnonzero(pre != dbg['best'])[:5]}"
+            cost = np.frombuffer(ctx.debug_fetch(12, 0, 4 * 258), np.uint32)
+            assert np.array_equal(cost, dbg["dp_cost"]), f"stage3a cost table differs at {np.flatnonzero(cost != dbg['dp_cost'])[:5]}"
         best = np.frombuffer(ctx.debug_fetch(1, 0, 4 * n), np.uint32)
-        assert np.array_equal(best, dbg["best"]), f"stage2 search differs at {np.flatnonzero(best != dbg['best'])[:5]}"
+        assert np.array_equal(best, dbg["best_dp"]), f"stage2/3a entries differ at {np.flatnonzero(best != dbg['best_dp'])[:5]}"
         nseg = (n + SEG - 1) // SEG
         sn = np.frombuffer(ctx.debug_fetch(3, 0, 4 * 64), np.uint32)
         assert np.array_equal(sn, dbg["seg_ntok"]), "stage3 token counts differ"
@@ -64,8 +74,8 @@ def _stage_compare(ctx, O, data, zdict, level, flags):
 
 @pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7, 8, 9, 0])
 def test_stagewise_parity(ctx, fastq, level):
-    """Every level of the table (one, two and three unrolled chain steps with and without the lazy rule; the work-list search of
-    levels 7-9 with six, eight and twelve steps in visits of four), every stage against the oracle."""
+    """Every level of the table (one, two and three unrolled chain steps, with and without table C and the dynamic programme; the
+    work-list search of levels 7-9 with four, eight and twelve steps in visits of four), every stage against the oracle."""
     from oracle import oracle as O
     for name, data in _inputs(fastq).items():
         if level >= 7 and name not in ("fastq128k", "fastq_tail", "zeros", "period36", "tiny5", "empty"):

@@ -1,0 +1,48 @@
+"""Held-out ratio gate through the HIP path (twin of tests/test_oracle_ratio_heldout.py): the engine's level N against the system
+zlib's level N on real files of this box, bench protocol (128 KiB units primed with the previous 32 KiB of input, sync flush per
+unit; zlib_ngmodule.c:1725-1742, gzip_ng_threaded.py:317).  Within 2 % at levels 1, 6 and 9; the stream must inflate with the
+system zlib; a sample of units must be the oracle's bytes."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+B = 131072
+TOL = 1.02
+
+
+def _zlib_units(data, level):
+    tot = 0
+    for off in range(0, len(data), B):
+        zd = data[max(0, off - 32768):off]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, 0, zd) if zd else zlib.compressobj(level, zlib.DEFLATED, -15, 8, 0)
+        tot += len(co.compress(data[off:off + B]) + co.flush(zlib.Z_SYNC_FLUSH))
+    return tot
+
+
+@pytest.fixture(scope="module")
+def corpora():
+    from zlib_ng_amd import corpus
+    c = corpus.heldout(4 << 20)
+    if not c:
+        pytest.skip("no held-out files on this box")
+    return c
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_heldout_within_two_percent_of_zlib_at_the_same_level(ctx, corpora, level):
+    from oracle import oracle as O
+    for name, data in corpora.items():
+        nb = (len(data) + B - 1) // B
+        blocks = [(b * B, min(B, len(data) - b * B), 32768 if b else 0, 0) for b in range(nb)]
+        outs, crcs, ovf = ctx.deflate_blocks(data, blocks, level, B + B // 8 + 600)
+        assert not ovf
+        stream = b"".join(outs)
+        assert zlib.decompressobj(-15).decompress(stream + b"\x03\x00") == data, name
+        for b in range(0, nb, 7):
+            exp, ecrc = O.deflate_unit(data[b * B:(b + 1) * B], data[max(0, b * B - 32768):b * B], level, 0)
+            assert outs[b] == exp and crcs[b] == ecrc, f"{name} level {level}: unit {b} differs from the oracle"
+        ref = _zlib_units(data, level)
+        assert len(stream) <= TOL * ref, f"{name} level {level}: {len(data) / len(stream):.4f} against zlib's {len(data) / ref:.4f}"
