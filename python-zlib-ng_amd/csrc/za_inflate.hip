@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(256) void za_k_scan_members(const uint8_t *__restri
     }
 }
 
-#define ZA_MATCHQ_PER_SEG 688      // queue entries per segment: >= 2048/4 matches + skip entries, a multiple of 4
+#define ZA_MATCHQ_PER_SEG 688      // queue entries per segment: >= 2048/3 matches (one entry per round at most), a multiple of 4
 #ifndef ZA_IROW_LOADS
 #define ZA_IROW_LOADS 4            // 16-byte loads per row of staged input
 #endif
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
         // per block: 36 stores for the 570 literal bytes of an average 2 KiB of text.
         uint8_t *litp = dst + seg0;
         uint64_t blk_lo = 0, blk_hi = 0;
-        // Queue entries: distance - 1 | (length - 3) << 15 | (literals since the previous entry) << 23.  A run of literals is cut
+        // Queue entries: distance - 1 | (length - 2) << 15 | (literals since the previous entry) << 24.  A run of literals is cut
         // into entries of its own (length field 0: the word is the count) before it exceeds 32, so that phase B moves every run
         // with two 16-byte copies.  Entries leave four at a time as one 16-byte store.
         uint32_t qb0 = 0, qb1 = 0, qb2 = 0;
@@ -1444,8 +1444,8 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                     // a match is due unless the segment ends behind the literals or a fourth literal follows
                     const bool want = pos1 < end && !(em != 0u && em < 0x8000u);
                     const bool bad_data = em == 0u || ((em & 0x7000u) != 0x7000u && (d == 0u || (int)dist > pos1));
-                    // end of block inside a segment, a length this queue cannot hold, a match across the segment end, queue full
-                    const bool bad_index = (em & 0x7000u) == 0x7000u || len < 4u || pos1 + (int)len > end || nmatch + 2u > ZA_MATCHQ_PER_SEG;
+                    // end of block inside a segment, a match across the segment end, queue full
+                    const bool bad_index = (em & 0x7000u) == 0x7000u || pos1 + (int)len > end || nmatch + 2u > ZA_MATCHQ_PER_SEG;
                     const bool take = want && !bad_data && !bad_index;
                     const int err = want && !take ? (bad_data && (em & 0x7000u) != 0x7000u ? 2 : 1) : 0;
                     // -- the literals go into the open block
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                     }
                     // -- one queue entry per round at most: the match with the literals in front of it, or a long run's count
                     const uint32_t g2 = gap + nl;                     // <= 26 + 6
-                    if (take) push((dist - 1u) | ((len - 3u) << 15) | (g2 << 23));
+                    if (take) push((dist - 1u) | ((len - 2u) << 15) | (g2 << 24));
                     else if (g2 >= 27u) push(g2);
                     gap = (take || g2 >= 27u) ? 0u : g2;
                     pos = pos1 + (take ? (int)len : 0);
@@ -1560,10 +1560,10 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                 const bool hasq = g + (uint32_t)lane < cnt;
                 const uint32_t ent = ent_next;
                 ent_next = g + 64u + (uint32_t)lane < cnt ? q[g + 64u + lane] : 0u;      // the next group's entries travel while this group is resolved
-                const uint32_t l3 = (ent >> 15) & 0xFFu;
-                const bool has = hasq && l3 != 0u;                      // a real match (length field 0: a run of literals)
-                const uint32_t mlen = has ? l3 + 3u : 0u, mdist = (ent & 0x7FFFu) + 1u;
-                const uint32_t glit = !hasq ? 0u : has ? (ent >> 23) : ent;       // literals in front of the match (<= 32)
+                const uint32_t l2 = (ent >> 15) & 0x1FFu;
+                const bool has = hasq && l2 != 0u;                      // a real match (length field 0: a run of literals)
+                const uint32_t mlen = has ? l2 + 2u : 0u, mdist = (ent & 0x7FFFu) + 1u;
+                const uint32_t glit = !hasq ? 0u : has ? (ent >> 24) : ent;       // literals in front of the match (<= 32)
                 const uint32_t incl = za_wave_incl_scan(glit + mlen), incm = za_wave_incl_scan(mlen);
                 const uint32_t mdst = segpos + incl - mlen;
                 const uint32_t up = mrem - (incm - mlen);               // my literals sit `up` bytes above their place
