@@ -490,7 +490,7 @@ def main():
 
     # ---- per-leg numbers -----------------------------------------------------------------------------
     steps = args.steps
-    deflate_ms = sum(kt[k][0] for k in ("chains", "search", "parse", "plan", "pack", "gather")) / steps
+    deflate_ms = sum(kt[k][0] for k in ("chains", "search", "optparse", "parse", "plan", "pack", "gather")) / steps
     inflate_ms = (kt["scan"][0] + kt["inflate"][0]) / steps
     # The roofline of the step's dominant LEG: deflate = the kernels chains + search + parse + plan + pack + gather
     # together move N_in + C_out algorithmic bytes per unit -- no single one of them can be credited with those bytes -- so the
@@ -498,14 +498,14 @@ def main():
     # (`dominant_kernel` names the longest single kernel, with the bytes its own role makes it move and its instruction issue.)
     legs = {"deflate": deflate_ms, "inflate": inflate_ms}
     dom_leg = max(legs, key=legs.get)
-    dom = max(("chains", "search", "parse", "plan", "pack", "inflate"), key=lambda k: kt[k][0])
+    dom = max(("chains", "search", "optparse", "parse", "plan", "pack", "inflate"), key=lambda k: kt[k][0])
     launches = max(1, kt[dom][1])
     avg_ms = kt[dom][0] / launches
     launches_per_step = launches / steps
     if dom_leg == "deflate":
-        leg_kernels = ("chains", "search", "parse", "plan", "pack", "gather")
+        leg_kernels = ("chains", "search", "optparse", "parse", "plan", "pack", "gather")
         leg_bytes = size + comp_bytes
-        leg_name = "deflate pipeline: za_k_chains + za_k_search + za_k_parse + za_k_plan + za_k_offsets + za_k_pack (packed: no gather)"
+        leg_name = "deflate pipeline: za_k_chains x3 (tables A, B, C) + za_k_search + za_k_optparse + za_k_parse + za_k_plan + za_k_offsets + za_k_pack (packed: no gather)"
     else:
         leg_kernels = ("scan", "inflate")
         leg_bytes = size + ms_len.value
@@ -520,7 +520,7 @@ def main():
                 "units_per_launch": int(nblocks / leg_sets)}
     # bytes the dominant kernel's own role makes it move per input byte N (by design, not measured): chains read N + dictionary,
     # write 2 B links; search reads links and input, writes 4 B entries; parse reads the entries, writes tokens; ...
-    own = {"chains": 1.0 + 2.0, "search": 2.0 + 1.0 + 4.0, "parse": 4.0 + 0.8, "pack": 1.6 + comp_bytes / size, "plan": 0.02,
+    own = {"chains": 3 * (1.0 + 2.0), "search": 2.0 + 2.0 + 2.0 + 1.0 + 4.0, "optparse": 4.0 + 4.0 + 4.0, "parse": 4.0 + 0.8, "pack": 1.6 + comp_bytes / size, "plan": 0.02,
            "inflate": (ms_len.value + size) / size}
     dom_bytes = own[dom] * size / launches_per_step
     # the longest single kernel: NOT a roofline fraction of the path (its bytes are intermediates) -- the bytes its own role makes it
@@ -537,7 +537,7 @@ def main():
             pmc_per_unit = pj
             traffic_src = "PMC passes of build '%s' taken at %s units per launch (profiles/pmc_traffic.json), scaled to %d units" % (
                 pj.get("build", "?"), pj.get("units_per_launch", "?"), nblocks)
-            for k in ("chains", "search", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
+            for k in ("chains", "search", "optparse", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
                 if pj.get("za_k_" + k):
                     traffic_step[k] = int(pj["za_k_" + k] * nblocks)
                 elif k == "gather":    # packed deflate: what is left under this timer is za_k_offsets (4 B read + 8 B written per unit: below the counters' floor)
@@ -580,7 +580,7 @@ def main():
         "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kt.items() if v[1]},
         "roofline": roofline,
         "dominant_kernel": roofline_dom,
-        "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains+search+parse+plan+offsets+pack",
+        "roofline_deflate_pipeline": {"bound": "hbm", "kernels": "chains(A,B,C)+search+optparse+parse+plan+offsets+pack",
                                       "achieved": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round((size + comp_bytes) / max(deflate_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5)},
         "device_memory_in_use_GB": round((total_b - free_b) / 1e9, 1),

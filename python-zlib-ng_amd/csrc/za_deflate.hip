@@ -864,28 +864,36 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_optparse : stage 3a, the dynamic programme of levels 4-9
+// k_dpstats + k_optparse : stage 3a, the dynamic programme of levels 4-9
 // ------------------------------------------------------------------------------------------------
-// One wave per unit, one lane per 2 KiB segment, like the parse kernel it feeds.  Going BACKWARDS through its segment a lane
-// works out, for every position p, the cheapest way to code everything from p to the segment's end: acc[p] = min(literal +
-// acc[p + 1], match of l bytes + acc[p + l]) over the position's match and its ZA_DP_SUB next shorter lengths, in estimated
-// quarter bits.  The choice is written back INTO the `best` entry (no match / the chosen length), so that the greedy walk of
-// the parse kernel is the programme's parse.
-//   costs      worked out first, from the unit's entries alone (oracle dp_costs): a coalesced pass of the whole
-//              wave over the entries -- bytes of the literal-like positions (LDS atomics), their count U, the count NM of
-//              positions where a new match starts -- then 256 literal costs and one match base cost, integer logarithms in
-//              quarter bits, by all lanes;
-//   acc[]      a lane needs acc[p + 1 .. p + 258]: a ring of 264 16-bit slots per lane in LDS (costs are kept modulo 2^16 --
-//              two entries at most 258 positions apart differ by less than 2^15 -- and compared through signed differences), its
-//              first eight slots mirrored behind its end so that the five values a step reads never wrap; lane stride odd in
-//              dwords: the lanes stand at the same slot most of the time, and that is conflict-free;
-//   entries    staged through LDS rows in chunks of 32 positions, loaded and stored TRANSPOSED like the parse kernel's (eight
-//              lanes move the eight 16-byte pieces of one segment's row), last chunk first.
-#define ZA_PCH 32                     // positions of a chunk of entries (this kernel's and the parse kernel's)
-#define ZA_PROW (ZA_PCH + 1)          // dwords of a lane's LDS row: (parse: the carried entry +) the chunk; an odd stride
-#define ZA_DP_RING   264
-#define ZA_DP_RSTRIDE 274         // u16 per lane: ring + 8 mirrored slots, rounded to an odd number of dwords (137)
-#define ZA_DP_COSTS  258          // per unit: [0..255] literal costs, [256] match base, [257] 0
+// Going BACKWARDS through a 2 KiB segment the programme works out, for every position p, the cheapest way to code everything
+// from p to the segment's end: acc[p] = min(literal + acc[p + 1], match of l bytes + acc[p + l]) over the position's match and
+// its ZA_DP_SUB next shorter lengths, in estimated quarter bits.  The choice is written back INTO the `best` entry (no match /
+// the chosen length), so that the greedy walk of the parse kernel is the programme's parse.
+//
+// za_k_dpstats (one 256-thread workgroup per unit): the unit's cost table (oracle dp_costs) from its entries
+// alone -- a coalesced pass over the entries: bytes of the literal-like positions (LDS atomics), their count U, the count NM of
+// positions where a new match starts; then 256 literal costs and one match base cost, integer logarithms in quarter bits.
+//
+// za_k_optparse (one wave per unit, one lane per segment, like the parse kernel it feeds):
+//   acc[]      a step reads acc[p + l] for l up to 258, but lengths above 64 are rare: the last ZA_DP_NEAR = 64 values live in
+//              an LDS ring (two 16-bit slots per dword, slot-major -- dword row (slot >> 1), column lane: a lane only ever touches
+//              its own bank; costs are kept modulo 2^16, two entries at most 258 positions apart differ by less than 2^15, and
+//              are compared through signed differences; four rows mirrored behind the end so that a step's five values never
+//              wrap), and EVERY value also goes to a per-segment array in global memory (the token workspace, not in use yet) at
+//              the end of its chunk, from where the rare long match fetches its five (behind a device-scope fence: the only
+//              traffic between lanes through memory; it is at least 61 positions = 3 chunks old).  9.5 KiB of LDS instead of
+//              the 35 KiB a full ring takes: ten waves per CU instead of three, and this kernel is all latency.
+//   entries    staged through LDS rows in chunks of 16 positions, loaded and stored TRANSPOSED (four lanes move the four 16-byte
+//              pieces of one segment's 64-byte row), last chunk first.
+#define ZA_PCH 32                     // positions of a chunk of entries in the parse kernel
+#define ZA_PROW (ZA_PCH + 1)          // dwords of a lane's LDS row there: the carried entry + the chunk; an odd stride
+#define ZA_DP_COSTS  258              // per unit: [0..255] literal costs, [256] match base, [257] 0
+#define ZA_DP_NEAR   64               // acc[p + 1 .. p + 64] come from the LDS ring
+#define ZA_DP_ROWS   (ZA_DP_NEAR / 2 + 4)
+#define ZA_DCH       16               // positions per chunk
+#define ZA_DROW      (ZA_DCH + 1)
+#define ZA_DP_SEGSLOTS 2064           // u16 slots per segment in the global array: 2 049 used, 16-byte multiples
 
 // 4 * log2(a / b) in whole quarter bits, a >= b >= 1, a < 2^22
 __device__ __forceinline__ int za_ilog4(uint32_t a, uint32_t b)
@@ -896,113 +904,126 @@ __device__ __forceinline__ int za_ilog4(uint32_t a, uint32_t b)
     return 4 * lg + (t >= 304u ? 1 : 0) + (t >= 362u ? 1 : 0) + (t >= 431u ? 1 : 0);
 }
 
+__global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ units, const uint32_t *__restrict__ best_ws,
+                                                    uint32_t *__restrict__ cost_ws /* ZA_DP_COSTS per unit */)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t cnt[2], tsum;
+    const int n = (int)units[blockIdx.x].in_len;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
+    hist[tid] = 0;
+    if (tid < 2) cnt[tid] = 0;
+    if (tid == 0) tsum = 0;
+    __syncthreads();
+    uint32_t U = 0, NM = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i0 = base + 4 * tid;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t pv = 0;
+        if (i0 < n) v = *(const uint4 *)(best + i0);               // (rows are 16-byte aligned; what lies behind n is not looked at)
+        if (lane == 0 && i0 > 0 && i0 < n) pv = best[i0 - 1];      // the entry in front of my wave's first
+        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+        uint32_t lp = (uint32_t)__shfl_up((int)ZA_ELEN(v.w), 1, 64);
+        if (lane == 0) lp = ZA_ELEN(pv);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t len = ZA_ELEN(e[k]);
+            if (i0 + k < n) {
+                if (len == 0u || (len == 3u && ZA_EDIST(e[k]) > (uint32_t)ZA_DP_WEAK_DIST)) { atomicAdd(&hist[e[k] >> 24], 1u); U++; }
+                else if (len + 1u != lp) NM++;
+            }
+            lp = len;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { U += (uint32_t)__shfl_xor((int)U, d, 64); NM += (uint32_t)__shfl_xor((int)NM, d, 64); }
+    if (lane == 0) { atomicAdd(&cnt[0], U); atomicAdd(&cnt[1], NM); }
+    __syncthreads();
+    U = cnt[0]; NM = cnt[1];
+    const uint32_t hh = 16u * hist[tid] + 1u + (U >> 6);
+    uint32_t T = hh;
+    for (int d = 32; d >= 1; d >>= 1) T += (uint32_t)__shfl_xor((int)T, d, 64);
+    if (lane == 0) atomicAdd(&tsum, T);
+    __syncthreads();
+    T = tsum;
+    uint32_t *cost = cost_ws + (size_t)blockIdx.x * ZA_DP_COSTS;
+    if (n == 0) return;
+    int lbias = za_ilog4(U + NM, U ? U : 1u), mbias = za_ilog4(U + NM, NM ? NM : 1u);
+    lbias = lbias > 24 ? 24 : lbias;
+    mbias = mbias > 24 ? 24 : mbias;
+    const int c = za_ilog4(T, hh) + lbias;
+    cost[tid] = (uint32_t)(c < 12 ? 12 : c > 52 ? 52 : c);
+    if (tid == 0) { cost[256] = (uint32_t)(12 + mbias + 20); cost[257] = 0u; }
+}
+
 __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ units, uint32_t *__restrict__ best_ws,
-                                                    uint32_t *__restrict__ cost_out /* debug: ZA_DP_COSTS per unit, or null */, ZaLevel L)
+                                                    const uint32_t *__restrict__ cost_ws, uint32_t *__restrict__ tok_ws /* scratch: acc[] */,
+                                                    ZaLevel L)
 {
     __shared__ uint32_t costt[ZA_DP_COSTS + 6];
     __shared__ uint8_t lxt[ZA_MAX_MATCH + 6];                     // 4 * extra bits of a length
-    __shared__ __attribute__((aligned(16))) uint16_t ring[64 * ZA_DP_RSTRIDE];
-    __shared__ uint32_t rowb[64 * ZA_PROW];
-    uint32_t *hist = (uint32_t *)ring;                            // (statistics first: the ring is not in use yet)
+    __shared__ uint32_t ring[ZA_DP_ROWS * 64];                    // row r, column lane: slots 2 r (low half) and 2 r + 1
+    __shared__ uint32_t rowb[64 * ZA_DROW];
     const ZaUnit u = units[blockIdx.x];
     const int n = (int)u.in_len;
     const int lane = za_lane();
     const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
     uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     if (n == 0) return;
-    // ---- the unit's cost table
-    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    for (int i = lane; i < ZA_DP_COSTS; i += 64) costt[i] = cost_ws[(size_t)blockIdx.x * ZA_DP_COSTS + i];
     for (int l = lane; l <= ZA_MAX_MATCH + 5; l += 64) {
         int lc, ln = 0, le;
         if (l >= 3 && l <= ZA_MAX_MATCH) za_len_sym(l, lc, ln, le);
         lxt[l] = (uint8_t)(4 * ln);
     }
     __syncthreads();
-    uint32_t U = 0, NM = 0;
-    {
-        uint32_t carry_len = 0;                                    // length field of the position in front of this round's first
-        for (int base = 0; base < n; base += 256) {
-            const int i0 = base + 4 * lane;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i0 < n) v = *(const uint4 *)(best + i0);           // (rows are 16-byte aligned; what lies behind n is not looked at)
-            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
-            uint32_t lp = (uint32_t)__shfl_up((int)ZA_ELEN(v.w), 1, 64);
-            if (lane == 0) lp = carry_len;
-            carry_len = (uint32_t)__builtin_amdgcn_readlane((int)ZA_ELEN(v.w), 63);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t len = ZA_ELEN(e[k]);
-                if (i0 + k < n) {
-                    if (len == 0u || (len == 3u && ZA_EDIST(e[k]) > (uint32_t)ZA_DP_WEAK_DIST)) { atomicAdd(&hist[e[k] >> 24], 1u); U++; }
-                    else if (len + 1u != lp) NM++;
-                }
-                lp = len;
-            }
-        }
-    }
-    for (int d = 32; d >= 1; d >>= 1) { U += (uint32_t)__shfl_xor((int)U, d, 64); NM += (uint32_t)__shfl_xor((int)NM, d, 64); }
-    __syncthreads();
-    uint32_t hh[4], T = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { hh[k] = 16u * hist[lane + 64 * k] + 1u + (U >> 6); T += hh[k]; }
-    for (int d = 32; d >= 1; d >>= 1) T += (uint32_t)__shfl_xor((int)T, d, 64);
-    {
-        int lbias = za_ilog4(U + NM, U ? U : 1u), mbias = za_ilog4(U + NM, NM ? NM : 1u);
-        lbias = lbias > 24 ? 24 : lbias;
-        mbias = mbias > 24 ? 24 : mbias;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c = za_ilog4(T, hh[k]) + lbias;
-            costt[lane + 64 * k] = (uint32_t)(c < 12 ? 12 : c > 52 ? 52 : c);
-        }
-        if (lane == 0) { costt[256] = (uint32_t)(12 + mbias + 20); costt[257] = 0u; }
-    }
-    __syncthreads();
-    if (cost_out) for (int i = lane; i < ZA_DP_COSTS; i += 64) cost_out[(size_t)blockIdx.x * ZA_DP_COSTS + i] = costt[i];
-    __syncthreads();                                               // (the statistics' counters lie in the ring)
 
-    // ---- the programme, last chunk first
     const int s0 = lane << ZA_SEG_SHIFT;
     int s1 = s0 + ZA_SEG;
     if (s1 > n) s1 = n;
     const bool active = lane < nseg;
-    uint32_t *myb = rowb + lane * ZA_PROW;
-    uint16_t *myr = ring + lane * ZA_DP_RSTRIDE;
+    uint32_t *myb = rowb + lane * ZA_DROW;
+    uint8_t *myring = (uint8_t *)(ring + lane);                    // byte address of slot s: (s >> 1) * 256 + (s & 1) * 2
+    uint16_t *accg = (uint16_t *)(tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE) + (size_t)lane * ZA_DP_SEGSLOTS;     // my segment's acc[], index p - s0
+    auto ring_put = [&](int slot, uint32_t v) {
+        *(uint16_t *)(myring + (slot >> 1) * 256 + (slot & 1) * 2) = (uint16_t)v;
+        if (slot < 8) *(uint16_t *)(myring + ((slot >> 1) + ZA_DP_NEAR / 2) * 256 + (slot & 1) * 2) = (uint16_t)v;
+    };
     const uint32_t mbase = costt[256];
-    int slot = active ? (s1 - s0) % ZA_DP_RING : 0;                // slot of position s1: acc = 0
-    if (active) { myr[slot] = 0; if (slot < 8) myr[slot + ZA_DP_RING] = 0; }
+    int idx = active ? s1 - s0 : 0;                                // p - s0 of the position whose acc was written last
+    if (active) { ring_put(idx & (ZA_DP_NEAR - 1), 0u); accg[idx] = 0; }     // acc[s1] = 0
     int acc_next = 0;                                              // acc[p + 1], the whole number (at most 2 048 x 52)
-    uint4 pb[8];
+    uint4 pb[4];
     auto prefetch = [&](int c) {
-        const int rel = c * ZA_PCH;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + rel + 4 * (lane & 7);
+        for (int j = 0; j < 4; j++) {
+            const int sg = 16 * j + (lane >> 2), off = (sg << ZA_SEG_SHIFT) + c * ZA_DCH + 4 * (lane & 3);
             pb[j] = make_uint4(0, 0, 0, 0);
             if (c >= 0 && sg < nseg && off < n) pb[j] = *(const uint4 *)(best + off);
         }
     };
-    const int nch = ((n < ZA_SEG ? n : ZA_SEG) + ZA_PCH - 1) / ZA_PCH;      // chunks of the longest segment
+    const int nch = ((n < ZA_SEG ? n : ZA_SEG) + ZA_DCH - 1) / ZA_DCH;      // chunks of the longest segment
     prefetch(nch - 1);
 #pragma unroll 1
     for (int c = nch - 1; c >= 0; c--) {
-        const int cb = s0 + c * ZA_PCH;
+        const int cb = s0 + c * ZA_DCH;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t *r = rowb + (8 * j + (lane >> 3)) * ZA_PROW + 4 * (lane & 7);
+        for (int j = 0; j < 4; j++) {
+            uint32_t *r = rowb + (16 * j + (lane >> 2)) * ZA_DROW + 4 * (lane & 3);
             r[0] = pb[j].x; r[1] = pb[j].y; r[2] = pb[j].z; r[3] = pb[j].w;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         prefetch(c - 1);
-        int ce = cb + ZA_PCH;
+        int ce = cb + ZA_DCH;
         if (ce > s1) ce = s1;
         if (active && cb < s1) {
 #pragma unroll 1
             for (int p = ce - 1; p >= cb; p--) {
-                slot = slot ? slot - 1 : ZA_DP_RING - 1;
+                idx--;                                             // = p - s0
+                const int slot = idx & (ZA_DP_NEAR - 1);
                 const uint32_t e = myb[p - cb];
                 const uint32_t len = ZA_ELEN(e), dm1 = e & 0x7FFFu;
                 int c_best = (int)costt[e >> 24];                  // the literal, relative to acc[p + 1]
@@ -1012,11 +1033,25 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
                     de = de < 0 ? 0 : de;
                     const int mc0 = (int)mbase + 4 * de;
                     const uint32_t l0 = len > 7u ? len - (uint32_t)ZA_DP_SUB : 3u;       // the shortest length tried
-                    int st = slot + (int)l0;
-                    st = st >= ZA_DP_RING ? st - ZA_DP_RING : st;
                     uint32_t a[ZA_DP_SUB + 1], x[ZA_DP_SUB + 1];
 #pragma unroll
-                    for (int k = 0; k <= ZA_DP_SUB; k++) { a[k] = myr[st + k]; x[k] = lxt[l0 + (uint32_t)k]; }
+                    for (int k = 0; k <= ZA_DP_SUB; k++) x[k] = lxt[l0 + (uint32_t)k];
+                    if (len <= (uint32_t)ZA_DP_NEAR) {
+                        const uint32_t st = (uint32_t)(slot + (int)l0) & (uint32_t)(ZA_DP_NEAR - 1);
+                        const uint8_t *rp = myring + (st >> 1) * 256;
+                        const uint32_t w0 = *(const uint32_t *)rp, w1 = *(const uint32_t *)(rp + 256), w2 = *(const uint32_t *)(rp + 512);
+                        const uint32_t sh = (st & 1u) * 2u;
+                        const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh), v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                        a[0] = v0 & 0xFFFFu; a[1] = v0 >> 16; a[2] = v1 & 0xFFFFu; a[3] = v1 >> 16;
+                        a[4] = (st & 1u) ? w2 >> 16 : w2 & 0xFFFFu;
+                    } else {
+                        // a long match: its five values from memory, written at least three chunks ago by this wave (other lanes'
+                        // stores among them: a fence, and loads that go to the device's L2)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+#pragma unroll
+                        for (int k = 0; k <= ZA_DP_SUB; k++)
+                            a[k] = __hip_atomic_load(accg + idx + (int)l0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     const bool far3 = dm1 >= (uint32_t)L.too_far3;                       // a 3-byte match that far back is no candidate
 #pragma unroll
                     for (int k = ZA_DP_SUB; k >= 0; k--) {                                // the longest first: it keeps a tie
@@ -1029,19 +1064,27 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
                     }
                 }
                 acc_next += c_best;
-                myr[slot] = (uint16_t)acc_next;
-                if (slot < 8) myr[slot + ZA_DP_RING] = (uint16_t)acc_next;
+                ring_put(slot, (uint32_t)acc_next);
                 myb[p - cb] = choice ? ((e & 0xFF007FFFu) | (choice << 15)) : (e & 0xFF000000u);
             }
         }
-        // ---- the chunk's entries go back
+        // ---- the chunk's entries go back, and its acc values go to memory (the ring's slots of this chunk: 16 slots = 8 rows)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active && cb < s1) {
+            const uint8_t *rp = myring + ((c * ZA_DCH) & (ZA_DP_NEAR - 1)) / 2 * 256;
+            uint32_t w[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + c * ZA_PCH + 4 * (lane & 7);
-            const uint32_t *r = rowb + sg * ZA_PROW + 4 * (lane & 7);
+            for (int k = 0; k < 8; k++) w[k] = *(const uint32_t *)(rp + 256 * k);
+            uint4 *g = (uint4 *)(accg + c * ZA_DCH);               // (segment arrays are 16-byte multiples apart)
+            g[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            g[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sg = 16 * j + (lane >> 2), off = (sg << ZA_SEG_SHIFT) + c * ZA_DCH + 4 * (lane & 3);
+            const uint32_t *r = rowb + sg * ZA_DROW + 4 * (lane & 3);
             if (sg < nseg && off < n) *(uint4 *)(best + off) = make_uint4(r[0], r[1], r[2], r[3]);
         }
     }

@@ -450,7 +450,8 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE + 8)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
         HIPCHK(c, c->linkb.ensure((size_t)ch * ZA_PREV_STRIDE + 8));
         if (ZA_LEVELS[level].use_c) HIPCHK(c, c->linkc.ensure((size_t)ch * ZA_PREV_STRIDE + 8));
-        if (c->debug_keep) { HIPCHK(c, c->best_keep.ensure((size_t)ch * ZA_BEST_STRIDE)); HIPCHK(c, c->dpcost.ensure((size_t)ch * ZA_DP_COSTS)); }
+        if (ZA_LEVELS[level].dp) HIPCHK(c, c->dpcost.ensure((size_t)ch * ZA_DP_COSTS));
+        if (c->debug_keep) HIPCHK(c, c->best_keep.ensure((size_t)ch * ZA_BEST_STRIDE));
         HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
     }
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
@@ -527,7 +528,8 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             if (L.dp) {
                 if (c->debug_keep) HIPCHK(c, hipMemcpyAsync(c->best_keep.p, c->best.p, (size_t)m * ZA_BEST_STRIDE * 4, hipMemcpyDeviceToDevice, c->stream));
                 ProfScope ps(c, ZNGAMD_K_OPTPARSE);
-                hipLaunchKernelGGL(za_k_optparse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->debug_keep ? c->dpcost.p : (uint32_t *)nullptr, L);
+                hipLaunchKernelGGL(za_k_dpstats, dim3(m), dim3(256), 0, c->stream, du, c->best.p, c->dpcost.p);
+                hipLaunchKernelGGL(za_k_optparse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->dpcost.p, c->tok.p, L);
             }
             { ProfScope ps(c, ZNGAMD_K_PARSE);
               hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
