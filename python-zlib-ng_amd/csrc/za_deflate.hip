@@ -888,11 +888,14 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 //              pieces of one segment's 64-byte row), last chunk first.
 #define ZA_PCH 32                     // positions of a chunk of entries in the parse kernel
 #define ZA_PROW (ZA_PCH + 1)          // dwords of a lane's LDS row there: the carried entry + the chunk; an odd stride
-#define ZA_DP_COSTS  258              // per unit: [0..255] literal costs, [256] match base, [257] 0
+#define ZA_DP_COSTS  260              // per unit: [0..255] literal costs, [256] match base, [257] 0, [258] 1 if a match of the unit is longer than ZA_DP_NEAR
 #define ZA_DP_NEAR   64               // acc[p + 1 .. p + 64] come from the LDS ring
 #define ZA_DP_ROWS   (ZA_DP_NEAR / 2 + 4)
-#define ZA_DCH       16               // positions per chunk
+#ifndef ZA_DCH
+#define ZA_DCH       16               // positions per chunk (16 or 32)
+#endif
 #define ZA_DROW      (ZA_DCH + 1)
+#define ZA_DPIECES   (ZA_DCH / 4)     // 16-byte pieces of a segment's row of one chunk = lanes per segment in the transposed moves
 #define ZA_DP_SEGSLOTS 2064           // u16 slots per segment in the global array: 2 049 used, 16-byte multiples
 
 // 4 * log2(a / b) in whole quarter bits, a >= b >= 1, a < 2^22
@@ -908,15 +911,16 @@ __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ u
                                                     uint32_t *__restrict__ cost_ws /* ZA_DP_COSTS per unit */)
 {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t cnt[2], tsum;
+    __shared__ uint32_t cnt[3], tsum;
     const int n = (int)units[blockIdx.x].in_len;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     hist[tid] = 0;
-    if (tid < 2) cnt[tid] = 0;
+    if (tid < 3) cnt[tid] = 0;
     if (tid == 0) tsum = 0;
     __syncthreads();
     uint32_t U = 0, NM = 0;
+    bool any_long = false;
     for (int base = 0; base < n; base += 1024) {
         const int i0 = base + 4 * tid;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -932,12 +936,14 @@ __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ u
             if (i0 + k < n) {
                 if (len == 0u || (len == 3u && ZA_EDIST(e[k]) > (uint32_t)ZA_DP_WEAK_DIST)) { atomicAdd(&hist[e[k] >> 24], 1u); U++; }
                 else if (len + 1u != lp) NM++;
+                any_long = any_long || len > (uint32_t)ZA_DP_NEAR;
             }
             lp = len;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) { U += (uint32_t)__shfl_xor((int)U, d, 64); NM += (uint32_t)__shfl_xor((int)NM, d, 64); }
-    if (lane == 0) { atomicAdd(&cnt[0], U); atomicAdd(&cnt[1], NM); }
+    const bool wave_long = __ballot(any_long) != 0ull;
+    if (lane == 0) { atomicAdd(&cnt[0], U); atomicAdd(&cnt[1], NM); if (wave_long) cnt[2] = 1u; }
     __syncthreads();
     U = cnt[0]; NM = cnt[1];
     const uint32_t hh = 16u * hist[tid] + 1u + (U >> 6);
@@ -953,15 +959,28 @@ __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ u
     mbias = mbias > 24 ? 24 : mbias;
     const int c = za_ilog4(T, hh) + lbias;
     cost[tid] = (uint32_t)(c < 12 ? 12 : c > 52 ? 52 : c);
-    if (tid == 0) { cost[256] = (uint32_t)(12 + mbias + 20); cost[257] = 0u; }
+    if (tid == 0) { cost[256] = (uint32_t)(12 + mbias + 20); cost[257] = 0u; cost[258] = cnt[2]; cost[259] = 0u; }
 }
 
+__device__ __forceinline__ uint32_t za_pk_add_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// The step is written for a wave that is alone on its SIMD most of the time (ten waves per CU): no branch in the common path
+// (a position without a match reads a table row of "impossible" candidates), the five candidates of a match as packed 16-bit
+// sums -- ring values (two slots per dword as they lie), the length table's row (extra bits of the five lengths, 0x3FFF where
+// the length is not tried) and the base (distance cost - acc[p + 1]) -- and ONE minimum over (cost << 3 | 4 - k): the cheapest,
+// among equals the longest.  The next position's entry, literal cost, table row and ring dwords are fetched before this
+// position's sums (they do not depend on it: the nearest slot a step reads was written two steps ago).
 __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ units, uint32_t *__restrict__ best_ws,
                                                     const uint32_t *__restrict__ cost_ws, uint32_t *__restrict__ tok_ws /* scratch: acc[] */,
                                                     ZaLevel L)
 {
-    __shared__ uint32_t costt[ZA_DP_COSTS + 6];
-    __shared__ uint8_t lxt[ZA_MAX_MATCH + 6];                     // 4 * extra bits of a length
+    __shared__ uint32_t costt[ZA_DP_COSTS + 4];
+    __shared__ uint32_t xt[3 * (ZA_MAX_MATCH + 1)];               // row `len`: 4 x extra bits of the lengths l0 .. l0 + 4 (u16 each; 0x3FFF: not tried), l0 in the last half
     __shared__ uint32_t ring[ZA_DP_ROWS * 64];                    // row r, column lane: slots 2 r (low half) and 2 r + 1
     __shared__ uint32_t rowb[64 * ZA_DROW];
     const ZaUnit u = units[blockIdx.x];
@@ -971,11 +990,22 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     if (n == 0) return;
     for (int i = lane; i < ZA_DP_COSTS; i += 64) costt[i] = cost_ws[(size_t)blockIdx.x * ZA_DP_COSTS + i];
-    for (int l = lane; l <= ZA_MAX_MATCH + 5; l += 64) {
-        int lc, ln = 0, le;
-        if (l >= 3 && l <= ZA_MAX_MATCH) za_len_sym(l, lc, ln, le);
-        lxt[l] = (uint8_t)(4 * ln);
+    for (int len = lane; len <= ZA_MAX_MATCH; len += 64) {
+        const int l0 = len > 7 ? len - ZA_DP_SUB : 3;
+        uint32_t x[ZA_DP_SUB + 1];
+#pragma unroll
+        for (int k = 0; k <= ZA_DP_SUB; k++) {
+            const int l = l0 + k;
+            int lc, ln = 0, le;
+            if (l <= ZA_MAX_MATCH) za_len_sym(l, lc, ln, le);
+            x[k] = (len >= 3 && l <= len) ? (uint32_t)(4 * ln) : 0x3FFFu;
+        }
+        xt[3 * len] = x[0] | (x[1] << 16); xt[3 * len + 1] = x[2] | (x[3] << 16); xt[3 * len + 2] = x[4] | ((uint32_t)l0 << 16);
     }
+    // the ring starts as zeros: a step reads five slots whatever its match is, and the ones it does not try (0x3FFF in the table)
+    // must hold something near acc[p + 1] for the packed sums to stay inside 16 signed bits -- real values, or, behind the segment's
+    // end, acc[s1] = 0
+    for (int i = lane; i < ZA_DP_ROWS * 64; i += 64) ring[i] = 0;
     __syncthreads();
 
     const int s0 = lane << ZA_SEG_SHIFT;
@@ -989,105 +1019,154 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         *(uint16_t *)(myring + (slot >> 1) * 256 + (slot & 1) * 2) = (uint16_t)v;
         if (slot < 8) *(uint16_t *)(myring + ((slot >> 1) + ZA_DP_NEAR / 2) * 256 + (slot & 1) * 2) = (uint16_t)v;
     };
-    const uint32_t mbase = costt[256];
-    int idx = active ? s1 - s0 : 0;                                // p - s0 of the position whose acc was written last
-    if (active) { ring_put(idx & (ZA_DP_NEAR - 1), 0u); accg[idx] = 0; }     // acc[s1] = 0
+    const int mbase = (int)costt[256];
+    const bool has_long = costt[258] != 0u;                        // (uniform) some match of the unit is longer than the ring: acc[] goes to memory too
+    if (active) { ring_put((s1 - s0) & (ZA_DP_NEAR - 1), 0u); accg[s1 - s0] = 0; }     // acc[s1] = 0
     int acc_next = 0;                                              // acc[p + 1], the whole number (at most 2 048 x 52)
-    uint4 pb[4];
+    // what the last long match fetched from memory: a run of positions inside one long match all end at the same place
+    int far_end = -1;
+    uint32_t fv0 = 0, fv1 = 0, fv2 = 0;
+    uint4 pb[ZA_DPIECES];
     auto prefetch = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int sg = 16 * j + (lane >> 2), off = (sg << ZA_SEG_SHIFT) + c * ZA_DCH + 4 * (lane & 3);
+        for (int j = 0; j < ZA_DPIECES; j++) {
+            const int sg = (64 / ZA_DPIECES) * j + lane / ZA_DPIECES, off = (sg << ZA_SEG_SHIFT) + c * ZA_DCH + 4 * (lane % ZA_DPIECES);
             pb[j] = make_uint4(0, 0, 0, 0);
             if (c >= 0 && sg < nseg && off < n) pb[j] = *(const uint4 *)(best + off);
         }
     };
+    // stage B of a step: what needs the position's entry and nothing of the steps in front of it -- the literal's cost, the
+    // length table's row, the ring's three dwords from acc[p + l0] on.  (idx = p - s0 is the same number in every lane.)
+    struct Fetch { uint32_t e, clit, x0, x1, x2, w0, w1, w2; };
+    auto stage_b = [&](uint32_t e, int idx_p) -> Fetch {
+        Fetch f;
+        f.e = e;
+        f.clit = costt[e >> 24];
+        const uint32_t len = ZA_ELEN(e);
+        const uint32_t *xr = xt + 3u * len;
+        f.x0 = xr[0]; f.x1 = xr[1]; f.x2 = xr[2];
+        const uint32_t l0 = len > 7u ? len - (uint32_t)ZA_DP_SUB : 3u;
+        const uint32_t st = ((uint32_t)idx_p + l0) & (uint32_t)(ZA_DP_NEAR - 1);      // slot of acc[p + l0]
+        const uint8_t *rp = myring + (st >> 1) * 256;
+        f.w0 = *(const uint32_t *)rp; f.w1 = *(const uint32_t *)(rp + 256); f.w2 = *(const uint32_t *)(rp + 512);
+        return f;
+    };
     const int nch = ((n < ZA_SEG ? n : ZA_SEG) + ZA_DCH - 1) / ZA_DCH;      // chunks of the longest segment
+    uint4 po[ZA_DPIECES];                                           // the last chunk's entries on their way out
+    uint32_t wacc[ZA_DCH / 2];                                      // ... and its acc values
+    int pend = -1;
+    auto flush_pending = [&]() {
+        if (pend < 0) return;
+        const int pcb = s0 + pend * ZA_DCH;
+        if (has_long && active && pcb < s1) {
+            uint4 *g = (uint4 *)(accg + pend * ZA_DCH);             // (segment arrays are 16-byte multiples apart)
+#pragma unroll
+            for (int k = 0; k < ZA_DCH / 8; k++) g[k] = make_uint4(wacc[4 * k], wacc[4 * k + 1], wacc[4 * k + 2], wacc[4 * k + 3]);
+        }
+#pragma unroll
+        for (int j = 0; j < ZA_DPIECES; j++) {
+            const int sg = (64 / ZA_DPIECES) * j + lane / ZA_DPIECES, off = (sg << ZA_SEG_SHIFT) + pend * ZA_DCH + 4 * (lane % ZA_DPIECES);
+            if (sg < nseg && off < n) *(uint4 *)(best + off) = po[j];
+        }
+    };
     prefetch(nch - 1);
 #pragma unroll 1
     for (int c = nch - 1; c >= 0; c--) {
         const int cb = s0 + c * ZA_DCH;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t *r = rowb + (16 * j + (lane >> 2)) * ZA_DROW + 4 * (lane & 3);
+        for (int j = 0; j < ZA_DPIECES; j++) {
+            uint32_t *r = rowb + ((64 / ZA_DPIECES) * j + lane / ZA_DPIECES) * ZA_DROW + 4 * (lane % ZA_DPIECES);
             r[0] = pb[j].x; r[1] = pb[j].y; r[2] = pb[j].z; r[3] = pb[j].w;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        flush_pending();
         prefetch(c - 1);
-        int ce = cb + ZA_DCH;
-        if (ce > s1) ce = s1;
-        if (active && cb < s1) {
-#pragma unroll 1
-            for (int p = ce - 1; p >= cb; p--) {
-                idx--;                                             // = p - s0
-                const int slot = idx & (ZA_DP_NEAR - 1);
-                const uint32_t e = myb[p - cb];
-                const uint32_t len = ZA_ELEN(e), dm1 = e & 0x7FFFu;
-                int c_best = (int)costt[e >> 24];                  // the literal, relative to acc[p + 1]
-                uint32_t choice = 0;
-                if (len != 0u) {
-                    int de = 30 - (int)__builtin_clz(dm1 | 1u);    // extra bits of the distance: 0 for distances 1 .. 4
-                    de = de < 0 ? 0 : de;
-                    const int mc0 = (int)mbase + 4 * de;
-                    const uint32_t l0 = len > 7u ? len - (uint32_t)ZA_DP_SUB : 3u;       // the shortest length tried
-                    uint32_t a[ZA_DP_SUB + 1], x[ZA_DP_SUB + 1];
+        if (__ballot(active && cb < s1) != 0ull) {
+            // Every lane walks the chunk's 16 positions in step (a segment's last chunk may be short: its positions at and behind s1
+            // are walked without effect), as a pipeline of two stages: while position j is decided, stage B of position j - 1
+            // and the entry of position j - 2 are on their way from the LDS.
+            const int ib = c * ZA_DCH;                                // p - s0 of the chunk's first position, in every lane
+            uint32_t e_a = myb[ZA_DCH - 2];                            // entry of position j - 1 (stage A: read one step ahead of stage B)
+            Fetch f = stage_b(myb[ZA_DCH - 1], ib + ZA_DCH - 1);
+#pragma unroll 4
+            for (int j = ZA_DCH - 1; j >= 0; j--) {
+                const int idx = ib + j;                                // = p - s0
+                const bool live = active && cb + j < s1;
+                const Fetch g = f;
+                if (j >= 1) f = stage_b(e_a, idx - 1);
+                if (j >= 2) e_a = myb[j - 2];
+                const uint32_t e = g.e, len = ZA_ELEN(e), dm1 = e & 0x7FFFu, l0 = g.x2 >> 16;
+                const uint32_t st1 = ((uint32_t)idx + l0) & 1u;
+                uint32_t v0 = __builtin_amdgcn_alignbyte(g.w1, g.w0, 2u * st1), v1 = __builtin_amdgcn_alignbyte(g.w2, g.w1, 2u * st1);
+                uint32_t v2 = st1 ? g.w2 >> 16 : g.w2;
+                if (__builtin_expect(__ballot(live && len > (uint32_t)ZA_DP_NEAR) != 0ull, 0)) {
+                    // a long match: its five values from memory, written at least three chunks ago by this wave (other lanes'
+                    // stores among them: a fence, and loads that go to the device's L2); the positions of one long match all end
+                    // at the same place, so what the last one fetched mostly serves
+                    if (live && len > (uint32_t)ZA_DP_NEAR) {
+                        const int end = idx + (int)len;
+                        if (end != far_end) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                            uint32_t a[ZA_DP_SUB + 1];
 #pragma unroll
-                    for (int k = 0; k <= ZA_DP_SUB; k++) x[k] = lxt[l0 + (uint32_t)k];
-                    if (len <= (uint32_t)ZA_DP_NEAR) {
-                        const uint32_t st = (uint32_t)(slot + (int)l0) & (uint32_t)(ZA_DP_NEAR - 1);
-                        const uint8_t *rp = myring + (st >> 1) * 256;
-                        const uint32_t w0 = *(const uint32_t *)rp, w1 = *(const uint32_t *)(rp + 256), w2 = *(const uint32_t *)(rp + 512);
-                        const uint32_t sh = (st & 1u) * 2u;
-                        const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh), v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                        a[0] = v0 & 0xFFFFu; a[1] = v0 >> 16; a[2] = v1 & 0xFFFFu; a[3] = v1 >> 16;
-                        a[4] = (st & 1u) ? w2 >> 16 : w2 & 0xFFFFu;
-                    } else {
-                        // a long match: its five values from memory, written at least three chunks ago by this wave (other lanes'
-                        // stores among them: a fence, and loads that go to the device's L2)
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-#pragma unroll
-                        for (int k = 0; k <= ZA_DP_SUB; k++)
-                            a[k] = __hip_atomic_load(accg + idx + (int)l0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    const bool far3 = dm1 >= (uint32_t)L.too_far3;                       // a 3-byte match that far back is no candidate
-#pragma unroll
-                    for (int k = ZA_DP_SUB; k >= 0; k--) {                                // the longest first: it keeps a tie
-                        const uint32_t l = l0 + (uint32_t)k;
-                        const int rel = (int)(int16_t)(uint16_t)(a[k] - (uint32_t)acc_next);
-                        const int mc = mc0 + (int)x[k] + rel;
-                        const bool ok = l <= len && !(l == 3u && far3) && mc < c_best;
-                        c_best = ok ? mc : c_best;
-                        choice = ok ? l : choice;
+                            for (int k = 0; k <= ZA_DP_SUB; k++)
+                                a[k] = __hip_atomic_load(accg + end - ZA_DP_SUB + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            fv0 = a[0] | (a[1] << 16); fv1 = a[2] | (a[3] << 16); fv2 = a[4];
+                            far_end = end;
+                        }
+                        v0 = fv0; v1 = fv1; v2 = fv2;
                     }
                 }
-                acc_next += c_best;
-                ring_put(slot, (uint32_t)acc_next);
-                myb[p - cb] = choice ? ((e & 0xFF007FFFu) | (choice << 15)) : (e & 0xFF000000u);
+                int de = 30 - (int)__builtin_clz(dm1 | 1u);        // extra bits of the distance: 0 for distances 1 .. 4
+                de = de < 0 ? 0 : de;
+                const uint32_t b16 = (uint32_t)(mbase + 4 * de - acc_next) & 0xFFFFu;
+                const uint32_t bb = b16 | (b16 << 16);
+                uint32_t sA = za_pk_add_u16(za_pk_add_u16(v0, g.x0), bb);
+                const uint32_t sB = za_pk_add_u16(za_pk_add_u16(v1, g.x1), bb);
+                const uint32_t sC = za_pk_add_u16(za_pk_add_u16(v2, g.x2), bb);
+                if (l0 == 3u && dm1 >= (uint32_t)L.too_far3) sA = (sA & 0xFFFF0000u) | 0x3FFFu;      // a 3-byte match that far back is no candidate
+                // cost << 3 | (4 - k): the minimum is the cheapest, and the longest among equals
+                const int t0 = (__builtin_amdgcn_sbfe((int)sA, 0, 16) << 3) | 4, t1 = (((int)sA >> 16) << 3) | 3;
+                const int t2 = (__builtin_amdgcn_sbfe((int)sB, 0, 16) << 3) | 2, t3 = (((int)sB >> 16) << 3) | 1;
+                const int t4 = __builtin_amdgcn_sbfe((int)sC, 0, 16) << 3;
+                int t = t0 < t1 ? t0 : t1;
+                t = t < t2 ? t : t2;
+                int tb = t3 < t4 ? t3 : t4;
+                t = t < tb ? t : tb;
+                const int mc = t >> 3;
+                const bool ok = mc < (int)g.clit;
+                const int c_best = ok ? mc : (int)g.clit;
+                const uint32_t choice = ok ? l0 + 4u - ((uint32_t)t & 7u) : 0u;
+                if (live) {
+                    acc_next += c_best;
+                    ring_put(idx & (ZA_DP_NEAR - 1), (uint32_t)acc_next);
+                    myb[j] = choice ? ((e & 0xFF007FFFu) | (choice << 15)) : (e & 0xFF000000u);
+                }
             }
         }
-        // ---- the chunk's entries go back, and its acc values go to memory (the ring's slots of this chunk: 16 slots = 8 rows)
+        // ---- the chunk's entries (and, where the unit has long matches, its acc values: the ring's slots of this chunk, 16 slots =
+        // 8 rows) are taken into registers now and STORED at the start of the next round, in front of that round's loads: the wait
+        // for those loads at the top of the loop is then a wait for the youngest operations in flight, and the stores -- a whole
+        // round old by then -- cost nothing (stored here, behind the loads, every round waited for its stores' round trip).
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active && cb < s1) {
+        if (has_long && active && cb < s1) {
             const uint8_t *rp = myring + ((c * ZA_DCH) & (ZA_DP_NEAR - 1)) / 2 * 256;
-            uint32_t w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = *(const uint32_t *)(rp + 256 * k);
-            uint4 *g = (uint4 *)(accg + c * ZA_DCH);               // (segment arrays are 16-byte multiples apart)
-            g[0] = make_uint4(w[0], w[1], w[2], w[3]);
-            g[1] = make_uint4(w[4], w[5], w[6], w[7]);
+            for (int k = 0; k < ZA_DCH / 2; k++) wacc[k] = *(const uint32_t *)(rp + 256 * k);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int sg = 16 * j + (lane >> 2), off = (sg << ZA_SEG_SHIFT) + c * ZA_DCH + 4 * (lane & 3);
-            const uint32_t *r = rowb + sg * ZA_DROW + 4 * (lane & 3);
-            if (sg < nseg && off < n) *(uint4 *)(best + off) = make_uint4(r[0], r[1], r[2], r[3]);
+        for (int j = 0; j < ZA_DPIECES; j++) {
+            const uint32_t *r = rowb + ((64 / ZA_DPIECES) * j + lane / ZA_DPIECES) * ZA_DROW + 4 * (lane % ZA_DPIECES);
+            po[j] = make_uint4(r[0], r[1], r[2], r[3]);
         }
+        pend = c;
     }
+    flush_pending();
 }
 
 // ------------------------------------------------------------------------------------------------
