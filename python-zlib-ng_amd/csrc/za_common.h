@@ -78,8 +78,9 @@ typedef uint64_t __attribute__((aligned(1))) za_u64u;
 __device__ __forceinline__ uint32_t za_ld32(const uint8_t *p) { return *(const za_u32u *)p; }
 __device__ __forceinline__ uint64_t za_ld64(const uint8_t *p) { return *(const za_u64u *)p; }
 typedef uint16_t __attribute__((aligned(1))) za_u16u;
-struct __attribute__((aligned(1))) ZaU4u { uint32_t x, y, z, w; };      // 16 bytes at any address
-struct __attribute__((aligned(1))) ZaU2u { uint32_t x, y; };
+struct __attribute__((packed, aligned(1))) ZaU4u { uint32_t x, y, z, w; };      // 16 bytes at any address
+struct __attribute__((packed, aligned(1))) ZaU2u { uint32_t x, y; };
+static_assert(alignof(ZaU4u) == 1 && alignof(ZaU2u) == 1, "under-aligned vector types");
 __device__ __forceinline__ uint32_t za_ld16(const uint8_t *p) { return *(const za_u16u *)p; }
 // the full 32-bit hash of a table's context out of its little-endian dwords w0 = bytes 0..3, w1 = bytes 4..7, w2 = bytes 8..11
 // (the bucket is its top ZA_HASH_BITS bits; bytes behind the context do not matter: A masks byte 4 out of w1, B's product has

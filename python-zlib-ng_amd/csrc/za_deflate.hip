@@ -2062,8 +2062,8 @@ __global__ __launch_bounds__(256) void za_k_gather(const uint8_t *__restrict__ s
 // units != nullptr: indexed members -- every unit also takes 4 bytes of index per 256 bytes of its input
 __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict__ out_len, uint32_t n, uint32_t extra,
                                                      uint64_t base, uint64_t *__restrict__ dst_off,
-                                                     uint64_t *__restrict__ total, const ZaUnit *__restrict__ units,
-                                                     const uint64_t *__restrict__ d_base = nullptr)      // (+ *d_base: the total of the launches in front)
+                                                     uint64_t *total, const ZaUnit *__restrict__ units,
+                                                     const uint64_t *d_base = nullptr)      // (+ *d_base: the total of the launches in front; may BE `total`: no __restrict__ on either)
 {
     if (d_base) base += *d_base;
     auto ext = [&](uint32_t i) -> unsigned long long {

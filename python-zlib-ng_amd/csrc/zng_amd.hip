@@ -76,7 +76,7 @@ struct zngamd_ctx {
     std::vector<ZaUnit> last_hu;                 // the units of the last deflate call as the kernels saw them (zngamd_debug_fetch)
     std::vector<ZaUnit> plan_in; std::vector<uint32_t> plan_runs; uint32_t plan_ch = 0;     // the unit table the device holds was planned from this one: a caller that compresses batch after batch of the same shape pays for the planning once
     std::vector<zngamd_block> blocks_in; std::vector<ZaUnit> blocks_hu; uint64_t blocks_len = 0;
-    uint32_t chain_slots = 1024;                 // chain-kernel workgroups the device holds at once: CUs x 4 (34 KiB of LDS each)
+    uint32_t chain_slots = 512;                  // chain-kernel workgroups the device holds at once: CUs x ZA_CH_STREAMS_PER_CU (two with the 64 KiB table)
     uint32_t chain_run = 0;                      // ZNGAMD_CHAIN_RUN: fixed run length of the chain kernel (0 = sized to the device)
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux, hdr; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
@@ -1352,7 +1352,13 @@ static int inflate_chunked_dev(zngamd_ctx *c, const uint8_t *d_def, uint64_t ava
         ChunkOpts bo; bo.start_bit = (uint32_t)(pos_bit & 7ull); bo.d_dict = dict; bo.dict_len = dict_len; bo.allow_cut = lastb ? o.allow_cut : true;
         ChunkInfo bi; uint64_t bl = 0, bu = 0;
         const int r = inflate_chunked_once(c, d_def + byte0, lastb ? avail - byte0 : batch, d_out + acc, out_room - acc, &bl, &bu, bo, &bi);
-        if (r == ZNGAMD_BUF_ERROR) { *out_len = acc + bl; *info = bi; return r; }
+        if (r == ZNGAMD_BUF_ERROR) {
+            // the room this batch needs is known, the batches behind it are not decoded yet: their share is extrapolated from the
+            // expansion so far (+ 1/16), so that a caller who resizes to the reported size retries once, not once per batch
+            uint64_t need = acc + bl;
+            if (!lastb) need = std::max<uint64_t>(need, (uint64_t)((long double)need * (long double)avail / (long double)(byte0 + batch) * 1.0625L) + (1u << 20));
+            *out_len = need; *info = bi; return r;
+        }
         if (r < 0) return r;
         if (r != 0 || (!lastb && !bi.ended && (bl == 0 || acc + bl < (uint64_t)ZA_WIN))) {
             // a batch this path does not take (or one that made no headway): the whole stream the old way, as one
@@ -1731,17 +1737,21 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
                 prof_collect(c);
                 bool all_ok = true;
                 for (size_t i = 0; i < st.size(); i++) if (st[i] != ZA_I_OK) { all_ok = false; break; }
-                if (all_ok && (covered == in_len || partial)) {
+                // NUL padding behind the members is skipped, as the reference's reader does (zlib_ngmodule.c:2604-2612) and as the member
+                // loop below does behind every member it decodes
+                uint64_t behind = covered;
+                while (behind < in_len && ((const uint8_t *)in)[behind] == 0) behind++;
+                if (all_ok && (behind == in_len || partial)) {
                     if (total) { const int rc_ = d2h_payload(c, out, c->st_out.p, total); if (rc_) return rc_; }
                     *out_len = total;
                     if (n_members) *n_members = (uint32_t)hm.size();
                     c->paths[ZNGAMD_PATH_INDEXED] += hm.size();
-                    *in_consumed = covered;          // == in_len unless partial
+                    *in_consumed = behind == in_len ? in_len : covered;
                     return ZNGAMD_OK;
                 }
                 if (all_ok) {                        // the indexed members are a prefix of the buffer: their bytes stay where they are
                     c->paths[ZNGAMD_PATH_INDEXED] += hm.size();
-                    op = total; members = (uint32_t)hm.size(); pos = covered;
+                    op = total; members = (uint32_t)hm.size(); pos = behind;
                     prefix_done = true;
                 }
                 // anything unexpected (foreign 'ZA' field, stored blocks, corruption): the sequential

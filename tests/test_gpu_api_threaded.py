@@ -544,6 +544,30 @@ def test_writer_of_indexed_members(T, tmp_path, monkeypatch):
     assert target.read_bytes()[3] == 0 and std_gzip.decompress(target.read_bytes()) == data[:100000]
 
 
+def test_indexed_members_followed_by_padding_and_foreign_members(T, tmp_path):
+    """A file of indexed members with NUL padding behind it -- and with a member of another writer behind the padding -- decodes:
+    the reference's reader skips NUL bytes between and behind members (zlib_ngmodule.c:2604-2612; CPython's gzip does too)."""
+    import gzip as std_gzip
+    from zlib_ng_amd import corpus, gzip_ng, zlib_ng
+    data = corpus.text(400000, seed=43).tobytes()
+    target = tmp_path / "pad.gz"
+    with T.open(target, "wb", compresslevel=6, threads=1, block_size=128 * 1024, indexed_members=True) as f:
+        f.write(data)
+    members = target.read_bytes()
+    assert members[3] == 4
+    tail = b"the tail of another writer\n" * 300
+    for raw, want in ((members + bytes(50), data), (members + bytes(7), data),
+                      (members + bytes(50) + std_gzip.compress(tail, mtime=0), data + tail),
+                      (members + std_gzip.compress(tail, mtime=0) + bytes(13), data + tail)):
+        assert std_gzip.decompress(raw) == want
+        assert gzip_ng.decompress(raw) == want
+        target.write_bytes(raw)
+        with gzip_ng.open(target, "rb") as f:
+            assert f.read() == want
+        with T.open(target, "rb", threads=1) as f:
+            assert f.read() == want
+
+
 def test_gzip_ng_open_writes_members_when_the_environment_asks(tmp_path, monkeypatch):
     """ZNGAMD_WRITER_MEMBERS=1 also reaches gzip_ng.open(..., "w?"): the file is independent indexed members (binary and text
     mode), any gzip reader reads it; without the variable the writer is GzipNGFile as ever."""
