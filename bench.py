@@ -643,9 +643,39 @@ def main():
                                   "note": "independent blocks, no dictionary"}
         except Exception:
             out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
+    # ---- what the level compresses like OFF the bench corpus (rank 0, N = 1; outside the timed region): real files of this box
+    # (zlib_ng_amd.corpus.heldout: Python sources, two ELF binaries, C headers; 4 MiB each) through the HIP path, 128 KiB units with
+    # the previous 32 KiB as dictionary and a sync flush each -- the bench's own protocol -- beside the system zlib at the SAME level
+    if rank == 0 and world == 1:
+        from zlib_ng_amd import corpus as _corpus
+        rh = {}
+        for cname, cdata in _corpus.heldout(4 << 20).items():
+            nbk = (len(cdata) + BLOCK - 1) // BLOCK
+            blks = [(b * BLOCK, min(BLOCK, len(cdata) - b * BLOCK), 32768 if b else 0, 0) for b in range(nbk)]
+            row = {}
+            for lv in sorted({1, args.level, 9}):
+                outs, _crcs, ovf = ctx.deflate_blocks(cdata, blks, lv, BLOCK + BLOCK // 8 + 600)
+                assert not ovf
+                stream = b"".join(outs)
+                assert zlib.decompressobj(-15).decompress(stream + b"\x03\x00") == cdata, f"held-out {cname} level {lv} does not inflate"
+                zt = 0
+                for b in range(nbk):
+                    zdct = cdata[max(0, b * BLOCK - 32768):b * BLOCK]
+                    co = zlib.compressobj(lv, zlib.DEFLATED, -15, 8, 0, zdct) if zdct else zlib.compressobj(lv, zlib.DEFLATED, -15, 8, 0)
+                    zt += len(co.compress(cdata[b * BLOCK:(b + 1) * BLOCK]) + co.flush(zlib.Z_SYNC_FLUSH))
+                row[f"level_{lv}"] = {"ours": round(len(cdata) / len(stream), 4), "zlib_same_level": round(len(cdata) / zt, 4),
+                                      "size_vs_zlib": round(len(stream) / zt, 4)}
+            rh[cname] = row
+        out["ratio_heldout"] = rh
+        out["ratio_heldout_note"] = ("HIP path (zngamd_deflate_blocks) on files of this box, bench protocol; zlib " + zlib.ZLIB_RUNTIME_VERSION +
+                                     " at the same level beside it; gate: size_vs_zlib <= 1.02 (tests/test_gpu_ratio_heldout.py)")
     if foreign is not None:
         out["roofline_inflate_foreign"] = foreign
     if chained is not None:
+        # compress + the decode of the very stream the compress leg wrote (what gzip_ng_threaded.open("rb") gets for a file of the
+        # default writer), beside `value`, whose decode leg reads indexed members
+        out["value_chained"] = round(total_size / ((deflate_ms + chained["ms"]) * 1e-3) / 1e6, 1)
+        out["value_chained_note"] = "MB/s of compress + chunk-parallel decode of the compress leg's own single-member stream (kernel time of the deflate leg + the whole device-resident decode call)"
         # HBM bytes of the chunk pipeline's kernels for one decode of the stream: the counter passes give every kernel's average
         # launch (per unit of the launch size they were taken at); a decode launches each of them once per batch of compressed input
         # (ZNGAMD_CHUNK_BATCH_MIB, 512 by default), so average x batches = the kernel's share of one decode

@@ -1343,7 +1343,11 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
         const uint8_t *org = (const uint8_t *)((uintptr_t)a0 & ~(uintptr_t)15);
         const uint32_t org_bit = my_start - ((uint32_t)(a0 - org) * 8u + (my_start & 7u));      // bit offset (from src bit 0) of the origin; may be "negative" (wraps): only differences are used
         const uint8_t *lim = in + in_total;
+#ifdef ZA_ABL_NO_A
+        bool done = true;                                       // (instruction split only: nothing is decoded, the checks below fail)
+#else
         bool done = !act || lane_err != 0 || pos >= end;
+#endif
         // The literal bytes are collected in a 16-byte block (nlit & 15 bytes of it are taken) and leave as one 16-byte store
         // per block: 36 stores for the 570 literal bytes of an average 2 KiB of text.
         uint8_t *litp = dst + seg0;
