@@ -180,6 +180,8 @@ static int ilog4(uint32_t a, uint32_t b)
  * is "literal-like" if it has no match, or only a 3-byte match farther back than ZA_DP_WEAK_DIST (such a match costs about what
  * its three literals cost; on data whose every position has one -- a small alphabet at random -- counting them as matches would
  * price literals out of the parse altogether):
+ * (all of it counted over a SAMPLE of the unit, the positions p with (p >> 8) & 3 == 0 -- every fourth block of 256: the costs
+ * are estimates of estimates, and a quarter of the entries gives the same parse within 0.03 % of size on every corpus tried)
  *   U  = literal-like positions, hU[b] = their bytes: the literals to come are mostly these;
  *   NM = other positions whose length is not one less than the length in front of them: "a new match starts here", the
  *        number of match tokens to come;
@@ -190,6 +192,7 @@ static void dp_costs(const uint8_t *data, int n, const uint32_t *best, uint32_t 
     uint32_t h[256], U = 0, NM = 0, T = 0;
     memset(h, 0, sizeof h);
     for (int p = 0; p < n; p++) {
+        if (((p >> 8) & 3) != 0) continue;              /* a sample: every fourth block of 256 positions */
         uint32_t len = best[p] >> 16, lp = p ? best[p - 1] >> 16 : 0;
         if (len == 0 || (len == 3 && (best[p] & 0xFFFF) > ZA_DP_WEAK_DIST)) { h[data[p]]++; U++; }
         else if (len + 1 != lp) NM++;

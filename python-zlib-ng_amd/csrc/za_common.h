@@ -25,6 +25,7 @@
 #define ZA_HASH_BYTES_C 12
 #define ZA_MAX_MATCH  258
 #define ZA_DP_SUB     4         // the dynamic programme also tries the 4 next shorter lengths of a position's match
+#define ZA_DP_COSTS  260         // u32 per unit: [0..255] literal costs, [256] match base, [257] 0, [258] 1 if a match of the unit is longer than 64, [259] 0
 #define ZA_DP_WEAK_DIST 256     // cost statistics: a 3-byte match farther back than this counts as literals
 // a `best` entry: distance - 1 (bits 0..14) | length (bits 15..23: 0 = no match, else 3..258) | the position's own byte << 24
 #define ZA_ELEN(e)  (((e) >> 15) & 0x1FFu)

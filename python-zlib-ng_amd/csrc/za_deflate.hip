@@ -94,7 +94,8 @@ __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t 
 template <int TABLE>
 __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
                                                    const uint32_t *__restrict__ run_start,
-                                                   uint16_t *__restrict__ prev_ws)
+                                                   uint16_t *__restrict__ prev_ws,
+                                                   uint32_t *__restrict__ cost_ws = nullptr)     // (table A only) the units' "has a long match" words are cleared for the search
 {
     // the bucket's last position as a run-absolute number that starts ABOVE the window size, 0 = none: `position - entry` is then
     // a valid link exactly if it is at most 32 768 (an empty bucket gives more), and it is below 1 exactly if the LDS served
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
     for (uint32_t ui = u0; ui < u1; ui++) {
         const ZaUnit u = units[ui];
         const int n = (int)u.in_len, dict_len = (int)u.dict_len;
+        if (cost_ws && threadIdx.x == 0) cost_ws[(size_t)ui * ZA_DP_COSTS + 258] = 0u;
         const uint8_t *row = in + u.in_off - dict_len;                 // byte of row index 0 (row index i = position + dictionary length)
         uint16_t *prevdist = prev_ws + (size_t)ui * ZA_PREV_STRIDE;
 #ifdef ZA_ABL_NO_CARRY
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                                                                  const uint16_t *__restrict__ prev_ws,
                                                                  const uint16_t *__restrict__ linkb_ws,
                                                                  const uint16_t *__restrict__ linkc_ws,
-                                                                 uint32_t *__restrict__ best_ws, ZaLevel L)
+                                                                 uint32_t *__restrict__ best_ws, uint32_t *__restrict__ cost_ws, ZaLevel L)
 {
     // One block of LDS with the byte window FIRST: a candidate's LDS address is then its position's low 16 bits (no base to add),
     // and the link ring is walked with byte addresses that have its base in them (no shift and no add per step).  A link of
@@ -496,6 +498,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     // bytes that may be read starting at data[0] without leaving the caller's buffer
     const long long readable = (long long)(in_total - u.in_off);
     goff = carried ? goff + (uint32_t)n_prev : 0u;
+    bool longm = false;                              // some match of the unit is longer than the dynamic programme's ring (ZA_DP_NEAR): it then keeps acc[] in memory too
     int links_loaded = carried ? 0 : -dict_len;                        // positions p < links_loaded have their chain link in the ring
     int bytes_loaded = carried ? carry_bytes - n_prev : (-dict_len) & ~3;   // positions p < bytes_loaded have their byte in the byte ring (aligned dwords)
     if (carried && tid < ZA_HASH_BYTES_A - 1)
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             uint32_t result = 0;
             if (best_len >= ZA_MIN_MATCH && !(best_len == 3 && best_dist > L.too_far3) && !(best_len == 4 && best_dist > L.too_far4))
                 result = ((uint32_t)best_len << 15) | (uint32_t)(best_dist - 1);
+            longm = longm || best_len > 64;
             best[p] = __builtin_amdgcn_perm(me0, result, 0x04020100u);
         };
         // the unfinished walks of this visit go to the list: position in the tile | best length << 12 | steps left << 21, and
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 }
                 if (best_len >= ZA_MIN_MATCH && !(best_len == 3 && best_dist > L.too_far3) && !(best_len == 4 && best_dist > L.too_far4))
                     result = ((uint32_t)best_len << 15) | (uint32_t)(best_dist - 1);
+                longm = longm || best_len > 64;
             }
 #ifdef ZA_ABL_SEARCH_NOLIT
             best[p] = result;                                                 // (timing only: the parse then sees zero bytes)
@@ -859,6 +864,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         links_loaded = need_links; bytes_loaded = need_bytes;
         __syncthreads();
     }
+    if (L.dp && __ballot(longm) != 0ull && (tid & 63) == 0) cost_ws[(size_t)ui * ZA_DP_COSTS + 258] = 1u;     // (every writer writes the same)
     carry_bytes = bytes_loaded; n_prev = n;
     }
 }
@@ -872,8 +878,9 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 // the chosen length), so that the greedy walk of the parse kernel is the programme's parse.
 //
 // za_k_dpstats (one 256-thread workgroup per unit): the unit's cost table (oracle dp_costs) from its entries
-// alone -- a coalesced pass over the entries: bytes of the literal-like positions (LDS atomics), their count U, the count NM of
-// positions where a new match starts; then 256 literal costs and one match base cost, integer logarithms in quarter bits.
+// alone -- a coalesced pass over a QUARTER of the entries (every fourth block of 256 positions: the same parse within 0.03 % of
+// size, a quarter of the 4 N bytes): bytes of the literal-like positions (LDS atomics), their count U, the count NM of positions
+// where a new match starts; then 256 literal costs and one match base cost, integer logarithms in quarter bits.
 //
 // za_k_optparse (one wave per unit, one lane per segment, like the parse kernel it feeds):
 //   acc[]      a step reads acc[p + l] for l up to 258, but lengths above 64 are rare: the last ZA_DP_NEAR = 64 values live in
@@ -888,7 +895,6 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 //              pieces of one segment's 64-byte row), last chunk first.
 #define ZA_PCH 32                     // positions of a chunk of entries in the parse kernel
 #define ZA_PROW (ZA_PCH + 1)          // dwords of a lane's LDS row there: the carried entry + the chunk; an odd stride
-#define ZA_DP_COSTS  260              // per unit: [0..255] literal costs, [256] match base, [257] 0, [258] 1 if a match of the unit is longer than ZA_DP_NEAR
 #define ZA_DP_NEAR   64               // acc[p + 1 .. p + 64] come from the LDS ring
 #define ZA_DP_ROWS   (ZA_DP_NEAR / 2 + 4)
 #ifndef ZA_DCH
@@ -920,13 +926,13 @@ __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ u
     if (tid == 0) tsum = 0;
     __syncthreads();
     uint32_t U = 0, NM = 0;
-    bool any_long = false;
-    for (int base = 0; base < n; base += 1024) {
-        const int i0 = base + 4 * tid;
+    // a SAMPLE of the unit: every fourth block of 256 positions (the positions p with (p >> 8) & 3 == 0), one block per wave and round
+    for (int base = 1024 * (tid >> 6); base < n; base += 4096) {
+        const int i0 = base + 4 * lane;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         uint32_t pv = 0;
         if (i0 < n) v = *(const uint4 *)(best + i0);               // (rows are 16-byte aligned; what lies behind n is not looked at)
-        if (lane == 0 && i0 > 0 && i0 < n) pv = best[i0 - 1];      // the entry in front of my wave's first
+        if (lane == 0 && i0 > 0 && i0 < n) pv = best[i0 - 1];      // the entry in front of the block
         const uint32_t e[4] = {v.x, v.y, v.z, v.w};
         uint32_t lp = (uint32_t)__shfl_up((int)ZA_ELEN(v.w), 1, 64);
         if (lane == 0) lp = ZA_ELEN(pv);
@@ -936,14 +942,12 @@ __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ u
             if (i0 + k < n) {
                 if (len == 0u || (len == 3u && ZA_EDIST(e[k]) > (uint32_t)ZA_DP_WEAK_DIST)) { atomicAdd(&hist[e[k] >> 24], 1u); U++; }
                 else if (len + 1u != lp) NM++;
-                any_long = any_long || len > (uint32_t)ZA_DP_NEAR;
             }
             lp = len;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) { U += (uint32_t)__shfl_xor((int)U, d, 64); NM += (uint32_t)__shfl_xor((int)NM, d, 64); }
-    const bool wave_long = __ballot(any_long) != 0ull;
-    if (lane == 0) { atomicAdd(&cnt[0], U); atomicAdd(&cnt[1], NM); if (wave_long) cnt[2] = 1u; }
+    if (lane == 0) { atomicAdd(&cnt[0], U); atomicAdd(&cnt[1], NM); }
     __syncthreads();
     U = cnt[0]; NM = cnt[1];
     const uint32_t hh = 16u * hist[tid] + 1u + (U >> 6);
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ u
     mbias = mbias > 24 ? 24 : mbias;
     const int c = za_ilog4(T, hh) + lbias;
     cost[tid] = (uint32_t)(c < 12 ? 12 : c > 52 ? 52 : c);
-    if (tid == 0) { cost[256] = (uint32_t)(12 + mbias + 20); cost[257] = 0u; cost[258] = cnt[2]; cost[259] = 0u; }
+    if (tid == 0) { cost[256] = (uint32_t)(12 + mbias + 20); cost[257] = 0u; }       // ([258]: the search's "has a long match" word)
 }
 
 __device__ __forceinline__ uint32_t za_pk_add_u16(uint32_t a, uint32_t b)
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         if (slot < 8) *(uint16_t *)(myring + ((slot >> 1) + ZA_DP_NEAR / 2) * 256 + (slot & 1) * 2) = (uint16_t)v;
     };
     const int mbase = (int)costt[256];
-    const bool has_long = costt[258] != 0u;                        // (uniform) some match of the unit is longer than the ring: acc[] goes to memory too
+    const bool has_long = costt[258] != 0u;                        // (uniform, from the search) some match of the unit is longer than the ring: acc[] goes to memory too (a quarter of this kernel's time where it must)
     if (active) { ring_put((s1 - s0) & (ZA_DP_NEAR - 1), 0u); accg[s1 - s0] = 0; }     // acc[s1] = 0
     int acc_next = 0;                                              // acc[p + 1], the whole number (at most 2 048 x 52)
     // what the last long match fetched from memory: a run of positions inside one long match all end at the same place

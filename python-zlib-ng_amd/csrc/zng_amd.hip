@@ -512,12 +512,12 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         run_pos += nruns + 1;
         if (level > 0) {
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
-              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_A>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p);
-              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_B>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkb.p);
-              if (L.use_c) hipLaunchKernelGGL(za_k_chains<ZA_TABLE_C>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkc.p); }
+              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_A>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p, L.dp ? c->dpcost.p : (uint32_t *)nullptr);
+              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_B>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkb.p, (uint32_t *)nullptr);
+              if (L.use_c) hipLaunchKernelGGL(za_k_chains<ZA_TABLE_C>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkc.p, (uint32_t *)nullptr); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
 #define ZA_LAUNCH_SEARCH(...) hipLaunchKernelGGL((za_k_search<__VA_ARGS__>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, \
-                                                 c->prev.p, c->linkb.p, L.use_c ? c->linkc.p : c->linkb.p, c->best.p, L)
+                                                 c->prev.p, c->linkb.p, L.use_c ? c->linkc.p : c->linkb.p, c->best.p, c->dpcost.p, L)
               if (L.cap > 16) { if (L.use_c) ZA_LAUNCH_SEARCH(true, 0, true); else ZA_LAUNCH_SEARCH(true, 0, false); }
               else if (L.chain == 1) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 1, true); else ZA_LAUNCH_SEARCH(false, 1, false); }
               else if (L.chain == 2) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 2, true); else ZA_LAUNCH_SEARCH(false, 2, false); }
