@@ -139,6 +139,8 @@ def load():
         L.zngamd_decode_paths.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
         L.zngamd_debug_keep.argtypes = [vp, C.c_int]
+        L.zngamd_comm_offsets.restype = C.c_uint64
+        L.zngamd_comm_offsets.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
         _lib = L
         return L
 

@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads and exports every symbol include/zng_amd.h declares, the product fails
 loudly without a GPU, and the host-side logic (header maths, framing, sharding + all-gather reassembly
 with world_size 2 on gloo) is right.  No compute call is made here."""
+import ctypes as C
 import os
 import re
 import socket
@@ -156,6 +157,70 @@ def test_two_rank_allgather_reassembly_gloo(tmp_path):
     for p in procs:
         p.join(30)
     assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]
+
+
+def _gloo_worker8(rank, world, port, q, path):
+    """world 8, uneven slices, ranks WITHOUT any block (more ranks than blocks in their range): the layout arithmetic and the
+    write-at-own-offset assembly of shard.py, over gloo."""
+    import torch.distributed as dist
+    sys.path.insert(0, PKG_DIR)
+    from zlib_ng_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng_bytes = bytes((i * 131 + (i >> 7) * 17) & 0xFF for i in range(5 * 8192 + 1234))      # 6 blocks (the last one short) over 8 ranks
+    bs = 8192
+    nb = -(-len(rng_bytes) // bs)
+    lo, hi = shard.shard_range(nb, rank, world)
+    parts, crcs = [], []
+    for b in range(lo, hi):
+        blk = rng_bytes[b * bs:(b + 1) * bs]
+        zd = rng_bytes[max(0, b * bs - 32768):b * bs]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0, zd) if zd else zlib.compressobj(6, zlib.DEFLATED, -15)
+        parts.append(co.compress(blk) + co.flush(zlib.Z_SYNC_FLUSH))
+        crcs.append((zlib.crc32(blk), len(blk)))
+    mine = b"".join(parts)
+
+    def allgather(rec):
+        out = [None] * world
+        dist.all_gather_object(out, rec)
+        return out
+    off, total, sizes, crc, usize = shard.exchange_layout(len(mine), shard.combine_crcs(crcs), sum(n for _, n in crcs), rank, allgather)
+    ok = sizes[rank] == len(mine) and off == sum(sizes[:rank]) and total == sum(sizes) and crc == zlib.crc32(rng_bytes) and usize == len(rng_bytes)
+    ok = ok and sizes.count(0) >= 2 and len(set(s for s in sizes if s)) > 1          # empty and uneven slices were exercised
+    offs = (C.c_uint64 * world)()
+    ok = ok and shard._lib.load().zngamd_comm_offsets((C.c_uint64 * world)(*sizes), world, offs) == total and list(offs) == [sum(sizes[:r]) for r in range(world)]
+    header, trailer = shard.gzip_frame(total, crc, usize, 6)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+    if mine:
+        os.pwrite(fd, mine, len(header) + off)
+    if rank == world - 1:                       # (any rank may write the frame: it follows from the layout alone)
+        os.pwrite(fd, header, 0)
+        os.pwrite(fd, trailer, len(header) + total)
+    os.close(fd)
+    dist.barrier()
+    import gzip
+    ok = ok and gzip.decompress(open(path, "rb").read()) == rng_bytes
+    q.put((rank, ok, total))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_layout_with_empty_and_uneven_slices_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    path = str(tmp_path / "written_by_eight_ranks.gz")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker8, args=(r, 8, port, q, path)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok, _ in res) and len({t for _, _, t in res}) == 1
 
 
 def test_rendezvous_skips_a_busy_port():
