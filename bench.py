@@ -124,8 +124,7 @@ def main():
     os.dup2(2, 1)
 
     import numpy as np
-    import torch
-    from zlib_ng_amd import _lib, corpus, shard
+    from zlib_ng_amd import _lib, corpus, devmem, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,13 +135,14 @@ def main():
                   file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    if not torch.cuda.is_available():
+    if _lib.load().zngamd_device_count() <= local:
         print(f"bench.py: rank {rank} of {world} needs a GPU (the engine has no CPU path)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # device memory, copies, fills and compares all go through the engine's C ABI (zlib_ng_amd.devmem): no tensor library
     ctx = _lib.Context(device=local)
     L, h = ctx.L, ctx.h
+    dempty = lambda nbytes: devmem.empty(ctx, nbytes)
+    i32 = lambda buf, n=None: buf.cpu(np.int32) if n is None else buf[:4 * n].cpu(np.int32)
     # BENCH_FORCE_EXCHANGE=1 runs the exchange leg even with one rank (rehearsal of the N > 1 path on one GPU).
     # Default exchange (north_star): the member stream is reassembled on every rank over RCCL (shard.Comm = zngamd_comm_*, no
     # torch in the data path), asynchronously so that it overlaps the inflate leg.  BENCH_EXCHANGE=layout exchanges only the
@@ -168,11 +168,11 @@ def main():
     uniq = min(args.unique_mib << 20, args.size_mib << 20)
     uniq -= uniq % BLOCK
     host = corpus.text(uniq, seed=1)
-    base = torch.from_numpy(host).to(dev)
+    base = devmem.from_host(ctx, host)
     HALO = 32768
     start = blo * BLOCK                                     # byte offset of my range in the whole stream
     # d_buf = [32 KiB halo: the bytes in front of my range][my range][64 zero bytes]; the stream is the tile repeated
-    d_buf = torch.empty(HALO + size + 64, dtype=torch.uint8, device=dev)
+    d_buf = dempty(HALO + size + 64)
     idx0 = (start - HALO) % uniq
     pos = 0
     while pos < HALO + size:
@@ -182,33 +182,33 @@ def main():
         pos += k
     d_buf[HALO + size:] = 0
     d_in = d_buf[HALO:]
-    torch.cuda.synchronize()
+    ctx.sync()
 
     blocks = (_lib.Block * nblocks)()
     for b in range(nblocks):        # offsets inside d_buf; only the very first block of the whole stream has no dictionary
         blocks[b] = _lib.Block(HALO + b * BLOCK, BLOCK, 32768 if (b or blo) else 0, 0, 0)
     n_units = L.zngamd_count_units(blocks, nblocks)
     assert n_units == nblocks
-    d_ulen = torch.empty(n_units, dtype=torch.int32, device=dev)
-    d_ucrc = torch.empty(n_units, dtype=torch.int32, device=dev)
-    d_comp = torch.empty(size // 2 + (64 << 20), dtype=torch.uint8, device=dev)   # text compresses ~3x
-    d_stream = torch.empty(world * (size // 2 + (8 << 20)) + (64 << 20), dtype=torch.uint8, device=dev) if exchange_stream else None
-    d_out = torch.empty(size + 64, dtype=torch.uint8, device=dev)
-    ptr = lambda t: C.c_void_p(t.data_ptr())
+    d_ulen = dempty(4 * n_units)
+    d_ucrc = dempty(4 * n_units)
+    d_comp = dempty(size // 2 + (64 << 20))   # text compresses ~3x
+    d_stream = dempty(world * (size // 2 + (8 << 20)) + (64 << 20)) if exchange_stream else None
+    d_out = dempty(size + 64)
+    ptr = lambda t: t.vp()
 
     def chk(r, what):
         if r != 0:
             raise RuntimeError(f"{what} failed: {r} {ctx.err()}")
 
     # pre-built multi-member stream for the inflate leg (outside the timed region)
-    d_members_stream = torch.empty(size // 2 + nblocks * 400 + (64 << 20), dtype=torch.uint8, device=dev)
+    d_members_stream = dempty(size // 2 + nblocks * 400 + (64 << 20))
     ms_len, ms_n = C.c_uint64(0), C.c_uint32(0)
     chk(L.zngamd_gzip_members_dev(h, ptr(d_in), size, BLOCK, args.level, ptr(d_members_stream),
                                   d_members_stream.numel() - 64, C.byref(ms_len), C.byref(ms_n)), "gzip_members_dev")
     d_members_stream[ms_len.value:ms_len.value + 64] = 0
-    d_mtab = torch.empty(nblocks * C.sizeof(_lib.Member), dtype=torch.uint8, device=dev)
-    d_mstat = torch.empty(nblocks, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+    d_mtab = dempty(nblocks * C.sizeof(_lib.Member))
+    d_mstat = dempty(4 * nblocks)
+    ctx.sync()
 
     comp_total = C.c_uint64(0)
     gathered = {}
@@ -236,10 +236,10 @@ def main():
             comm.wait()
 
     def barrier():
-        torch.cuda.synchronize()
+        ctx.sync()
         if exchange:
             comm.barrier()
-        torch.cuda.synchronize()
+        ctx.sync()
 
     for _ in range(args.warmup):
         step()
@@ -260,13 +260,13 @@ def main():
     # Every collective of the verification runs BEFORE the first assert, and the verdicts are exchanged afterwards: a rank whose
     # check fails must not leave the others waiting for it in RCCL for ever (it would look like a hang, not like a failure).
     kblk = min(nblocks, 2048)
-    pre = comm.layout(int(d_ulen[:kblk].to(torch.int64).sum().item()), 0, 0)[2] if exchange_stream else None   # compressed bytes of every rank's first kblk blocks
+    pre = comm.layout(int(i32(d_ulen, kblk).astype(np.int64).sum()), 0, 0)[2] if exchange_stream else None   # compressed bytes of every rank's first kblk blocks
     rccl_ranks = comm.count() if comm is not None else None
-    comp_bytes = int(d_ulen.to(torch.int64).sum().item())
+    comp_bytes = int(i32(d_ulen).astype(np.int64).sum())
 
     def verify():
-        assert int((d_mstat != 0).sum().item()) == 0, "inflate reported member errors"
-        assert torch.equal(d_out[:size], d_in[:size]), "inflate output differs from the input"
+        assert not i32(d_mstat).any(), "inflate reported member errors"
+        assert d_out[:size].equal(d_in[:size]), "inflate output differs from the input"
         assert comp_bytes == comp_total.value
         # The WHOLE dict-chained compressed stream -- with N > 1 the stream assembled from the slices of all ranks, on rank 0 -- is
         # closed with an empty final block, inflated on the device by the chunk-parallel decoder (sync-flush points) and compared
@@ -282,7 +282,7 @@ def main():
                 assert want == whole_crc, "trailer CRC-32 folded from the ranks differs from the CRC-32 of the whole input"
         if exchange_stream:
             # (a) my slice lies at its offset in my copy of the assembled stream
-            assert torch.equal(d_stream[off:off + comp_bytes], d_comp[:comp_bytes]), "my slice is not at its offset in the assembled stream"
+            assert d_stream[off:off + comp_bytes].equal(d_comp[:comp_bytes]), "my slice is not at its offset in the assembled stream"
             # (b) every rank decodes the head of a slice ANOTHER rank compressed (rank r: slice r + 1), taken from its own copy of
             # the assembled stream: up to 2 048 blocks behind a stored block that holds the 32 KiB of input in front of them (the
             # dictionary that slice was primed with on the other GPU), compared with the input they must decode to
@@ -291,36 +291,34 @@ def main():
             qoff = sum(sizes[:q])
 
             def tile_bytes(first, count):                       # bytes [first, first + count) of the whole stream (negative: halo of block 0)
-                parts, pos = [], 0
+                outb, pos = dempty(count), 0
                 while pos < count:
                     o = (first + pos) % uniq
                     k = min(uniq - o, count - pos)
-                    parts.append(base[o:o + k])
+                    outb[pos:pos + k] = base[o:o + k]
                     pos += k
-                return torch.cat(parts)
-            d_v = torch.empty(5 + HALO + pre[q] + 66, dtype=torch.uint8, device=dev)
-            d_v[:5] = torch.tensor([0, 0x00, 0x80, 0xFF, 0x7F], dtype=torch.uint8, device=dev)     # stored block, not final, 32 768 bytes
+                return outb
+            d_v = dempty(5 + HALO + pre[q] + 66)
+            d_v[:5] = bytes([0, 0x00, 0x80, 0xFF, 0x7F])        # stored block, not final, 32 768 bytes
             d_v[5:5 + HALO] = tile_bytes(qlo * BLOCK - HALO, HALO)
             d_v[5 + HALO:5 + HALO + pre[q]] = d_stream[qoff:qoff + pre[q]]
             d_v[5 + HALO + pre[q]:] = 0
             d_v[5 + HALO + pre[q]] = 3                           # empty final block
-            d_vo = torch.empty(HALO + kblk * BLOCK + 64, dtype=torch.uint8, device=dev)
+            d_vo = dempty(HALO + kblk * BLOCK + 64)
             vlen, vused = C.c_uint64(0), C.c_uint64(0)
-            torch.cuda.synchronize()             # (what torch wrote above must be there before the engine's stream reads it)
             rc = L.zngamd_inflate_raw_dev(h, ptr(d_v), 5 + HALO + pre[q] + 2, ptr(d_vo), HALO + kblk * BLOCK, C.byref(vlen), C.byref(vused))
             assert rc == _lib.STREAM_END and vlen.value == HALO + kblk * BLOCK, (rc, vlen.value, vused.value, ctx.err())
-            assert torch.equal(d_vo[HALO:HALO + kblk * BLOCK], tile_bytes(qlo * BLOCK, kblk * BLOCK)), \
+            assert d_vo[HALO:HALO + kblk * BLOCK].equal(tile_bytes(qlo * BLOCK, kblk * BLOCK)), \
                 f"rank {rank}: the head of slice {q} in the assembled stream does not inflate to its input"
             del d_v, d_vo
             # (c) jobs of at most 4 GiB: rank 0 inflates the WHOLE assembled stream on the device and compares it with the input
             if rank == 0 and total_size <= (4 << 30) and total_size % uniq == 0:
                 d_stream[total:total + 66] = 0
                 d_stream[total] = 3
-                d_big = torch.empty(total_size + 64, dtype=torch.uint8, device=dev) if world > 1 else d_out
-                torch.cuda.synchronize()
+                d_big = dempty(total_size + 64) if world > 1 else d_out
                 rc = L.zngamd_inflate_raw_dev(h, ptr(d_stream), total + 2, ptr(d_big), total_size, C.byref(vlen), C.byref(vused))
                 assert rc == _lib.STREAM_END and vlen.value == total_size and vused.value == total + 2, (rc, vlen.value, vused.value, ctx.err())
-                assert bool((d_big[:total_size].view(-1, uniq) == base).all().item()), "the assembled stream does not inflate to the input"
+                assert all(d_big[t * uniq:(t + 1) * uniq].equal(base) for t in range(total_size // uniq)), "the assembled stream does not inflate to the input"
                 c = C.c_uint32(0)
                 chk(L.zngamd_crc32_dev(h, 0, ptr(d_big), total_size, C.byref(c)), "crc32_dev")
                 assert c.value == whole_crc, "CRC-32 of the inflated stream differs from the trailer value"
@@ -330,14 +328,13 @@ def main():
             d_comp[comp_bytes] = 3
             vlen, vused = C.c_uint64(0), C.c_uint64(0)
             d_out.zero_()
-            torch.cuda.synchronize()             # (torch's stream and the engine's are not ordered with each other)
             rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
             assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
-            assert torch.equal(d_out[:size], d_in[:size]), "the compressed stream does not inflate to the input"
+            assert d_out[:size].equal(d_in[:size]), "the compressed stream does not inflate to the input"
             nchk = min(nblocks, 64)
-            ul = d_ulen[:nchk].cpu().numpy().astype(np.int64)
-            pref = bytes(d_comp[:int(ul.sum())].cpu().numpy())
-            assert zlib.decompressobj(-15).decompress(pref) == bytes(d_in[:nchk * BLOCK].cpu().numpy()), \
+            ul = i32(d_ulen, nchk).astype(np.int64)
+            pref = bytes(d_comp[:int(ul.sum())].cpu())
+            assert zlib.decompressobj(-15).decompress(pref) == bytes(d_in[:nchk * BLOCK].cpu()), \
                 "compressed stream does not inflate to the input (system zlib)"
 
     verr = None
@@ -374,9 +371,10 @@ def main():
             mem = list(ex.map(zmember, range(uniq // BLOCK)))
         tile = b"".join(mem)
         tl = len(tile)
-        d_tile = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
-        d_for = torch.empty(reps * tl + 64, dtype=torch.uint8, device=dev)
-        d_for[:reps * tl].view(reps, tl)[:] = d_tile
+        d_tile = devmem.from_host(ctx, tile)
+        d_for = dempty(reps * tl + 64)
+        for t_ in range(reps):
+            d_for[t_ * tl:(t_ + 1) * tl] = d_tile
         d_for[reps * tl:] = 0
         ft = (_lib.Member * nblocks)()
         offs = np.concatenate([[0], np.cumsum([len(x) for x in mem])])
@@ -385,9 +383,8 @@ def main():
             o = (b // per) * tl + int(offs[b % per])
             ln = len(mem[b % per])
             ft[b] = _lib.Member(o + 10, ln - 18, b * BLOCK, BLOCK, 0, 0, 0)
-        d_ft = torch.frombuffer(bytearray(bytes(ft)), dtype=torch.uint8).to(dev)
+        d_ft = devmem.from_host(ctx, bytes(ft))
         d_out.zero_()
-        torch.cuda.synchronize()                 # (torch's stream and the engine's are not ordered with each other)
         f_ms = []
         for it in range(2):
             ctx.profiling(True); ctx.kernel_times(reset=True)
@@ -395,8 +392,8 @@ def main():
                 "gzip_inflate_plain_members_dev")
             f_ms.append(ctx.kernel_times(reset=True)["inflate"][0])
             ctx.profiling(False)
-        assert int((d_mstat != 0).sum().item()) == 0, "foreign members: errors"
-        assert torch.equal(d_out[:size], d_in[:size]), "foreign members: output differs"
+        assert not i32(d_mstat).any(), "foreign members: errors"
+        assert d_out[:size].equal(d_in[:size]), "foreign members: output differs"
         fbytes = reps * tl + size
         foreign = {"bound": "hbm", "kernel": "za_k_inflate_serial_members", "members": nblocks,
                    "writer": "system zlib " + zlib.ZLIB_RUNTIME_VERSION + f" level {args.level}, plain gzip members of 128 KiB",
@@ -416,7 +413,7 @@ def main():
         c_wall, c_kern = [], []
         for it in range(3):
             d_out.zero_()
-            torch.cuda.synchronize()             # (torch's stream and the engine's are not ordered with each other)
+            ctx.sync()
             ctx.profiling(True); ctx.kernel_times(reset=True)
             t = time.perf_counter()
             rc = L.zngamd_inflate_raw_dev(h, ptr(d_comp), comp_bytes + 2, ptr(d_out), size, C.byref(vlen), C.byref(vused))
@@ -424,7 +421,7 @@ def main():
             c_kern.append(sum(v[0] for v in ctx.kernel_times(reset=True).values()))
             ctx.profiling(False)
             assert rc == _lib.STREAM_END and vlen.value == size and vused.value == comp_bytes + 2, (rc, vlen.value, vused.value, ctx.err())
-        assert torch.equal(d_out[:size], d_in[:size]), "chained stream: output differs"
+        assert d_out[:size].equal(d_in[:size]), "chained stream: output differs"
         cbytes = comp_bytes + size
         cms = min(c_wall)
         chained = {"bound": "hbm", "kernel": "za_k_chunk_decode + za_k_chunk_compose / _chain / _resolve (+ za_k_scan_sync)",
@@ -456,9 +453,10 @@ def main():
             mem = list(ex.map(bmember, range(nbg)))
         tile = b"".join(mem)
         tl = len(tile)
-        d_tile = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
-        d_bg = torch.empty(reps * tl + 64, dtype=torch.uint8, device=dev)
-        d_bg[:reps * tl].view(reps, tl)[:] = d_tile
+        d_tile = devmem.from_host(ctx, tile)
+        d_bg = dempty(reps * tl + 64)
+        for t_ in range(reps):
+            d_bg[t_ * tl:(t_ + 1) * tl] = d_tile
         d_bg[reps * tl:] = 0
         nmem = reps * nbg
         bt = (_lib.Member * nmem)()
@@ -467,10 +465,9 @@ def main():
             r_, b = divmod(m, nbg)
             ilen = min(uniq, (b + 1) * BG) - b * BG
             bt[m] = _lib.Member(r_ * tl + int(offs[b]) + 18, len(mem[b]) - 26, r_ * uniq + b * BG, ilen, 0, 0, 0)
-        d_bt = torch.frombuffer(bytearray(bytes(bt)), dtype=torch.uint8).to(dev)
-        d_bstat = torch.empty(nmem, dtype=torch.int32, device=dev)
+        d_bt = devmem.from_host(ctx, bytes(bt))
+        d_bstat = dempty(4 * nmem)
         d_out.zero_()
-        torch.cuda.synchronize()
         b_ms = []
         for it in range(2):
             ctx.profiling(True); ctx.kernel_times(reset=True)
@@ -478,8 +475,8 @@ def main():
                 "gzip_inflate_plain_members_dev (BGZF)")
             b_ms.append(ctx.kernel_times(reset=True)["inflate"][0])
             ctx.profiling(False)
-        assert int((d_bstat != 0).sum().item()) == 0, "BGZF members: errors"
-        assert torch.equal(d_out[:size], d_in[:size]), "BGZF members: output differs"
+        assert not i32(d_bstat).any(), "BGZF members: errors"
+        assert d_out[:size].equal(d_in[:size]), "BGZF members: output differs"
         bbytes = reps * tl + size
         bgzf = {"bound": "hbm", "kernel": "za_k_inflate_serial_members", "members": nmem,
                 "writer": "system zlib " + zlib.ZLIB_RUNTIME_VERSION + f" level {args.level}, BGZF members ('BC' subfield) of 65 280 bytes",
@@ -562,7 +559,7 @@ def main():
         except Exception:
             pass
 
-    free_b, total_b = torch.cuda.mem_get_info(dev)
+    free_b, total_b = devmem.mem_info(ctx)
     out = {
         "metric": "MB/s compress+decompress, 128 KiB blocks level 6",
         "value": round(total_size / dt * steps / 1e6, 1), "unit": "MB/s",
@@ -794,7 +791,26 @@ def main():
             assert f.read(api_n) == blob, "gzip_ng.open: output differs"
         os.remove(gz_path)
         os.rmdir(tmpdir)
+        # the sizes of the reference's own micro-benchmark (benchmark_scripts/benchmark.py:16-27, :56-75): latency of one call
+        small = {}
+        for sz in (1 << 10, 16 << 10, 64 << 10):
+            piece = blob[:sz]
+            zc_piece = zlib.compress(piece, args.level)
+            assert zlib_ng.decompress(zlib_ng.compress(piece, args.level)) == piece and zlib_ng.decompress(zc_piece) == piece
+            for _ in range(3):
+                zlib_ng.compress(piece, args.level); zlib_ng.decompress(zc_piece)
+            reps = 40
+            t = time.perf_counter()
+            for _ in range(reps):
+                zlib_ng.compress(piece, args.level)
+            tc_s = (time.perf_counter() - t) / reps
+            t = time.perf_counter()
+            for _ in range(reps):
+                zlib_ng.decompress(zc_piece)
+            td_s = (time.perf_counter() - t) / reps
+            small[f"{sz >> 10}KiB"] = {"compress_us": round(tc_s * 1e6, 1), "decompress_us": round(td_s * 1e6, 1)}
         out["api"] = {"compress_MBps": round(api_n / t_c / 1e6, 1), "decompress_MBps": round(api_n / t_d / 1e6, 1),
+                      "small_calls": small,
                       "threaded_write_MBps": round(STREAM_REPS * api_n / t_w / 1e6, 1), "threaded_read_MBps": round(STREAM_REPS * api_n / t_r / 1e6, 1),
                       "threaded_members_write_MBps": round(STREAM_REPS * api_n / t_mw / 1e6, 1), "threaded_members_read_MBps": round(STREAM_REPS * api_n / t_mr / 1e6, 1),
                       "open_write_MBps": round(STREAM_REPS * api_n / t_ow / 1e6, 1), "open_read_MBps": round(STREAM_REPS * api_n / t_or / 1e6, 1),

@@ -75,6 +75,11 @@ int zngamd_dmalloc(zngamd_ctx *ctx, size_t bytes, void **dptr);
 int zngamd_dfree(zngamd_ctx *ctx, void *dptr);
 int zngamd_h2d(zngamd_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int zngamd_d2h(zngamd_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* device-to-device copy / fill on the context's stream (ordered with the engine's kernels, no host synchronisation), and the
+ * device's free / total memory: what a harness needs to do without a tensor library (bench.py) */
+int zngamd_d2d(zngamd_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+int zngamd_dmemset(zngamd_ctx *ctx, void *dst_dev, int value, size_t bytes);
+int zngamd_mem_info(zngamd_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- checksums (GPU) ---- */
 int      zngamd_crc32(zngamd_ctx *ctx, uint32_t crc, const uint8_t *buf, size_t len, uint32_t *out);

@@ -255,6 +255,34 @@ try {
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 
+// device-to-device copy and fill on the context's stream (ordered with the engine's kernels; no host synchronisation), and the
+// device's free / total memory: what a harness needs to do without a tensor library
+int zngamd_d2d(zngamd_ctx *c, void *dst, const void *src, size_t bytes)
+try {
+    if (!c) return ZNGAMD_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
+
+int zngamd_dmemset(zngamd_ctx *c, void *dst, int value, size_t bytes)
+try {
+    if (!c) return ZNGAMD_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
+
+int zngamd_mem_info(zngamd_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+try {
+    if (!c || !free_bytes || !total_bytes) return ZNGAMD_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
+
 int zngamd_decode_paths(zngamd_ctx *c, uint64_t *members, int reset)
 try {
     if (!c || !members) return ZNGAMD_E_ARG;

@@ -41,7 +41,7 @@ SYMBOLS = [
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch", "zngamd_debug_keep",
+    "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
 ]
 
 
@@ -139,6 +139,9 @@ def load():
         L.zngamd_decode_paths.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
         L.zngamd_debug_keep.argtypes = [vp, C.c_int]
+        L.zngamd_d2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.zngamd_dmemset.argtypes = [vp, vp, C.c_int, C.c_size_t]
+        L.zngamd_mem_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.zngamd_comm_offsets.restype = C.c_uint64
         L.zngamd_comm_offsets.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
         _lib = L
@@ -410,6 +413,10 @@ class Context:
         if r not in ok:
             raise EngineError(r, self.err())
         return r
+
+    def sync(self):
+        """wait for everything queued on the context's stream"""
+        self._chk(self.L.zngamd_sync(self.h))
 
     # ---- checksums
     def crc32(self, data, value=0):
