@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 /* ---- codec constants ---- */
-#define ZA_SEG        2048      /* parse segment: token boundaries are forced here */
+#define ZA_SEG        2048      /* segment of a full unit: token boundaries are forced at segment ends (za_o_seg_shift: small units take smaller ones) */
 #define ZA_MAX_UNIT   131072    /* one codec unit = at most 64 segments             */
 #define ZA_MAX_SEGS   64
 #define ZA_WIN        32768
@@ -98,6 +98,7 @@ typedef struct {
     uint32_t *dp_cost;    /* [258] the unit's cost table in quarter bits: [0..255] literals, [256] match base (stage 3a) */
 } za_o_debug;
 
+int za_o_seg_shift(int n, int flags);      /* log2 of the unit's segment size: 5 .. 11 */
 long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int flags,
                        uint8_t *out, size_t cap, uint32_t *crc, za_o_debug *dbg);
 

@@ -97,6 +97,11 @@ def crc32_combine(crc1, crc2, len2):
     return lib().za_o_crc32_combine(crc1, crc2, len2)
 
 
+def seg_shift(n, flags=0):
+    """log2 of the segment size of a unit of n bytes (oracle.h za_o_seg_shift)"""
+    return lib().za_o_seg_shift(int(n), int(flags))
+
+
 def deflate_unit(data, zdict=b"", level=6, flags=0, debug=False, cap=None):
     """One codec unit (<= 128 KiB) primed with `zdict` (<= 32 KiB): -> (bytes, crc[, debug dict])."""
     data = bytes(data)
@@ -110,9 +115,10 @@ def deflate_unit(data, zdict=b"", level=6, flags=0, debug=False, cap=None):
     dbg = None
     arrs = {}
     if debug:
-        nseg = (n + SEG - 1) // SEG
+        seg = 1 << seg_shift(n, flags)
+        nseg = (n + seg - 1) // seg
         arrs = dict(prevdist=np.zeros(dl + n, np.uint16), best=np.zeros(max(n, 1), np.uint32),
-                    tokens=np.zeros(max(nseg * SEG, 1), np.uint32),
+                    tokens=np.zeros(max(nseg * seg, 1), np.uint32),
                     seg_ntok=np.zeros(MAX_SEGS, np.uint32), hist=np.zeros(320, np.uint32),
                     lens=np.zeros(320, np.uint8), seg_bits=np.zeros(MAX_SEGS + 1, np.uint32),
                     btype=np.zeros(1, np.int32), chunk_idx=np.zeros(MAX_CHUNKS + 1, np.uint32),

@@ -44,9 +44,16 @@ static const za_level LEVELS[10] = {
     {4, 32, 258, 1, 1, 4096, 32768}, {8, 64, 258, 1, 1, 4096, 32768}, {12, 128, 258, 1, 1, 4096, 32768}
 };
 
-/* test-only: forced token-boundary granularity (default ZA_SEG) */
-static int g_cut = ZA_SEG;
-void za_o_set_cut(int cut) { g_cut = cut; }
+/* The segment size of a unit (token boundaries are forced at segment ends; at most 64 segments): 2 KiB for full units and for
+ * indexed members, smaller for the units of small calls -- the smallest power of two >= 32 that covers the unit with 64 segments --
+ * so that the kernels, which give a lane to each segment, do not walk a small input with one lane. */
+int za_o_seg_shift(int n, int flags)
+{
+    if ((flags & ZA_FLAG_FLATHDR) || n > 65536) return 11;
+    int s = 5;
+    while ((64 << s) < n) s++;
+    return s;
+}
 
 /* test-only override of the level table (parameter studies); chain <= 0 switches it off */
 static za_level g_override = {0, 0, 258, 1, 1, 4096, 32768};
@@ -110,9 +117,9 @@ static inline void try_candidate(const uint8_t *data, int p, int dist, int cap, 
 }
 
 static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const uint16_t *linkA, const uint16_t *linkB,
-                              const uint16_t *linkC, int p, const za_level *L, int max_dist)
+                              const uint16_t *linkC, int p, const za_level *L, int max_dist, int seg)
 {
-    int seg_end = (p / g_cut + 1) * g_cut;          /* g_cut == ZA_SEG except in parameter studies */
+    int seg_end = (p / seg + 1) * seg;
     if (seg_end > n) seg_end = n;
     int maxlen = seg_end - p;
     if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
@@ -209,14 +216,14 @@ static void dp_costs(const uint8_t *data, int n, const uint32_t *best, uint32_t 
     cost[257] = 0;
 }
 
-static void stage3a_dp(const uint8_t *data, int n, uint32_t *best, const za_level *L, uint32_t *cost_out)
+static void stage3a_dp(const uint8_t *data, int n, uint32_t *best, const za_level *L, uint32_t *cost_out, int seg)
 {
     uint32_t cost[258];
     static __thread uint32_t acc[ZA_SEG + 1];
     dp_costs(data, n, best, cost);
     if (cost_out) memcpy(cost_out, cost, sizeof cost);
-    for (int s0 = 0; s0 < n; s0 += ZA_SEG) {
-        int e = s0 + ZA_SEG > n ? n : s0 + ZA_SEG;
+    for (int s0 = 0; s0 < n; s0 += seg) {
+        int e = s0 + seg > n ? n : s0 + seg;
         acc[e - s0] = 0;
         for (int p = e - 1; p >= s0; p--) {
             uint32_t c = cost[data[p]] + acc[p + 1 - s0];
@@ -374,7 +381,8 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
     int flat = (flags & ZA_FLAG_FLATHDR) != 0;
     bitwr w = { out, cap, 0, 0, 0, 0 };
     if (crc) *crc = za_o_crc32(0, data, (size_t)n);
-    int nseg = (n + ZA_SEG - 1) / ZA_SEG;
+    const int sshift = za_o_seg_shift(n, flags), seg = 1 << sshift;
+    int nseg = (n + seg - 1) / seg;
     if (dbg && dbg->btype) *dbg->btype = -1;
 
     if (n == 0) {
@@ -406,12 +414,12 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         linkB = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(dict_len + n));
         linkC = (uint16_t *)calloc((size_t)(dict_len + n), sizeof(uint16_t));
         best = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
-        tokens = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
+        tokens = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nseg * seg));
         if (!prevdist || !linkB || !linkC || !best || !tokens) { free(prevdist); free(linkB); free(linkC); free(best); free(tokens); return ZA_MEM_ERROR; }
         stage1_chains(data, dict_len, n, 0, prevdist);
         stage1_chains(data, dict_len, n, 1, linkB);
         if (L->use_c) stage1_chains(data, dict_len, n, 2, linkC);
-        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, linkB, linkC, p, L, g_max_dist);
+        for (int p = 0; p < n; p++) best[p] = stage2_search(data, dict_len, n, prevdist, linkB, linkC, p, L, g_max_dist, seg);
         if (dbg) {
             if (dbg->prevdist) memcpy(dbg->prevdist, prevdist, sizeof(uint16_t) * (size_t)(dict_len + n));
             if (dbg->linkB) memcpy(dbg->linkB, linkB, sizeof(uint16_t) * (size_t)(dict_len + n));
@@ -420,12 +428,12 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         }
         /* stage 3a (levels 4-9): the dynamic programme rewrites the entries -- a position it makes a literal loses its match, a
          * match it shortens gets the shorter length -- so that the greedy walk of stage 3 follows its choices */
-        if (L->dp) stage3a_dp(data, n, best, L, dbg ? dbg->dp_cost : NULL);
+        if (L->dp) stage3a_dp(data, n, best, L, dbg ? dbg->dp_cost : NULL, seg);
         if (dbg && dbg->best_dp) memcpy(dbg->best_dp, best, sizeof(uint32_t) * (size_t)n);
         /* stage 3: parse every segment on its own */
         for (int s = 0; s < nseg; s++) {
-            int p = s * ZA_SEG, end = p + ZA_SEG;
-            uint32_t *t = tokens + (size_t)s * ZA_SEG;
+            int p = s * seg, end = p + seg;
+            uint32_t *t = tokens + (size_t)s * seg;
             int nt = 0;
             if (end > n) end = n;
             while (p < end) {
@@ -448,7 +456,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
                      * of its successor (its successor's entry must be at hand) */
                     uint32_t tk = data[p]; int nl = 1;
                     hist[data[p]]++; p++;
-                    int lim = s * ZA_SEG + 32 * ((p - s * ZA_SEG) / 32 + 1);
+                    int lim = s * seg + 32 * ((p - s * seg) / 32 + 1);
                     if (lim > end) lim = end;
                     while (nl < 3 && p < lim && (best[p] >> 16) == 0) { tk |= (uint32_t)data[p] << (8 * nl); hist[data[p]]++; nl++; p++; }
                     t[nt++] = tk | ((uint32_t)(nl - 1) << 24);
@@ -458,7 +466,7 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
         }
         hist[256] = 1;
         if (dbg) {
-            if (dbg->tokens) memcpy(dbg->tokens, tokens, sizeof(uint32_t) * (size_t)(nseg * ZA_SEG));
+            if (dbg->tokens) memcpy(dbg->tokens, tokens, sizeof(uint32_t) * (size_t)(nseg * seg));
             if (dbg->seg_ntok) memcpy(dbg->seg_ntok, seg_ntok, sizeof seg_ntok);
             if (dbg->hist) memcpy(dbg->hist, hist, sizeof hist);
         }
@@ -567,14 +575,14 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
             }
         }
         for (int s = 0; s < nseg; s++) {
-            const uint32_t *t = tokens + (size_t)s * ZA_SEG;
+            const uint32_t *t = tokens + (size_t)s * seg;
             seg_bits[s] = (uint32_t)bitpos(&w);
-            int op = s * ZA_SEG, oend = op + ZA_SEG, nextb = op;       /* output position, next 256-byte boundary to index */
+            int op = s * seg, oend = op + seg, nextb = op;               /* output position, next boundary to index (the index's grain is the segment) */
             if (oend > n) oend = n;
             for (uint32_t k = 0; k < seg_ntok[s]; k++) {
                 uint32_t tk = t[k];
-                for (; nextb <= op; nextb += 1 << ZA_CHUNK_SHIFT)
-                    chunk_idx[nextb >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w) | ((uint32_t)(op - nextb) << 23);
+                for (; nextb <= op; nextb += seg)
+                    chunk_idx[nextb >> sshift] = (uint32_t)bitpos(&w) | ((uint32_t)(op - nextb) << 23);
                 if (tk & 0x80000000u) {
                     int lc = (int)((tk >> 26) & 31), dc = (int)((tk >> 16) & 31);
                     putbits(&w, codes[257 + lc], lens[257 + lc]);
@@ -588,11 +596,11 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
                     op += nl;
                 }
             }
-            for (; nextb < oend; nextb += 1 << ZA_CHUNK_SHIFT)          /* boundaries behind the last token start */
-                chunk_idx[nextb >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w) | ((uint32_t)(oend - nextb) << 23);
+            for (; nextb < oend; nextb += seg)                          /* boundaries behind the last token start */
+                chunk_idx[nextb >> sshift] = (uint32_t)bitpos(&w) | ((uint32_t)(oend - nextb) << 23);
         }
         seg_bits[nseg] = (uint32_t)bitpos(&w);
-        chunk_idx[(n + (1 << ZA_CHUNK_SHIFT) - 1) >> ZA_CHUNK_SHIFT] = (uint32_t)bitpos(&w);
+        chunk_idx[nseg] = (uint32_t)bitpos(&w);
         putbits(&w, codes[256], lens[256]);
     }
     if (final) flushbyte(&w);

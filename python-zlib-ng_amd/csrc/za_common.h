@@ -36,6 +36,11 @@
 #define ZA_FLAG_CARRY   4u      // (set by the host) the unit's 32 KiB dictionary is the tail of the unit in front of it in the batch:
                                 // inside a run the chain tables are carried over instead of inserting the dictionary again
 #define ZA_FLAG_RUNHEAD 8u      // (set by the host) first unit of a chain-kernel run: its dictionary IS inserted, its links are all in its own row
+// bits 8..11 of a unit's flags (set by the host, za_seg_shift_for): log2 of the unit's SEGMENT size.  A unit is always cut into at
+// most 64 segments (token boundaries are forced there: parse, dynamic programme and packer give a lane to each); a full unit's are
+// 2 KiB, the units of small calls get smaller ones -- 32 bytes at least -- so that a call of a few KiB is not ONE lane walking
+// 2 048 positions (the latency of zlib_ng.compress(16 KiB): 1.4 ms -> 0.3).  Indexed members always use 2 KiB (their index's grain).
+#define ZA_UNIT_SEG_SHIFT(flags) ((int)(((flags) >> 8) & 15u))
 #define ZA_LIMIT_L     10       // longest literal/length code the encoder emits: one 2^10-entry table decodes every symbol
 #define ZA_LIMIT_D     9        // longest distance code
 #define ZA_CHUNK_SHIFT 11       // index granularity of indexed members: one entry per 2 KiB segment
@@ -52,6 +57,14 @@
 
 // unit status bits
 #define ZA_ST_OVERFLOW   1u     // compressed output did not fit the slot
+
+__host__ __device__ inline int za_seg_shift_for(uint32_t n, uint32_t flags)
+{
+    if ((flags & ZA_FLAG_FLATHDR) != 0u || n > 65536u) return ZA_SEG_SHIFT;
+    int s = 5;
+    while ((64u << s) < n) s++;
+    return s;
+}
 
 struct ZaUnit {
     uint64_t in_off;     // byte offset of the unit's first byte in the input buffer

@@ -493,6 +493,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     const uint16_t *prevdist = prev_ws + (size_t)ui * ZA_PREV_STRIDE;     // index p + dict_len
     const uint16_t *linkb = linkb_ws + (size_t)ui * ZA_PREV_STRIDE + dict_len;      // index p (own positions only: no walk through these)
     const uint16_t *linkc = linkc_ws + (size_t)ui * ZA_PREV_STRIDE + dict_len;
+    const int sshift = ZA_UNIT_SEG_SHIFT(u.flags);      // log2 of the unit's segment size (matches end at segment ends)
     const bool carried = ui > u0;           // (the host cuts a run wherever a unit's dictionary is not the tail of its predecessor)
     uint32_t *best = best_ws + (size_t)ui * ZA_BEST_STRIDE;
     // bytes that may be read starting at data[0] without leaving the caller's buffer
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 best_len = (int)((e0 >> 12) & 0x1FFu); depth = (int)(e0 >> 21); best_dist = (int)(e1 >> 16);
                 P = goff + (uint32_t)(ZA_WIN + p);
                 q = P - (e1 & 0xFFFFu);
-                int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
+                int seg_end = ((p >> sshift) + 1) << sshift;
                 if (seg_end > n) seg_end = n;
                 int maxlen = seg_end - p;
                 if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             uint32_t q = P;
             int best_len = ZA_MIN_MATCH - 1, best_dist = 0, depth = L.chain;
             if (p < n) {
-                int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
+                int seg_end = ((p >> sshift) + 1) << sshift;
                 if (seg_end > n) seg_end = n;
                 int maxlen = seg_end - p;
                 if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
             if (p >= n) continue;
-            int seg_end = ((p >> ZA_SEG_SHIFT) + 1) << ZA_SEG_SHIFT;
+            int seg_end = ((p >> sshift) + 1) << sshift;
             if (seg_end > n) seg_end = n;
             int maxlen = seg_end - p;
             if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
@@ -990,7 +991,8 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     const ZaUnit u = units[blockIdx.x];
     const int n = (int)u.in_len;
     const int lane = za_lane();
-    const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    const int sshift = ZA_UNIT_SEG_SHIFT(u.flags), seg = 1 << sshift;      // the unit's segment size: 32 .. 2 048
+    const int nseg = (n + seg - 1) >> sshift;
     uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
     if (n == 0) return;
     for (int i = lane; i < ZA_DP_COSTS; i += 64) costt[i] = cost_ws[(size_t)blockIdx.x * ZA_DP_COSTS + i];
@@ -1012,8 +1014,8 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     for (int i = lane; i < ZA_DP_ROWS * 64; i += 64) ring[i] = 0;
     __syncthreads();
 
-    const int s0 = lane << ZA_SEG_SHIFT;
-    int s1 = s0 + ZA_SEG;
+    const int s0 = lane << sshift;
+    int s1 = s0 + seg;
     if (s1 > n) s1 = n;
     const bool active = lane < nseg;
     uint32_t *myb = rowb + lane * ZA_DROW;
@@ -1034,7 +1036,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     auto prefetch = [&](int c) {
 #pragma unroll
         for (int j = 0; j < ZA_DPIECES; j++) {
-            const int sg = (64 / ZA_DPIECES) * j + lane / ZA_DPIECES, off = (sg << ZA_SEG_SHIFT) + c * ZA_DCH + 4 * (lane % ZA_DPIECES);
+            const int sg = (64 / ZA_DPIECES) * j + lane / ZA_DPIECES, off = (sg << sshift) + c * ZA_DCH + 4 * (lane % ZA_DPIECES);
             pb[j] = make_uint4(0, 0, 0, 0);
             if (c >= 0 && sg < nseg && off < n) pb[j] = *(const uint4 *)(best + off);
         }
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         f.w0 = *(const uint32_t *)rp; f.w1 = *(const uint32_t *)(rp + 256); f.w2 = *(const uint32_t *)(rp + 512);
         return f;
     };
-    const int nch = ((n < ZA_SEG ? n : ZA_SEG) + ZA_DCH - 1) / ZA_DCH;      // chunks of the longest segment
+    const int nch = ((n < seg ? n : seg) + ZA_DCH - 1) / ZA_DCH;            // chunks of the longest segment
     uint4 po[ZA_DPIECES];                                           // the last chunk's entries on their way out
     uint32_t wacc[ZA_DCH / 2];                                      // ... and its acc values
     int pend = -1;
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         }
 #pragma unroll
         for (int j = 0; j < ZA_DPIECES; j++) {
-            const int sg = (64 / ZA_DPIECES) * j + lane / ZA_DPIECES, off = (sg << ZA_SEG_SHIFT) + pend * ZA_DCH + 4 * (lane % ZA_DPIECES);
+            const int sg = (64 / ZA_DPIECES) * j + lane / ZA_DPIECES, off = (sg << sshift) + pend * ZA_DCH + 4 * (lane % ZA_DPIECES);
             if (sg < nseg && off < n) *(uint4 *)(best + off) = po[j];
         }
     };
@@ -1201,13 +1203,14 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
     const ZaUnit u = units[blockIdx.x];
     const int n = (int)u.in_len;
     const int lane = za_lane();
-    const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    const int sshift = ZA_UNIT_SEG_SHIFT(u.flags), seg = 1 << sshift;      // the unit's segment size: 32 .. 2 048
+    const int nseg = (n + seg - 1) >> sshift;
     for (int i = lane; i < ZA_HIST_STRIDE; i += 64) hist[i] = 0;
     for (int i = lane; i < 256; i += 64) crct[i] = crc_table[i];
     __syncthreads();
 
-    const int s0 = lane << ZA_SEG_SHIFT;
-    int s1 = s0 + ZA_SEG;
+    const int s0 = lane << sshift;
+    int s1 = s0 + seg;
     if (s1 > n) s1 = n;
     const bool active = lane < nseg;
     const uint32_t *best = best_ws + (size_t)blockIdx.x * ZA_BEST_STRIDE;
@@ -1218,10 +1221,10 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
         const int rel = c * ZA_PCH;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int sg = 8 * j + (lane >> 3), off = (sg << ZA_SEG_SHIFT) + rel;
+            const int sg = 8 * j + (lane >> 3), off = (sg << sshift) + rel;
             pb[j] = make_uint4(0, 0, 0, 0);
             // (streamed once: a non-temporal load)
-            if (c < ZA_SEG / ZA_PCH && sg < nseg && off < n) {
+            if (c < seg / ZA_PCH && sg < nseg && off < n) {
                 typedef uint32_t za_v4u __attribute__((ext_vector_type(4)));
                 const za_v4u v = __builtin_nontemporal_load((const za_v4u *)(best + off + 4 * (lane & 7)));   // rows are 128-byte aligned
                 pb[j] = make_uint4(v.x, v.y, v.z, v.w);
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
     uint32_t nchunk = 0;           // tokens of the current chunk in my row
     prefetch(0);
 #pragma unroll 1
-    for (int c = 0; c < ZA_SEG / ZA_PCH; c++) {
+    for (int c = 0; c < seg / ZA_PCH; c++) {
         const int cb = s0 + c * ZA_PCH;
         // wave-uniform early exit: every active lane is past its segment end
         if (__ballot(active && cb < s1) == 0ull) break;
@@ -1322,12 +1325,12 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
             const uint32_t first = 4u * (uint32_t)(lane & 7);
             // (a chunk holds at most 33 tokens: the ninth piece, one token, is stored by piece 7's lane as well)
             const uint32_t *r = rowb + sg * ZA_PROW;
-            uint32_t *dst = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + ((size_t)sg << ZA_SEG_SHIFT) + at;
+            uint32_t *dst = tok_ws + (size_t)blockIdx.x * ZA_TOK_STRIDE + ((size_t)sg << sshift) + at;
             // whole 16-byte pieces, the last one with up to three slots of no meaning behind the chunk's tokens: the next chunk's
             // tokens land on them.  Only where that would leave the segment's 2 048 slots (a segment of nothing but literals)
             // the last piece goes token by token.
             if (first < cnt) {
-                if (at + first + 4u <= (uint32_t)ZA_SEG) { ZaU4u v; v.x = r[first]; v.y = r[first + 1]; v.z = r[first + 2]; v.w = r[first + 3]; *(ZaU4u *)(dst + first) = v; }
+                if (at + first + 4u <= (uint32_t)seg) { ZaU4u v; v.x = r[first]; v.y = r[first + 1]; v.z = r[first + 2]; v.w = r[first + 3]; *(ZaU4u *)(dst + first) = v; }
                 else for (uint32_t i = first; i < cnt && i < first + 4u; i++) dst[i] = r[i];
             }
             if ((lane & 7) == 7 && cnt > 32u) dst[32] = r[32];
@@ -1340,10 +1343,19 @@ __global__ __launch_bounds__(64) void za_k_parse(const ZaUnit *__restrict__ unit
     if (active) {
         cseg = crc_r ^ 0xFFFFFFFFu;
         if (lane < nseg - 1) {
-            const int tail = n - ((nseg - 1) << ZA_SEG_SHIFT);
+            const int tail = n - ((nseg - 1) << sshift);
             uint32_t xt = 0x80000000u, sq = 0x00800000u;
             for (int m = tail; m; m >>= 1) { if (m & 1) xt = za_multmodp(sq, xt); sq = za_multmodp(sq, sq); }
-            cseg = za_multmodp(za_multmodp(x8k_table[nseg - 2 - lane], xt), cseg);
+            // x^(8 * seg * k), k = the whole segments between mine and the last: from the table for 2 KiB segments, worked out for
+            // the smaller segments of small units (x^8 squared sshift times, raised to the k)
+            uint32_t xk = 0x80000000u;
+            if (sshift == ZA_SEG_SHIFT) xk = x8k_table[nseg - 2 - lane];
+            else {
+                uint32_t xs = 0x00800000u;
+                for (int i = 0; i < sshift; i++) xs = za_multmodp(xs, xs);
+                for (int m = nseg - 2 - lane; m; m >>= 1) { if (m & 1) xk = za_multmodp(xs, xk); xs = za_multmodp(xs, xs); }
+            }
+            cseg = za_multmodp(za_multmodp(xk, xt), cseg);
         }
     }
     cseg = za_wave_xor_reduce(cseg);
@@ -1875,7 +1887,8 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     const uint32_t cap_words = packed ? (b0 + out_stride + 3u) / 4u : out_stride / 4;
     uint32_t *segbits = segbits_ws + (size_t)blockIdx.x * ZA_SEGB_STRIDE;
     uint32_t *cidx = cidx_ws + (size_t)blockIdx.x * ZA_CIDX_STRIDE;       // chunk index of indexed members (oracle: chunk_idx)
-    const int nseg = (n + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+    const int sshift = ZA_UNIT_SEG_SHIFT(units[blockIdx.x].flags);
+    const int nseg = (n + (1 << sshift) - 1) >> sshift;
     bool ovf = false;
     uint32_t total_bytes = 0;
 
@@ -1983,7 +1996,7 @@ __global__ __launch_bounds__(64) void za_k_pack(const uint8_t *__restrict__ in, 
     for (int sg = 0; sg < nseg; sg++) {
         const uint32_t cnt = (uint32_t)__shfl((int)mycnt, sg, 64);
         if (lane == 0) { segbits[sg] = bitpos - bit0; cidx[sg] = bitpos - bit0; }      // (index entries: the codec forces a token boundary at every segment start)
-        const uint32_t *tk = tok_unit + ((size_t)sg << ZA_SEG_SHIFT);
+        const uint32_t *tk = tok_unit + ((size_t)sg << sshift);
         uint32_t tnext = (uint32_t)lane < cnt ? tk[lane] : 0u;
         for (uint32_t g = 0; g < cnt; g += 64) {
             const uint32_t t = tnext;

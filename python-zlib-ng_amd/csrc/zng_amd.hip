@@ -448,6 +448,7 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
             u.in_len = (uint32_t)std::min<uint64_t>(ZA_MAX_UNIT, B.len - rel);
             u.dict_len = (uint32_t)std::min<uint64_t>(ZA_WIN, (uint64_t)B.dict_len + rel);
             u.flags = (B.flags & ZNGAMD_FLAG_FLATHDR) | ((k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u);
+            u.flags |= (uint32_t)za_seg_shift_for(u.in_len, u.flags) << 8;       // the unit's segment size (za_common.h: small units take small segments)
             u.block = b;
             // the unit's whole 32 KiB dictionary is the tail of the unit in front of it: the chain tables may be carried over
             if (!hu.empty()) {
@@ -2074,7 +2075,7 @@ static int gzip_members_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len,
     std::vector<ZaUnit> hu(nb);
     for (uint32_t b = 0; b < nb; b++) {
         ZaUnit u; u.in_off = (uint64_t)b * block_size; u.in_len = (uint32_t)std::min<uint64_t>(block_size, in_len - u.in_off);
-        u.dict_len = 0; u.flags = ZA_FLAG_FINAL | ZA_FLAG_FLATHDR; u.block = b; hu[b] = u;
+        u.dict_len = 0; u.flags = ZA_FLAG_FINAL | ZA_FLAG_FLATHDR; u.flags |= (uint32_t)za_seg_shift_for(u.in_len, u.flags) << 8; u.block = b; hu[b] = u;
     }
     HIPCHK(c, c->st_slots.ensure((size_t)nb * ZNGAMD_SLOT_STRIDE)); HIPCHK(c, c->st_len.ensure(nb)); HIPCHK(c, c->st_crc.ensure(nb));
     int r = deflate_units_dev(c, d_in, in_len, hu, level, c->st_slots.p, c->st_len.p, c->st_crc.p);
