@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-foreign", action="store_true", help="skip the foreign-member inflate leg (outside the timed region)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="0 = sized for ~10-30 s")
     ap.add_argument("--no-api", action="store_true", help="skip the drop-in API leg (host buffers over PCIe; outside the timed region)")
+    ap.add_argument("--no-heldout", action="store_true", help="skip the held-out ratio leg (small deflate calls outside the timed region; counter passes average per launch)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)                  # does not return
@@ -643,7 +644,7 @@ def main():
     # ---- what the level compresses like OFF the bench corpus (rank 0, N = 1; outside the timed region): real files of this box
     # (zlib_ng_amd.corpus.heldout: Python sources, two ELF binaries, C headers; 4 MiB each) through the HIP path, 128 KiB units with
     # the previous 32 KiB as dictionary and a sync flush each -- the bench's own protocol -- beside the system zlib at the SAME level
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_heldout:
         from zlib_ng_amd import corpus as _corpus
         rh = {}
         for cname, cdata in _corpus.heldout(4 << 20).items():

@@ -19,7 +19,8 @@ for line in open(path):
         continue
     m = re.match(r"\s+(\S+)\s+total\s+(\d+)\s+launches\s+(\d+)\s+per-launch\s+([\d.]+)", line)
     if m and cur:
-        per[cur][m.group(1)] = float(m.group(4))
+        # the instantiations of a template (za_k_chains<0>, <1>, <2>: one launch each per step) add up under the plain name
+        per[cur][m.group(1)] = per[cur].get(m.group(1), 0.0) + float(m.group(4))
 out = {"_comment": "HBM bytes PER UNIT (128 KiB block / member) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB units, separate passes, "
                    "profiles/run_pmc.sh): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / units per launch; FETCH_SIZE doubled because gfx950 counts "
                    "half the bytes of wide coalesced reads.  bench.py multiplies by the units of one launch.",

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/pmc_$TAG
 PASSES=${PASSES:-"sq sq2 fetch write rdreq"}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--size-mib ${SIZE_MIB:-4096} --steps 1 --warmup 1 --no-cpu-baseline --no-api $@"      # the shape the driver times: 32 768 units per launch
+ARGS="--size-mib ${SIZE_MIB:-4096} --steps 1 --warmup 1 --no-cpu-baseline --no-api --no-heldout $@"      # the shape the driver times: 32 768 units per launch
 for P in $PASSES; do
   case $P in
     sq)    C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" ;;
