@@ -1029,9 +1029,9 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     const bool has_long = costt[258] != 0u;                        // (uniform, from the search) some match of the unit is longer than the ring: acc[] goes to memory too (a quarter of this kernel's time where it must)
     if (active) { ring_put((s1 - s0) & (ZA_DP_NEAR - 1), 0u); accg[s1 - s0] = 0; }     // acc[s1] = 0
     int acc_next = 0;                                              // acc[p + 1], the whole number (at most 2 048 x 52)
-    // what the last long match fetched from memory: a run of positions inside one long match all end at the same place
-    int far_end = -1;
-    uint32_t fv0 = 0, fv1 = 0, fv2 = 0;
+    // what the last long match fetched from memory: a window of sixteen values of acc[] (eight dwords), and where it starts
+    int far_base = -100;
+    uint32_t fw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     uint4 pb[ZA_DPIECES];
     auto prefetch = [&](int c) {
 #pragma unroll
@@ -1109,21 +1109,30 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
                 uint32_t v0 = __builtin_amdgcn_alignbyte(g.w1, g.w0, 2u * st1), v1 = __builtin_amdgcn_alignbyte(g.w2, g.w1, 2u * st1);
                 uint32_t v2 = st1 ? g.w2 >> 16 : g.w2;
                 if (__builtin_expect(__ballot(live && len > (uint32_t)ZA_DP_NEAR) != 0ull, 0)) {
-                    // a long match: its five values from memory, written at least three chunks ago by this wave (other lanes'
-                    // stores among them: a fence, and loads that go to the device's L2); the positions of one long match all end
-                    // at the same place, so what the last one fetched mostly serves
+                    // a long match: its five values acc[e - 4 .. e], e = p + len, from memory -- written at least three chunks ago
+                    // by this wave (other lanes' stores among them: a fence, and loads that go to the device's L2).  A WINDOW of 16
+                    // values is fetched, [fbase, fbase + 16) with e near its top: the positions inside one long match all end at the
+                    // same place, and in a run longer than 258 (zeros) the end moves down by one per step, so a fetch serves the
+                    // next eleven steps at least (one fetch per step made such units nine times slower)
                     if (live && len > (uint32_t)ZA_DP_NEAR) {
-                        const int end = idx + (int)len;
-                        if (end != far_end) {
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                            uint32_t a[ZA_DP_SUB + 1];
+                        const int e_lo = idx + (int)len - ZA_DP_SUB;               // index of the first of the five
+                        if (e_lo < far_base || e_lo + ZA_DP_SUB > far_base + 15) {
+                            far_base = (e_lo + ZA_DP_SUB - 14) & ~1;               // even: the window is eight aligned dwords
+                            // this wave's own stores of rounds ago must have reached the L2 (a wait for its vector-memory
+                            // counter: a workgroup-scope fence; a device-scope one would write the whole L2 back first), and the
+                            // loads must come from there, not from a line the L1 fetched before those stores (device-scope loads)
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                            const uint32_t *g32 = (const uint32_t *)(accg + far_base);
 #pragma unroll
-                            for (int k = 0; k <= ZA_DP_SUB; k++)
-                                a[k] = __hip_atomic_load(accg + end - ZA_DP_SUB + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            fv0 = a[0] | (a[1] << 16); fv1 = a[2] | (a[3] << 16); fv2 = a[4];
-                            far_end = end;
+                            for (int k = 0; k < 8; k++) fw[k] = __hip_atomic_load(g32 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        v0 = fv0; v1 = fv1; v2 = fv2;
+                        const uint32_t o = (uint32_t)(e_lo - far_base), q = o >> 1;   // 0 .. 11; dwords q, q + 1, q + 2 of the window
+                        uint32_t w0 = fw[0], w1 = fw[1], w2 = fw[2];
+#pragma unroll
+                        for (uint32_t k = 1; k <= 5; k++) { w0 = q == k ? fw[k] : w0; w1 = q == k ? fw[k + 1] : w1; w2 = q == k ? fw[k + 2] : w2; }
+                        const uint32_t sh = (o & 1u) * 2u;
+                        v0 = __builtin_amdgcn_alignbyte(w1, w0, sh); v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                        v2 = (o & 1u) ? w2 >> 16 : w2;
                     }
                 }
                 int de = 30 - (int)__builtin_clz(dm1 | 1u);        // extra bits of the distance: 0 for distances 1 .. 4
