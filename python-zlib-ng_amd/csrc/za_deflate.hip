@@ -1455,7 +1455,8 @@ __device__ void za_lengths_serial(ZaPlanLds &S, int nsym, int limit, uint8_t *le
         if (next < 0) break;
         avbl = 2 * used; dpth++; used = 0;
     }
-    int cnt[17];
+    int *cnt = (int *)(S.A + 256);                 // (LDS, behind the at most 256 symbols this lane-0 form is used for: a local array
+                                                   // indexed by a variable would live in scratch memory)
     for (int i = 0; i < 17; i++) cnt[i] = 0;
     bool over = false;
     for (int i = 0; i < m; i++) {
@@ -1593,9 +1594,9 @@ __device__ void za_lengths_wave(ZaPlanLds &S, int nsym, int limit, uint8_t *lens
 }
 
 // lane 0 only: canonical codes, bit-reversed for LSB-first emission
-__device__ void za_canon_serial(const uint8_t *lens, int n, uint16_t *codes)
+__device__ void za_canon_serial(const uint8_t *lens, int n, uint16_t *codes, uint32_t *scratch32 /* 32 dwords of LDS */)
 {
-    uint32_t bl[16], nc[16];
+    uint32_t *bl = scratch32, *nc = scratch32 + 16;
     for (int i = 0; i < 16; i++) bl[i] = 0;
     for (int i = 0; i < n; i++) bl[lens[i]]++;
     bl[0] = 0;
@@ -1776,7 +1777,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         }
         S.m = m;
         za_lengths_serial(S, 19, 7, S.cl_lens);
-        za_canon_serial(S.cl_lens, 19, S.cl_codes);
+        za_canon_serial(S.cl_lens, 19, S.cl_codes, S.A + 192);
         int hclen = 19; while (hclen > 4 && S.cl_lens[za_cl_order[hclen - 1]] == 0) hclen--;
         // exact costs
         const unsigned long long data_dyn = cost_dd, data_fix = cost_df;        // (at most 131 072 tokens of at most 48 bits: 32 bits hold the sums)
