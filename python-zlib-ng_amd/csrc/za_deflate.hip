@@ -4,18 +4,20 @@
 // ParallelCompress_compress_and_crc (reference src/zlib_ng/zlib_ngmodule.c:1696-1782):
 // zng_deflateReset + zng_deflateSetDictionary + zng_crc32_z + zng_deflate(Z_SYNC_FLUSH).
 //
-// Pipeline over a batch of units (unit = <=128 KiB of input + <=32 KiB dictionary before it):
-//   k_chains  one wave per run of units; 32-bit head table (32 KiB) in LDS; the 64 positions of a step are
-//             inserted by ONE returning LDS atomic maximum, which also yields every position's link
-//   k_search  one 1024-thread workgroup per unit; chain links of the sliding window staged in a
-//             128 KiB LDS ring; every position searched in parallel
-//   k_optparse (levels 4-9) one wave per unit, one lane per 2 KiB segment: backward dynamic programme over estimated bit
-//             costs, rewrites the search results so that the greedy parse follows its choices
-//   k_parse   one wave per unit, one lane per 2 KiB segment: greedy selection, symbol
-//             histogram with LDS atomics, CRC-32 per segment folded with GF(2) products
-//   k_plan    one wave per unit: length-limited canonical Huffman, block-type choice, header bits
-//   k_pack    one wave per unit, one lane per segment: bit lengths -> wave prefix sum -> packing,
-//             boundary words merged with atomic OR
+// Pipeline over a batch of units (unit = <=128 KiB of input + <=32 KiB dictionary before it; at most 64 segments: 2 KiB each for
+// full units, 32 bytes .. 1 KiB for the units of small calls):
+//   k_chains<A|B|C>  one 4-wave workgroup per run of units, launched once per link table (5-, 3-, 12-byte contexts); 32-bit head
+//             table (64 KiB) in LDS; the 64 positions of a step are inserted by ONE returning LDS atomic maximum, which also
+//             yields every position's link
+//   k_search  one 1024-thread workgroup per run; links of table A and the bytes of the sliding window staged in LDS rings;
+//             every position searched in parallel: a walk over chain A, then its own links in tables B and C
+//   k_dpstats + k_optparse (levels 4-9)  the unit's cost table from a quarter of its entries; then one wave per unit, one lane per
+//             segment: backward dynamic programme over estimated bit costs, rewrites the search results so that the greedy parse
+//             follows its choices
+//   k_parse   one wave per unit, one lane per segment: greedy selection, symbol histogram with LDS atomics, CRC-32 per segment
+//             folded with GF(2) products
+//   k_plan    one wave per unit: length-limited canonical Huffman, block-type choice, header bits, the unit's exact size
+//   k_pack    one wave per unit, token-parallel: bit lengths -> wave prefix sum -> an LDS ring of the stream's open dwords
 #include "za_common.h"
 #include "za_crc.h"
 #include <type_traits>
