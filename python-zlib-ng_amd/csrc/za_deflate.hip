@@ -552,6 +552,22 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, load_bytes(p));
         bytes_loaded = need_bytes;
     }
+    // the positions' own links in tables B and C travel ONE TILE AHEAD in registers (levels 1-6): fetched where they are used,
+    // behind the first position's walk, every tile stalled for their trip to memory (13 % of the kernel)
+    uint32_t nlkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], nlkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
+    auto load_own_links = [&](int tile_base) {
+#pragma unroll
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
+            const int p = tile_base + k * ZA_SEARCH_THREADS + tid;
+#ifdef ZA_ABL_NO_LINKLOADS
+            nlkb[k] = ((uint32_t)p * 7u & 0xFFu) | 1u; nlkc[k] = ((uint32_t)p * 13u & 0x3FFu) | 1u;      // (timing only: candidates without the loads)
+#else
+            nlkb[k] = p < n ? (uint32_t)linkb[p] : 0u;
+            nlkc[k] = USEC && p < n ? (uint32_t)linkc[p] : 0u;
+#endif
+        }
+    };
+    load_own_links(0);
     __syncthreads();
     for (int base = 0; base < n; base += ZA_SEARCH_TILE) {
         // ---- the NEXT tile's links and bytes are fetched into registers now and put into the rings after this tile's
@@ -634,10 +650,10 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         // a walk is over: the position's own links in tables B and C (one candidate each, compared in full; skipped behind a nice
         // match), the drop rules, the entry
         auto finish = [&](int p, uint32_t P, uint32_t me0, uint32_t me1, uint32_t me2, uint32_t me3, int maxlen, int cap, int nice,
-                          int best_len, int best_dist) {
+                          int best_len, int best_dist, uint32_t own_b, uint32_t own_c) {
 #pragma unroll
             for (int t = 0; t < (USEC ? 2 : 1); t++) {
-                const int dl = maxlen >= ZA_MIN_MATCH ? (int)(t == 0 ? linkb : linkc)[p] : 0;
+                const int dl = maxlen >= ZA_MIN_MATCH ? (int)(t == 0 ? own_b : own_c) : 0;
                 if (dl != 0 && dl <= L.max_dist && best_len < nice) {
                     const uint32_t q = P - (uint32_t)dl;
                     const uint32_t sh = q & 3u;
@@ -705,12 +721,17 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 uint32_t qb = RING_B0 + 2u * sq;
                 uint32_t d = *(const uint16_t *)(lds + qb);
                 alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
-                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist);
+                // (a position that comes off the list fetches its own links here: they travelled ahead only for the lane that started it)
+                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist, (uint32_t)linkb[p], USEC ? (uint32_t)linkc[p] : 0u);
             }
             push(alive, p, P, q, best_len, best_dist, depth);
         };
         uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;
-#pragma unroll 1
+        uint32_t flkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], flkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];      // my positions' own links, fetched a tile ago
+#pragma unroll
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) { flkb[k] = nlkb[k]; flkc[k] = nlkc[k]; }
+        load_own_links(base + ZA_SEARCH_TILE);
+#pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
             bool alive = false;
@@ -730,7 +751,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     uint32_t d = *(const uint16_t *)(lds + qb);
                     alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
                 }
-                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist);
+                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist, flkb[k], flkc[k]);
             }
             push(alive, p, P, q, best_len, best_dist, depth);
             while (__builtin_amdgcn_readfirstlane((int)wl_n) >= 64) batch(64u);
@@ -742,14 +763,11 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         }
         } else {
         uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;      // ring slot of my position, moved on by 1 024 per round
-        // my four positions' own links in tables B and C (issued at the tile's start, used behind the walks)
+        // my four positions' own links in tables B and C: what was fetched a tile ago; the next tile's are asked for now
         uint32_t lkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], lkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
 #pragma unroll
-        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
-            const int p = base + k * ZA_SEARCH_THREADS + tid;
-            lkb[k] = p < n ? (uint32_t)linkb[p] : 0u;
-            lkc[k] = USEC && p < n ? (uint32_t)linkc[p] : 0u;
-        }
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) { lkb[k] = nlkb[k]; lkc[k] = nlkc[k]; }
+        load_own_links(base + ZA_SEARCH_TILE);
 #ifndef ZA_SEARCH_KUNROLL
 #define ZA_SEARCH_KUNROLL 4              // the four positions of a thread per tile as straight code (18.9 against 19.4 ms per 4 GiB at level 6)
 #endif
