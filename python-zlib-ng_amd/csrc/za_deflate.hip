@@ -858,10 +858,12 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     best_len = better ? len : best_len;
                     best_dist = better ? (int)dl : best_dist;
                 }
+#ifndef ZA_ABL_NO_EXTEND
                 if (!FULL && best_len == cap && cap < maxlen) {
                     // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
                     best_len = za_search_extend(win32, P - (uint32_t)best_dist, P, best_len, maxlen);
                 }
+#endif
                 if (best_len >= ZA_MIN_MATCH && !(best_len == 3 && best_dist > L.too_far3) && !(best_len == 4 && best_dist > L.too_far4))
                     result = ((uint32_t)best_len << 15) | (uint32_t)(best_dist - 1);
                 longm = longm || best_len > 64;
