@@ -1,7 +1,17 @@
 /* oracle/study -- TEST INFRASTRUCTURE ONLY: parameter studies for the ZA codec spec (round 5).
  * Includes the oracle's own stages and adds experimental variants of stage 1-3; prints compressed sizes
  * beside the system zlib's under the bench protocol (128 KiB units, 32 KiB dictionary = previous input,
- * sync flush per unit).   gcc -O2 -o /tmp/ratio_study ratio_study.c -lz -lpthread
+ * sync flush per unit).   make -C oracle study;  oracle/study/ratio_study <corpus files...> < parameter lines
+ *
+ * A parameter line (what DESIGN.md 3.6 quotes; '#' lines are echoed):
+ *   name  a_bytes a_bits a_chain  b_bytes b_bits b_chain  nice lazy cap  min_match too_far3 too_far4  seg blk  limL limD  parse ref
+ *         [c_bytes c_bits c_chain  prop dp_sub dp_lit too_far5 dp_mlen]
+ * a / b / c: up to three link tables (context bytes, bucket bits, steps walked; 0 bytes = off); parse 0 = greedy / one-step lazy,
+ * 1 = backward dynamic programme (dp_sub shorter lengths tried; dp_lit 0 flat costs, 1 bytes of the whole unit, 2 bytes of the
+ * match-less positions + log-odds terms, 3 + length / distance code statistics, 4.. = 2 with matches shorter than dp_lit counted as
+ * literals, env WKD = only if farther back than that); blk = Huffman block size (0 = the unit); ref = index of the zlib level the
+ * percentage is taken against (0..4 = -1 -3 -4 -6 -9).  The spec that came out of it: "L6 5 14 2 3 14 1 16 0 16 3 4096 32768 2048 0 10 9 1 3
+ * 12 14 1 0 4 2 32768 12" plus the weak-match rule (WKD=256, dp_lit 4) and sampled statistics, which only the oracle itself has.
  */
 #include "../oracle_deflate.c"
 #include <stdio.h>
