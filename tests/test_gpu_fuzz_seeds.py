@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_compress_objects.py", 301, 40),
     ("fuzz_stream_objects.py", 301, 40),
     ("fuzz_reader_windows.py", 1, 6),
+    ("fuzz_long_matches.py", 11, 30),        # zero runs, periods and sparse bytes at levels 4-9: the dynamic programme's long-match path, multi-unit batches
 ])
 def test_fuzz_script_smallest_seed(script, seed, cases):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", script), str(seed), str(cases)], cwd=ROOT,
