@@ -7,7 +7,8 @@ One "step" = one pass of the hot path over this rank's shard of synthetic text a
       deflate kernels, gathered into one contiguous raw-deflate slice.  With N > 1 ranks every rank owns a contiguous
       block range of ONE stream (its first block is primed with the 32 KiB of input in front of the range: the previous
       rank's tail) and the slices are exchanged over RCCL through the engine's own entry points (zngamd_comm_*: layout
-      all-gather, then exact-size grouped ncclSend / ncclRecv; issued on a stream of its own, overlapping leg 2), which
+      all-gather, then exact-size grouped ncclSend / ncclRecv; issued on a stream of its own: it overlaps leg 2 and, through a
+      second slice buffer, the next step's leg 1; the last step's exchange is waited for inside the timed region), which
       leaves the whole member stream on every rank (BENCH_EXCHANGE=layout: sizes only, for ranks that write their slice
       by offset).  --scaling weak (default): every rank brings --size-mib of its own; strong: --size-mib is the whole job;
   (2) decompress: two-pass inflate (member scan, then one wavefront per member) of a pre-built stream
@@ -192,7 +193,11 @@ def main():
     assert n_units == nblocks
     d_ulen = dempty(4 * n_units)
     d_ucrc = dempty(4 * n_units)
-    d_comp = dempty(size // 2 + (64 << 20))   # text compresses ~3x
+    # the compressed slice, twice where the slices are exchanged: the exchange of step i reads one while step i + 1 compresses into the
+    # other (the transfer -- about 10 GB arriving per rank and step at N = 8 -- then overlaps the inflate leg AND the next step's
+    # compress instead of the inflate leg alone)
+    d_comps = [dempty(size // 2 + (64 << 20)) for _ in range(2 if exchange_stream else 1)]   # text compresses ~3x
+    d_comp = d_comps[0]
     d_stream = dempty(world * (size // 2 + (8 << 20)) + (64 << 20)) if exchange_stream else None
     d_out = dempty(size + 64)
     ptr = lambda t: t.vp()
@@ -214,11 +219,20 @@ def main():
     comp_total = C.c_uint64(0)
     gathered = {}
 
+    step_no = [0]
+    pending = [False]
+
     def step():
+        nonlocal d_comp
         # (1) compress straight into the one contiguous stream: every unit's size is known before it is packed, so the packer
         #     writes at the unit's final byte offset (no slots, no gather) (+ exchange of the slices)
+        d_comp = d_comps[step_no[0] % len(d_comps)]
+        step_no[0] += 1
         chk(L.zngamd_deflate_blocks_packed_dev(h, ptr(d_buf), HALO + size, blocks, nblocks, args.level, ptr(d_comp), d_comp.numel() - 64,
                                                ptr(d_ulen), ptr(d_ucrc), None, C.byref(comp_total)), "deflate_blocks_packed_dev")
+        if exchange_stream and pending[0]:
+            comm.wait()                   # the exchange of the step in front (it ran beside that step's inflate and this step's compress)
+            pending[0] = False
         if exchange:
             # CRC-32 of my range from the per-block values (the writer thread's fold, gzip_ng_threaded.py:394), then the layout of
             # the one stream: 24 bytes per rank over RCCL
@@ -227,17 +241,19 @@ def main():
             gathered["layout"] = comm.layout(comp_total.value, crc.value, size)
             if exchange_stream:  # the slices travel (grouped ncclSend / ncclRecv on the communicator's stream) while this rank inflates
                 comm.allgather_stream(d_comp.data_ptr(), gathered["layout"][2], d_stream.data_ptr(), d_stream.numel() - 64)
+                pending[0] = True
         # (2) two-pass inflate of the pre-built member stream
         nm, tot = C.c_uint32(0), C.c_uint64(0)
         chk(L.zngamd_gzip_scan_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nblocks, C.byref(nm),
                                    C.byref(tot)), "gzip_scan_dev")
         chk(L.zngamd_gzip_inflate_members_dev(h, ptr(d_members_stream), ms_len.value, ptr(d_mtab), nm.value,
                                               ptr(d_out), size, ptr(d_mstat)), "gzip_inflate_members_dev")
-        if exchange_stream:
-            comm.wait()
 
     def barrier():
         ctx.sync()
+        if exchange_stream and pending[0]:
+            comm.wait()                   # the last step's exchange ends inside the timed region
+            pending[0] = False
         if exchange:
             comm.barrier()
         ctx.sync()
