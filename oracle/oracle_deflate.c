@@ -30,7 +30,7 @@
 typedef struct { int chain, nice, cap, use_c, dp, too_far3, too_far4; } za_level;
 /* Level table.  Three link tables: A = chains over 5-byte contexts, walked `chain` steps; B = the nearest
  * earlier position with the same 3-byte context (one candidate, every level); C = the nearest earlier position with the same 12-byte
- * context (one candidate, levels 6-9: "skip ahead in chain A to the first long match").  Levels 1-3 take the longest candidate
+ * context (one candidate, levels 5-9: "skip ahead in chain A to the first long match").  Levels 1-3 take the longest candidate
  * greedily; levels 4-9 choose literals / matches per 2 KiB segment by a backward dynamic programme over estimated bit costs (dp).
  * cap: candidates are compared on their first `cap` bytes only (longest wins, nearest wins ties); the winner is then extended to
  * its true length.  16 on the fast levels (one 16-byte compare per candidate on the GPU), 258 = compare in full, and only those
@@ -40,7 +40,7 @@ typedef struct { int chain, nice, cap, use_c, dp, too_far3, too_far4; } za_level
 static const za_level LEVELS[10] = {
     {0, 0, 0, 0, 0, 0, 0},
     {1, 16, 16, 0, 0, 256, 4096}, {2, 16, 16, 0, 0, 256, 4096}, {3, 16, 16, 0, 0, 256, 4096},
-    {1, 16, 16, 0, 1, 4096, 32768}, {2, 16, 16, 0, 1, 4096, 32768}, {2, 16, 16, 1, 1, 4096, 32768},
+    {2, 16, 16, 0, 1, 4096, 32768}, {2, 16, 16, 1, 1, 4096, 32768}, {3, 16, 16, 1, 1, 4096, 32768},
     {4, 32, 258, 1, 1, 4096, 32768}, {8, 64, 258, 1, 1, 4096, 32768}, {12, 128, 258, 1, 1, 4096, 32768}
 };
 

@@ -29,7 +29,7 @@ static_assert(ZNGAMD_UNIT_MAX == ZA_MAX_UNIT && ZNGAMD_SEG == ZA_SEG, "constants
 static const ZaLevel ZA_LEVELS[10] = {
     {0, 0, ZA_WIN, 0, 0, 0, 0, 0},
     {1, 16, ZA_WIN, 16, 0, 0, 256, 4096}, {2, 16, ZA_WIN, 16, 0, 0, 256, 4096}, {3, 16, ZA_WIN, 16, 0, 0, 256, 4096},
-    {1, 16, ZA_WIN, 16, 0, 1, 4096, 32768}, {2, 16, ZA_WIN, 16, 0, 1, 4096, 32768}, {2, 16, ZA_WIN, 16, 1, 1, 4096, 32768},
+    {2, 16, ZA_WIN, 16, 0, 1, 4096, 32768}, {2, 16, ZA_WIN, 16, 1, 1, 4096, 32768}, {3, 16, ZA_WIN, 16, 1, 1, 4096, 32768},
     {4, 32, ZA_WIN, 258, 1, 1, 4096, 32768}, {8, 64, ZA_WIN, 258, 1, 1, 4096, 32768}, {12, 128, ZA_WIN, 258, 1, 1, 4096, 32768}};
 
 template <typename T> struct DevBuf {

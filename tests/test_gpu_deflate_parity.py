@@ -39,7 +39,7 @@ def _stage_compare(ctx, O, data, zdict, level, flags):
     if n and lv > 0:
         prev = np.frombuffer(ctx.debug_fetch(0, 0, 2 * (dl + n)), np.uint16)
         assert np.array_equal(prev, dbg["prevdist"]), f"stage1 chains differ at {np.flatnonzero(prev != dbg['prevdist'])[:5]}"
-        for what, key in ((9, "linkB"), (10, "linkC")) if lv >= 6 else ((9, "linkB"),):
+        for what, key in ((9, "linkB"), (10, "linkC")) if lv >= 5 else ((9, "linkB"),):
             lk = np.frombuffer(ctx.debug_fetch(what, 0, 2 * (dl + n)), np.uint16)
             assert np.array_equal(lk, dbg[key]), f"stage1 {key} differs at {np.flatnonzero(lk != dbg[key])[:5]}"
         if lv >= 4:      # the dynamic programme rewrites the entries: the search's own results are the kept copy
