@@ -922,12 +922,12 @@ try {
 } ZA_ABI_GUARD
 
 int zngamd_debug_keep(zngamd_ctx *c, int on)
-{
+try {
     if (!c) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     c->debug_keep = on != 0;
     return ZNGAMD_OK;
-}
+} ZA_ABI_GUARD
 
 int zngamd_debug_fetch(zngamd_ctx *c, int what, uint32_t unit, void *dst, size_t bytes)
 try {
