@@ -1431,7 +1431,11 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_members(const uint8_t *__r
                     uint32_t u1, g1, u2, g2b;
                     const uint32_t n1 = lit3(lo, room, true, u1, g1);
                     const uint32_t lo1 = __builtin_amdgcn_alignbit(hi, lo, u1), hi1 = __builtin_amdgcn_alignbit(h2, hi, u1), h21 = __builtin_amdgcn_alignbit(h3, h2, u1);
+#ifdef ZA_ABL_ONE_LIT3
+                    const uint32_t n2 = 0; u2 = 0; g2b = 0;                  // (experiment: three literals per round at most)
+#else
                     const uint32_t n2 = lit3(lo1, room - 3, n1 == 3u, u2, g2b);
+#endif
                     const uint32_t nl = n1 + n2, u = u1 + u2;
                     const uint64_t grp = (uint64_t)g1 | ((uint64_t)g2b << 24);
                     // -- the token behind them (64 bits from there on)
