@@ -553,7 +553,8 @@ def main():
                 pj.get("build", "?"), pj.get("units_per_launch", "?"), nblocks)
             for k in ("chains", "search", "optparse", "parse", "plan", "pack", "gather", "scan_members", "inflate_members"):
                 if pj.get("za_k_" + k):
-                    traffic_step[k] = int(pj["za_k_" + k] * nblocks)
+                    # (a timer class may hold a second kernel: za_k_dpstats ran under "optparse" until it moved into the search)
+                    traffic_step[k] = int((pj["za_k_" + k] + (pj.get("za_k_dpstats", 0) if k == "optparse" else 0)) * nblocks)
                 elif k == "gather":    # packed deflate: what is left under this timer is za_k_offsets (4 B read + 8 B written per unit: below the counters' floor)
                     traffic_step[k] = int(pj.get("za_k_offsets", 12) * nblocks)
             names = {"scan": "scan_members", "inflate": "inflate_members"}
@@ -605,6 +606,8 @@ def main():
                              "alg_bytes_per_launch": int(ms_len.value + size), "traffic": traffic_step.get("inflate_members"),
                              "traffic_source": traffic_src},
         "hbm_traffic_bytes_per_step": traffic_step or None,
+        # what bounds every kernel here: vector wave-instructions per 128 KiB unit (SQ pass of the build named in traffic_source)
+        "valu_wave_insts_per_unit": {k: int(v) for k, v in (pmc_per_unit.get("valu_wave_insts_per_unit") or {}).items()} or None,
     }
     if foreign is not None and pmc_per_unit.get("za_k_inflate_serial_members"):
         foreign["traffic"] = int(pmc_per_unit["za_k_inflate_serial_members"] * nblocks)
@@ -619,13 +622,15 @@ def main():
         sample -= sample % BLOCK
         arr = np.ascontiguousarray(np.tile(host, (sample + uniq - 1) // uniq)[:sample])
         td, ti, cb = O.bench_blocks(arr, BLOCK, args.level, cores)
-        out["cpu_baseline"] = {"value": round(sample / (td + ti) / 1e6, 1), "unit": "MB/s", "cores": cores,
-                               "kind": "port",
-                               "sample": f"first {sample >> 20} MiB of the same tiled text, 128 KiB blocks + 32 KiB dictionary, "
-                                         f"level {args.level}, oracle C codec on {cores} threads",
-                               "compress_MBps": round(sample / td / 1e6, 1),
-                               "decompress_MBps": round(sample / ti / 1e6, 1), "ratio": round(sample / cb, 4)}
-        # context: the system zlib (1.2.x) on the same sample, same protocol, thread pool releases the GIL
+        out["cpu_oracle"] = {"value": round(sample / (td + ti) / 1e6, 1), "unit": "MB/s", "cores": cores,
+                             "kind": "port",
+                             "sample": f"first {sample >> 20} MiB of the same tiled text, 128 KiB blocks + 32 KiB dictionary, "
+                                       f"level {args.level}, oracle C codec (the parity checker, not a competitor) on {cores} threads",
+                             "compress_MBps": round(sample / td / 1e6, 1),
+                             "decompress_MBps": round(sample / ti / 1e6, 1), "ratio": round(sample / cb, 4)}
+        # THE CPU baseline: the system zlib on the same sample, same protocol (deflateReset -> SetDictionary -> deflate(Z_SYNC_FLUSH)
+        # per block, zlib_ngmodule.c:1725-1742), one block per task on all host cores (the pool's calls release the GIL) -- the
+        # standard library every box has; a real zlib-ng, the reference's own CPU path, is probed for below
         from concurrent.futures import ThreadPoolExecutor
         mv = memoryview(arr)
 
@@ -643,10 +648,13 @@ def main():
             t = time.perf_counter(); comp = list(ex.map(zc, range(nb))); tzc = time.perf_counter() - t
             t = time.perf_counter(); n_out = sum(ex.map(zd, enumerate(comp))); tzd = time.perf_counter() - t
         assert n_out == sample
-        out["cpu_zlib"] = {"value": round(sample / (tzc + tzd) / 1e6, 1), "unit": "MB/s", "cores": cores,
-                           "library": "zlib " + zlib.ZLIB_RUNTIME_VERSION,
-                           "compress_MBps": round(sample / tzc / 1e6, 1), "decompress_MBps": round(sample / tzd / 1e6, 1),
-                           "ratio": round(sample / sum(map(len, comp)), 4)}
+        out["cpu_baseline"] = {"value": round(sample / (tzc + tzd) / 1e6, 1), "unit": "MB/s", "cores": cores,
+                               "kind": "zlib " + zlib.ZLIB_RUNTIME_VERSION,
+                               "sample": f"first {sample >> 20} MiB of the same tiled text, 128 KiB blocks + 32 KiB dictionary, "
+                                         f"level {args.level}, system zlib {zlib.ZLIB_RUNTIME_VERSION} on {cores} threads (a cgroup share, not a socket)",
+                               "compress_MBps": round(sample / tzc / 1e6, 1), "decompress_MBps": round(sample / tzd / 1e6, 1),
+                               "ratio": round(sample / sum(map(len, comp)), 4)}
+        out["cpu_zlib"] = dict(out["cpu_baseline"], library="zlib " + zlib.ZLIB_RUNTIME_VERSION)      # (the field's older name)
         # a real zlib-ng on this host would be the true reference CPU path; say plainly if there is none
         try:
             from zlib_ng import zlib_ng as _real                              # the reference's wheel, if the box has one
@@ -656,7 +664,7 @@ def main():
             out["cpu_zlib_ng"] = {"available": True, "compress_MBps": round(sample / tn / 1e6, 1), "cores": cores,
                                   "note": "independent blocks, no dictionary"}
         except Exception:
-            out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = oracle port + zlib 1.2.x"}
+            out["cpu_zlib_ng"] = {"available": False, "note": "no zlib-ng wheel or library on this host: CPU column = zlib 1.2.x (cpu_baseline) + the oracle port (cpu_oracle)"}
     # ---- what the level compresses like OFF the bench corpus (rank 0, N = 1; outside the timed region): real files of this box
     # (zlib_ng_amd.corpus.heldout: Python sources, two ELF binaries, C headers; 4 MiB each) through the HIP path, 128 KiB units with
     # the previous 32 KiB as dictionary and a sync flush each -- the bench's own protocol -- beside the system zlib at the SAME level

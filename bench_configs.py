@@ -21,31 +21,44 @@ sys.path.insert(0, os.path.join(ROOT, "python-zlib-ng_amd"))
 BLOCK = 131072
 
 
-def deflate_dev(ctx, _lib, torch, d_in, size, level, chained=True, steps=2):
+def tiled_dev(ctx, devmem, host, size):
+    """`size` bytes of device memory holding `host` (a numpy uint8 array) tiled, + 64 readable bytes of slack: one upload, then
+    device-to-device doubling (no tensor library: zlib_ng_amd.devmem over the C ABI)"""
+    d = devmem.empty(ctx, size + 64)
+    n = min(host.size, size)
+    d[0:n] = host[:n]
+    while n < size:
+        k = min(n, size - n)
+        d[n:n + k] = d[0:k]
+        n += k
+    d[size:size + 64] = 0
+    return d
+
+
+def deflate_dev(ctx, _lib, devmem, d_in, size, level, chained=True, steps=2):
+    import numpy as np
     L, h = ctx.L, ctx.h
     nb = size // BLOCK
     blocks = (_lib.Block * nb)()
     for b in range(nb):
         blocks[b] = _lib.Block(b * BLOCK, BLOCK, 32768 if (b and chained) else 0, 0, 0)
-    slots = torch.empty(nb * _lib.SLOT_STRIDE, dtype=torch.uint8, device="cuda")
-    ul = torch.empty(nb, dtype=torch.int32, device="cuda")
-    uc = torch.empty(nb, dtype=torch.int32, device="cuda")
-    p = lambda t: C.c_void_p(t.data_ptr())
+    slots = devmem.empty(ctx, nb * _lib.SLOT_STRIDE)
+    ul = devmem.empty(ctx, 4 * nb)
+    uc = devmem.empty(ctx, 4 * nb)
     best = None
     for _ in range(steps + 1):
-        torch.cuda.synchronize()
+        ctx.sync()
         t0 = time.perf_counter()
-        r = L.zngamd_deflate_blocks_dev(h, p(d_in), size, blocks, nb, level, p(slots), p(ul), p(uc), None)
+        r = L.zngamd_deflate_blocks_dev(h, d_in.vp(), size, blocks, nb, level, slots.vp(), ul.vp(), uc.vp(), None)
         dt = time.perf_counter() - t0
         assert r == 0, ctx.err()
         best = dt if best is None else min(best, dt)
-    comp = int(ul.to(torch.int64).sum().item())
-    return best, comp, slots, ul
+    lens = ul.cpu(np.int32)
+    return best, int(lens.astype(np.int64).sum()), slots, lens
 
 
 def main():
-    import torch
-    from zlib_ng_amd import _lib, corpus, zlib_ng
+    from zlib_ng_amd import _lib, corpus, devmem, zlib_ng
     ctx = _lib.default_context()
     out = []
 
@@ -85,13 +98,13 @@ def main():
     # ---- config 1: level 1 (and 6 for comparison), 1 GiB text
     size = 1 << 30
     host = corpus.text(64 << 20, seed=1)
-    d_in = torch.cat([torch.from_numpy(host).cuda().repeat(size // host.size), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    d_in = tiled_dev(ctx, devmem, host, size)
     for level in (1, 6):
-        dt, comp, slots, ul = deflate_dev(ctx, _lib, torch, d_in, size, level)
+        dt, comp, slots, ul = deflate_dev(ctx, _lib, devmem, d_in, size, level)
         parts = []
         for b in range(64):                        # first 64 blocks through the system zlib
-            n = int(ul[b].item())
-            parts.append(bytes(slots[b * _lib.SLOT_STRIDE:b * _lib.SLOT_STRIDE + n].cpu().numpy()))
+            n = int(ul[b])
+            parts.append(slots[b * _lib.SLOT_STRIDE:b * _lib.SLOT_STRIDE + n].cpu().tobytes())
         assert zlib.decompressobj(-15).decompress(b"".join(parts)) == host[:64 * BLOCK].tobytes()
         out.append({"config": 1 if level == 1 else "1b",
                     "workload": f"deflate level {level}, 1 GiB Zipf text, 128 KiB dict-chained blocks, device resident",
@@ -103,8 +116,8 @@ def main():
     # ---- config 4: level 9 on the mixed corpus
     mixed = corpus.mixed(200 << 20, seed=5)
     size = (mixed.size // BLOCK) * BLOCK
-    d_in = torch.cat([torch.from_numpy(mixed[:size]).cuda(), torch.zeros(64, dtype=torch.uint8, device="cuda")])
-    dt, comp, slots, ul = deflate_dev(ctx, _lib, torch, d_in, size, 9, steps=1)
+    d_in = tiled_dev(ctx, devmem, mixed[:size], size)
+    dt, comp, slots, ul = deflate_dev(ctx, _lib, devmem, d_in, size, 9, steps=1)
     import numpy as np
     # 16 x 1 MiB taken evenly across the corpus (every data class is represented)
     sample = np.concatenate([mixed[o:o + (1 << 20)] for o in range(0, size - (1 << 20), size // 16)][:16]).tobytes()

@@ -377,8 +377,14 @@ int zngamd_comm_max_f64(zngamd_comm *comm, double *value);
 #define ZNGAMD_K_OPTPARSE 9     /* the dynamic programme between search and parse (levels 4-9) */
 #define ZNGAMD_K_COUNT  10
 int zngamd_profiling(zngamd_ctx *ctx, int on);
-/* accumulated milliseconds and launch counts per kernel class since the last reset */
+/* accumulated milliseconds and launch counts per kernel class since the last reset.  The library writes
+ * zngamd_kernel_class_count() elements into each array: a caller built against an older header (ZNGAMD_K_COUNT was 9 before the
+ * dynamic programme's class) asks the library, not its own header, how much room to give -- or compares ZNGAMD_ABI with
+ * zngamd_abi() once. */
 int zngamd_kernel_times(zngamd_ctx *ctx, double *ms /*[ZNGAMD_K_COUNT]*/, uint64_t *launches /*[ZNGAMD_K_COUNT]*/, int reset);
+int zngamd_kernel_class_count(void);
+#define ZNGAMD_ABI 6            /* bumped whenever an array size, a struct layout or an argument list of this header changes */
+int zngamd_abi(void);
 
 /* how many gzip members zngamd_gunzip (and whole streams zngamd_inflate_raw) decoded through each path since the last reset:
  * ZA-indexed two-pass, BGZF one-launch, chunk-parallel (sync points / block finder), one sequential wavefront */
@@ -393,7 +399,8 @@ int zngamd_decode_paths(zngamd_ctx *ctx, uint64_t *members /*[ZNGAMD_PATH_COUNT]
  * deflate call to the host.  what: 0 links of table A (u16) 1 best(u32, as the parse kernel read it: behind the dynamic
  * programme on levels 4-9) 2 tokens(u32) 3 seg_ntok(u32) 4 hist(u32) 5 codes(u32) 6 seg_bits(u32) 7 plan(4 x u32)
  * 8 chunk index(u32) 9 / 10 links of tables B / C (u16) 11 best as the search left it (u32) 12 the dynamic programme's cost
- * table (258 x u32); 11 and 12 exist only after zngamd_debug_keep(ctx, 1) (a copy of 4 bytes per input byte per call) */
+ * table (258 x u32, levels 4-9).  Stages 0, 9, 10 and 11 exist only for calls made after zngamd_debug_keep(ctx, 1): without it the
+ * token words are written over the link tables (a third of the workspace saved), and nothing copies the search results aside. */
 int zngamd_debug_keep(zngamd_ctx *ctx, int on);
 int zngamd_debug_fetch(zngamd_ctx *ctx, int what, uint32_t unit, void *host_dst, size_t bytes);
 

@@ -75,7 +75,7 @@ static inline uint32_t hash_of(const uint8_t *p, int table)
 {
     uint32_t x;
     if (table == 0) x = (ld32(p) * ZA_K1) ^ ((uint32_t)p[4] * ZA_K2);
-    else if (table == 1) x = ld32(p) * (ZA_K1 << 8);                 /* the product's top bits depend on bytes 0..2 only */
+    else if (table == 1) x = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) * (ZA_K1 << 8);     /* three bytes, no fourth read (it could not reach the product's low 32 bits anyway) */
     else {
         x = (ld32(p) * ZA_K1) ^ (ld32(p + 4) * ZA_K2);
         x = ((x ^ (x >> 15)) * ZA_K2) ^ (ld32(p + 8) * ZA_K3);
@@ -137,15 +137,28 @@ static uint32_t stage2_search(const uint8_t *data, int dict_len, int n, const ui
         try_candidate(data, p, dist, cap, &best_len, &best_dist);
         if (best_len >= nice) break;
     }
-    /* tables B and C: the position's own link, one candidate each (the levels that compare in full skip them behind a nice match) */
+    /* tables B and C: the position's own link, one candidate each.
+     * Levels that compare 16 bytes (1-6): a link counts only if the candidate really shares the table's context -- its first 3
+     * (B) or 12 (C) bytes -- and then stands for a match of exactly that length (longer wins, nearer wins ties, as before); a
+     * winner that came from B or C is extended to its true length like a winner at `cap`.  (What the 16-byte compare of these
+     * two candidates bought beyond that was nothing on any corpus: a B candidate that shares five bytes is in chain A, and a
+     * C candidate beats the walk only when the walk stopped short.)  C is left out where fewer than 12 bytes remain.
+     * Levels that compare in full (7-9): both are compared in full, and skipped behind a nice match. */
+    int from_bc = 0;
     for (int t = 1; t <= (L->use_c ? 2 : 1); t++) {
         int d = (t == 1 ? linkB : linkC)[p + dict_len];
         if (d == 0 || d > max_dist) continue;
-        if (L->cap > 16 && best_len >= nice) break;
-        try_candidate(data, p, d, cap, &best_len, &best_dist);
+        if (L->cap > 16) {
+            if (best_len >= nice) break;
+            try_candidate(data, p, d, cap, &best_len, &best_dist);
+            continue;
+        }
+        const int ctx = t == 1 ? ZA_HASH_BYTES_B : ZA_HASH_BYTES_C;
+        if (cap < ctx || memcmp(data + p - d, data + p, (size_t)ctx) != 0) continue;
+        if (ctx > best_len || (ctx == best_len && d < best_dist)) { best_len = ctx; best_dist = d; from_bc = 1; }
     }
     if (best_len < ZA_MIN_MATCH) return 0;
-    if (best_len == cap)                                      /* the winner's true length */
+    if (best_len == cap || from_bc)                           /* the winner's true length */
         while (best_len < maxlen && data[p - best_dist + best_len] == data[p + best_len]) best_len++;
     if (best_len == 3 && best_dist > L->too_far3) return 0;
     if (best_len == 4 && best_dist > L->too_far4) return 0;

@@ -1,18 +1,20 @@
 import sys,os,ctypes as C,time
 sys.path.insert(0,"python-zlib-ng_amd")
-import torch
-from zlib_ng_amd import _lib, corpus
+from zlib_ng_amd import _lib, corpus, devmem
 ctx=_lib.Context(0); L,h=ctx.L,ctx.h
 n=1<<30; B=131072
 host=corpus.text(32<<20)
-d=torch.from_numpy(host).cuda().repeat(n//(32<<20)); d=torch.cat([d,torch.zeros(64,dtype=torch.uint8,device="cuda")])
+d=devmem.empty(ctx,n+64); d[0:host.size]=host
+k=host.size
+while k<n:
+    m=min(k,n-k); d[k:k+m]=d[0:m]; k+=m
+d[n:n+64]=0
 nb=n//B
 blocks=(_lib.Block*nb)()
 for b in range(nb): blocks[b]=_lib.Block(b*B,B,32768 if b else 0,0,0)
-slots=torch.empty(nb*_lib.SLOT_STRIDE,dtype=torch.uint8,device="cuda"); ul=torch.empty(nb,dtype=torch.int32,device="cuda"); uc=torch.empty(nb,dtype=torch.int32,device="cuda")
-p=lambda t:C.c_void_p(t.data_ptr())
+slots=devmem.empty(ctx,nb*_lib.SLOT_STRIDE); ul=devmem.empty(ctx,4*nb); uc=devmem.empty(ctx,4*nb)
 for it in range(2):
     ctx.profiling(True); ctx.kernel_times(True)
-    r=L.zngamd_deflate_blocks_dev(h,p(d),n,blocks,nb,int(os.environ.get("LEVEL","6")),p(slots),p(ul),p(uc),None)
+    r=L.zngamd_deflate_blocks_dev(h,d.vp(),n,blocks,nb,int(os.environ.get("LEVEL","6")),slots.vp(),ul.vp(),uc.vp(),None)
     kt=ctx.kernel_times(True)
 print("ablate",os.environ.get("ZNGAMD_ABLATE"),"rc",r,{k:round(v[0],2) for k,v in kt.items() if v[1]})

@@ -118,6 +118,16 @@ typedef __attribute__((address_space(3))) volatile unsigned long long za_lds_vu6
 
 __device__ __forceinline__ int za_lane() { return (int)(threadIdx.x & 63); }
 
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's global stores (its release fence
+// covers every address space: s_waitcnt vmcnt(0) -- on gfx9 stores count there too), which a kernel that hands nothing through
+// global memory inside the workgroup does not need
+__device__ __forceinline__ void za_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // wave-wide inclusive scan (64 lanes): DPP row shifts inside the rows of 16 lanes, then the two row broadcasts of gfx9 --
 // six VALU instructions with a DPP operand instead of six LDS-pipe shuffles
 __device__ __forceinline__ uint32_t za_wave_incl_scan(uint32_t v)

@@ -155,7 +155,13 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
             if (role == 2u) {
                 uint32_t h = 0xFFFFFFFFu;
                 const bool ins = (int)lane >= first && (int)lane <= total - HB;
-                if (ins) h = za_hash_x<TABLE>(za_ld32(row + lane), HB > 4 ? za_ld32(row + lane + 4) : 0u, HB > 8 ? za_ld32(row + lane + 8) : 0u) >> (32 - ZA_HASH_BITS);     // (the input has 8 readable bytes of slack; what lies behind the context does not reach the bucket)
+                if (ins) {
+                    // exactly the context's bytes, one by one (the row may end at the caller's last byte: no dword loads here)
+                    uint32_t w[3] = {0u, 0u, 0u};
+#pragma unroll
+                    for (int b = 0; b < HB; b++) w[b >> 2] |= (uint32_t)row[lane + b] << (8 * (b & 3));
+                    h = za_hash_x<TABLE>(w[0], w[1], w[2]) >> (32 - ZA_HASH_BITS);
+                }
                 uint32_t d = 0;
                 for (int j = 0; j < 16; j++) {
                     const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
@@ -377,6 +383,9 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
 // 40960 positions (u16 ring) and the input bytes of the last 65536 positions (byte ring), both indexed
 // by the absolute position P = 32768 + p.  A tile of 4096 positions is staged per barrier; every
 // position of the tile is then searched in parallel with LDS traffic only.
+#ifndef ZA_STATS_FOLD
+#define ZA_STATS_FOLD 0            // 1: the dynamic programme's cost statistics taken inside the search of levels 4-6 (measured, lost: see the kernel)
+#endif
 #define ZA_SEARCH_THREADS 1024
 #define ZA_SEARCH_TILE    4096
 #define ZA_RING           40960            // chain-link ring: window 32768 + two tiles
@@ -444,12 +453,22 @@ __device__ __forceinline__ int za_search_extend(const uint32_t *win32, uint32_t 
     return len < maxlen ? len : maxlen;
 }
 
+// 4 * log2(a / b) in whole quarter bits, a >= b >= 1, a < 2^22
+__device__ __forceinline__ int za_ilog4(uint32_t a, uint32_t b)
+{
+    const uint32_t q = (a << 8) / b;                  // >= 256
+    const int lg = 23 - (int)__builtin_clz(q);
+    const uint32_t t = q >> lg;                       // 256 .. 511
+    return 4 * lg + (t >= 304u ? 1 : 0) + (t >= 362u ? 1 : 0) + (t >= 431u ? 1 : 0);
+}
+
 // FULL: candidates are compared in full (levels with cap 258); otherwise on 16 bytes, winner extended afterwards
 // STEPS: the chain steps of the level as a constant (1 .. 3: the walk is unrolled, no loop counter, no loop) or 0 = L.chain
-// USEC: table C's candidate is tried too (levels 6-9)
+// USEC: table C's candidate is tried too (levels 5-9)
 // Candidates of a position: the first L.chain entries of its chain in table A (a walk through the link ring in LDS), then its own
 // link in table B and in table C (the nearest earlier 3- / 12-byte context: one global 2-byte load each, no walk).  Longest wins,
-// nearest wins ties; the levels that compare in full stop at L.nice equal bytes.
+// nearest wins ties; the levels that compare in full stop at L.nice equal bytes.  On the 16-byte levels the candidates of B and C
+// are only TESTED for their context (3 / 12 equal bytes = a match of that length) and a winner among them is extended afterwards.
 template <bool FULL, int STEPS = 0, bool USEC = false>
 __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *__restrict__ in, uint64_t in_total,
                                                                  const ZaUnit *__restrict__ units,
@@ -465,6 +484,12 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     // instead of two per step.  (8 % fewer vector instructions per step, 1.5 % of the kernel's time: the candidates' LDS reads --
     // five dwords at a random address, 26 LDS cycles per wave -- weigh as much as the instructions.)
     __shared__ __attribute__((aligned(16))) uint8_t lds[ZA_BYTES + 32 + 2 * ZA_RING + (FULL ? ZA_WL_BYTES : 0)];
+    // (r06) the dynamic programme's cost statistics (za_k_dpstats until round 5: a kernel and a pass over a quarter of the entries
+    // of its own) are taken here, from the entries this workgroup has just written: levels 4-6.  The levels that compare in full
+    // have no LDS left for the histogram (their work lists take the CU's last 16 KiB) and keep the separate kernel.
+    constexpr bool STATS = !FULL && ZA_STATS_FOLD;
+    __shared__ uint32_t st_hist[STATS ? 256 : 1];
+    __shared__ uint32_t st_cnt[4];                               // U, NM, the sum T of the smoothed histogram
     uint32_t *win32 = (uint32_t *)lds;
     uint16_t *ring = (uint16_t *)(lds + ZA_BYTES + 32);
     constexpr uint32_t RING_B0 = ZA_BYTES + 32, RING_BYTES = 2 * ZA_RING;      // the ring's byte range in the block
@@ -487,6 +512,8 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
     uint32_t goff = 0;
     int carry_bytes = 0, n_prev = 0;
+    const bool stats = STATS && L.dp != 0;                         // (uniform)
+    if (stats) { if (tid < 256) st_hist[tid] = 0u; if (tid < 4) st_cnt[tid] = 0u; }     // (the first tile's staging barrier orders these)
 #pragma unroll 1
     for (uint32_t ui = u0; ui < u1; ui++) {
     const ZaUnit u = units[ui];
@@ -568,8 +595,56 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         }
     };
     load_own_links(0);
+    // (r06, levels 1-6) A tile's four results per thread stay in registers and are stored at the top of the NEXT tile, behind the
+    // take-over of the own links and in front of the new loads (the unit's last tile: behind the loop).  Stored where they were
+    // made, the last of them was in flight when the tile's end asked for the links and bytes fetched at its top -- stores count
+    // in vmcnt on this chip, and behind the divergent search the compiler's wait is for everything: every wave sat out a store's
+    // round trip per tile.
+    uint32_t res[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
+    int res_base = -1;                                             // tile whose results wait in res[], -1: none
+    auto flush_results = [&]() {
+        if (res_base < 0) return;
+#pragma unroll
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
+            const int p = res_base + k * ZA_SEARCH_THREADS + tid;
+            if (p < n) best[p] = res[k];
+        }
+        res_base = -1;
+    };
+    // ---- cost statistics (oracle dp_costs): the SAMPLE is every fourth block of 256 positions, i.e. four blocks per
+    // tile and one position per thread.  The thread reads its position's entry and the one in front of it back from memory -- this
+    // workgroup wrote them, the tile's barrier lies in between -- one tile LATE: the loads are issued at the top of the next
+    // tile and used at its end, so that nobody waits for them.  U / NM in registers until the unit ends, the bytes by LDS atomics.
+    uint32_t st_e = 0u, st_pe = 0u, st_U = 0u, st_NM = 0u;
+    bool st_have = false;
+    auto stats_issue = [&](int tile_base) {
+        const int p = tile_base + ((tid >> 8) << 10) + (tid & 255);
+        st_have = p < n;
+        st_e = 0u; st_pe = 0u;
+        if (st_have) { st_e = best[p]; if (p > 0) st_pe = best[p - 1]; }
+    };
+    auto stats_use = [&]() {
+        const uint32_t len = ZA_ELEN(st_e), lp = ZA_ELEN(st_pe);
+        if (st_have) {
+            if (len == 0u || (len == 3u && ZA_EDIST(st_e) > (uint32_t)ZA_DP_WEAK_DIST)) { atomicAdd(&st_hist[st_e >> 24], 1u); st_U++; }
+            else if (len + 1u != lp) st_NM++;
+        }
+        st_have = false;
+    };
     __syncthreads();
     for (int base = 0; base < n; base += ZA_SEARCH_TILE) {
+        // ---- (r06) FIRST this tile's own links in tables B and C are taken over from the registers they were fetched into a tile
+        // ago -- before any new load goes out.  The compiler cannot count loads across the loop's back edge: its wait in front of
+        // the first use of something loaded in the last iteration is for EVERY load in flight, and with the take-over behind the
+        // next tile's link and byte loads (where it stood until r05) that wait covered loads issued a moment ago: all sixteen
+        // waves sat through a trip to memory at the top of every tile.
+        uint32_t lkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], lkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
+#pragma unroll
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
+            lkb[k] = nlkb[k]; lkc[k] = nlkc[k];
+            asm volatile("" : "+v"(lkb[k]), "+v"(lkc[k]) : : "memory");       // (here and now: nothing is moved across)
+        }
+        if constexpr (!FULL) flush_results();
         // ---- the NEXT tile's links and bytes are fetched into registers now and put into the rings after this tile's
         // search: the global-memory latency hides behind the search instead of stalling all 16 waves in front of it
         // (at most 4 links and 2 dwords per thread: one tile of each)
@@ -578,25 +653,24 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         int need_bytes = base + 2 * ZA_SEARCH_TILE + ZA_LOOKAHEAD;
         if (need_bytes > n) need_bytes = n;
         need_bytes = (need_bytes + 3) & ~3;
-        uint32_t nb[2];
+        uint64_t nbv; uint32_t nsh;
         const int pq = links_loaded + 4 * tid;                  // my four links of the next tile
         const uint2 nq = load_quad(pq, need_links);
-        // (Plain predicated loads where the whole tile lies inside the caller's buffer -- a wave-uniform test.  The careful
-        // form has branches with byte loads inside, and a register that a pending load may still write cannot be reused
-        // without waiting: the compiler then waits for ALL loads in flight right here, links included, and every tile paid
-        // the whole memory latency with all sixteen waves idle.)
-        if ((long long)need_bytes <= readable) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
-                nb[k] = p < need_bytes ? za_ld32(data + p) : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
-                nb[k] = p < need_bytes ? load_bytes(p) : 0u;
-            }
+        // (r06) ONE branch-free form for every tile: a dword that reaches over the end of the caller's buffer (the last unit's last
+        // one to three bytes) is loaded from as far in front as it reaches over, and shifted down -- zeros behind the buffer's end
+        // as before.  In front of the dictionary nothing is ever fetched here (the loop stages from the second tile on).  Until r05
+        // the edge had a careful path of its own, byte loads in branches, and at the join of the two paths the compiler waited for
+        // every load in flight -- the link and byte loads issued a moment before: all sixteen waves sat through a trip to memory
+        // at the top of every tile (a ninth of the kernel; the ablation without the own-link loads had shown it and blamed them).
+        // A thread takes EIGHT consecutive bytes (one load instruction instead of two: vector-memory instructions are what this
+        // kernel's waves queue for -- every one of them is worth about a percent of the tile).
+        {
+            const int rd_i = (int)(readable < (long long)0x7FFFFFF0 ? readable : (long long)0x7FFFFFF0);
+            const int p = bytes_loaded + 8 * tid;
+            int over = p + 8 - rd_i;
+            over = over > 0 ? over : 0;                           // 0 .. 7 for every p < need_bytes (p < n <= readable)
+            nbv = 0ull; nsh = 8u * (uint32_t)over;                // (the shift is applied where the bytes are stored: not here, where it would wait for the load)
+            if (p < need_bytes) nbv = za_ld64(data + p - over);
         }
         if constexpr (FULL) {
         // ---- levels 7-9: ZA_WL_STEPS chain steps per visit, the unfinished positions through the wave's work list
@@ -727,10 +801,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             push(alive, p, P, q, best_len, best_dist, depth);
         };
         uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;
-        uint32_t flkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], flkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];      // my positions' own links, fetched a tile ago
-#pragma unroll
-        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) { flkb[k] = nlkb[k]; flkc[k] = nlkc[k]; }
-        load_own_links(base + ZA_SEARCH_TILE);
+        load_own_links(base + ZA_SEARCH_TILE);                                                        // (lkb / lkc: my positions' own links, fetched a tile ago)
 #pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
@@ -751,7 +822,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     uint32_t d = *(const uint16_t *)(lds + qb);
                     alive = visit(P, me0, me1, me2, me3, maxlen, cap, nice, q, qb, d, best_len, best_dist, depth);
                 }
-                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist, flkb[k], flkc[k]);
+                if (!alive) finish(p, P, me0, me1, me2, me3, maxlen, cap, nice, best_len, best_dist, lkb[k], lkc[k]);
             }
             push(alive, p, P, q, best_len, best_dist, depth);
             while (__builtin_amdgcn_readfirstlane((int)wl_n) >= 64) batch(64u);
@@ -763,17 +834,19 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         }
         } else {
         uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;      // ring slot of my position, moved on by 1 024 per round
-        // my four positions' own links in tables B and C: what was fetched a tile ago; the next tile's are asked for now
-        uint32_t lkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], lkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
-#pragma unroll
-        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) { lkb[k] = nlkb[k]; lkc[k] = nlkc[k]; }
+        // my four positions' own links in tables B and C are what was fetched a tile ago (lkb / lkc); the next tile's are asked for now
         load_own_links(base + ZA_SEARCH_TILE);
+        // (the statistics' loads go out BEHIND the point where last tile's loads are used: the compiler's wait there, across the
+        // loop's back edge, is for every load in flight -- issued at the top of the tile, these two made all sixteen waves wait a
+        // trip to memory per tile: search 8.18 -> 8.60 ms per GiB, more than the separate kernel costs)
+        if (stats && base > 0) stats_issue(base - ZA_SEARCH_TILE);
 #ifndef ZA_SEARCH_KUNROLL
 #define ZA_SEARCH_KUNROLL 4              // the four positions of a thread per tile as straight code (18.9 against 19.4 ms per 4 GiB at level 6)
 #endif
 #pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
             const int p = base + k * ZA_SEARCH_THREADS + tid;
+            res[k] = 0u;
             if (p >= n) continue;
             int seg_end = ((p >> sshift) + 1) << sshift;
             if (seg_end > n) seg_end = n;
@@ -837,30 +910,53 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                     best_dist = better ? dist : best_dist;
                     if (best_len >= nice) break;
                 }
-                // tables B and C: one candidate each, the same branch-free 16-byte compare (no link: the position against itself,
-                // masked out); a tie goes to the nearer one
-#pragma unroll
-                for (int t = 0; t < (USEC ? 2 : 1); t++) {
-                    const uint32_t dl = t == 0 ? lkb[k] : lkc[k];
+                // tables B and C (r06): a link counts only if the candidate really shares the table's context -- its first 3 (B) or
+                // 12 (C) bytes, an equality test on one / three dwords instead of the 16-byte compare with its first-difference
+                // arithmetic -- and then stands for a match of exactly that length (longer wins, nearer wins ties); a winner that
+                // came from B or C is extended to its true length below, like a winner at `cap`.  (No link: the position against
+                // itself, masked out.)  C is left out where fewer than 12 bytes remain.
+                bool from_bc = false;
+#ifndef ZA_ABL_SEARCH_NO_B
+                {
+                    const uint32_t dl = lkb[k];
+#ifdef ZA_ABL_BC_SELF
+                    const uint32_t q2 = P - (dl & 3u);             // (timing only: the candidates' LDS reads at the positions' own, consecutive addresses)
+#else
                     const uint32_t q2 = P - dl;
+#endif
+                    const uint32_t *cw = (const uint32_t *)(lds + (q2 & (uint32_t)(ZA_BYTES - 4)));
+                    const uint32_t c0 = cw[0], c1 = cw[1];
+                    const uint32_t x = (__builtin_amdgcn_alignbyte(c1, c0, q2 & 3u) ^ me0) << 8;        // 0: the first three bytes are equal
+                    const bool better = x == 0u && dl != 0u && (int)dl <= L.max_dist &&
+                                        (ZA_HASH_BYTES_B > best_len || (ZA_HASH_BYTES_B == best_len && (int)dl < best_dist));
+                    best_len = better ? ZA_HASH_BYTES_B : best_len;
+                    best_dist = better ? (int)dl : best_dist;
+                    from_bc = better;
+                }
+#endif
+#ifndef ZA_ABL_SEARCH_NO_C
+                if (USEC) {
+                    const uint32_t dl = lkc[k];
+#ifdef ZA_ABL_BC_SELF
+                    const uint32_t q2 = P - (dl & 3u);
+#else
+                    const uint32_t q2 = P - dl;
+#endif
                     const uint32_t sh = q2 & 3u;
                     const uint32_t *cw = (const uint32_t *)(lds + (q2 & (uint32_t)(ZA_BYTES - 4)));
-                    const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4];
-                    const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0, x1 = __builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1;
-                    const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2, x3 = __builtin_amdgcn_alignbyte(c4, c3, sh) ^ me3;
-                    uint32_t fbit, f1, f2, f3;
-                    asm("v_ffbl_b32 %0, %4\n\tv_ffbl_b32 %1, %5\n\tv_ffbl_b32 %2, %6\n\tv_ffbl_b32 %3, %7\n\t"
-                        "v_add_u32_e64 %1, %1, 32 clamp\n\tv_add_u32_e64 %2, %2, 64 clamp\n\tv_add_u32_e64 %3, %3, %8 clamp\n\t"
-                        "v_min3_u32 %0, %0, %1, %2\n\tv_min_u32_e32 %0, %0, %3"
-                        : "=&v"(fbit), "=&v"(f1), "=&v"(f2), "=&v"(f3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(96u));
-                    const int len = (int)min(fbit >> 3, (uint32_t)cap);
-                    const bool better = dl != 0u && (int)dl <= L.max_dist && (len > best_len || (len == best_len && (int)dl < best_dist));
-                    best_len = better ? len : best_len;
+                    const uint32_t c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3];
+                    const uint32_t x = (__builtin_amdgcn_alignbyte(c1, c0, sh) ^ me0) | (__builtin_amdgcn_alignbyte(c2, c1, sh) ^ me1) |
+                                       (__builtin_amdgcn_alignbyte(c3, c2, sh) ^ me2);                 // 0: the first twelve bytes are equal
+                    const bool better = x == 0u && dl != 0u && (int)dl <= L.max_dist && cap >= ZA_HASH_BYTES_C &&
+                                        (ZA_HASH_BYTES_C > best_len || (ZA_HASH_BYTES_C == best_len && (int)dl < best_dist));
+                    best_len = better ? ZA_HASH_BYTES_C : best_len;
                     best_dist = better ? (int)dl : best_dist;
+                    from_bc = from_bc || better;
                 }
+#endif
 #ifndef ZA_ABL_NO_EXTEND
-                if (!FULL && best_len == cap && cap < maxlen) {
-                    // the winner of a 16-byte comparison: its true length (once per position, not per candidate)
+                if (!FULL && (best_len == cap || from_bc) && best_len < maxlen) {
+                    // the winner of a 16-byte comparison, or of a context test: its true length (once per position, not per candidate)
                     best_len = za_search_extend(win32, P - (uint32_t)best_dist, P, best_len, maxlen);
                 }
 #endif
@@ -869,23 +965,63 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 longm = longm || best_len > 64;
             }
 #ifdef ZA_ABL_SEARCH_NOLIT
-            best[p] = result;                                                 // (timing only: the parse then sees zero bytes)
+            res[k] = result;                                                  // (timing only: the parse then sees zero bytes)
 #else
-            best[p] = __builtin_amdgcn_perm(me0, result, 0x04020100u);       // byte 3 = my byte (byte 0 of me0), bytes 0..2 = result
+            res[k] = __builtin_amdgcn_perm(me0, result, 0x04020100u);        // byte 3 = my byte (byte 0 of me0), bytes 0..2 = result
 #endif
         }
+        res_base = base;
         }
         // ---- put the next tile into the rings.  No barrier is needed in front of these stores: they land at least
         // 65536-4096-272-32768 byte slots / 40960-4096-32768 link slots behind any walk of this tile that is still
         // running in another wave.  The barrier behind them makes the next tile visible.
         if (pq < need_links) store_quad(pq, need_links, nq);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int p = bytes_loaded + 4 * (tid + k * ZA_SEARCH_THREADS);
-            if (p < need_bytes) store_bytes(p, nb[k]);
+        {
+            const int p = bytes_loaded + 8 * tid;
+            if (p < need_bytes) {
+                const uint64_t v = nbv >> nsh;
+                store_bytes(p, (uint32_t)v);
+                if (p + 4 < need_bytes) store_bytes(p + 4, (uint32_t)(v >> 32));
+            }
         }
         links_loaded = need_links; bytes_loaded = need_bytes;
+        // (r06) the tile's barrier orders the rings -- LDS -- and nothing else: the plain __syncthreads() also waited for this wave's
+        // result stores, the last of them issued a moment ago (the read-back of the folded statistics is the one thing that needs it)
+        if (stats) { flush_results(); stats_use(); __syncthreads(); }      // (the read-back needs the results in memory behind this barrier)
+        else za_lds_barrier();
+    }
+    if constexpr (!FULL) flush_results();
+    if (stats && n > 0) {
+        // the unit's last tile, then the cost table: 256 literal costs and the match base cost (what za_k_dpstats did)
         __syncthreads();
+        stats_issue((n - 1) & ~(ZA_SEARCH_TILE - 1));
+        stats_use();
+        for (int d = 32; d >= 1; d >>= 1) { st_U += (uint32_t)__shfl_xor((int)st_U, d, 64); st_NM += (uint32_t)__shfl_xor((int)st_NM, d, 64); }
+        if ((tid & 63) == 0) { atomicAdd(&st_cnt[0], st_U); atomicAdd(&st_cnt[1], st_NM); }
+        __syncthreads();
+        const uint32_t U = st_cnt[0], NM = st_cnt[1];
+        uint32_t hh = 0u;
+        if (tid < 256) {
+            hh = 16u * st_hist[tid] + 1u + (U >> 6);
+            st_hist[tid] = 0u;                                        // (ready for the run's next unit)
+            uint32_t T = hh;
+            for (int d = 32; d >= 1; d >>= 1) T += (uint32_t)__shfl_xor((int)T, d, 64);
+            if ((tid & 63) == 0) atomicAdd(&st_cnt[2], T);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const uint32_t T = st_cnt[2];
+            uint32_t *cost = cost_ws + (size_t)ui * ZA_DP_COSTS;
+            int lbias = za_ilog4(U + NM, U ? U : 1u), mbias = za_ilog4(U + NM, NM ? NM : 1u);
+            lbias = lbias > 24 ? 24 : lbias;
+            mbias = mbias > 24 ? 24 : mbias;
+            const int cl = za_ilog4(T, hh) + lbias;
+            cost[tid] = (uint32_t)(cl < 12 ? 12 : cl > 52 ? 52 : cl);
+            if (tid == 0) { cost[256] = (uint32_t)(12 + mbias + 20); cost[257] = 0u; }
+        }
+        __syncthreads();
+        if (tid < 4) st_cnt[tid] = 0u;                                // (the next unit's staging barrier orders this)
+        st_U = 0u; st_NM = 0u;
     }
     if (L.dp && __ballot(longm) != 0ull && (tid & 63) == 0) cost_ws[(size_t)ui * ZA_DP_COSTS + 258] = 1u;     // (every writer writes the same)
     carry_bytes = bytes_loaded; n_prev = n;
@@ -918,7 +1054,9 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 //              pieces of one segment's 64-byte row), last chunk first.
 #define ZA_PCH 32                     // positions of a chunk of entries in the parse kernel
 #define ZA_PROW (ZA_PCH + 1)          // dwords of a lane's LDS row there: the carried entry + the chunk; an odd stride
+#ifndef ZA_DP_NEAR
 #define ZA_DP_NEAR   64               // acc[p + 1 .. p + 64] come from the LDS ring
+#endif
 #define ZA_DP_ROWS   (ZA_DP_NEAR / 2 + 4)
 #ifndef ZA_DCH
 #define ZA_DCH       16               // positions per chunk (16 or 32)
@@ -926,15 +1064,6 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #define ZA_DROW      (ZA_DCH + 1)
 #define ZA_DPIECES   (ZA_DCH / 4)     // 16-byte pieces of a segment's row of one chunk = lanes per segment in the transposed moves
 #define ZA_DP_SEGSLOTS 2064           // u16 slots per segment in the global array: 2 049 used, 16-byte multiples
-
-// 4 * log2(a / b) in whole quarter bits, a >= b >= 1, a < 2^22
-__device__ __forceinline__ int za_ilog4(uint32_t a, uint32_t b)
-{
-    const uint32_t q = (a << 8) / b;                  // >= 256
-    const int lg = 23 - (int)__builtin_clz(q);
-    const uint32_t t = q >> lg;                       // 256 .. 511
-    return 4 * lg + (t >= 304u ? 1 : 0) + (t >= 362u ? 1 : 0) + (t >= 431u ? 1 : 0);
-}
 
 __global__ __launch_bounds__(256) void za_k_dpstats(const ZaUnit *__restrict__ units, const uint32_t *__restrict__ best_ws,
                                                     uint32_t *__restrict__ cost_ws /* ZA_DP_COSTS per unit */)
@@ -1010,6 +1139,19 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     __shared__ uint32_t xt[3 * (ZA_MAX_MATCH + 1)];               // row `len`: 4 x extra bits of the lengths l0 .. l0 + 4 (u16 each; 0x3FFF: not tried), l0 in the last half
     __shared__ uint32_t ring[ZA_DP_ROWS * 64];                    // row r, column lane: slots 2 r (low half) and 2 r + 1
     __shared__ uint32_t rowb[64 * ZA_DROW];
+    // (r06) The kernel's 17.3 KiB let a CU hold NINE of these one-wave workgroups: three on one SIMD, two on each of the others,
+    // and the three share an issue port that two already fill -- eight (two per SIMD) run 6.5 % faster than nine (occupancy sweep:
+    // 4 / 5 / 7 / 8 / 9 per CU: 5.33 / 3.76 / 3.34 / 2.89 / 3.09 ms per GiB; twelve, with a ring of 32 slots: within 1 % of eight).
+    // So the workgroup asks for 20 KiB: ZA_DP_PAD bytes that nobody uses.
+#ifndef ZA_DP_PAD
+#define ZA_DP_PAD 2304
+#endif
+#if ZA_DP_PAD > 0
+    __shared__ uint32_t dp_pad[ZA_DP_PAD / 4];
+    if (units[blockIdx.x].in_len == 0xFFFFFFFFu) {               // (never: but the compiler cannot know, and must keep the array)
+        dp_pad[threadIdx.x] = blockIdx.x; __syncthreads(); best_ws[threadIdx.x] = dp_pad[(threadIdx.x * 7u + best_ws[0]) % (ZA_DP_PAD / 4)];
+    }
+#endif
     const ZaUnit u = units[blockIdx.x];
     const int n = (int)u.in_len;
     const int lane = za_lane();
@@ -1048,7 +1190,11 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         if (slot < 8) *(uint16_t *)(myring + ((slot >> 1) + ZA_DP_NEAR / 2) * 256 + (slot & 1) * 2) = (uint16_t)v;
     };
     const int mbase = (int)costt[256];
+#ifdef ZA_ABL_DP_NOLONG
+    const bool has_long = false;                                   // (timing only: the ring's size against the waves a CU holds, wrong for matches longer than the ring)
+#else
     const bool has_long = costt[258] != 0u;                        // (uniform, from the search) some match of the unit is longer than the ring: acc[] goes to memory too (a quarter of this kernel's time where it must)
+#endif
     if (active) { ring_put((s1 - s0) & (ZA_DP_NEAR - 1), 0u); accg[s1 - s0] = 0; }     // acc[s1] = 0
     int acc_next = 0;                                              // acc[p + 1], the whole number (at most 2 048 x 52)
     // what the last long match fetched from memory: a window of sixteen values of acc[] (eight dwords), and where it starts
@@ -1083,10 +1229,10 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
     uint4 po[ZA_DPIECES];                                           // the last chunk's entries on their way out
     uint32_t wacc[ZA_DCH / 2];                                      // ... and its acc values
     int pend = -1;
-    auto flush_pending = [&]() {
+    auto flush_pending = [&](auto longs_tag) {
         if (pend < 0) return;
         const int pcb = s0 + pend * ZA_DCH;
-        if (has_long && active && pcb < s1) {
+        if (decltype(longs_tag)::value && active && pcb < s1) {
             uint4 *g = (uint4 *)(accg + pend * ZA_DCH);             // (segment arrays are 16-byte multiples apart)
 #pragma unroll
             for (int k = 0; k < ZA_DCH / 8; k++) g[k] = make_uint4(wacc[4 * k], wacc[4 * k + 1], wacc[4 * k + 2], wacc[4 * k + 3]);
@@ -1098,6 +1244,11 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         }
     };
     prefetch(nch - 1);
+    // The walk comes in two instantiations, chosen per unit (uniform): a unit whose search saw no match longer than the ring -- all
+    // of the bench's text -- never looks for one (no ballot per step, no window registers, no acc[] on its way to memory); the
+    // other form is the general one.
+    auto walk = [&](auto longs_tag) {
+    constexpr bool LONGS = decltype(longs_tag)::value;
 #pragma unroll 1
     for (int c = nch - 1; c >= 0; c--) {
         const int cb = s0 + c * ZA_DCH;
@@ -1110,7 +1261,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        flush_pending();
+        flush_pending(longs_tag);
         prefetch(c - 1);
         if (__ballot(active && cb < s1) != 0ull) {
             // Every lane walks the chunk's 16 positions in step (a segment's last chunk may be short: its positions at and behind s1
@@ -1130,7 +1281,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
                 const uint32_t st1 = ((uint32_t)idx + l0) & 1u;
                 uint32_t v0 = __builtin_amdgcn_alignbyte(g.w1, g.w0, 2u * st1), v1 = __builtin_amdgcn_alignbyte(g.w2, g.w1, 2u * st1);
                 uint32_t v2 = st1 ? g.w2 >> 16 : g.w2;
-                if (__builtin_expect(__ballot(live && len > (uint32_t)ZA_DP_NEAR) != 0ull, 0)) {
+                if (LONGS && __builtin_expect(__ballot(live && len > (uint32_t)ZA_DP_NEAR) != 0ull, 0)) {
                     // a long match: its five values acc[e - 4 .. e], e = p + len, from memory -- written at least three chunks ago
                     // by this wave (other lanes' stores among them: a fence, and loads that go to the device's L2).  A WINDOW of 16
                     // values is fetched, [fbase, fbase + 16) with e near its top: the positions inside one long match all end at the
@@ -1191,7 +1342,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (has_long && active && cb < s1) {
+        if (LONGS && active && cb < s1) {
             const uint8_t *rp = myring + ((c * ZA_DCH) & (ZA_DP_NEAR - 1)) / 2 * 256;
 #pragma unroll
             for (int k = 0; k < ZA_DCH / 2; k++) wacc[k] = *(const uint32_t *)(rp + 256 * k);
@@ -1203,7 +1354,9 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
         }
         pend = c;
     }
-    flush_pending();
+    flush_pending(longs_tag);
+    };
+    if (has_long) walk(std::true_type{}); else walk(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,7 +38,9 @@ template <typename T> struct DevBuf {
     {
         if (n <= cap) return hipSuccess;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = n + n / 8 + 64;
+        // (small buffers grow with an eighth of slack so that a caller whose batches creep up does not reallocate every call; the
+        // large per-chunk workspaces are sized exactly: an eighth of 48 GB is memory another context on the device may need)
+        size_t want = n * sizeof(T) >= ((size_t)64 << 20) ? n + 64 : n + n / 8 + 64;
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         if (e != hipSuccess) { want = n; e = hipMalloc((void **)&p, want * sizeof(T)); }
         if (e == hipSuccess) cap = want;
@@ -67,9 +69,14 @@ struct zngamd_ctx {
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
     uint32_t *d_crc_slice4 = nullptr;                                         // CRC slice-by-4 table of za_k_inflate_members
     // deflate workspaces (per chunk of units)
-    uint32_t chunk_units = 32768;                // units per launch: 1.4 MiB of workspace each (46 GB at 4 GiB of input); fewer, fuller launches
-    DevBuf<uint16_t> prev, linkb, linkc; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
-    bool debug_keep = false; DevBuf<uint32_t> best_keep, dpcost;     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
+    // units per launch (ZNGAMD_CHUNK_UNITS; fewer, fuller launches: 16 384 instead of 32 768 costs 2 % of compress throughput).  Workspace
+    // per unit (r06): link tables 3 x 320 KiB (two below level 5), entries 512 KiB, about 5 KiB of small arrays -- 1.44 MiB, 47 GB for a
+    // 4 GiB shard; the token words (512 KiB) live IN the link tables' memory, which nobody reads once the search is through (r05:
+    // 1.94 MiB with an eighth of slack on top, 73 GB).  A chunk that does not fit the device's free memory is halved until it does.
+    uint32_t chunk_units = 32768;
+    DevBuf<uint16_t> links; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
+    uint16_t *prev_p = nullptr, *linkb_p = nullptr, *linkc_p = nullptr; uint32_t *tok_p = nullptr;     // where the current chunk size puts the tables inside `links`, and the token words (inside `links` too unless zngamd_debug_keep asked for all stages to stay)
+    bool debug_keep = false, last_kept = false; DevBuf<uint32_t> best_keep, dpcost;     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
     // per call
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status, runs;
     uint32_t last_units = 0; bool last_single_chunk = false;
@@ -135,7 +142,9 @@ static void prof_collect(zngamd_ctx *c)
 
 extern "C" {
 
-const char *zngamd_version(void) { return "zng_amd 0.1 (gfx950)"; }
+const char *zngamd_version(void) { return "zng_amd 0.6 (gfx950)"; }
+int zngamd_abi(void) { return ZNGAMD_ABI; }
+int zngamd_kernel_class_count(void) { return ZNGAMD_K_COUNT; }
 
 int zngamd_device_count(void)
 try {
@@ -200,7 +209,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    c->prev.release(); c->linkb.release(); c->linkc.release(); c->best_keep.release(); c->dpcost.release(); c->hdr.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
+    c->links.release(); c->best_keep.release(); c->dpcost.release(); c->hdr.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
     c->plan.release(); c->units.release(); c->segbits.release(); c->cidx.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
@@ -473,15 +482,35 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
     const uint32_t n = (uint32_t)hu.size();
     if (n == 0) return ZNGAMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t ch = std::min(n, c->chunk_units);
+    uint32_t ch = std::min(n, c->chunk_units);
+    const size_t ntab = ZA_LEVELS[level].use_c ? 3 : 2;
+    if (level > 0) {
+        // a chunk's workspaces must fit what the device has free (plus what these buffers hold already): halve it until they do
+        // (a hipMalloc failure further down is still a hard error, but no longer the first thing a smaller device or a second
+        // context on this one meets)
+        const size_t held = c->links.cap * 2 + c->best.cap * 4 + c->tok.cap * 4 + c->best_keep.cap * 4;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            auto need = [&](uint32_t k) { return (size_t)k * (ntab * ZA_PREV_STRIDE * 2 + ZA_BEST_STRIDE * 4 + (c->debug_keep ? (ZA_BEST_STRIDE + ZA_TOK_STRIDE) * 4 : 0) + 8192); };
+            while (ch > 64 && need(ch) > held && need(ch) - held > free_b - free_b / 16) ch = (ch + 1) / 2;
+        }
+    }
     HIPCHK(c, c->units.ensure(n)); HIPCHK(c, c->segbits.ensure((size_t)n * ZA_SEGB_STRIDE)); HIPCHK(c, c->cidx.ensure((size_t)n * ZA_CIDX_STRIDE)); HIPCHK(c, c->status.ensure(n));
     if (level > 0) {
-        HIPCHK(c, c->prev.ensure((size_t)ch * ZA_PREV_STRIDE + 8)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
-        HIPCHK(c, c->linkb.ensure((size_t)ch * ZA_PREV_STRIDE + 8));
-        if (ZA_LEVELS[level].use_c) HIPCHK(c, c->linkc.ensure((size_t)ch * ZA_PREV_STRIDE + 8));
+        const size_t tab = (size_t)ch * ZA_PREV_STRIDE + 8;              // entries of one link table (+ slack for the search's four-link loads)
+        HIPCHK(c, c->links.ensure(ntab * tab)); HIPCHK(c, c->best.ensure((size_t)ch * ZA_BEST_STRIDE));
+        c->prev_p = c->links.p; c->linkb_p = c->links.p + tab; c->linkc_p = ntab > 2 ? c->links.p + 2 * tab : nullptr;
         if (ZA_LEVELS[level].dp) HIPCHK(c, c->dpcost.ensure((size_t)ch * ZA_DP_COSTS));
-        if (c->debug_keep) HIPCHK(c, c->best_keep.ensure((size_t)ch * ZA_BEST_STRIDE));
-        HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
+        if (c->debug_keep) {
+            HIPCHK(c, c->best_keep.ensure((size_t)ch * ZA_BEST_STRIDE));
+            HIPCHK(c, c->tok.ensure((size_t)ch * ZA_TOK_STRIDE));
+            c->tok_p = c->tok.p;
+        } else {
+            // the token words (and the dynamic programme's acc[] scratch inside them) take the place of the link tables: written by
+            // kernels that run after the search of the same chunk on the same stream, 512 KiB a unit inside >= 640 KiB a unit
+            static_assert(2 * ZA_PREV_STRIDE * 2 >= ZA_TOK_STRIDE * 4, "token words fit two link tables");
+            c->tok_p = (uint32_t *)c->links.p;
+        }
     }
     HIPCHK(c, c->segtok.ensure((size_t)ch * ZA_MAX_SEGS)); HIPCHK(c, c->hist.ensure((size_t)ch * ZA_HIST_STRIDE));
     HIPCHK(c, c->codes.ensure((size_t)ch * ZA_CODE_STRIDE)); HIPCHK(c, c->plan.ensure(ch));
@@ -541,12 +570,12 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         run_pos += nruns + 1;
         if (level > 0) {
             { ProfScope ps(c, ZNGAMD_K_CHAINS);
-              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_A>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev.p, L.dp ? c->dpcost.p : (uint32_t *)nullptr);
-              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_B>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkb.p, (uint32_t *)nullptr);
-              if (L.use_c) hipLaunchKernelGGL(za_k_chains<ZA_TABLE_C>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkc.p, (uint32_t *)nullptr); }
+              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_A>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->prev_p, L.dp ? c->dpcost.p : (uint32_t *)nullptr);
+              hipLaunchKernelGGL(za_k_chains<ZA_TABLE_B>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkb_p, (uint32_t *)nullptr);
+              if (L.use_c) hipLaunchKernelGGL(za_k_chains<ZA_TABLE_C>, dim3(nruns), dim3(256), 0, c->stream, d_in, du, d_runs, c->linkc_p, (uint32_t *)nullptr); }
             { ProfScope ps(c, ZNGAMD_K_SEARCH);
 #define ZA_LAUNCH_SEARCH(...) hipLaunchKernelGGL((za_k_search<__VA_ARGS__>), dim3(nruns), dim3(ZA_SEARCH_THREADS), 0, c->stream, d_in, in_len, du, d_runs, \
-                                                 c->prev.p, c->linkb.p, L.use_c ? c->linkc.p : c->linkb.p, c->best.p, c->dpcost.p, L)
+                                                 c->prev_p, c->linkb_p, L.use_c ? c->linkc_p : c->linkb_p, c->best.p, c->dpcost.p, L)
               if (L.cap > 16) { if (L.use_c) ZA_LAUNCH_SEARCH(true, 0, true); else ZA_LAUNCH_SEARCH(true, 0, false); }
               else if (L.chain == 1) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 1, true); else ZA_LAUNCH_SEARCH(false, 1, false); }
               else if (L.chain == 2) { if (L.use_c) ZA_LAUNCH_SEARCH(false, 2, true); else ZA_LAUNCH_SEARCH(false, 2, false); }
@@ -557,11 +586,12 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             if (L.dp) {
                 if (c->debug_keep) HIPCHK(c, hipMemcpyAsync(c->best_keep.p, c->best.p, (size_t)m * ZA_BEST_STRIDE * 4, hipMemcpyDeviceToDevice, c->stream));
                 ProfScope ps(c, ZNGAMD_K_OPTPARSE);
-                hipLaunchKernelGGL(za_k_dpstats, dim3(m), dim3(256), 0, c->stream, du, c->best.p, c->dpcost.p);
-                hipLaunchKernelGGL(za_k_optparse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->dpcost.p, c->tok.p, L);
+                // (levels 4-6: the search took the statistics itself)
+                if (L.cap > 16 || !ZA_STATS_FOLD) hipLaunchKernelGGL(za_k_dpstats, dim3(m), dim3(256), 0, c->stream, du, c->best.p, c->dpcost.p);
+                hipLaunchKernelGGL(za_k_optparse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->dpcost.p, c->tok_p, L);
             }
             { ProfScope ps(c, ZNGAMD_K_PARSE);
-              hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok.p, c->segtok.p, c->hist.p,
+              hipLaunchKernelGGL(za_k_parse, dim3(m), dim3(64), 0, c->stream, du, c->best.p, c->tok_p, c->segtok.p, c->hist.p,
                                  d_unit_crc + c0, c->d_crc_table, c->d_x8k, L); }
         } else {       // level 0: stored blocks, nothing to search or parse -- only the units' CRC-32
             ProfScope ps(c, ZNGAMD_K_PARSE);
@@ -575,7 +605,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
               hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(1024), 0, c->stream, d_unit_len + c0, m, 0u, 0ull, d_offs + c0, d_run_total,
                                  (const ZaUnit *)nullptr, (const uint64_t *)d_run_total); }
             { ProfScope ps(c, ZNGAMD_K_PACK);
-              hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok.p, c->segtok.p, c->codes.p, c->plan.p,
+              hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok_p, c->segtok.p, c->codes.p, c->plan.p,
                                  c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, c->cidx.p + (size_t)c0 * ZA_CIDX_STRIDE, packed->d_dst,
                                  0u, d_unit_len + c0, c->status.p + c0, (const uint64_t *)(d_offs + c0), packed->cap, (const uint8_t *)c->hdr.p); }
         } else {
@@ -583,13 +613,13 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
           hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
                              d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE, (uint32_t)ZNGAMD_SLOT_STRIDE, level, (uint8_t *)nullptr, (uint32_t *)nullptr); }
         { ProfScope ps(c, ZNGAMD_K_PACK);
-          hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok.p, c->segtok.p, c->codes.p, c->plan.p,
+          hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok_p, c->segtok.p, c->codes.p, c->plan.p,
                              c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, c->cidx.p + (size_t)c0 * ZA_CIDX_STRIDE, d_slots + (size_t)c0 * ZNGAMD_SLOT_STRIDE,
                              (uint32_t)ZNGAMD_SLOT_STRIDE, d_unit_len + c0, c->status.p + c0, (const uint64_t *)nullptr, 0ull, (const uint8_t *)nullptr); }
         }
         HIPCHK(c, hipGetLastError());
     }
-    c->last_units = n; c->last_single_chunk = (n <= ch);
+    c->last_units = n; c->last_single_chunk = (n <= ch); c->last_kept = c->debug_keep;
     return ZNGAMD_OK;
 }
 
@@ -936,29 +966,31 @@ try {
     if (unit >= c->last_units || !c->last_single_chunk) return fail(c, ZNGAMD_E_ARG, "unit not resident");
     const void *src = nullptr; size_t lim = 0;
     switch (what) {
-    case 0: src = c->prev.p + (size_t)unit * ZA_PREV_STRIDE; lim = ZA_PREV_STRIDE * 2ull; break;
+    case 0: src = c->prev_p ? c->prev_p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
     case 1: src = c->best.p + (size_t)unit * ZA_BEST_STRIDE; lim = ZA_BEST_STRIDE * 4ull; break;
-    case 2: src = c->tok.p + (size_t)unit * ZA_TOK_STRIDE; lim = ZA_TOK_STRIDE * 4ull; break;
+    case 2: src = c->tok_p ? c->tok_p + (size_t)unit * ZA_TOK_STRIDE : nullptr; lim = ZA_TOK_STRIDE * 4ull; break;
     case 3: src = c->segtok.p + (size_t)unit * ZA_MAX_SEGS; lim = ZA_MAX_SEGS * 4ull; break;
     case 4: src = c->hist.p + (size_t)unit * ZA_HIST_STRIDE; lim = ZA_HIST_STRIDE * 4ull; break;
     case 5: src = c->codes.p + (size_t)unit * ZA_CODE_STRIDE; lim = ZA_CODE_STRIDE * 4ull; break;
     case 6: src = c->segbits.p + (size_t)unit * ZA_SEGB_STRIDE; lim = ZA_SEGB_STRIDE * 4ull; break;
     case 7: src = c->plan.p + unit; lim = sizeof(ZaPlan); break;
     case 8: src = c->cidx.p + (size_t)unit * ZA_CIDX_STRIDE; lim = ZA_CIDX_STRIDE * 4ull; break;
-    case 9: src = c->linkb.p ? c->linkb.p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
-    case 10: src = c->linkc.p ? c->linkc.p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
+    case 9: src = c->linkb_p ? c->linkb_p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
+    case 10: src = c->linkc_p ? c->linkc_p + (size_t)unit * ZA_PREV_STRIDE : nullptr; lim = ZA_PREV_STRIDE * 2ull; break;
     case 11: src = c->best_keep.p ? c->best_keep.p + (size_t)unit * ZA_BEST_STRIDE : nullptr; lim = ZA_BEST_STRIDE * 4ull; break;
     case 12: src = c->dpcost.p ? c->dpcost.p + (size_t)unit * ZA_DP_COSTS : nullptr; lim = ZA_DP_COSTS * 4ull; break;
     default: return fail(c, ZNGAMD_E_ARG, "unknown stage");
     }
     if (!src || bytes > lim) return fail(c, ZNGAMD_E_ARG, "stage not available");
+    // (without zngamd_debug_keep the token words are written over the link tables: only one of the two survives a call)
+    if (!c->last_kept && (what == 0 || what == 9 || what == 10)) return fail(c, ZNGAMD_E_ARG, "link tables are kept only after zngamd_debug_keep(1): the token words take their place");
     HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     if ((what == 0 || what == 9 || what == 10) && unit < c->last_hu.size() && (c->last_hu[unit].flags & ZA_FLAG_CARRY) && !(c->last_hu[unit].flags & ZA_FLAG_RUNHEAD) && unit > 0) {
         // a unit whose chain tables were carried over: the links of its dictionary are the links of the last 32 KiB of the unit in
         // front of it (that unit's row) -- all but the last few (context length - 1), which this unit inserted itself; links that
         // reach in front of the dictionary are "no link" for this unit
         const ZaUnit &u = c->last_hu[unit], &pv = c->last_hu[unit - 1];
-        const uint16_t *tab = what == 0 ? c->prev.p : what == 9 ? c->linkb.p : c->linkc.p;
+        const uint16_t *tab = what == 0 ? c->prev_p : what == 9 ? c->linkb_p : c->linkc_p;
         const size_t late = (what == 0 ? ZA_HASH_BYTES_A : what == 9 ? ZA_HASH_BYTES_B : ZA_HASH_BYTES_C) - 1;
         const size_t nd = std::min<size_t>(bytes / 2, u.dict_len - late);
         uint16_t *d16 = (uint16_t *)dst;

@@ -41,7 +41,7 @@ SYMBOLS = [
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_decode_paths", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
+    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
 ]
 
 
@@ -620,8 +620,11 @@ class Context:
         self._chk(self.L.zngamd_profiling(self.h, 1 if on else 0))
 
     def kernel_times(self, reset=True):
-        ms = (C.c_double * len(K_NAMES))()
-        ln = (C.c_uint64 * len(K_NAMES))()
+        # the library says how many it writes (a library older than the query -- a variant build of an earlier round under
+        # ZNGAMD_LIB -- wrote as many as this table is long)
+        nk = max(len(K_NAMES), int(self.L.zngamd_kernel_class_count())) if hasattr(self.L, "zngamd_kernel_class_count") else len(K_NAMES)
+        ms = (C.c_double * nk)()
+        ln = (C.c_uint64 * nk)()
         self._chk(self.L.zngamd_kernel_times(self.h, ms, ln, 1 if reset else 0))
         return {k: (ms[i], ln[i]) for i, k in enumerate(K_NAMES)}
 

@@ -157,6 +157,7 @@ def test_chain_tables_carried_across_units_equal_the_oracle(monkeypatch):
         for level in (1, 6, 8, 9):      # (8 and 9: the work-list search, eight and twelve chain steps in visits of four)
             d_slots, d_len, d_crc = Dev(ctx, nu * _lib.SLOT_STRIDE), Dev(ctx, nu * 4), Dev(ctx, nu * 4)
             ublock = (C.c_uint32 * nu)()
+            ctx.debug_keep(level == 6)          # (the link tables survive a call only on request: the token words take their memory)
             assert L.zngamd_deflate_blocks_dev(h, d_in.p, total, blocks, nb, level, d_slots.p, d_len.p, d_crc.p, ublock) == 0, ctx.err()
             lens, crcs = d_len.get(dtype=np.uint32), d_crc.get(dtype=np.uint32)
             slots = d_slots.get()
@@ -173,6 +174,7 @@ def test_chain_tables_carried_across_units_equal_the_oracle(monkeypatch):
                         assert np.array_equal(links, dbg["prevdist"]), (run, bi, k, int(np.argmax(links != dbg["prevdist"])))
                     u += 1
             assert u == nu
+            ctx.debug_keep(False)
             for dv in (d_slots, d_len, d_crc):
                 dv.free()
         d_in.free()

@@ -15,6 +15,11 @@ import pytest
 UNIT = 131072
 WIN = 32768
 TOL = 1.02
+# The bars below were set against zlib 1.2.x (1.2.11 in this image).  Another deflate behind the same module name (zlib-ng's compat
+# build, a later zlib with other level tables) is another bar, and the corpora are whatever files this box has: the gate is then
+# skipped, not failed.  (bench.py reports the same comparison, with the library's version beside it, on every box.)
+pytestmark = pytest.mark.skipif(not zlib.ZLIB_RUNTIME_VERSION.startswith("1.2."),
+                                reason="ratio bars were set against zlib 1.2.x, this box has " + zlib.ZLIB_RUNTIME_VERSION)
 
 
 def zlib_units(data, level):
