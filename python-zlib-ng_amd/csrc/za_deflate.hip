@@ -579,8 +579,13 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             for (int p = bytes_loaded + 4 * tid; p < need_bytes; p += 4 * ZA_SEARCH_THREADS) store_bytes(p, load_bytes(p));
         bytes_loaded = need_bytes;
     }
-    // the positions' own links in tables B and C travel ONE TILE AHEAD in registers (levels 1-6): fetched where they are used,
-    // behind the first position's walk, every tile stalled for their trip to memory (13 % of the kernel)
+    // The positions' own links in tables B and C travel ONE TILE AHEAD in registers (fetched where they are used, behind the first
+    // position's walk, every tile stalled for their trip to memory).  Eight 2-byte loads per thread and tile: 12 % of the kernel
+    // (`-DZA_ABL_NO_LINKLOADS`, r06: 7.68 -> 6.76 ms per GiB) with everything they fetch sitting in the L2 -- a third of it the
+    // loads' address arithmetic, which is why they are unconditional now (a position behind the unit's end reads the unit's last
+    // link, and is never searched) with 32-bit offsets from a scalar base.  Measured and dropped: one 8-byte load per table and
+    // thread, each lane picking its four links out of its neighbours' registers with ds_bpermute -- 2 loads and 16 permutes
+    // instead of 8 loads: 7.74 -> 7.95 ms per GiB, the permutes alone cost what the loads did.
     uint32_t nlkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], nlkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
     auto load_own_links = [&](int tile_base) {
 #pragma unroll
@@ -589,8 +594,9 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #ifdef ZA_ABL_NO_LINKLOADS
             nlkb[k] = ((uint32_t)p * 7u & 0xFFu) | 1u; nlkc[k] = ((uint32_t)p * 13u & 0x3FFu) | 1u;      // (timing only: candidates without the loads)
 #else
-            nlkb[k] = p < n ? (uint32_t)linkb[p] : 0u;
-            nlkc[k] = USEC && p < n ? (uint32_t)linkc[p] : 0u;
+            const uint32_t off = 2u * (uint32_t)(p < n ? p : n - 1);        // (n >= 1 inside the tile loop; the prologue's call guards itself)
+            nlkb[k] = n > 0 ? (uint32_t)*(const uint16_t *)((const uint8_t *)linkb + off) : 0u;
+            nlkc[k] = USEC && n > 0 ? (uint32_t)*(const uint16_t *)((const uint8_t *)linkc + off) : 0u;
 #endif
         }
     };

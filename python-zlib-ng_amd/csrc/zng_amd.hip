@@ -69,11 +69,13 @@ struct zngamd_ctx {
     uint32_t *d_crc_table = nullptr, *d_x8k = nullptr;
     uint32_t *d_crc_slice4 = nullptr;                                         // CRC slice-by-4 table of za_k_inflate_members
     // deflate workspaces (per chunk of units)
-    // units per launch (ZNGAMD_CHUNK_UNITS; fewer, fuller launches: 16 384 instead of 32 768 costs 2 % of compress throughput).  Workspace
-    // per unit (r06): link tables 3 x 320 KiB (two below level 5), entries 512 KiB, about 5 KiB of small arrays -- 1.44 MiB, 47 GB for a
-    // 4 GiB shard; the token words (512 KiB) live IN the link tables' memory, which nobody reads once the search is through (r05:
-    // 1.94 MiB with an eighth of slack on top, 73 GB).  A chunk that does not fit the device's free memory is halved until it does.
-    uint32_t chunk_units = 32768;
+    // units per launch (ZNGAMD_CHUNK_UNITS).  Workspace per unit (r06): link tables 3 x 320 KiB (two below level 5), entries 512 KiB,
+    // about 5 KiB of small arrays -- 1.44 MiB; the token words (512 KiB) live IN the link tables' memory, which nobody reads once the
+    // search is through (r05: 1.94 MiB with an eighth of slack on top).  16 384 units = 24 GB: a 4 GiB shard takes two launches per
+    // kernel and 2.1 % longer than in one (32 768: 47 GB; measured on the r06 kernels: deflate 64.5 -> 65.9 ms, the device holds
+    // 58.7 instead of 83.5 GB during the bench; 8 192: 68.4 ms, 46.3 GB) -- the default since r06, the review's choice.  A chunk
+    // that does not fit the device's free memory is halved until it does.
+    uint32_t chunk_units = 16384;
     DevBuf<uint16_t> links; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     uint16_t *prev_p = nullptr, *linkb_p = nullptr, *linkc_p = nullptr; uint32_t *tok_p = nullptr;     // where the current chunk size puts the tables inside `links`, and the token words (inside `links` too unless zngamd_debug_keep asked for all stages to stay)
     bool debug_keep = false, last_kept = false; DevBuf<uint32_t> best_keep, dpcost;     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
