@@ -47,6 +47,7 @@ typedef struct zngamd_ctx zngamd_ctx;
 #define ZNGAMD_E_HIP         (-201)   /* HIP runtime error or no usable GPU */
 #define ZNGAMD_E_ARG         (-202)
 #define ZNGAMD_E_OVERFLOW    (-203)   /* a block's compressed output reached its buffer size */
+#define ZNGAMD_E_INDEX       (-204)   /* a segment index does not fit its stream: decode the stream without the index */
 
 #define ZNGAMD_FLAG_FINAL      1u     /* block ends the deflate stream (BFINAL=1, no sync flush) */
 #define ZNGAMD_FLAG_FLATHDR    2u     /* dynamic block headers in their flat form: the code-length code is the fixed 4-bit
@@ -140,6 +141,24 @@ int zngamd_deflate_blocks_packed_dev(zngamd_ctx *ctx, const void *d_in, uint64_t
                                      const zngamd_block *blocks, uint32_t n_blocks, int level,
                                      void *d_out, uint64_t out_cap, uint32_t *d_unit_len, uint32_t *d_unit_crc,
                                      uint64_t *d_unit_off, uint64_t *total_bytes);
+/* ---- the writer's segment index for a dict-chained stream (r06).  A batch compressed with ZNGAMD_FLAG_FLATHDR on its blocks
+ * (one Huffman block per unit with the header in its flat form, 2 KiB segments) leaves, per unit, ZNGAMD_INDEX_STRIDE u32: entry s
+ * = bit offset of the first token of segment s from the unit's first byte, entry nseg = bit offset of the end-of-block code, the
+ * rest zeros (all zeros: a unit of stored blocks).  zngamd_deflate_index_dev copies the index of the context's LAST deflate call
+ * (n_units as zngamd_count_units gave it) to device memory of the caller.  zngamd_inflate_units_indexed_dev decodes such a
+ * stream -- what the reference's threaded writer frames as one gzip member (gzip_ng_threaded.py:299-338), and what
+ * GzipReader_read_into_buffer (zlib_ngmodule.c:2426-2637) reads with one zng_inflate stream -- unit-parallel: a lane per 2 KiB
+ * segment decodes, matches that reach in front of their unit become markers, the window kernels of the chunk-parallel inflate
+ * resolve them.  unit_in_len / unit_out_len are HOST arrays (compressed bytes of a unit including its sync marker; its output
+ * bytes), d_index device memory, d_dict / dict_len the history in front of the first unit (may be NULL / 0).  Returns
+ * ZNGAMD_STREAM_END with *out_len, ZNGAMD_BUF_ERROR with the size needed, ZNGAMD_E_INDEX when stream and index do not fit (the
+ * caller then decodes with zngamd_inflate_raw_dev), ZNGAMD_DATA_ERROR for invalid deflate data. */
+#define ZNGAMD_INDEX_STRIDE 68
+int zngamd_deflate_index_dev(zngamd_ctx *ctx, uint32_t *d_index, uint32_t n_units);
+int zngamd_inflate_units_indexed_dev(zngamd_ctx *ctx, const void *d_def, uint64_t def_len, const uint32_t *unit_in_len,
+                                     const uint32_t *unit_out_len, uint32_t n_units, const uint32_t *d_index,
+                                     const void *d_dict, uint32_t dict_len, void *d_out, uint64_t out_cap, uint64_t *out_len);
+
 /* Packs unit slots back to back at d_dst + dst_base; returns the total in *total_bytes (host).
  * d_unit_off (device, n_units x u64, may be NULL) receives each unit's byte offset. */
 int zngamd_gather_dev(zngamd_ctx *ctx, const void *d_slots, const uint32_t *d_unit_len, uint32_t n_units,

@@ -6,6 +6,7 @@
 // kernels and assembles container framing bytes (gzip / zlib headers and trailers).
 #include "za_deflate.hip"
 #include "za_inflate.hip"
+#include "za_inflate_units.hip"
 #include "za_checksum.hip"
 #include "../../include/zng_amd.h"
 
@@ -90,6 +91,7 @@ struct zngamd_ctx {
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux, hdr; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
     DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
+    DevBuf<uint16_t> uarea; uint32_t uarea_marked = 0; const void *uarea_marked_at = nullptr;     // symbol areas of the indexed unit decoder (32 768 marker symbols + 131 072 per unit) and how many of them have their markers
     DevBuf<ZaCkPart> ck; DevBuf<uint32_t> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
@@ -214,7 +216,7 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->links.release(); c->best_keep.release(); c->dpcost.release(); c->hdr.release(); c->best.release(); c->tok.release(); c->segtok.release(); c->hist.release(); c->codes.release();
     c->plan.release(); c->units.release(); c->segbits.release(); c->cidx.release(); c->status.release();
     c->st_in.release(); c->st_out.release(); c->st_slots.release(); c->st_aux.release(); c->st_len.release(); c->st_crc.release();
-    c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release();
+    c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release(); c->uarea.release();
     c->st_off.release(); c->runs.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto &e : c->ev_copy) if (e) (void)hipEventDestroy(e);
@@ -1295,6 +1297,112 @@ try {
     if (in_used) *in_used = (res.in_bits + 7) >> 3;
     if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
     return map_status(res.status);
+} ZA_ABI_GUARD
+
+// ---- the default writer's stream with the writer's index (za_inflate_units.hip)
+int zngamd_deflate_index_dev(zngamd_ctx *c, uint32_t *d_index, uint32_t n_units)
+try {
+    if (!c || !d_index) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_units == 0) return ZNGAMD_OK;
+    if (n_units != c->last_units || !c->cidx.p) return fail(c, ZNGAMD_E_ARG, "the index is that of the context's last deflate call: its unit count differs");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(d_index, c->cidx.p, (size_t)n_units * ZA_CIDX_STRIDE * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
+
+static_assert(ZNGAMD_INDEX_STRIDE == ZA_CIDX_STRIDE, "index stride");
+int zngamd_inflate_units_indexed_dev(zngamd_ctx *c, const void *d_def_, uint64_t def_len, const uint32_t *unit_in_len, const uint32_t *unit_out_len,
+                                     uint32_t n_units, const uint32_t *d_index, const void *d_dict, uint32_t dict_len,
+                                     void *d_out_, uint64_t out_cap, uint64_t *out_len)
+try {
+    if (!c || !d_def_ || !unit_in_len || !unit_out_len || !d_index || !d_out_ || !out_len || dict_len > ZA_WIN) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t *d_def = (const uint8_t *)d_def_;
+    uint8_t *d_out = (uint8_t *)d_out_;
+    *out_len = 0;
+    uint64_t tin = 0, tout = 0;
+    for (uint32_t u = 0; u < n_units; u++) {
+        if (unit_out_len[u] > ZA_MAX_UNIT) return fail(c, ZNGAMD_E_ARG, "a unit is larger than 128 KiB");
+        tin += unit_in_len[u]; tout += unit_out_len[u];
+    }
+    if (tin > def_len) return fail(c, ZNGAMD_E_ARG, "the units' bytes exceed the stream");
+    *out_len = tout;
+    if (tout > out_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small");
+    constexpr uint64_t AREA = (uint64_t)ZA_WIN + ZA_MAX_UNIT;                 // symbols of a unit's area: markers, then the unit
+    static const uint32_t batch = [] { const char *e = getenv("ZNGAMD_UNIT_BATCH"); long v = e ? atol(e) : 16384; return (uint32_t)(v < 64 ? 64 : v > 65536 ? 65536 : v); }();
+    uint64_t in_at = 0, out_at = 0;
+    std::vector<ZaMember> hm; std::vector<ZaChunk> chain; std::vector<ZaChunkRes> res; std::vector<uint32_t> uidx;
+    for (uint32_t u0 = 0; u0 < n_units; u0 += batch) {
+        const uint32_t u1 = std::min(n_units, u0 + batch);
+        hm.clear(); chain.clear(); uidx.clear();
+        uint64_t acc = 0;                                                     // output of this batch so far
+        for (uint32_t u = u0; u < u1; u++) {
+            if (unit_out_len[u] != 0) {
+                ZaMember m;
+                m.in_off = in_at; m.in_len = unit_in_len[u]; m.out_off = (uint64_t)hm.size() * AREA; m.out_len = unit_out_len[u];
+                m.crc = (uint32_t)std::min<uint64_t>(ZA_WIN, out_at + acc + dict_len);       // (history in front of the unit)
+                m.index_off = 0; m.nseg = (unit_out_len[u] + ZA_SEG - 1) >> ZA_SEG_SHIFT;
+                ZaChunk ch; ch.in_bit = in_at * 8ull; ch.out_off = acc; ch.out_len = unit_out_len[u]; ch.end_bit = (in_at + unit_in_len[u]) * 8ull;
+                ch.src_off = m.out_off + ZA_WIN;
+                hm.push_back(m); chain.push_back(ch); uidx.push_back(u);
+                acc += unit_out_len[u];
+            }
+            in_at += unit_in_len[u];
+        }
+        const uint32_t m = (uint32_t)hm.size();
+        if (m == 0) continue;
+        // the units' index rows are picked by unit number: the kernel reads row blockIdx.x, so a batch without empty units passes
+        // its first row; one with empty units has its rows gathered
+        const uint32_t *d_rows = d_index + (size_t)u0 * ZA_CIDX_STRIDE;
+        if (m != u1 - u0) {
+            HIPCHK(c, c->st_len.ensure((size_t)m * ZA_CIDX_STRIDE));
+            for (uint32_t k = 0; k < m; k++)
+                HIPCHK(c, hipMemcpyAsync(c->st_len.p + (size_t)k * ZA_CIDX_STRIDE, d_index + (size_t)uidx[k] * ZA_CIDX_STRIDE, ZA_CIDX_STRIDE * 4, hipMemcpyDeviceToDevice, c->stream));
+            d_rows = c->st_len.p;
+        }
+        HIPCHK(c, c->uarea.ensure((size_t)std::min<uint32_t>(batch, n_units) * AREA + 64));
+        if (c->uarea.cap < (size_t)m * AREA + 64) return fail(c, ZNGAMD_E_HIP, "unit areas");
+        if (c->uarea_marked_at != (const void *)c->uarea.p) { c->uarea_marked = 0; c->uarea_marked_at = c->uarea.p; }      // (the buffer was reallocated: its markers are gone)
+        HIPCHK(c, c->members.ensure(m)); HIPCHK(c, c->cres.ensure(m)); HIPCHK(c, c->cchunks.ensure(m));
+        HIPCHK(c, c->matchq.ensure((size_t)m * 64 * ZA_MATCHQ_PER_SEG));
+        const uint32_t groups = (m + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
+        HIPCHK(c, c->winbuf.ensure((size_t)groups * ZA_WIN)); HIPCHK(c, c->ccomp.ensure((size_t)m * ZA_WIN));
+        HIPCHK(c, hipMemcpyAsync(c->members.p, hm.data(), (size_t)m * sizeof(ZaMember), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->cchunks.p, chain.data(), (size_t)m * sizeof(ZaChunk), hipMemcpyHostToDevice, c->stream));
+        { ProfScope ps(c, ZNGAMD_K_INFLATE);
+          if (c->uarea_marked < m) {
+              hipLaunchKernelGGL(za_k_fill_marker_prefix, dim3(m - c->uarea_marked), dim3(256), 0, c->stream, c->uarea.p + (uint64_t)c->uarea_marked * AREA, AREA);
+              c->uarea_marked = m;
+          }
+          hipLaunchKernelGGL(za_k_inflate_units_marked, dim3(m), dim3(64), 0, c->stream, d_def, def_len, c->members.p, c->uarea.p, (uint64_t)c->uarea.cap,
+                             c->matchq.p, d_rows, c->cres.p); }
+        HIPCHK(c, hipGetLastError());
+        res.resize(m);
+        HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)m * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t k = 0; k < m; k++) {
+            if (res[k].status == ZA_I_DATA) return fail(c, ZNGAMD_DATA_ERROR, "invalid deflate data");
+            if ((res[k].status != ZA_I_SYNC && res[k].status != ZA_I_END) || res[k].out_len != hm[k].out_len)
+                return fail(c, ZNGAMD_E_INDEX, "the index does not fit the stream (or the stream is not this engine's indexed form): decode it without the index");
+        }
+        // windows in front of the units, then markers -> bytes (the chunk pipeline's kernels: a unit is a chunk)
+        const uint8_t *bd = out_at ? d_out + out_at - std::min<uint64_t>(ZA_WIN, out_at) : (const uint8_t *)d_dict;
+        const uint32_t bdl = out_at ? (uint32_t)std::min<uint64_t>(ZA_WIN, out_at) : dict_len;
+        if (out_at && out_at < (uint64_t)ZA_WIN) return fail(c, ZNGAMD_E_ARG, "a batch of units shorter than the window");
+        { ProfScope ps(c, ZNGAMD_K_INFLATE);
+          hipLaunchKernelGGL(za_k_chunk_compose, dim3(groups), dim3(1024), 0, c->stream, c->uarea.p, c->cchunks.p, m, c->ccomp.p);
+          hipLaunchKernelGGL(za_k_chunk_chain, dim3(1), dim3(1024), 0, c->stream, c->ccomp.p, m, c->winbuf.p, bd, bdl);
+          hipLaunchKernelGGL(za_k_chunk_resolve, dim3(m), dim3(ZA_RESOLVE_THREADS), 0, c->stream, c->uarea.p, c->cchunks.p, c->ccomp.p, c->winbuf.p, d_out + out_at); }
+        HIPCHK(c, hipGetLastError());
+        out_at += acc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    c->paths[ZNGAMD_PATH_CHUNKED]++;
+    return ZNGAMD_STREAM_END;
 } ZA_ABI_GUARD
 
 int zngamd_crc32_fold_dev(zngamd_ctx *c, const uint32_t *d_crcs, uint32_t n, uint64_t each_len, uint64_t last_len, uint32_t *crc)

@@ -25,6 +25,8 @@ CHUNK_SHIFT = 11
 UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
+INDEX_STRIDE = 68        # ZNGAMD_INDEX_STRIDE
+E_INDEX = -204
 K_NAMES = ["chains", "search", "parse", "plan", "pack", "gather", "scan", "inflate", "other", "optparse"]
 
 # every symbol include/zng_amd.h declares (tests check that the library exports all of them)
@@ -41,7 +43,7 @@ SYMBOLS = [
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
+    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_deflate_index_dev", "zngamd_inflate_units_indexed_dev", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
 ]
 
 
@@ -138,6 +140,9 @@ def load():
         L.zngamd_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_decode_paths.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
+        L.zngamd_deflate_index_dev.argtypes = [vp, vp, C.c_uint32]
+        L.zngamd_inflate_units_indexed_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, vp, vp, C.c_uint32,
+                                                       vp, C.c_uint64, C.POINTER(C.c_uint64)]
         L.zngamd_debug_keep.argtypes = [vp, C.c_int]
         L.zngamd_d2d.argtypes = [vp, vp, vp, C.c_size_t]
         L.zngamd_dmemset.argtypes = [vp, vp, C.c_int, C.c_size_t]
@@ -614,6 +619,28 @@ class Context:
         out = _Out(cap)
         self._chk(self.L.zngamd_gzip_members(self.h, p, n, block_size, level, out.addr(), cap, C.byref(ol)))
         return out.take(ol.value)
+
+    # ---- the writer's segment index (dict-chained streams written with FLAG_FLATHDR)
+    def deflate_index(self, n_units):
+        """The segment index of this context's LAST deflate call: n_units rows of INDEX_STRIDE u32, as a device buffer
+        (zngamd_deflate_index_dev)."""
+        from . import devmem
+        d = devmem.empty(self, 4 * INDEX_STRIDE * max(1, n_units))
+        self._chk(self.L.zngamd_deflate_index_dev(self.h, d.vp(), n_units))
+        return d
+
+    def inflate_units_indexed_dev(self, d_def, def_len, unit_in_len, unit_out_len, d_index, d_out, out_cap, d_dict=None, dict_len=0):
+        """zngamd_inflate_units_indexed_dev: unit-parallel decode of ONE dict-chained stream of this engine with its index.
+        d_def / d_index / d_out / d_dict: device pointers (ints or c_void_p); unit_*_len: sequences of ints.
+        -> (code, out_len); code STREAM_END, or E_INDEX / DATA_ERROR / BUF_ERROR as the C call returns them."""
+        n = len(unit_in_len)
+        a = (C.c_uint32 * max(1, n))(*unit_in_len)
+        b = (C.c_uint32 * max(1, n))(*unit_out_len)
+        ol = C.c_uint64(0)
+        r = self.L.zngamd_inflate_units_indexed_dev(self.h, C.c_void_p(int(d_def)), def_len, a, b, n, C.c_void_p(int(d_index)),
+                                                    C.c_void_p(int(d_dict)) if d_dict else None, dict_len,
+                                                    C.c_void_p(int(d_out)), out_cap, C.byref(ol))
+        return r, ol.value
 
     # ---- measurement
     def profiling(self, on):

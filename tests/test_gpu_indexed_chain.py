@@ -1,0 +1,137 @@
+"""The default writer's framing -- ONE deflate stream of dict-chained, sync-flushed blocks (gzip_ng_threaded.py:299-338) -- decoded
+unit-parallel with the writer's own segment index (zngamd_inflate_units_indexed_dev): inflate output is unique, so parity is
+"equals the input", for every kind of unit (dynamic, fixed, stored, empty, short last one), with and without a dictionary in front
+of the stream; the same stream must decode with the system zlib (the flat headers are ordinary RFC 1951) and through the engine's
+index-free path; damage is reported, never decoded to something else."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+B = 131072
+FLATHDR = 2
+
+
+def _mix(n, seed):
+    from zlib_ng_amd import corpus
+    rng = np.random.default_rng(seed)
+    parts = [corpus.text(n // 3, seed + 1).tobytes(), bytes(n // 8), rng.integers(0, 256, n // 6, dtype=np.uint8).tobytes(),
+             corpus.fastq(n // 4, seed + 2).tobytes(), (b"abcdefgh" * 4096)[:n // 16]]
+    out = b"".join(parts)
+    return (out + corpus.text(max(0, n - len(out)), seed + 3).tobytes())[:n]
+
+
+def _compress_indexed(ctx, data, level, block=B, dict_first=b""):
+    """-> (stream bytes incl. a final empty block, unit_in_len, unit_out_len, device index)"""
+    buf = dict_first + data
+    off0 = len(dict_first)
+    blocks, off = [], off0
+    while off < len(buf):
+        n = min(block, len(buf) - off)
+        blocks.append((off, n, min(32768, off), FLATHDR))
+        off += n
+    outs, crcs, ovf = ctx.deflate_blocks(buf, blocks, level, block + block // 8 + 600)
+    assert not ovf
+    nu = len(blocks)            # (blocks of at most a unit's size: a unit each -- the host call reports sizes per block, and the index is per unit)
+    assert block <= B
+    d_index = ctx.deflate_index(nu)
+    for (o, n, d, _), c, crc in zip(blocks, outs, crcs):
+        assert crc == zlib.crc32(buf[o:o + n])
+    return b"".join(outs) + b"\x03\x00", [len(c) for c in outs], [b[1] for b in blocks], d_index
+
+
+def _decode(ctx, stream, uin, uout, d_index, dict_first=b""):
+    from zlib_ng_amd import devmem
+    d_def = devmem.from_host(ctx, stream + bytes(64))
+    total = sum(uout)
+    d_out = devmem.empty(ctx, total + 64)
+    d_dict = devmem.from_host(ctx, dict_first) if dict_first else None
+    r, n = ctx.inflate_units_indexed_dev(d_def.ptr, len(stream), uin, uout, d_index.ptr, d_out.ptr, total,
+                                         d_dict.ptr if d_dict else None, len(dict_first))
+    return r, n, (d_out[0:n].cpu().tobytes() if r == 1 and n <= total else b"")
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_indexed_chain_equals_input(ctx, level):
+    from zlib_ng_amd import _lib
+    data = _mix(5 * B + 12345, seed=level)
+    stream, uin, uout, d_index = _compress_indexed(ctx, data, level)
+    assert zlib.decompressobj(-15).decompress(stream) == data           # any inflater reads it
+    r, n, back = _decode(ctx, stream, uin, uout, d_index)
+    assert r == _lib.STREAM_END and n == len(data) and back == data
+
+
+def test_stored_fixed_empty_and_tiny_units(ctx):
+    from zlib_ng_amd import _lib
+    rng = np.random.default_rng(7)
+    pieces = [rng.integers(0, 256, B, dtype=np.uint8).tobytes(),            # stored (two blocks of <= 65 535)
+              b"ab" * 40,                                                   # a tiny unit: fixed code
+              _mix(B, 3), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), b"x", _mix(3 * B + 17, 5)]
+    # blocks of the pieces' own sizes (each <= one unit), chained through 32 KiB of the input before them
+    buf = b"".join(pieces)
+    blocks, off = [], 0
+    for p in pieces:
+        for o in range(0, len(p), B):
+            n = min(B, len(p) - o)
+            blocks.append((off + o, n, min(32768, off + o), FLATHDR))
+        off += len(p)
+    outs, crcs, ovf = ctx.deflate_blocks(buf, blocks, 6, B + B // 8 + 600)
+    assert not ovf
+    d_index = ctx.deflate_index(len(blocks))
+    stream = b"".join(outs) + b"\x03\x00"
+    assert zlib.decompressobj(-15).decompress(stream) == buf
+    r, n, back = _decode(ctx, stream, [len(c) for c in outs], [b[1] for b in blocks], d_index)
+    assert r == _lib.STREAM_END and back == buf
+
+
+def test_dictionary_in_front_of_the_stream(ctx):
+    from zlib_ng_amd import _lib
+    d = _mix(40000, 11)
+    data = d[-9000:] * 3 + _mix(2 * B + 999, 12)
+    stream, uin, uout, d_index = _compress_indexed(ctx, data, 6, dict_first=d[-32768:])
+    zd = zlib.decompressobj(-15, zdict=d[-32768:])
+    assert zd.decompress(stream) == data
+    r, n, back = _decode(ctx, stream, uin, uout, d_index, dict_first=d[-32768:])
+    assert r == _lib.STREAM_END and back == data
+
+
+def test_many_units_in_batches(ctx, monkeypatch):
+    """more units than one batch of the decoder holds (ZNGAMD_UNIT_BATCH is read once per process: the default, 16 384, needs
+    2 GiB; 260 units of 16 KiB go through the same code with blocks below a unit's size)"""
+    from zlib_ng_amd import _lib
+    data = _mix(260 * 16384, 21)
+    stream, uin, uout, d_index = _compress_indexed(ctx, data, 6, block=16384)
+    assert zlib.decompressobj(-15).decompress(stream) == data
+    r, n, back = _decode(ctx, stream, uin, uout, d_index)
+    assert r == _lib.STREAM_END and back == data
+
+
+def test_damage_is_reported(ctx):
+    from zlib_ng_amd import _lib
+    data = _mix(3 * B, 31)
+    stream, uin, uout, d_index = _compress_indexed(ctx, data, 6)
+    rng = np.random.default_rng(5)
+    verdicts = set()
+    for _ in range(24):
+        bad = bytearray(stream)
+        pos = int(rng.integers(0, len(stream) - 2))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        r, n, back = _decode(ctx, bytes(bad), uin, uout, d_index)
+        # raw deflate carries no checksum: a flip that turns one literal code into another of its length decodes, to other bytes,
+        # with ANY inflater (the gzip layer's CRC-32 is what catches it) -- so a "fine" verdict must come with exactly the bytes
+        # the system zlib decodes
+        try:
+            ref = zlib.decompressobj(-15).decompress(bytes(bad))
+        except zlib.error:
+            ref = None
+        if r == _lib.STREAM_END:
+            assert ref is not None and back == ref, pos
+        else:
+            assert r in (_lib.E_INDEX, _lib.DATA_ERROR), (r, pos)
+        verdicts.add(r)
+    assert verdicts - {_lib.STREAM_END}, "no flip was noticed"
+    # a wrong index: the neighbour's rows
+    r, n, back = _decode(ctx, stream, uin[::-1], uout, d_index)
+    assert r != _lib.STREAM_END or back == data
