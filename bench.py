@@ -449,6 +449,46 @@ def main():
                    "frac": round(cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(cbytes),
                    "note": "ms = the whole device-resident call (its host-side planning between the kernels included), best of 3"}
 
+    # ---- the same single-member framing WITH the writer's segment index (r06: flat dynamic headers, the index in the file's
+    # trailing empty members): the units decode side by side, a lane per 2 KiB segment, matches that reach in front of their unit
+    # through markers (zngamd_inflate_units_indexed_dev) ----
+    chained_ix = None
+    if rank == 0 and blo == 0 and not args.no_foreign:
+        fblocks = (_lib.Block * nblocks)()
+        for b in range(nblocks):
+            fblocks[b] = _lib.Block(HALO + b * BLOCK, BLOCK, 32768 if b else 0, 2, 0)          # ZNGAMD_FLAG_FLATHDR
+        ftotal = C.c_uint64(0)
+        chk(L.zngamd_deflate_blocks_packed_dev(h, ptr(d_buf), HALO + size, fblocks, nblocks, args.level, ptr(d_comp), d_comp.numel() - 64,
+                                               ptr(d_ulen), ptr(d_ucrc), None, C.byref(ftotal)), "deflate_blocks_packed_dev (flat headers)")
+        d_index = ctx.deflate_index(n_units)
+        uin = d_ulen.cpu(np.uint32)[:n_units].tolist()
+        fbytes_c = int(ftotal.value)
+        d_comp[fbytes_c:fbytes_c + 66] = 0
+        d_comp[fbytes_c] = 3
+        x_wall, x_kern = [], []
+        for it in range(3):
+            d_out.zero_()
+            ctx.sync()
+            ctx.profiling(True); ctx.kernel_times(reset=True)
+            t = time.perf_counter()
+            rc, xl = ctx.inflate_units_indexed_dev(d_comp.ptr, fbytes_c + 2, uin, [BLOCK] * n_units, d_index.ptr, d_out.ptr, size)
+            x_wall.append((time.perf_counter() - t) * 1e3)
+            x_kern.append(sum(v[0] for v in ctx.kernel_times(reset=True).values()))
+            ctx.profiling(False)
+            assert rc == _lib.STREAM_END and xl == size, (rc, xl, ctx.err())
+        assert d_out[:size].equal(d_in[:size]), "indexed chained stream: output differs"
+        xb = fbytes_c + size
+        xms = min(x_wall)
+        chained_ix = {"bound": "hbm", "kernel": "za_k_inflate_units_marked + za_k_chunk_compose / _chain / _resolve",
+                      "stream": f"ONE raw deflate stream, {nblocks} dict-chained blocks of 128 KiB ending in sync flushes, flat dynamic headers; "
+                                f"the writer's segment index beside it ({68 * 4} bytes per unit on the device, 2-byte deltas in a file)",
+                      "ratio": round(size / fbytes_c, 4), "ms": round(xms, 3), "kernel_ms": round(min(x_kern), 3),
+                      "decompress_MBps": round(size / (xms * 1e-3) / 1e6, 1),
+                      "achieved": round(xb / (xms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(xb / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(xb),
+                      "note": "ms = the whole device-resident call, best of 3"}
+        del d_index
+
     # ---- BGZF: standard 'BC' members (at most 65 280 bytes of input each, FEXTRA subfield BC = member size - 1) written by the
     # system zlib, one wavefront per member; outside the timed region ----
     bgzf = None
@@ -708,6 +748,9 @@ def main():
             chained["traffic"] = int(sum(pmc_per_unit[k] for k in ck) * nblocks * nbatch)
             chained["traffic_source"] = traffic_src + f"; {nbatch} batches per decode"
         out["roofline_inflate_chained"] = chained
+    if chained_ix is not None:
+        out["roofline_inflate_chained_indexed"] = chained_ix
+        out["value_chained_indexed"] = round(total_size / ((deflate_ms + chained_ix["ms"]) * 1e-3) / 1e6, 1)
     if bgzf is not None:
         if pmc_per_unit.get("za_k_inflate_serial_members"):
             # (the counter passes average this kernel's launches over the foreign-member and the BGZF leg: both decode the same text)

@@ -281,7 +281,16 @@ typedef struct zngamd_gz_state {
     uint32_t window_len;     /* valid bytes in window[] */
     uint64_t out_total;      /* bytes the member has produced so far */
     uint8_t  window[32768];  /* the last window_len bytes of the member's output */
+    void    *index;          /* (r06, may be NULL) zngamd_index_create's handle for the member being read: the writer's segment index,
+                              * taken from the file's trailing members by the caller; the units inside a window then decode side by side */
 } zngamd_gz_state;
+/* The index of one data member for the windowed reader: per unit its compressed bytes (sync marker included), its output bytes and
+ * its ZNGAMD_INDEX_STRIDE u32 of segment bit offsets (host arrays; see zngamd_deflate_index, which gives them for the units of the
+ * context's last deflate call).  The handle belongs to the caller (zngamd_index_destroy) and must outlive every state that names it. */
+int zngamd_index_create(zngamd_ctx *ctx, uint32_t n_units, const uint32_t *unit_in_len, const uint32_t *unit_out_len,
+                        const uint32_t *rows, void **handle);
+void zngamd_index_destroy(void *handle);
+int zngamd_deflate_index(zngamd_ctx *ctx, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows);
 int zngamd_gunzip_stream(zngamd_ctx *ctx, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, int last,
                          uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members,
                          uint64_t *in_consumed);
@@ -413,6 +422,8 @@ int zngamd_abi(void);
 #define ZNGAMD_PATH_SEQUENTIAL 3
 #define ZNGAMD_PATH_COUNT      4
 int zngamd_decode_paths(zngamd_ctx *ctx, uint64_t *members /*[ZNGAMD_PATH_COUNT]*/, int reset);
+/* units decoded with a writer's segment index (zngamd_inflate_units_indexed_dev, or the windowed reader with zngamd_gz_state.index) */
+uint64_t zngamd_indexed_units(zngamd_ctx *ctx, int reset);
 
 /* ---- debugging aid for the parity tests: copy a stage's intermediate of unit `u` of the last
  * deflate call to the host.  what: 0 links of table A (u16) 1 best(u32, as the parse kernel read it: behind the dynamic

@@ -79,7 +79,8 @@ struct zngamd_ctx {
     uint32_t chunk_units = 16384;
     DevBuf<uint16_t> links; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     uint16_t *prev_p = nullptr, *linkb_p = nullptr, *linkc_p = nullptr; uint32_t *tok_p = nullptr;     // where the current chunk size puts the tables inside `links`, and the token words (inside `links` too unless zngamd_debug_keep asked for all stages to stay)
-    bool debug_keep = false, last_kept = false; DevBuf<uint32_t> best_keep, dpcost;     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
+    bool debug_keep = false, last_kept = false; DevBuf<uint32_t> best_keep, dpcost;
+    const uint32_t *last_unit_len = nullptr;     // the last deflate call's per-unit compressed sizes (device; the caller's array or a staging buffer of this context)     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
     // per call
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status, runs;
     uint32_t last_units = 0; bool last_single_chunk = false;
@@ -91,11 +92,12 @@ struct zngamd_ctx {
     // staging
     DevBuf<uint8_t> st_in, st_out, st_slots, st_aux, hdr; DevBuf<uint32_t> st_len, st_crc; DevBuf<uint64_t> st_off;
     DevBuf<uint64_t> ccand, csurv; DevBuf<ZaChunkRes> cres; DevBuf<ZaChunk> cchunks; DevBuf<uint16_t> out16, ccomp; DevBuf<uint8_t> winbuf;
-    DevBuf<uint16_t> uarea; uint32_t uarea_marked = 0; const void *uarea_marked_at = nullptr;     // symbol areas of the indexed unit decoder (32 768 marker symbols + 131 072 per unit) and how many of them have their markers
+    DevBuf<uint16_t> uarea; uint32_t uarea_marked = 0;     // symbol areas of the indexed unit decoder (32 768 marker symbols + 131 072 per unit) and how many of them have their markers
     DevBuf<ZaCkPart> ck; DevBuf<uint32_t> matchq; DevBuf<ZaCand> cands; DevBuf<ZaMember> members; DevBuf<int32_t> mstatus;
     void *d_small = nullptr;     // 256 B scratch for counters / results
     // profiling
     uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
+    uint64_t indexed_units = 0;                  // units decoded with a writer's index (zngamd_indexed_units)
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // pinned host staging for device-to-host results (grow-only)
     hipEvent_t ev_copy[2] = {nullptr, nullptr};              // ends of the staged device-to-host pieces
     bool prof = false; std::vector<EvPair> evs; std::vector<hipEvent_t> pool;
@@ -303,6 +305,7 @@ try {
     for (int i = 0; i < ZNGAMD_PATH_COUNT; i++) { members[i] = c->paths[i]; if (reset) c->paths[i] = 0; }
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
+uint64_t zngamd_indexed_units(zngamd_ctx *c, int reset) { if (!c) return 0; std::lock_guard<std::mutex> g(c->mu); const uint64_t v = c->indexed_units; if (reset) c->indexed_units = 0; return v; }
 int zngamd_profiling(zngamd_ctx *c, int on) { if (!c) return ZNGAMD_E_ARG; c->prof = on != 0; return ZNGAMD_OK; }
 int zngamd_kernel_times(zngamd_ctx *c, double *ms, uint64_t *launches, int reset)
 try {
@@ -623,7 +626,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         }
         HIPCHK(c, hipGetLastError());
     }
-    c->last_units = n; c->last_single_chunk = (n <= ch); c->last_kept = c->debug_keep;
+    c->last_units = n; c->last_single_chunk = (n <= ch); c->last_kept = c->debug_keep; c->last_unit_len = d_unit_len;
     return ZNGAMD_OK;
 }
 
@@ -1313,15 +1316,11 @@ try {
 } ZA_ABI_GUARD
 
 static_assert(ZNGAMD_INDEX_STRIDE == ZA_CIDX_STRIDE, "index stride");
-int zngamd_inflate_units_indexed_dev(zngamd_ctx *c, const void *d_def_, uint64_t def_len, const uint32_t *unit_in_len, const uint32_t *unit_out_len,
-                                     uint32_t n_units, const uint32_t *d_index, const void *d_dict, uint32_t dict_len,
-                                     void *d_out_, uint64_t out_cap, uint64_t *out_len)
-try {
-    if (!c || !d_def_ || !unit_in_len || !unit_out_len || !d_index || !d_out_ || !out_len || dict_len > ZA_WIN) return ZNGAMD_E_ARG;
-    std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint8_t *d_def = (const uint8_t *)d_def_;
-    uint8_t *d_out = (uint8_t *)d_out_;
+// (the caller holds the context's lock; device pointers, host size arrays; leaves the stream drained)
+static int inflate_units_core(zngamd_ctx *c, const uint8_t *d_def, uint64_t def_len, const uint32_t *unit_in_len, const uint32_t *unit_out_len,
+                              uint32_t n_units, const uint32_t *d_index, const void *d_dict, uint32_t dict_len,
+                              uint8_t *d_out, uint64_t out_cap, uint64_t *out_len)
+{
     *out_len = 0;
     uint64_t tin = 0, tout = 0;
     for (uint32_t u = 0; u < n_units; u++) {
@@ -1363,9 +1362,15 @@ try {
                 HIPCHK(c, hipMemcpyAsync(c->st_len.p + (size_t)k * ZA_CIDX_STRIDE, d_index + (size_t)uidx[k] * ZA_CIDX_STRIDE, ZA_CIDX_STRIDE * 4, hipMemcpyDeviceToDevice, c->stream));
             d_rows = c->st_len.p;
         }
-        HIPCHK(c, c->uarea.ensure((size_t)std::min<uint32_t>(batch, n_units) * AREA + 64));
+        {
+            // (grown with a quarter of head-room: the windows of a reader hold a few units more or fewer each time, and every
+            // reallocation loses the areas' markers)
+            const size_t want = (size_t)std::min<uint32_t>(batch, n_units) * AREA + 64, cap0 = c->uarea.cap;
+            const uint16_t *p0 = c->uarea.p;
+            if (want > cap0) HIPCHK(c, c->uarea.ensure(std::min<size_t>((size_t)batch * AREA + 64, want + want / 4)));
+            if (c->uarea.cap != cap0 || c->uarea.p != p0) c->uarea_marked = 0;
+        }
         if (c->uarea.cap < (size_t)m * AREA + 64) return fail(c, ZNGAMD_E_HIP, "unit areas");
-        if (c->uarea_marked_at != (const void *)c->uarea.p) { c->uarea_marked = 0; c->uarea_marked_at = c->uarea.p; }      // (the buffer was reallocated: its markers are gone)
         HIPCHK(c, c->members.ensure(m)); HIPCHK(c, c->cres.ensure(m)); HIPCHK(c, c->cchunks.ensure(m));
         HIPCHK(c, c->matchq.ensure((size_t)m * 64 * ZA_MATCHQ_PER_SEG));
         const uint32_t groups = (m + ZA_CHUNK_GROUP - 1) / ZA_CHUNK_GROUP;
@@ -1383,6 +1388,7 @@ try {
         res.resize(m);
         HIPCHK(c, hipMemcpyAsync(res.data(), c->cres.p, (size_t)m * sizeof(ZaChunkRes), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->indexed_units += m;
         for (uint32_t k = 0; k < m; k++) {
             if (res[k].status == ZA_I_DATA) return fail(c, ZNGAMD_DATA_ERROR, "invalid deflate data");
             if ((res[k].status != ZA_I_SYNC && res[k].status != ZA_I_END) || res[k].out_len != hm[k].out_len)
@@ -1401,8 +1407,71 @@ try {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
-    c->paths[ZNGAMD_PATH_CHUNKED]++;
     return ZNGAMD_STREAM_END;
+}
+
+int zngamd_inflate_units_indexed_dev(zngamd_ctx *c, const void *d_def, uint64_t def_len, const uint32_t *unit_in_len, const uint32_t *unit_out_len,
+                                     uint32_t n_units, const uint32_t *d_index, const void *d_dict, uint32_t dict_len,
+                                     void *d_out, uint64_t out_cap, uint64_t *out_len)
+try {
+    if (!c || !d_def || !unit_in_len || !unit_out_len || !d_index || !d_out || !out_len || dict_len > ZA_WIN) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int r = inflate_units_core(c, (const uint8_t *)d_def, def_len, unit_in_len, unit_out_len, n_units, d_index, d_dict, dict_len, (uint8_t *)d_out, out_cap, out_len);
+    if (r == ZNGAMD_STREAM_END) c->paths[ZNGAMD_PATH_CHUNKED]++;
+    return r;
+} ZA_ABI_GUARD
+
+// ---- the index of a FILE's data member: what the writer leaves in the trailing empty members, parsed by the caller and handed to
+// the windowed reader through zngamd_gz_state.index
+struct ZaFileIndex {
+    uint32_t n = 0; int device = 0;
+    std::vector<uint32_t> in_len, out_len;
+    std::vector<uint64_t> cum_in, cum_out;       // bytes in front of unit k (n + 1 entries)
+    uint32_t *d_rows = nullptr;
+    bool dead = false;                           // it did not fit the stream once: never tried again
+};
+int zngamd_index_create(zngamd_ctx *c, uint32_t n_units, const uint32_t *unit_in_len, const uint32_t *unit_out_len, const uint32_t *rows, void **handle)
+try {
+    if (!c || !handle || (n_units && (!unit_in_len || !unit_out_len || !rows))) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    ZaFileIndex *ix = new ZaFileIndex();
+    ix->n = n_units; ix->device = c->device;
+    ix->in_len.assign(unit_in_len, unit_in_len + n_units); ix->out_len.assign(unit_out_len, unit_out_len + n_units);
+    ix->cum_in.resize((size_t)n_units + 1); ix->cum_out.resize((size_t)n_units + 1);
+    ix->cum_in[0] = ix->cum_out[0] = 0;
+    for (uint32_t u = 0; u < n_units; u++) {
+        if (unit_out_len[u] > ZA_MAX_UNIT) { delete ix; return fail(c, ZNGAMD_E_ARG, "a unit is larger than 128 KiB"); }
+        ix->cum_in[u + 1] = ix->cum_in[u] + unit_in_len[u]; ix->cum_out[u + 1] = ix->cum_out[u] + unit_out_len[u];
+    }
+    if (n_units) {
+        if (hipMalloc((void **)&ix->d_rows, (size_t)n_units * ZA_CIDX_STRIDE * 4) != hipSuccess) { delete ix; return fail(c, ZNGAMD_MEM_ERROR, "index rows"); }
+        if (hipMemcpy(ix->d_rows, rows, (size_t)n_units * ZA_CIDX_STRIDE * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(ix->d_rows); delete ix; return fail(c, ZNGAMD_E_HIP, "index rows"); }
+    }
+    *handle = ix;
+    return ZNGAMD_OK;
+} ZA_ABI_GUARD
+void zngamd_index_destroy(void *handle)
+{
+    ZaFileIndex *ix = (ZaFileIndex *)handle;
+    if (!ix) return;
+    if (ix->d_rows) { (void)hipSetDevice(ix->device); (void)hipFree(ix->d_rows); }
+    delete ix;
+}
+// the index of the context's last deflate call on the HOST, with the units' sizes (what a writer keeps for its file's trailing members)
+int zngamd_deflate_index(zngamd_ctx *c, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows)
+try {
+    if (!c || !unit_in_len || !unit_out_len || !rows) return ZNGAMD_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_units == 0) return ZNGAMD_OK;
+    if (n_units != c->last_units || !c->cidx.p || !c->last_unit_len || c->last_hu.size() != n_units) return fail(c, ZNGAMD_E_ARG, "the index is that of the context's last deflate call: its unit count differs");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(rows, c->cidx.p, (size_t)n_units * ZA_CIDX_STRIDE * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(unit_in_len, c->last_unit_len, (size_t)n_units * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t u = 0; u < n_units; u++) unit_out_len[u] = c->last_hu[u].in_len;
+    return ZNGAMD_OK;
 } ZA_ABI_GUARD
 
 int zngamd_crc32_fold_dev(zngamd_ctx *c, const uint32_t *d_crcs, uint32_t n, uint64_t each_len, uint64_t last_len, uint32_t *crc)
@@ -1875,8 +1944,12 @@ static int stream_finish(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, 
 // With a stream state (st, partial only) a FIRST member that runs past the window is not left alone: the blocks of it that
 // are complete were decoded on the way to finding that out, so they are handed out and the state says where the next
 // window continues (what zngamd_gunzip_stream would otherwise do in a second pass over the same window).
+struct ZaFileIndex;
+static int decode_stream_prefix_indexed(zngamd_ctx *c, ZaFileIndex *ix, uint64_t out_total, const uint8_t *h_def, const uint8_t *d_def, uint64_t avail,
+                                        const uint8_t *d_dict, uint32_t dict_len, uint8_t *d_out, uint64_t out_room, bool allow_cut,
+                                        StreamRun *run, uint64_t *needed);
 static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool partial, uint8_t *out, uint64_t out_cap,
-                       uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed, zngamd_gz_state *st = nullptr)
+                       uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed, zngamd_gz_state *st = nullptr, void *index = nullptr)
 {
     *out_len = 0;
     *in_consumed = 0;
@@ -2017,6 +2090,22 @@ static int gunzip_impl(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, bool p
             uint64_t piece = rest;
             if (members > 0) piece = std::min<uint64_t>(rest, std::max<uint64_t>(4ull << 20, 2 * last_member_bytes));
             int cr;
+            if (index && members == 0 && op == 0 && pos == 0) {
+                // the file's first member with the writer's index (zngamd_gz_state.index): its units inside the window side by side --
+                // all of the member if the window holds it, else as far as the window goes (the state then continues it)
+                StreamRun run; uint64_t needed = 0;
+                HIPCHK(c, c->st_out.ensure(out_cap + 64));
+                const int ri = decode_stream_prefix_indexed(c, (ZaFileIndex *)index, 0, in + doff, c->st_in.p + doff, in_len - doff, nullptr, 0,
+                                                            c->st_out.p, out_cap, partial && st, &run, &needed);
+                if (ri == ZNGAMD_BUF_ERROR) { *out_len = needed; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
+                if (ri < 0) return ri;
+                if (ri == 1 && (run.status == ZA_I_END || (partial && st && run.out_len))) {
+                    zngamd_gz_state tmp_state; zngamd_gz_state *ss = st;
+                    if (!ss) { memset(&tmp_state, 0, sizeof tmp_state); ss = &tmp_state; }
+                    ss->in_member = 0; ss->start_bit = 0; ss->crc = 0; ss->window_len = 0; ss->out_total = 0;
+                    return stream_finish(c, ss, in, in_len, doff, !partial, run, 0, out, out_cap, out_len, n_members, in_consumed);
+                }
+            }
             const bool may_continue = partial && st && members == 0 && op == 0 && pos == 0;
             ChunkOpts copts; copts.allow_cut = may_continue;
             for (;;) {
@@ -2105,6 +2194,40 @@ static int decode_stream_prefix(zngamd_ctx *c, const uint8_t *d_def, uint64_t av
     return ZNGAMD_OK;
 }
 
+// A window of a member whose units the writer indexed (zngamd_gz_state.index): the whole units inside the window, decoded side by
+// side.  1 = done (*run says how far), 0 = not applicable here (the caller decodes the window without the index), < 0 = error.
+static int decode_stream_prefix_indexed(zngamd_ctx *c, ZaFileIndex *ix, uint64_t out_total, const uint8_t *h_def, const uint8_t *d_def, uint64_t avail,
+                                        const uint8_t *d_dict, uint32_t dict_len, uint8_t *d_out, uint64_t out_room, bool allow_cut,
+                                        StreamRun *run, uint64_t *needed)
+{
+    if (!ix || ix->dead || ix->device != c->device) return 0;
+    const size_t k0 = (size_t)(std::lower_bound(ix->cum_out.begin(), ix->cum_out.end(), out_total) - ix->cum_out.begin());
+    if (k0 > ix->n || ix->cum_out[k0] != out_total) return 0;               // the reader does not stand at a unit's start
+    size_t k1 = k0;
+    while (k1 < ix->n && ix->cum_in[k1 + 1] - ix->cum_in[k0] <= avail && ix->cum_out[k1 + 1] - out_total <= out_room) k1++;
+    if (k1 < ix->n && ix->cum_in[k1 + 1] - ix->cum_in[k0] <= avail && !allow_cut) {       // (room, not input, ended the run, and nothing may be left over)
+        *needed = ix->cum_out[ix->n] - out_total; return ZNGAMD_BUF_ERROR;
+    }
+    uint64_t olen = 0;
+    const uint64_t used = ix->cum_in[k1] - ix->cum_in[k0];
+    if (k1 > k0) {
+        const int r = inflate_units_core(c, d_def, used, ix->in_len.data() + k0, ix->out_len.data() + k0, (uint32_t)(k1 - k0),
+                                         ix->d_rows + k0 * ZA_CIDX_STRIDE, d_dict, dict_len, d_out, out_room, &olen);
+        // (nothing was handed out: the window is decoded again, the ordinary way -- also behind "invalid data", which a wrong index
+        // entry looks like to the lane it sends into the middle of a code; real damage is then reported by the decoder that needs no index)
+        if (r == ZNGAMD_E_INDEX || r == ZNGAMD_DATA_ERROR) { ix->dead = true; return 0; }
+        if (r != ZNGAMD_STREAM_END) return r;
+    }
+    run->chunked = true; run->out_len = olen;
+    if (k1 == ix->n) {
+        // behind the last unit the writer closes the stream with an empty final block (03 00: gzip_ng_threaded.py:333)
+        if (avail >= used + 2 && h_def[used] == 0x03 && h_def[used + 1] == 0x00) { run->status = ZA_I_END; run->in_bits = (used + 2) * 8ull; return 1; }
+        if (avail >= used + 2) { ix->dead = true; if (k1 == k0) return 0; }  // something else follows: the rest without the index
+    }
+    run->status = ZA_I_INPUT; run->in_bits = used * 8ull;
+    return 1;
+}
+
 static int stream_step(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, uint64_t doff, bool last,
                        uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members, uint64_t *in_consumed)
 {
@@ -2115,6 +2238,12 @@ static int stream_step(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, ui
     if (dl) HIPCHK(c, hipMemcpyAsync(c->st_in.p, st->window, dl, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->st_out.ensure(out_cap + 64));
     StreamRun run; uint64_t needed = 0;
+    r = 0;
+    if (st->index && (st->start_bit & 7u) == 0u)
+        r = decode_stream_prefix_indexed(c, (ZaFileIndex *)st->index, st->out_total, in + doff, c->st_in.p + front + doff, in_len - doff,
+                                         c->st_in.p, dl, c->st_out.p, out_cap, !last, &run, &needed);
+    if (r == 1) r = ZNGAMD_OK;
+    else if (r == 0)
     r = decode_stream_prefix(c, c->st_in.p + front + doff, in_len - doff, st->start_bit & 7u, c->st_in.p, dl, c->st_out.p, out_cap, !last, &run, &needed);
     if (r == ZNGAMD_BUF_ERROR) { *out_len = needed > out_cap ? needed : out_cap; return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
     if (r) return r;
@@ -2152,6 +2281,7 @@ static int stream_finish(zngamd_ctx *c, zngamd_gz_state *st, const uint8_t *in, 
         if (n_members) *n_members = 1;
         c->paths[run.chunked ? ZNGAMD_PATH_CHUNKED : ZNGAMD_PATH_SEQUENTIAL]++;
         st->in_member = 0; st->start_bit = 0; st->crc = 0; st->window_len = 0; st->out_total = 0;
+        st->index = nullptr;                         // (the index was this member's; the handle stays the caller's)
         return ZNGAMD_OK;
     }
     // the member goes on: hand out the complete blocks, remember where and with what history to continue
@@ -2177,7 +2307,8 @@ try {
     *out_len = 0; *in_consumed = 0;
     if (n_members) *n_members = 0;
     if (st->in_member) return stream_step(c, st, in, in_len, 0, last != 0, out, out_cap, out_len, n_members, in_consumed);
-    int r = gunzip_impl(c, in, in_len, !last, out, out_cap, out_len, n_members, in_consumed, last ? nullptr : st);
+    int r = gunzip_impl(c, in, in_len, !last, out, out_cap, out_len, n_members, in_consumed, last ? nullptr : st, st->index);
+    if (*in_consumed > 0 && !st->in_member) st->index = nullptr;      // (the index was the first member's, and that one is through)
     if (r != ZNGAMD_OK || last || *in_consumed > 0 || in_len == 0) return r;
     // not even the first member is complete in this window: start it and hand out the blocks that are
     uint64_t doff = 0; bool za = false; uint32_t hl = 0;

@@ -4,6 +4,8 @@ There is no fallback: if the library is missing, or no MI355X-class GPU is usabl
 works but the first call that needs the engine raises ``RuntimeError``.
 """
 import ctypes as C
+
+import numpy as np
 import mmap as _mmap
 import os
 import sys
@@ -26,6 +28,16 @@ UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
 INDEX_STRIDE = 68        # ZNGAMD_INDEX_STRIDE
+FLAG_FINAL, FLAG_FLATHDR = 1, 2
+# The writer's segment index in a FILE (r06): behind the data member, EMPTY gzip members (header with FEXTRA, `03 00`, zero CRC and
+# ISIZE) whose 'Z','A' subfield holds: version 3, kind 1, the number of records (u16), the first record's unit number (u32), then
+# records of 138 bytes -- a unit's compressed bytes (u32, sync marker included), its output bytes (u32), 65 x u16: the bit offset of
+# its first segment's first token, then each segment's length in bits (the last one ends at the end-of-block code; zeros behind
+# it; all zeros = stored blocks).  The LAST of these members is a locator of 54 bytes (kind 2): members, units, bytes of the index
+# members, bytes of the data member in front of them -- a reader that can seek finds the index from the file's end.
+INDEX_REC = None
+INDEX_PER_MEMBER = 470
+INDEX_LOCATOR_BYTES = 54
 E_INDEX = -204
 K_NAMES = ["chains", "search", "parse", "plan", "pack", "gather", "scan", "inflate", "other", "optparse"]
 
@@ -43,13 +55,13 @@ SYMBOLS = [
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_deflate_index_dev", "zngamd_inflate_units_indexed_dev", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
+    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_deflate_index_dev", "zngamd_inflate_units_indexed_dev", "zngamd_index_create", "zngamd_index_destroy", "zngamd_deflate_index", "zngamd_indexed_units", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
 ]
 
 
 class GzState(C.Structure):                    # zngamd_gz_state
     _fields_ = [("in_member", C.c_uint32), ("start_bit", C.c_uint32), ("crc", C.c_uint32), ("window_len", C.c_uint32),
-                ("out_total", C.c_uint64), ("window", C.c_uint8 * 32768)]
+                ("out_total", C.c_uint64), ("window", C.c_uint8 * 32768), ("index", C.c_void_p)]
 
 
 class Block(C.Structure):
@@ -141,6 +153,12 @@ def load():
         L.zngamd_decode_paths.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.zngamd_debug_fetch.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t]
         L.zngamd_deflate_index_dev.argtypes = [vp, vp, C.c_uint32]
+        L.zngamd_index_create.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(vp)]
+        L.zngamd_index_destroy.argtypes = [vp]
+        L.zngamd_index_destroy.restype = None
+        L.zngamd_deflate_index.argtypes = [vp, C.c_uint32, vp, vp, vp]
+        L.zngamd_indexed_units.argtypes = [vp, C.c_int]
+        L.zngamd_indexed_units.restype = C.c_uint64
         L.zngamd_inflate_units_indexed_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, vp, vp, C.c_uint32,
                                                        vp, C.c_uint64, C.POINTER(C.c_uint64)]
         L.zngamd_debug_keep.argtypes = [vp, C.c_int]
@@ -359,6 +377,101 @@ def crc32_combine_many(crc, crcs, lens):
     a = (C.c_uint32 * max(n, 1))(*crcs)
     b = (C.c_uint64 * max(n, 1))(*lens)
     return load().zngamd_crc32_combine_many(crc & 0xFFFFFFFF, a, b, n)
+
+
+def _index_rec_dtype():
+    global INDEX_REC
+    if INDEX_REC is None:
+        INDEX_REC = np.dtype([("in_len", "<u4"), ("out_len", "<u4"), ("e", "<u2", (65,))])
+        assert INDEX_REC.itemsize == 138
+    return INDEX_REC
+
+
+def _za_member(payload):
+    """an empty gzip member whose FEXTRA field is one 'Z','A' subfield"""
+    import struct
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 4 + len(payload)) + b"ZA" + struct.pack("<H", len(payload)) +
+            payload + b"\x03\x00" + bytes(8))
+
+
+def index_members(recs, data_member_bytes):
+    """The index members + locator for the records of one data member (a list of INDEX_REC arrays in unit order)."""
+    import struct
+    allrec = np.concatenate(recs) if len(recs) != 1 else recs[0]
+    out, nm = [], 0
+    for lo in range(0, len(allrec), INDEX_PER_MEMBER):
+        part = allrec[lo:lo + INDEX_PER_MEMBER]
+        out.append(_za_member(struct.pack("<BBHI", 3, 1, len(part), lo) + part.tobytes()))
+        nm += 1
+    body = b"".join(out)
+    loc = _za_member(struct.pack("<BBHIIQQ", 3, 2, 0, nm, len(allrec), len(body), data_member_bytes))
+    assert len(loc) == INDEX_LOCATOR_BYTES
+    return body + loc
+
+
+def parse_index_tail(fp, start, end):
+    """The index of a file [start, end) that is ONE data member followed by index members (and, possibly, the plain empty member
+    the reference's close() leaves): -> (in_len, out_len, rows) as numpy arrays (rows: units x INDEX_STRIDE u32), or None.  The
+    file position is left where it was."""
+    import struct
+    here = fp.tell()
+    try:
+        tail_skip = 0
+        for attempt in (0, 1):
+            if end - start < INDEX_LOCATOR_BYTES + tail_skip + 20:
+                return None
+            fp.seek(end - tail_skip - INDEX_LOCATOR_BYTES)
+            loc = fp.read(INDEX_LOCATOR_BYTES)
+            if len(loc) == INDEX_LOCATOR_BYTES and loc[:4] == b"\x1f\x8b\x08\x04" and loc[12:14] == b"ZA" and loc[16] == 3 and loc[17] == 2:
+                break
+            if attempt == 0:                          # behind a trailing plain empty member?
+                fp.seek(end - 20)
+                plain = fp.read(20)
+                if len(plain) == 20 and plain[:4] == b"\x1f\x8b\x08\x00" and plain[10:] == b"\x03\x00" + bytes(8):
+                    tail_skip = 20
+                    continue
+            return None
+        _v, _k, _p, nm, nu, ibytes, dbytes = struct.unpack("<BBHIIQQ", loc[16:44])
+        if loc[44:] != b"\x03\x00" + bytes(8):
+            return None
+        ix0 = end - tail_skip - INDEX_LOCATOR_BYTES - ibytes
+        if ix0 - dbytes != start or nu == 0 or nu > (1 << 26) or ibytes > (1 << 34):
+            return None
+        fp.seek(ix0)
+        blob = fp.read(ibytes)
+        if len(blob) != ibytes:
+            return None
+        rt = _index_rec_dtype()
+        parts, at, seen = [], 0, 0
+        for _ in range(nm):
+            if blob[at:at + 4] != b"\x1f\x8b\x08\x04" or blob[at + 12:at + 14] != b"ZA":
+                return None
+            slen = struct.unpack_from("<H", blob, at + 14)[0]
+            v, k, n, first = struct.unpack_from("<BBHI", blob, at + 16)
+            if v != 3 or k != 1 or first != seen or slen != 8 + n * rt.itemsize:
+                return None
+            parts.append(np.frombuffer(blob, rt, n, at + 24))
+            seen += n
+            at += 16 + slen + 10
+        if seen != nu or at != ibytes:
+            return None
+        rec = np.concatenate(parts) if len(parts) != 1 else parts[0]
+        if int(rec["in_len"].astype(np.int64).sum()) + 10 + 10 != dbytes:        # header, units, 03 00, trailer
+            return None
+        rows = np.zeros((nu, INDEX_STRIDE), np.uint32)
+        nseg = (rec["out_len"].astype(np.int64) + 2047) >> 11
+        cum = np.cumsum(rec["e"].astype(np.uint32), axis=1, dtype=np.uint32)
+        cum[np.arange(65)[None, :] > nseg[:, None]] = 0
+        cum[rec["e"].max(axis=1) == 0] = 0                          # stored units
+        rows[:, :65] = cum
+        return np.ascontiguousarray(rec["in_len"]), np.ascontiguousarray(rec["out_len"]), rows
+    except (OSError, ValueError, struct.error):
+        return None
+    finally:
+        try:
+            fp.seek(here)
+        except (OSError, ValueError):
+            pass
 
 
 def block_table(blocks):
@@ -642,6 +755,26 @@ class Context:
                                                     C.c_void_p(int(d_out)), out_cap, C.byref(ol))
         return r, ol.value
 
+    def deflate_index_records(self, blocks):
+        """The units of this context's LAST deflate call (made with `blocks`: a list or a block_table) as index records
+        (INDEX_REC: compressed bytes, output bytes, 65 two-byte entries -- the first segment's bit offset, then every segment's
+        length in bits; all zeros: a unit of stored blocks)."""
+        arr, n = blocks if isinstance(blocks, tuple) and len(blocks) == 2 and isinstance(blocks[0], C.Array) else block_table(blocks)
+        nu = int(self.L.zngamd_count_units(arr, n))
+        uin = np.empty(nu, np.uint32); uout = np.empty(nu, np.uint32); rows = np.empty((nu, INDEX_STRIDE), np.uint32)
+        self._chk(self.L.zngamd_deflate_index(self.h, nu, uin.ctypes.data_as(C.c_void_p), uout.ctypes.data_as(C.c_void_p),
+                                              rows.ctypes.data_as(C.c_void_p)))
+        rec = np.zeros(nu, _index_rec_dtype())
+        rec["in_len"], rec["out_len"] = uin, uout
+        nseg = (uout.astype(np.int64) + 2047) >> 11
+        e = rows[:, :65].astype(np.int64)
+        d = np.diff(e, axis=1, prepend=0)
+        d[np.arange(65)[None, :] > nseg[:, None]] = 0            # (entries behind the end-of-block one mean nothing)
+        if d.min(initial=0) < 0 or d.max(initial=0) > 0xFFFF:
+            raise EngineError(E_ARG, "segment index out of range")
+        rec["e"] = d.astype(np.uint16)
+        return rec
+
     # ---- measurement
     def profiling(self, on):
         self._chk(self.L.zngamd_profiling(self.h, 1 if on else 0))
@@ -706,7 +839,7 @@ def contexts(limit=None):
     return out
 
 
-def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=None):
+def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=None, index=None):
     """deflate_blocks(joined=True) over several contexts: the blocks are cut into contiguous ranges of about equal input,
     one per context; every range goes to its GPU as the slice of `buf` it needs (its blocks and the dictionary in front of
     its first block -- the previous range's input tail), the ranges run side by side (the engine calls release the GIL) and
@@ -716,11 +849,18 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=Non
     made once by a caller whose batches repeat) serve the one-GPU case."""
     n = len(blocks)
     g = min(len(ctxs), n)
+    # `index` (a list, or None): the batch's segment-index records are appended to it, in unit order (Context.deflate_index_records
+    # of every range, taken right behind the range's engine call on its own context)
+    def one():
+        r = ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into)
+        if index is not None and not r[2]:
+            index.append(ctxs[0].deflate_index_records(table if table is not None else blocks))
+        return r
     if g <= 1 or sys.is_finalizing():      # (no new threads while the interpreter shuts down)
-        return ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into)
+        return one()
     total = sum(b[1] for b in blocks)
     if total < (8 << 20):
-        return ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into)
+        return one()
     mv = memoryview(buf)
     if mv.format != "B" or mv.ndim != 1:
         mv = mv.cast("B")
@@ -733,6 +873,7 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=Non
             k += 1
     cuts.append(n)
     parts = [None] * (len(cuts) - 1)
+    recs = [None] * (len(cuts) - 1)
     errs = []
 
     def run(j):
@@ -740,7 +881,10 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=Non
             sub = blocks[cuts[j]:cuts[j + 1]]
             lo = min(o - d for o, _, d, _ in sub)
             hi = max(o + ln for o, ln, _, _ in sub)
-            parts[j] = ctxs[j].deflate_blocks(mv[lo:hi], [(o - lo, ln, d, f) for o, ln, d, f in sub], level, out_cap, joined=True)
+            rel = [(o - lo, ln, d, f) for o, ln, d, f in sub]
+            parts[j] = ctxs[j].deflate_blocks(mv[lo:hi], rel, level, out_cap, joined=True)
+            if index is not None and not parts[j][2]:
+                recs[j] = ctxs[j].deflate_index_records(rel)
         except BaseException as exc:                      # raised in the caller's thread below
             errs.append(exc)
     ths = [threading.Thread(target=run, args=(j,), name=f"zng-amd-gpu{j}") for j in range(1, len(parts))]
@@ -751,6 +895,8 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=Non
         t.join()
     if errs:
         raise errs[0]
+    if index is not None and all(r is not None for r in recs):
+        index.extend(recs)
     packed = b"".join(p[0] for p in parts)
     crcs = [c for p in parts for c in p[1]]
     lens = [x for p in parts for x in p[3]]

@@ -787,6 +787,26 @@ class _GzipReader:
                 self._bulk_ok = bool(fp.seekable())
             except (AttributeError, OSError, ValueError):
                 self._bulk_ok = False
+        # (r06) a file written by this package's threaded writer carries, behind its data member, the segment index of that
+        # member's blocks (empty members with a 'ZA' FEXTRA subfield, a locator last: _lib.parse_index_tail): a source that can
+        # be sought is asked for it once, here, before anything reads ahead; the engine then decodes the units of every window
+        # side by side (zngamd_gz_state.index).  Any doubt -- no locator, sizes that do not add up -- and the file is read as
+        # any gzip file is.
+        self._index = None
+        if self._bulk_ok and _os.environ.get("ZNGAMD_NO_INDEX") is None:
+            try:
+                end = fp.seek(0, 2)
+                fp.seek(self._start)
+                got = _lib.parse_index_tail(fp, self._start, end) if end - self._start >= (1 << 16) else None
+                if got is not None:
+                    uin, uout, rows = got
+                    h = _C.c_void_p()
+                    ctx = _ctx()
+                    if ctx.L.zngamd_index_create(ctx.h, len(uin), uin.ctypes.data_as(_C.c_void_p), uout.ctypes.data_as(_C.c_void_p),
+                                                 rows.ctypes.data_as(_C.c_void_p), _C.byref(h)) == 0:
+                        self._index = h
+            except Exception:
+                self._index = None
         self._reset()
 
     @property
@@ -807,6 +827,8 @@ class _GzipReader:
         self._error = None       # raised once the buffered good bytes are gone
         self._first = True
         self._state = _lib.GzState()      # where a member larger than the window is being continued
+        if getattr(self, "_index", None) is not None:
+            self._state.index = self._index   # (the first member's; the engine forgets it when that member ends)
         self._out = None                  # decoded window (buffer, address); reused, so its pages are faulted in once
         self._spare = []                  # buffers given back by a consumer that took whole windows (_take_window)
         self._in_buf = None               # the compressed window: one buffer, refilled (the engine call is through by then)
@@ -1182,6 +1204,13 @@ class _GzipReader:
         self._closed = True
         with self._lock:
             self._release_windows()
+            ix, self._index = getattr(self, "_index", None), None
+            if ix is not None:                   # (no window is being decoded any more: nothing names the handle)
+                try:
+                    self._state.index = None
+                    _ctx().L.zngamd_index_destroy(ix)
+                except Exception:
+                    pass
 
     def readable(self):
         return True

@@ -59,7 +59,7 @@ def test_threaded_write_framing_matches_reference_layout(T, fastq):
     outs = []
     for threads in (1, 3):
         bio = io.BytesIO()
-        with T.open(bio, "wb", compresslevel=6, threads=threads, block_size=128 * 1024) as f:
+        with T.open(bio, "wb", compresslevel=6, threads=threads, block_size=128 * 1024, exact_framing=True) as f:
             f.write(data)
         outs.append(bio.getvalue())
     assert outs[0] == outs[1]
@@ -330,7 +330,9 @@ def test_writer_pieces_of_every_size_class(T):
     d = zlib.decompressobj(31)
     got = d.decompress(out.getvalue())
     assert got == src[:pos] and d.eof
-    assert d.unused_data[:4] == b"\x1f\x8b\x08\x00"             # the trailing empty member of the reference's writer
+    # behind the data: the empty members that carry the writer's segment index (FEXTRA), then the plain empty member of the
+    # reference's close()
+    assert d.unused_data[:4] == b"\x1f\x8b\x08\x04" and d.unused_data.endswith(b"\x1f\x8b\x08\x00" + bytes(4) + b"\xff\x00\x03\x00" + bytes(8))
 
 
 def test_packed_batch_output_equals_the_per_block_form():

@@ -135,3 +135,88 @@ def test_damage_is_reported(ctx):
     # a wrong index: the neighbour's rows
     r, n, back = _decode(ctx, stream, uin[::-1], uout, d_index)
     assert r != _lib.STREAM_END or back == data
+
+
+# ---- the same through files: the threaded writer leaves the index behind its data member, the reader finds and uses it ----
+
+def _write(T, data, **kw):
+    import io
+    bio = io.BytesIO()
+    with T.open(bio, "wb", compresslevel=6, threads=1, **kw) as f:
+        for o in range(0, len(data), 1 << 20):
+            f.write(data[o:o + (1 << 20)])
+    return bio.getvalue()
+
+
+def test_writer_leaves_an_index_any_reader_skips(ctx):
+    import gzip
+    import io
+    import struct
+    from zlib_ng_amd import gzip_ng_threaded as T, _lib
+    data = _mix(9 * B + 4321, 41)
+    blob = _write(T, data, block_size=B)
+    # layout: the reference's (header 1f8b0800 00000000 ff xfl | blocks | 03 00 | crc isize), then empty members with FEXTRA, the
+    # locator, and the plain empty member close() leaves (gzip_ng_threaded.py:340-342)
+    assert blob[:10] == bytes.fromhex("1f8b0800" "00000000" "ff00")
+    assert blob.endswith(bytes.fromhex("1f8b0800" "00000000" "ff00" "0300" "00000000" "00000000"))
+    loc = blob[-20 - _lib.INDEX_LOCATOR_BYTES:-20]
+    assert loc[:4] == b"\x1f\x8b\x08\x04" and loc[12:14] == b"ZA" and loc[16:18] == b"\x03\x02"
+    nm, nu, ibytes, dbytes = struct.unpack("<IIQQ", loc[20:44])
+    assert nu == 10 and blob[dbytes - 10:dbytes - 8] == b"\x03\x00"
+    assert struct.unpack("<II", blob[dbytes - 8:dbytes]) == (zlib.crc32(data), len(data))
+    assert gzip.decompress(blob) == data                     # the system gzip reads all of it: one member of data, empty ones behind
+    got = _lib.parse_index_tail(io.BytesIO(blob), 0, len(blob))
+    assert got is not None and len(got[0]) == 10 and int(got[1].sum()) == len(data)
+    # the r05 bytes on request: no index, nothing between the trailer and the plain empty member
+    exact = _write(T, data, block_size=B, exact_framing=True)
+    assert b"ZA" not in exact[-200:] and gzip.decompress(exact) == data and _lib.parse_index_tail(io.BytesIO(exact), 0, len(exact)) is None
+
+
+def test_reader_decodes_windows_with_the_index(ctx, monkeypatch):
+    import io
+    from zlib_ng_amd import gzip_ng_threaded as T, gzip_ng, _lib
+    data = _mix(40 * B + 777, 43)
+    blob = _write(T, data, block_size=B)
+    monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(1 << 20))         # a member much larger than the window: it is read window by window
+    ctx.L.zngamd_indexed_units(ctx.h, 1)
+    with T.open(io.BytesIO(blob), "rb") as f:
+        back = f.read()
+    assert back == data
+    used = ctx.L.zngamd_indexed_units(ctx.h, 1)
+    assert used == 41, used                                          # every unit, the first window's included
+    with gzip_ng.open(io.BytesIO(blob), "rb") as f:
+        assert f.read() == data
+    # a damaged index is no index: the file still reads
+    bad = bytearray(blob)
+    at = blob.rindex(b"ZA", 0, len(blob) - 100)
+    bad[at + 40] ^= 0x55
+    ctx.L.zngamd_indexed_units(ctx.h, 1)
+    with T.open(io.BytesIO(bytes(bad)), "rb") as f:
+        assert f.read() == data
+    # damage in the data is reported as the CRC check reports it (the index changes how, not whether)
+    bad = bytearray(blob)
+    bad[len(blob) // 3] ^= 0x10
+    with pytest.raises(Exception):
+        with T.open(io.BytesIO(bytes(bad)), "rb") as f:
+            f.read()
+    monkeypatch.setenv("ZNGAMD_NO_INDEX", "1")
+    ctx.L.zngamd_indexed_units(ctx.h, 1)
+    with T.open(io.BytesIO(blob), "rb") as f:
+        assert f.read() == data
+    assert ctx.L.zngamd_indexed_units(ctx.h, 1) == 0
+
+
+def test_reader_many_windows_of_varying_size(ctx, monkeypatch):
+    """windows that hold a different number of units each time (the decoder's unit areas grow, and with them go the markers in
+    front of every unit): a file of 700 units read through windows of 3 MiB, then 5 MiB"""
+    import io
+    from zlib_ng_amd import gzip_ng_threaded as T, corpus
+    data = corpus.text(700 * B + 99, seed=77).tobytes()
+    blob = _write(T, data, block_size=B)
+    for win in (3 << 20, 5 << 20, 1 << 20):
+        monkeypatch.setenv("ZNGAMD_READ_WINDOW", str(win))
+        ctx.L.zngamd_indexed_units(ctx.h, 1)
+        with T.open(io.BytesIO(blob), "rb") as f:
+            back = f.read()
+        assert back == data, win
+        assert ctx.L.zngamd_indexed_units(ctx.h, 1) == 701, win

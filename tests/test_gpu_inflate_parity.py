@@ -260,13 +260,22 @@ def test_threaded_writer_output_is_read_chunk_parallel(ctx, fastq):
     from zlib_ng_amd import gzip_ng_threaded
     data = fastq + fastq
     bio = io.BytesIO()
-    with gzip_ng_threaded.open(bio, "wb", compresslevel=6, threads=8, block_size=128 * 1024) as f:
+    with gzip_ng_threaded.open(bio, "wb", compresslevel=6, threads=8, block_size=128 * 1024, exact_framing=True) as f:
         f.write(data)
     blob = bio.getvalue()
     ctx.profiling(True); ctx.kernel_times(True)
     code, out, nm = ctx.gunzip(blob, len(data))
     kt = ctx.kernel_times(True); ctx.profiling(False)
     assert code == 0 and out == data and nm == 2 and kt["scan"][1] >= 1
+    with gzip_ng_threaded.open(io.BytesIO(blob), "rb") as f:
+        assert f.read() == data
+    # the default framing: the same member, then the empty members that hold the segment index, the locator, the plain empty one
+    bio = io.BytesIO()
+    with gzip_ng_threaded.open(bio, "wb", compresslevel=6, threads=8, block_size=128 * 1024) as f:
+        f.write(data)
+    blob = bio.getvalue()
+    code, out, nm = ctx.gunzip(blob, len(data))
+    assert code == 0 and out == data and nm == 4
     with gzip_ng_threaded.open(io.BytesIO(blob), "rb") as f:
         assert f.read() == data
 
