@@ -186,9 +186,12 @@ def main():
     d_in = d_buf[HALO:]
     ctx.sync()
 
+    BLOCK_FLAGS = 0 if os.environ.get("BENCH_EXACT_FRAMING") == "1" else _lib.FLAG_SEG2K
     blocks = (_lib.Block * nblocks)()
     for b in range(nblocks):        # offsets inside d_buf; only the very first block of the whole stream has no dictionary
-        blocks[b] = _lib.Block(HALO + b * BLOCK, BLOCK, 32768 if (b or blo) else 0, 0, 0)
+        # (flags: what the default writer of r06 asks for -- gzip_ng_threaded.py in this package: 2 KiB segments in blocks of any
+        # size, which for these full-size blocks is what they have anyway; BENCH_EXACT_FRAMING=1: no flag, and no index leg)
+        blocks[b] = _lib.Block(HALO + b * BLOCK, BLOCK, 32768 if (b or blo) else 0, BLOCK_FLAGS, 0)
     n_units = L.zngamd_count_units(blocks, nblocks)
     assert n_units == nblocks
     d_ulen = dempty(4 * n_units)
@@ -272,6 +275,9 @@ def main():
     ctx.profiling(False)
     if exchange:
         dt = comm.max(dt)
+    # the segment index of the compress leg's last call (what the writer puts behind its data member): taken now, before any
+    # other deflate call of this context replaces it
+    d_index = ctx.deflate_index(n_units) if (rank == 0 and blo == 0 and BLOCK_FLAGS and not args.no_foreign) else None
 
     # ---- correctness of what was timed -------------------------------------------------------------
     # Every collective of the verification runs BEFORE the first assert, and the verdicts are exchanged afterwards: a rank whose
@@ -419,13 +425,40 @@ def main():
                    "frac": round(fbytes / (min(f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(fbytes)}
         del d_for, d_tile, d_ft
 
-    # ---- what the drop-in writer writes, decoded: the compress leg's OWN gathered stream (one raw deflate stream of dict-chained,
-    # sync-flushed 128 KiB blocks: gzip_ng_threaded.py:299-338 -- what gzip_ng_threaded.open(..., "rb") and zlib_ng.decompress get
-    # for every file this product or the reference writes) through the chunk-parallel decoder; outside the timed region ----
-    chained = None
+    # ---- what the drop-in writer writes, decoded: the compress leg's OWN stream (one raw deflate stream of dict-chained, sync-flushed
+    # 128 KiB blocks: gzip_ng_threaded.py:299-338 -- what gzip_ng_threaded.open(..., "rb") gets for a file of this package's default
+    # writer), (a) with the writer's segment index, as the reader decodes a file that carries it (zngamd_inflate_units_indexed_dev:
+    # the units side by side, a lane per 2 KiB segment, markers for what reaches in front of a unit), (b) without it -- a pipe, a file
+    # of the reference's writer, exact_framing=True: sync points found by a scan, self-synchronising sweeps inside the blocks
+    # (zngamd_inflate_raw_dev); outside the timed region ----
+    chained = chained_ix = None
     if rank == 0 and blo == 0 and not args.no_foreign:
         d_comp[comp_bytes:comp_bytes + 66] = 0
         d_comp[comp_bytes] = 3                                   # empty final block
+        if d_index is not None:
+            uin = i32(d_ulen).astype(np.uint32).tolist()
+            x_wall, x_kern = [], []
+            for it in range(3):
+                d_out.zero_()
+                ctx.sync()
+                ctx.profiling(True); ctx.kernel_times(reset=True)
+                t = time.perf_counter()
+                rc, xl = ctx.inflate_units_indexed_dev(d_comp.ptr, comp_bytes + 2, uin, [BLOCK] * n_units, d_index.ptr, d_out.ptr, size)
+                x_wall.append((time.perf_counter() - t) * 1e3)
+                x_kern.append(sum(v[0] for v in ctx.kernel_times(reset=True).values()))
+                ctx.profiling(False)
+                assert rc == _lib.STREAM_END and xl == size, (rc, xl, ctx.err())
+            assert d_out[:size].equal(d_in[:size]), "indexed chained stream: output differs"
+            xb = comp_bytes + size
+            xms = min(x_wall)
+            chained_ix = {"bound": "hbm", "kernel": "za_k_inflate_units_marked + za_k_chunk_compose / _chain / _resolve",
+                          "stream": f"the compress leg's own output: ONE raw deflate stream, {nblocks} dict-chained blocks of 128 KiB ending in sync flushes; "
+                                    f"the writer's segment index beside it (138 bytes per block in a file's trailing members)",
+                          "ms": round(xms, 3), "kernel_ms": round(min(x_kern), 3),
+                          "decompress_MBps": round(size / (xms * 1e-3) / 1e6, 1),
+                          "achieved": round(xb / (xms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(xb / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(xb),
+                          "note": "ms = the whole device-resident call (host-side tables and the result read-back included), best of 3"}
         vlen, vused = C.c_uint64(0), C.c_uint64(0)
         c_wall, c_kern = [], []
         for it in range(3):
@@ -442,52 +475,12 @@ def main():
         cbytes = comp_bytes + size
         cms = min(c_wall)
         chained = {"bound": "hbm", "kernel": "za_k_chunk_decode + za_k_chunk_compose / _chain / _resolve (+ za_k_scan_sync)",
-                   "stream": f"the compress leg's own output: ONE raw deflate stream, {nblocks} dict-chained blocks of 128 KiB ending in sync flushes",
+                   "stream": f"the same stream WITHOUT its index (what a pipe, or a file of the reference's writer, offers): {nblocks} dict-chained blocks of 128 KiB ending in sync flushes",
                    "ms": round(cms, 3), "kernel_ms": round(min(c_kern), 3),
                    "decompress_MBps": round(size / (cms * 1e-3) / 1e6, 1),
                    "achieved": round(cbytes / (cms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(cbytes),
                    "note": "ms = the whole device-resident call (its host-side planning between the kernels included), best of 3"}
-
-    # ---- the same single-member framing WITH the writer's segment index (r06: flat dynamic headers, the index in the file's
-    # trailing empty members): the units decode side by side, a lane per 2 KiB segment, matches that reach in front of their unit
-    # through markers (zngamd_inflate_units_indexed_dev) ----
-    chained_ix = None
-    if rank == 0 and blo == 0 and not args.no_foreign:
-        fblocks = (_lib.Block * nblocks)()
-        for b in range(nblocks):
-            fblocks[b] = _lib.Block(HALO + b * BLOCK, BLOCK, 32768 if b else 0, 2, 0)          # ZNGAMD_FLAG_FLATHDR
-        ftotal = C.c_uint64(0)
-        chk(L.zngamd_deflate_blocks_packed_dev(h, ptr(d_buf), HALO + size, fblocks, nblocks, args.level, ptr(d_comp), d_comp.numel() - 64,
-                                               ptr(d_ulen), ptr(d_ucrc), None, C.byref(ftotal)), "deflate_blocks_packed_dev (flat headers)")
-        d_index = ctx.deflate_index(n_units)
-        uin = d_ulen.cpu(np.uint32)[:n_units].tolist()
-        fbytes_c = int(ftotal.value)
-        d_comp[fbytes_c:fbytes_c + 66] = 0
-        d_comp[fbytes_c] = 3
-        x_wall, x_kern = [], []
-        for it in range(3):
-            d_out.zero_()
-            ctx.sync()
-            ctx.profiling(True); ctx.kernel_times(reset=True)
-            t = time.perf_counter()
-            rc, xl = ctx.inflate_units_indexed_dev(d_comp.ptr, fbytes_c + 2, uin, [BLOCK] * n_units, d_index.ptr, d_out.ptr, size)
-            x_wall.append((time.perf_counter() - t) * 1e3)
-            x_kern.append(sum(v[0] for v in ctx.kernel_times(reset=True).values()))
-            ctx.profiling(False)
-            assert rc == _lib.STREAM_END and xl == size, (rc, xl, ctx.err())
-        assert d_out[:size].equal(d_in[:size]), "indexed chained stream: output differs"
-        xb = fbytes_c + size
-        xms = min(x_wall)
-        chained_ix = {"bound": "hbm", "kernel": "za_k_inflate_units_marked + za_k_chunk_compose / _chain / _resolve",
-                      "stream": f"ONE raw deflate stream, {nblocks} dict-chained blocks of 128 KiB ending in sync flushes, flat dynamic headers; "
-                                f"the writer's segment index beside it ({68 * 4} bytes per unit on the device, 2-byte deltas in a file)",
-                      "ratio": round(size / fbytes_c, 4), "ms": round(xms, 3), "kernel_ms": round(min(x_kern), 3),
-                      "decompress_MBps": round(size / (xms * 1e-3) / 1e6, 1),
-                      "achieved": round(xb / (xms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(xb / (xms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": int(xb),
-                      "note": "ms = the whole device-resident call, best of 3"}
-        del d_index
 
     # ---- BGZF: standard 'BC' members (at most 65 280 bytes of input each, FEXTRA subfield BC = member size - 1) written by the
     # system zlib, one wavefront per member; outside the timed region ----
@@ -734,10 +727,6 @@ def main():
     if foreign is not None:
         out["roofline_inflate_foreign"] = foreign
     if chained is not None:
-        # compress + the decode of the very stream the compress leg wrote (what gzip_ng_threaded.open("rb") gets for a file of the
-        # default writer), beside `value`, whose decode leg reads indexed members
-        out["value_chained"] = round(total_size / ((deflate_ms + chained["ms"]) * 1e-3) / 1e6, 1)
-        out["value_chained_note"] = "MB/s of compress + chunk-parallel decode of the compress leg's own single-member stream (kernel time of the deflate leg + the whole device-resident decode call)"
         # HBM bytes of the chunk pipeline's kernels for one decode of the stream: the counter passes give every kernel's average
         # launch (per unit of the launch size they were taken at); a decode launches each of them once per batch of compressed input
         # (ZNGAMD_CHUNK_BATCH_MIB, 512 by default), so average x batches = the kernel's share of one decode
@@ -747,10 +736,22 @@ def main():
             nbatch = max(1, -(-comp_bytes // batch))
             chained["traffic"] = int(sum(pmc_per_unit[k] for k in ck) * nblocks * nbatch)
             chained["traffic_source"] = traffic_src + f"; {nbatch} batches per decode"
-        out["roofline_inflate_chained"] = chained
-    if chained_ix is not None:
-        out["roofline_inflate_chained_indexed"] = chained_ix
-        out["value_chained_indexed"] = round(total_size / ((deflate_ms + chained_ix["ms"]) * 1e-3) / 1e6, 1)
+    # compress + the decode of the very stream the compress leg wrote (what gzip_ng_threaded.open("rb") gets for a file of the default
+    # writer), beside `value`, whose decode leg reads indexed members: with the writer's index when the stream has one
+    primary = chained_ix if chained_ix is not None else chained
+    if primary is not None:
+        out["value_chained"] = round(total_size / ((deflate_ms + primary["ms"]) * 1e-3) / 1e6, 1)
+        out["value_chained_note"] = ("MB/s of compress + decode of the compress leg's own single-member stream " +
+                                     ("with the writer's segment index" if chained_ix is not None else "without an index") +
+                                     " (kernel time of the deflate leg + the whole device-resident decode call)")
+        if chained_ix is not None and pmc_per_unit.get("za_k_inflate_units_marked"):
+            ck2 = ("za_k_inflate_units_marked", "za_k_chunk_compose", "za_k_chunk_chain", "za_k_chunk_resolve")
+            chained_ix["traffic"] = int(sum(pmc_per_unit.get(k, 0) for k in ck2) * nblocks)
+            chained_ix["traffic_source"] = traffic_src
+        out["roofline_inflate_chained"] = primary
+        if chained_ix is not None and chained is not None:
+            out["roofline_inflate_chained_noindex"] = chained
+            out["value_chained_noindex"] = round(total_size / ((deflate_ms + chained["ms"]) * 1e-3) / 1e6, 1)
     if bgzf is not None:
         if pmc_per_unit.get("za_k_inflate_serial_members"):
             # (the counter passes average this kernel's launches over the foreign-member and the BGZF leg: both decode the same text)

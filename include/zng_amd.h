@@ -53,6 +53,8 @@ typedef struct zngamd_ctx zngamd_ctx;
 #define ZNGAMD_FLAG_FLATHDR    2u     /* dynamic block headers in their flat form: the code-length code is the fixed 4-bit
                                          code of the symbols 0..15, so a decoder finds every code length at a known bit offset
                                          (what zngamd_gzip_members* writes; any inflater reads it as an ordinary dynamic header) */
+#define ZNGAMD_FLAG_SEG2K      16u    /* segments of 2 KiB whatever the block's size (small blocks take smaller ones otherwise): what the
+                                       * segment index of a dict-chained stream is counted in (zngamd_deflate_index) */
 /* window of the stream the blocks belong to: match distances stay within 2^bits (deflateInit2's windowBits 9..15).
  * Taken from the FIRST block of a call and applied to all of them; 0 = 15. */
 #define ZNGAMD_FLAG_WBITS(bits) (((uint32_t)(bits) & 15u) << 8)

@@ -52,6 +52,7 @@ extern "C" {
 #define ZA_DP_SUB      4         /* the dynamic programme also tries the 4 next shorter lengths of a position's match */
 
 #define ZA_FLAG_FINAL 1         /* last block gets BFINAL=1, no sync-flush marker    */
+#define ZA_FLAG_SEG2K 16        /* segments of 2 KiB whatever the unit's size (the threaded writer: its segment index counts in them) */
 #define ZA_FLAG_FLATHDR 2       /* dynamic header in its flat form: the code-length code is the fixed 4-bit code of
                                    the symbols 0..15 (no run-length symbols), so every code length sits at a known bit
                                    offset and a decoder can read the header in parallel (indexed gzip members)        */

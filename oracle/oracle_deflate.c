@@ -49,7 +49,7 @@ static const za_level LEVELS[10] = {
  * so that the kernels, which give a lane to each segment, do not walk a small input with one lane. */
 int za_o_seg_shift(int n, int flags)
 {
-    if ((flags & ZA_FLAG_FLATHDR) || n > 65536) return 11;
+    if ((flags & (ZA_FLAG_FLATHDR | ZA_FLAG_SEG2K)) || n > 65536) return 11;
     int s = 5;
     while ((64 << s) < n) s++;
     return s;

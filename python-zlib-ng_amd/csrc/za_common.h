@@ -35,6 +35,7 @@
 #define ZA_FLAG_FLATHDR 2u      // dynamic header in its flat form (4-bit code lengths at fixed offsets): indexed members
 #define ZA_FLAG_CARRY   4u      // (set by the host) the unit's 32 KiB dictionary is the tail of the unit in front of it in the batch:
                                 // inside a run the chain tables are carried over instead of inserting the dictionary again
+#define ZA_FLAG_SEG2K   16u     // segments of 2 KiB whatever the unit's size (what the segment index of a dict-chained stream counts in: the threaded writer)
 #define ZA_FLAG_RUNHEAD 8u      // (set by the host) first unit of a chain-kernel run: its dictionary IS inserted, its links are all in its own row
 // bits 8..11 of a unit's flags (set by the host, za_seg_shift_for): log2 of the unit's SEGMENT size.  A unit is always cut into at
 // most 64 segments (token boundaries are forced there: parse, dynamic programme and packer give a lane to each); a full unit's are
@@ -60,7 +61,7 @@
 
 __host__ __device__ inline int za_seg_shift_for(uint32_t n, uint32_t flags)
 {
-    if ((flags & ZA_FLAG_FLATHDR) != 0u || n > 65536u) return ZA_SEG_SHIFT;
+    if ((flags & (ZA_FLAG_FLATHDR | ZA_FLAG_SEG2K)) != 0u || n > 65536u) return ZA_SEG_SHIFT;
     int s = 5;
     while ((64u << s) < n) s++;
     return s;

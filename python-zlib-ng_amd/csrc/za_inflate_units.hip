@@ -3,9 +3,10 @@
 // that the units need not wait for each other (a source in front of a unit is a marker; the chunk pipeline's window kernels
 // -- za_k_chunk_compose / _chain / _resolve -- turn markers into bytes).  Product code; included by zng_amd.hip behind za_inflate.hip.
 //
-// The unit's stream must be what this engine writes with ZA_FLAG_FLATHDR: one Huffman block per unit (fixed, or dynamic with the
-// flat header), token boundaries at every 2 KiB of output, codes of at most 10 / 9 bits; the index = cidx of za_k_pack.  Anything
-// else is reported (ZA_I_INDEX) and the caller decodes the stream without the index.
+// The unit's stream must be what this engine writes for full-size units (or with ZA_FLAG_FLATHDR for smaller ones): one block per
+// unit -- stored blocks, fixed, or dynamic with the header in either form --, token boundaries at every 2 KiB of output, codes of at
+// most 10 / 9 bits; the index = cidx of za_k_pack.  Anything else is reported (ZA_I_INDEX) and the caller decodes the stream
+// without the index.
 #pragma once
 
 __global__ __launch_bounds__(64, 5) void za_k_inflate_units_marked(const uint8_t *__restrict__ in, uint64_t in_total,
@@ -77,17 +78,73 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_units_marked(const uint8_t
     const int last = (int)(bits & 1u), type = (int)((bits >> 1) & 3u);
     uint32_t nlen = 288, ndist = 30, hdr_end = 3;
     bool hdr_ok = type == 1 || type == 2;                            // (a unit in mid-stream is not the last block; the stream's last one may be)
+    bool flat = false;
     if (hdr_ok && type == 2) {
         nlen = (uint32_t)((bits >> 3) & 31u) + 257u; ndist = (uint32_t)((bits >> 8) & 31u) + 1u;
         uint64_t want = 0;
         for (int i = 3; i < 19; i++) want |= 4ull << (3 * i);
-        hdr_end = 74u + 4u * (nlen + ndist);
-        hdr_ok = in_bits >= 74 && ((bits >> 13) & 15u) == 15u && (za_peek(src, 17) & ((1ull << 57) - 1ull)) == want && nlen <= 286 && ndist <= 30 &&
-                 hdr_end <= in_bits;
+        hdr_ok = in_bits >= 74 && nlen <= 286 && ndist <= 30;
+        flat = hdr_ok && ((bits >> 13) & 15u) == 15u && (za_peek(src, 17) & ((1ull << 57) - 1ull)) == want;
+        if (flat) { hdr_end = 74u + 4u * (nlen + ndist); hdr_ok = hdr_end <= in_bits; }
     }
-    if (!hdr_ok || __shfl(my_start, 0, 64) != hdr_end) ZA_UM_FAIL(ZA_I_INDEX);
+    if (!hdr_ok) ZA_UM_FAIL(ZA_I_INDEX);
     {
         bool toolong = false;
+        if (type == 2 && !flat) {
+            // The ordinary dynamic header (what the writer leaves unless asked for flat ones): HCLEN code-length code lengths, then
+            // the run-length coded lengths, decoded by ONE lane -- about 300 dependent steps through the header's bytes, a twentieth
+            // of what the unit's tokens cost its lanes -- into a byte per symbol; everything behind is the flat form's path.
+            const uint32_t ncode = (uint32_t)((bits >> 13) & 15u) + 4u;
+            if (17u + 3u * ncode > in_bits) ZA_UM_FAIL(ZA_I_INDEX);
+            __syncthreads();
+            if (lane < 19) B.lens[lane] = 0;
+            __syncthreads();
+            if (lane == 0) for (uint32_t i = 0; i < ncode; i++) B.lens[za_i_cl_order[i]] = (uint8_t)(za_peek(src, 17u + 3u * i) & 7u);
+            if (za_build_table(B.lens, 19, B.cnt_d, B.sym_d, B.tmp_d, 7, &scratch[0], &scratch[1]) != 0) ZA_UM_FAIL(ZA_I_INDEX);       // (must be complete)
+            __syncthreads();
+            uint8_t *seq = (uint8_t *)B.sym_l;                         // 576 bytes: the nlen + ndist <= 316 lengths in stream order
+            if (lane == 0) {
+                uint64_t bp = 17u + 3u * ncode;
+                uint32_t idx = 0, prev = 0;
+                int err = 0;
+                while (idx < nlen + ndist) {
+                    if (bp + 15u > in_bits) { err = 1; break; }
+                    const uint64_t b = za_peek(src, bp);
+                    const uint32_t e = za_decode_sym(b, B.tmp_d, 7, B.cnt_d, B.sym_d);
+                    if (!e) { err = 1; break; }
+                    const uint32_t sy = e >> 4, l = e & 15u;
+                    bp += l;
+                    if (sy < 16u) { seq[idx++] = (uint8_t)sy; prev = sy; continue; }
+                    uint32_t rep, val = 0;
+                    const uint64_t x = b >> l;
+                    if (sy == 16u) { if (idx == 0) { err = 1; break; } val = prev; rep = 3u + (uint32_t)(x & 3u); bp += 2; }
+                    else if (sy == 17u) { rep = 3u + (uint32_t)(x & 7u); bp += 3; }
+                    else { rep = 11u + (uint32_t)(x & 127u); bp += 7; }
+                    if (idx + rep > nlen + ndist) { err = 1; break; }
+                    while (rep--) seq[idx++] = (uint8_t)val;
+                    prev = val;
+                }
+                scratch[0] = err; scratch[1] = (int)bp;
+            }
+            __syncthreads();
+            if (scratch[0] != 0) ZA_UM_FAIL(ZA_I_INDEX);
+            hdr_end = (uint32_t)scratch[1];
+            __syncthreads();
+            uint32_t vv[5];
+#pragma unroll
+            for (int b5 = 0; b5 < 5; b5++) {
+                const int i = lane + 64 * b5;
+                const bool isl = (uint32_t)i < nlen, isd = i >= 288 && (uint32_t)(i - 288) < ndist;
+                vv[b5] = isl ? seq[i] : isd ? seq[nlen + (uint32_t)(i - 288)] : 0u;
+            }
+            __syncthreads();                                           // (the sequence lies where the tables' symbol lists go)
+#pragma unroll
+            for (int b5 = 0; b5 < 5; b5++) {
+                const int i = lane + 64 * b5;
+                toolong = toolong || vv[b5] > (i < 288 ? (uint32_t)ZA_ML_BITS : (uint32_t)ZA_MD_BITS);
+                B.lens[i] = (uint8_t)vv[b5];
+            }
+        } else
         for (int i = lane; i < 320; i += 64) {
             uint32_t v = 0;
             if (type == 1) v = i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : i < 288 ? 8u : i < 318 ? 5u : 0u;
@@ -102,6 +159,7 @@ __global__ __launch_bounds__(64, 5) void za_k_inflate_units_marked(const uint8_t
             toolong = toolong || v > (i < 288 ? (uint32_t)ZA_ML_BITS : (uint32_t)ZA_MD_BITS);
             B.lens[i] = (uint8_t)v;
         }
+        if (__shfl(my_start, 0, 64) != hdr_end) ZA_UM_FAIL(ZA_I_INDEX);
         if (__ballot(toolong) != 0ull) ZA_UM_FAIL(ZA_I_INDEX);
         __syncthreads();
         // plain tables ((symbol << 4) | length) first -- the distance one in the row area -- then the entries are rewritten

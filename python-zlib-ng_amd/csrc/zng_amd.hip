@@ -463,7 +463,7 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
             u.in_off = B.off + rel;
             u.in_len = (uint32_t)std::min<uint64_t>(ZA_MAX_UNIT, B.len - rel);
             u.dict_len = (uint32_t)std::min<uint64_t>(ZA_WIN, (uint64_t)B.dict_len + rel);
-            u.flags = (B.flags & ZNGAMD_FLAG_FLATHDR) | ((k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u);
+            u.flags = (B.flags & (ZNGAMD_FLAG_FLATHDR | ZNGAMD_FLAG_SEG2K)) | ((k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u);
             u.flags |= (uint32_t)za_seg_shift_for(u.in_len, u.flags) << 8;       // the unit's segment size (za_common.h: small units take small segments)
             u.block = b;
             // the unit's whole 32 KiB dictionary is the tail of the unit in front of it: the chain tables may be carried over

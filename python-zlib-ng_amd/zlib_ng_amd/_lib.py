@@ -28,7 +28,7 @@ UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
 INDEX_STRIDE = 68        # ZNGAMD_INDEX_STRIDE
-FLAG_FINAL, FLAG_FLATHDR = 1, 2
+FLAG_FINAL, FLAG_FLATHDR, FLAG_SEG2K = 1, 2, 16
 # The writer's segment index in a FILE (r06): behind the data member, EMPTY gzip members (header with FEXTRA, `03 00`, zero CRC and
 # ISIZE) whose 'Z','A' subfield holds: version 3, kind 1, the number of records (u16), the first record's unit number (u32), then
 # records of 138 bytes -- a unit's compressed bytes (u32, sync marker included), its output bytes (u32), 65 x u16: the bit offset of

@@ -223,14 +223,15 @@ class _ThreadedGzipWriter(io.RawIOBase):
             indexed_members = os.environ.get("ZNGAMD_WRITER_MEMBERS", "0") not in ("", "0")
         self._members = bool(indexed_members)
         # (r06) The single-member framing of the reference (header | sync-flushed blocks | 03 00 | CRC ISIZE | empty member) is kept
-        # byte for byte in its LAYOUT; two things differ unless exact_framing (ZNGAMD_WRITER_EXACT=1) asks for the r05 bytes: the
-        # blocks' dynamic headers take their flat form, and the member is followed by EMPTY members whose FEXTRA field holds the
-        # blocks' segment index (ZA_INDEX_*, below) -- any gzip reader skips them, this engine's reader decodes the units of a
-        # window side by side with them (19.7 against 39.5 ms per 4 GiB on the device).
+        # byte for byte in its LAYOUT; two things differ unless exact_framing (ZNGAMD_WRITER_EXACT=1) asks for the r05 bytes: a block
+        # of at most 64 KiB is cut into 2 KiB segments like every larger one (FLAG_SEG2K; the blocks of full size are the same bytes
+        # either way), and the member is followed by EMPTY members whose FEXTRA field holds the blocks' segment index (_lib.INDEX_*)
+        # -- any gzip reader skips them, this engine's reader decodes the units of a window side by side with them (19.7 against
+        # 39.5 ms per 4 GiB on the device).
         if exact_framing is None:
             exact_framing = os.environ.get("ZNGAMD_WRITER_EXACT", "0") not in ("", "0")
         self._exact = bool(exact_framing) or self._members
-        self._bflag = 0 if self._exact else _lib.FLAG_FLATHDR
+        self._bflag = 0 if self._exact else _lib.FLAG_SEG2K
         self._index_ok = not self._exact
         self._index_recs = []                        # packed records of the member being written (one array per batch)
         self._index_units = 0

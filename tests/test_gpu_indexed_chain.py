@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 B = 131072
 FLATHDR = 2
+SEG2K = 16
 
 
 def _mix(n, seed):
@@ -23,14 +24,14 @@ def _mix(n, seed):
     return (out + corpus.text(max(0, n - len(out)), seed + 3).tobytes())[:n]
 
 
-def _compress_indexed(ctx, data, level, block=B, dict_first=b""):
+def _compress_indexed(ctx, data, level, block=B, dict_first=b"", flag=SEG2K):
     """-> (stream bytes incl. a final empty block, unit_in_len, unit_out_len, device index)"""
     buf = dict_first + data
     off0 = len(dict_first)
     blocks, off = [], off0
     while off < len(buf):
         n = min(block, len(buf) - off)
-        blocks.append((off, n, min(32768, off), FLATHDR))
+        blocks.append((off, n, min(32768, off), flag))
         off += n
     outs, crcs, ovf = ctx.deflate_blocks(buf, blocks, level, block + block // 8 + 600)
     assert not ovf
@@ -53,11 +54,13 @@ def _decode(ctx, stream, uin, uout, d_index, dict_first=b""):
     return r, n, (d_out[0:n].cpu().tobytes() if r == 1 and n <= total else b"")
 
 
+@pytest.mark.parametrize("flag", [SEG2K, FLATHDR])
 @pytest.mark.parametrize("level", [1, 6, 9])
-def test_indexed_chain_equals_input(ctx, level):
+def test_indexed_chain_equals_input(ctx, level, flag):
+    """ordinary (run-length coded) block headers, as the threaded writer leaves them, and flat ones"""
     from zlib_ng_amd import _lib
     data = _mix(5 * B + 12345, seed=level)
-    stream, uin, uout, d_index = _compress_indexed(ctx, data, level)
+    stream, uin, uout, d_index = _compress_indexed(ctx, data, level, flag=flag)
     assert zlib.decompressobj(-15).decompress(stream) == data           # any inflater reads it
     r, n, back = _decode(ctx, stream, uin, uout, d_index)
     assert r == _lib.STREAM_END and n == len(data) and back == data
@@ -75,7 +78,7 @@ def test_stored_fixed_empty_and_tiny_units(ctx):
     for p in pieces:
         for o in range(0, len(p), B):
             n = min(B, len(p) - o)
-            blocks.append((off + o, n, min(32768, off + o), FLATHDR))
+            blocks.append((off + o, n, min(32768, off + o), SEG2K))
         off += len(p)
     outs, crcs, ovf = ctx.deflate_blocks(buf, blocks, 6, B + B // 8 + 600)
     assert not ovf
@@ -220,3 +223,18 @@ def test_reader_many_windows_of_varying_size(ctx, monkeypatch):
             back = f.read()
         assert back == data, win
         assert ctx.L.zngamd_indexed_units(ctx.h, 1) == 701, win
+
+
+def test_seg2k_units_match_the_oracle(ctx):
+    """FLAG_SEG2K (2 KiB segments in a unit of any size) is part of the codec's specification: HIP == oracle byte for byte"""
+    from oracle import oracle as O
+    data = _mix(3 * 20000 + 777, 91)
+    blocks = [(o, min(20000, len(data) - o), min(32768, o), SEG2K) for o in range(0, len(data), 20000)]
+    outs, crcs, ovf = ctx.deflate_blocks(data, blocks, 6, 40000)
+    assert not ovf
+    for (o, n, d, f), got in zip(blocks, outs):
+        exp, ecrc = O.deflate_unit(data[o:o + n], data[o - d:o], 6, SEG2K)
+        assert got == exp
+    plain, _, _ = ctx.deflate_blocks(data, [(o, n, d, 0) for o, n, d, _ in blocks], 6, 40000)
+    assert zlib.decompressobj(-15).decompress(b"".join(outs) + b"\x03\x00") == data
+    assert plain != outs                       # (small units cut otherwise: the flag changes their tokens)
