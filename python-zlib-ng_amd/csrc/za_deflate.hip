@@ -586,8 +586,41 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     // link, and is never searched) with 32-bit offsets from a scalar base.  Measured and dropped: one 8-byte load per table and
     // thread, each lane picking its four links out of its neighbours' registers with ds_bpermute -- 2 loads and 16 permutes
     // instead of 8 loads: 7.74 -> 7.95 ms per GiB, the permutes alone cost what the loads did.
+    // (r06, ZA_OWN_STAGE) ... and through LDS: a thread fetches EIGHT consecutive links of one table with one 16-byte load (threads
+    // 0-511 table B, 512-1023 table C: one vector-memory instruction per thread and tile instead of eight), writes them at the
+    // tile's end into a staging area, and at the top of the next tile every thread reads its own eight back (2-byte LDS reads at
+    // consecutive addresses: conflict-free).  The area needs 16 KiB and the kernel has 15.9 left: it lies in the BYTE RING, in the
+    // part no walk can reach at that time -- positions P + 4 608 .. P + 20 992 behind the tile's first position P (the ring holds
+    // valid bytes from P - 36 864 up to P + 8 468 while the area lives: written at the end of the tile in front, read at the top
+    // of this one; 65 536 - 45 332 = 20 204 bytes are nobody's).  One more barrier per tile, right behind the reads (the waves
+    // have just left the tile's barrier: it costs what its few instructions cost), keeps a fast wave's next write off a slow
+    // wave's reads.
+    // MEASURED AND NOT TAKEN (the switch stays for the comparison): level 6 7.69 against 7.69 ms per GiB, levels 1 and 4 3.5 % SLOWER
+    // (4.71 / 4.54, 5.71 / 5.52) -- the second barrier and the nine LDS operations cost what the seven loads saved; what the
+    // ablation without the loads had promised (0.9 ms per GiB) was its synthetic candidates' doing, not the loads'.
+#ifndef ZA_OWN_STAGE
+#define ZA_OWN_STAGE 0
+#endif
+    za_v4u32 oq = {0u, 0u, 0u, 0u};
+    auto own_area = [&](int tile_base) -> uint32_t { return (goff + (uint32_t)(ZA_WIN + tile_base) + 4608u + 15u) & 0xFFF0u; };      // (16-byte aligned, inside the ring)
+    auto own_load = [&](int tile_base) {                           // my eight links of that tile
+        const bool forc = tid >= ZA_SEARCH_THREADS / 2;
+        const int p = tile_base + 8 * (tid & (ZA_SEARCH_THREADS / 2 - 1));
+        oq = za_v4u32{0u, 0u, 0u, 0u};
+#ifdef ZA_ABL_NO_LINKLOADS
+        oq.x = oq.y = oq.z = oq.w = (((uint32_t)p * 7u & 0xFFu) | 1u) * 0x00010001u;
+#else
+        // (the last piece of a unit reads up to seven entries past its links: inside the row -- B and C rows are as long as A's)
+        if (p < n && (USEC || !forc)) { const ZaU4u t = *(const ZaU4u *)((forc ? linkc : linkb) + p); oq.x = t.x; oq.y = t.y; oq.z = t.z; oq.w = t.w; }
+#endif
+    };
+    auto own_store = [&](int tile_base) {
+        const uint32_t a = (own_area(tile_base) + (tid >= ZA_SEARCH_THREADS / 2 ? 8192u : 0u) + 16u * (uint32_t)(tid & (ZA_SEARCH_THREADS / 2 - 1))) & 0xFFFFu;
+        *(uint4 *)(lds + a) = make_uint4(oq.x, oq.y, oq.z, oq.w);
+    };
     uint32_t nlkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], nlkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
     auto load_own_links = [&](int tile_base) {
+        if (ZA_OWN_STAGE) { own_load(tile_base); return; }
 #pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
             const int p = tile_base + k * ZA_SEARCH_THREADS + tid;
@@ -601,6 +634,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         }
     };
     load_own_links(0);
+    if (ZA_OWN_STAGE) own_store(0);                               // (the barrier in front of the tile loop makes it visible)
     // (r06, levels 1-6) A tile's four results per thread stay in registers and are stored at the top of the NEXT tile, behind the
     // take-over of the own links and in front of the new loads (the unit's last tile: behind the loop).  Stored where they were
     // made, the last of them was in flight when the tile's end asked for the links and bytes fetched at its top -- stores count
@@ -647,9 +681,14 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         uint32_t lkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], lkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
 #pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
-            lkb[k] = nlkb[k]; lkc[k] = nlkc[k];
+            if (ZA_OWN_STAGE) {
+                const uint32_t a = own_area(base) + 2u * (uint32_t)(k * ZA_SEARCH_THREADS + tid);
+                lkb[k] = *(const uint16_t *)(lds + (a & 0xFFFFu));
+                lkc[k] = USEC ? (uint32_t)*(const uint16_t *)(lds + ((a + 8192u) & 0xFFFFu)) : 0u;
+            } else { lkb[k] = nlkb[k]; lkc[k] = nlkc[k]; }
             asm volatile("" : "+v"(lkb[k]), "+v"(lkc[k]) : : "memory");       // (here and now: nothing is moved across)
         }
+        if (ZA_OWN_STAGE) za_lds_barrier();                       // (every thread has its links: the area may be written at this tile's end)
         if constexpr (!FULL) flush_results();
         // ---- the NEXT tile's links and bytes are fetched into registers now and put into the rings after this tile's
         // search: the global-memory latency hides behind the search instead of stalling all 16 waves in front of it
@@ -990,6 +1029,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 if (p + 4 < need_bytes) store_bytes(p + 4, (uint32_t)(v >> 32));
             }
         }
+        if (ZA_OWN_STAGE) own_store(base + ZA_SEARCH_TILE);
         links_loaded = need_links; bytes_loaded = need_bytes;
         // (r06) the tile's barrier orders the rings -- LDS -- and nothing else: the plain __syncthreads() also waited for this wave's
         // result stores, the last of them issued a moment ago (the read-back of the folded statistics is the one thing that needs it)
