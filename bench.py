@@ -436,14 +436,14 @@ def main():
         d_comp[comp_bytes:comp_bytes + 66] = 0
         d_comp[comp_bytes] = 3                                   # empty final block
         if d_index is not None:
-            uin = i32(d_ulen).astype(np.uint32).tolist()
+            uin, uout = i32(d_ulen).astype(np.uint32), np.full(n_units, BLOCK, np.uint32)
             x_wall, x_kern = [], []
             for it in range(3):
                 d_out.zero_()
                 ctx.sync()
                 ctx.profiling(True); ctx.kernel_times(reset=True)
                 t = time.perf_counter()
-                rc, xl = ctx.inflate_units_indexed_dev(d_comp.ptr, comp_bytes + 2, uin, [BLOCK] * n_units, d_index.ptr, d_out.ptr, size)
+                rc, xl = ctx.inflate_units_indexed_dev(d_comp.ptr, comp_bytes + 2, uin, uout, d_index.ptr, d_out.ptr, size)
                 x_wall.append((time.perf_counter() - t) * 1e3)
                 x_kern.append(sum(v[0] for v in ctx.kernel_times(reset=True).values()))
                 ctx.profiling(False)

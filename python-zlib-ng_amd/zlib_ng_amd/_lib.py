@@ -747,8 +747,11 @@ class Context:
         d_def / d_index / d_out / d_dict: device pointers (ints or c_void_p); unit_*_len: sequences of ints.
         -> (code, out_len); code STREAM_END, or E_INDEX / DATA_ERROR / BUF_ERROR as the C call returns them."""
         n = len(unit_in_len)
-        a = (C.c_uint32 * max(1, n))(*unit_in_len)
-        b = (C.c_uint32 * max(1, n))(*unit_out_len)
+        # (numpy arrays go to the engine as they are: a list of 32 768 sizes costs a millisecond to turn into a C array)
+        ka = np.ascontiguousarray(unit_in_len, dtype=np.uint32)
+        kb = np.ascontiguousarray(unit_out_len, dtype=np.uint32)
+        a = ka.ctypes.data_as(C.POINTER(C.c_uint32))
+        b = kb.ctypes.data_as(C.POINTER(C.c_uint32))
         ol = C.c_uint64(0)
         r = self.L.zngamd_inflate_units_indexed_dev(self.h, C.c_void_p(int(d_def)), def_len, a, b, n, C.c_void_p(int(d_index)),
                                                     C.c_void_p(int(d_dict)) if d_dict else None, dict_len,
