@@ -1363,9 +1363,18 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
                 const uint32_t sC = za_pk_add_u16(za_pk_add_u16(v2, g.x2), bb);
                 if (l0 == 3u && dm1 >= (uint32_t)L.too_far3) sA = (sA & 0xFFFF0000u) | 0x3FFFu;      // a 3-byte match that far back is no candidate
                 // cost << 3 | (4 - k): the minimum is the cheapest, and the longest among equals
+#ifdef ZA_DP_TAGS_SHIFT
                 const int t0 = (__builtin_amdgcn_sbfe((int)sA, 0, 16) << 3) | 4, t1 = (((int)sA >> 16) << 3) | 3;
                 const int t2 = (__builtin_amdgcn_sbfe((int)sB, 0, 16) << 3) | 2, t3 = (((int)sB >> 16) << 3) | 1;
                 const int t4 = __builtin_amdgcn_sbfe((int)sC, 0, 16) << 3;
+#else
+                // (r06) ONE instruction per candidate: the signed 16-bit half times 8 plus the tag (v_mad_i32_i16, the upper half by op_sel)
+                // instead of a sign extension and a shift-or each
+                int t0, t1, t2, t3, t4;
+                asm("v_mad_i32_i16 %0, %5, 8, 4\n\tv_mad_i32_i16 %1, %5, 8, 3 op_sel:[1,0,0,0]\n\t"
+                    "v_mad_i32_i16 %2, %6, 8, 2\n\tv_mad_i32_i16 %3, %6, 8, 1 op_sel:[1,0,0,0]\n\tv_mad_i32_i16 %4, %7, 8, 0"
+                    : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4) : "v"(sA), "v"(sB), "v"(sC));
+#endif
                 int t = t0 < t1 ? t0 : t1;
                 t = t < t2 ? t : t2;
                 int tb = t3 < t4 ? t3 : t4;
@@ -1377,7 +1386,7 @@ __global__ __launch_bounds__(64) void za_k_optparse(const ZaUnit *__restrict__ u
                 if (live) {
                     acc_next += c_best;
                     ring_put(idx & (ZA_DP_NEAR - 1), (uint32_t)acc_next);
-                    myb[j] = choice ? ((e & 0xFF007FFFu) | (choice << 15)) : (e & 0xFF000000u);
+                    myb[j] = (e & (ok ? 0xFF007FFFu : 0xFF000000u)) | (choice << 15);     // (choice is 0 where the literal won)
                 }
             }
         }
