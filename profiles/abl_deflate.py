@@ -18,3 +18,8 @@ for it in range(2):
     r=L.zngamd_deflate_blocks_dev(h,d.vp(),n,blocks,nb,int(os.environ.get("LEVEL","6")),slots.vp(),ul.vp(),uc.vp(),None)
     kt=ctx.kernel_times(True)
 print("ablate",os.environ.get("ZNGAMD_ABLATE"),"rc",r,{k:round(v[0],2) for k,v in kt.items() if v[1]})
+if hasattr(L, "zngamd_debug_ch_stats"):
+    o=(C.c_ulonglong*32)(); L.zngamd_debug_ch_stats(o)
+    for t in range(3):
+        print(f"ablate chstats table {'ABC'[t]} (both iterations): " + " ".join(f"role{r}: waits {o[8*t+2*r]/max(1,o[8*t+2*r+1]):.2f} of {o[8*t+2*r+1]/1e9:.2f} Gclk" for r in range(4)))
+    if o[27]: print(f"ablate chstats table A atomic wave per group: reads {o[24]/o[27]:.0f} atomics {o[25]/o[27]:.0f} writes {o[26]/o[27]:.0f} clocks")

@@ -92,6 +92,11 @@ __device__ __noinline__ uint32_t za_chains_fix(uint32_t h, uint32_t A, uint32_t 
     return near ? near : pre;
 }
 
+#ifdef ZA_CH_STATS
+// profiling build only (profiles/abl_deflate.py prints them): per table and wave of the chain kernel, clocks spent at the barrier
+// and in all ([8 * table + 2 * wave]); [24..27]: table A's inserting wave per group -- reads, atomics, writes (with a wait behind each), groups
+__device__ unsigned long long za_ch_stat[32];
+#endif
 // TABLE: which of the three link tables (za_common.h): the context's length and hash are all that differs
 template <int TABLE>
 __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ in, const ZaUnit *__restrict__ units,
@@ -117,6 +122,10 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
     // two waves per stream would leave its SIMDs half idle.
     const uint32_t role = threadIdx.x >> 6;
     const uint32_t u0 = run_start[blockIdx.x], u1 = run_start[blockIdx.x + 1];
+#ifdef ZA_CH_STATS
+    unsigned long long st_wait = 0, st_ph[4] = {0, 0, 0, 0};
+    const unsigned long long st_t0 = clock64();
+#endif
     uint32_t goff = 0;                                // positions of the run in front of the current unit
     uint32_t n_prev = 0;
 #pragma unroll 1
@@ -247,8 +256,15 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
             const uint32_t li = (uint32_t)tbase + lane;                 // my row index in the group's first step
             uint32_t hh[ZA_CH_GROUP], old[ZA_CH_GROUP];
             const uint32_t A0 = abase + li;
+#ifdef ZA_CH_STATS
+            const unsigned long long T0 = clock64();
+#endif
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) hh[g] = hb[64 * g + lane];
+#ifdef ZA_CH_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long T1 = clock64();
+#endif
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) {
                 const int i = (int)li + 64 * g;
@@ -260,6 +276,10 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
                 if (ins) old[g] = atomicMax((uint32_t *)((uint8_t *)head + hh[g]), A0 + 64u * (uint32_t)g);
 #endif
             }
+#ifdef ZA_CH_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long T2 = clock64();
+#endif
             uint32_t top = 0;                                          // bit 31 set: some step got back an entry at or above its own position
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) top |= (A0 + 64u * (uint32_t)g - old[g] - 1u);
@@ -281,6 +301,10 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
 #endif
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) ob[64 * g + lane] = old[g];
+#ifdef ZA_CH_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_ph[0] += T1 - T0; st_ph[1] += T2 - T1; st_ph[2] += clock64() - T2; st_ph[3] += 1;
+#endif
         };
         // wave 3: what the atomics returned becomes links (position - entry if that is at most 32 768; positions with fewer than HB
         // bytes left were never inserted: 0), which leave 16 bytes per lane twice where the group lies wholly inside the row (rows
@@ -312,10 +336,16 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
                 }
             }
         };
-        auto wg_barrier = [] {
+        auto wg_barrier = [&] {
+#ifdef ZA_CH_STATS
+            const unsigned long long b0 = clock64();
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef ZA_CH_STATS
+            st_wait += clock64() - b0;
+#endif
         };
         // Ticks t = 0 .. ngroups + 1, one barrier behind each (and one behind wave 0's prologue).  Wave 0 asks for the bytes FOUR
         // groups ahead -- chunk c travels in register set c & 3, its loop is unrolled four times so that no set is ever copied --
@@ -374,6 +404,10 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
             }
         }
     }
+#ifdef ZA_CH_STATS
+    if (lane == 0 && role == 2u && TABLE == 0) for (int i = 0; i < 4; i++) atomicAdd(&za_ch_stat[24 + i], st_ph[i]);
+    if (lane == 0) { atomicAdd(&za_ch_stat[8 * TABLE + 2 * role], st_wait); atomicAdd(&za_ch_stat[8 * TABLE + 2 * role + 1], clock64() - st_t0); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2609,6 +2609,15 @@ try {
 
 #include "zng_stream.hip"
 
+#ifdef ZA_CH_STATS
+// profiling build only: the chain kernel's clocks (za_deflate.hip), read and cleared
+extern "C" int zngamd_debug_ch_stats(unsigned long long *out32)
+{
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(za_ch_stat), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[32] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(za_ch_stat), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef ZA_PS_STATS
 // profiling build only (profiles/ps_stats.sh): counters of the parallel sweep, read and cleared
 extern "C" int zngamd_debug_ps_stats(unsigned long long *out24)
