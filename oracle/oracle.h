@@ -39,6 +39,7 @@ extern "C" {
 
 /* ---- codec constants ---- */
 #define ZA_SEG        2048      /* segment of a full unit: token boundaries are forced at segment ends (za_o_seg_shift: small units take smaller ones) */
+#define ZA_SMALL_UNIT 16384     /* unit size of a one-shot stream of up to ZA_MAX_UNIT bytes (za_o_deflate_stream)  */
 #define ZA_MAX_UNIT   131072    /* one codec unit = at most 64 segments             */
 #define ZA_MAX_SEGS   64
 #define ZA_WIN        32768

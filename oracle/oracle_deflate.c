@@ -627,9 +627,12 @@ long za_o_deflate_unit(const uint8_t *data, int dict_len, int n, int level, int 
 long za_o_deflate_stream(const uint8_t *data, size_t n, int level, int flags, uint8_t *out, size_t cap)
 {
     size_t off = 0, op = 0;
+    /* a stream of up to one unit's size is cut into units of 16 KiB (the product: zngamd_deflate_stream sets ZNGAMD_FLAG_UNITS16K --
+     * latency before size for the small one-shot calls) */
+    const size_t U = n <= ZA_MAX_UNIT ? ZA_SMALL_UNIT : ZA_MAX_UNIT;
     if (n == 0) return za_o_deflate_unit(data, 0, 0, level, flags, out, cap, NULL, NULL);
     while (off < n) {
-        size_t len = n - off > ZA_MAX_UNIT ? ZA_MAX_UNIT : n - off;
+        size_t len = n - off > U ? U : n - off;
         int dict = off > ZA_WIN ? ZA_WIN : (int)off;
         int f = (off + len == n) ? flags : 0;
         long r = za_o_deflate_unit(data + off, dict, (int)len, level, f, out + op, cap - op, NULL, NULL);

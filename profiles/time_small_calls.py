@@ -8,16 +8,25 @@ for size in (1 << 10, 16 << 10, 64 << 10):
     d = data[:size]; z = zlib.compress(d, 6)
     for _ in range(3): zlib_ng.decompress(z); zlib_ng.compress(d)
     n = 50
-    t = time.perf_counter()
-    for _ in range(n): zlib_ng.compress(d)
-    tc = (time.perf_counter() - t) / n
-    t = time.perf_counter()
-    for _ in range(n): zlib_ng.decompress(z)
-    td = (time.perf_counter() - t) / n
+    def lap(f, x):
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter(); f(x); ts.append(time.perf_counter() - t)
+        ts.sort()
+        return sum(ts) / n, ts[n // 2], ts[-1]
+    tc, tc_med, tc_max = lap(zlib_ng.compress, d)
+    td, td_med, td_max = lap(zlib_ng.decompress, z)
+    body = z[2:]
+    tr, tr_med, tr_max = lap(lambda b: ctx.inflate_raw(b, 65536), body)
     ctx.profiling(True); ctx.kernel_times(True)
     for _ in range(10): zlib_ng.compress(d)
     kc = ctx.kernel_times(True)
     for _ in range(10): zlib_ng.decompress(z)
     kd = ctx.kernel_times(True); ctx.profiling(False)
-    print(f"{size:6d} B: compress {tc*1e6:7.1f} us (kernels {sum(v[0] for v in kc.values())/10*1e3:6.1f} us: { {k: round(v[0]/10*1e3,1) for k,v in kc.items() if v[1]} }), decompress {td*1e6:7.1f} us (kernels {sum(v[0] for v in kd.values())/10*1e3:6.1f} us)")
+    if hasattr(ctx.L, "zngamd_debug_plan_stats"):
+        import ctypes as C
+        o = (C.c_ulonglong * 16)(); ctx.L.zngamd_debug_plan_stats(o)
+        names = ["load", "sort L", "lengths L", "tree D", "canon+costs", "rle", "cl tree", "costs", "header", "codes out"]
+        print("   plan kernel, clocks per launch: " + ", ".join(f"{names[i]} {o[i] / max(1, o[15]):.0f}" for i in range(10)))
+    print(f"{size:6d} B: compress {tc*1e6:7.1f} us (kernels {sum(v[0] for v in kc.values())/10*1e3:6.1f} us: { {k: round(v[0]/10*1e3,1) for k,v in kc.items() if v[1]} }), decompress {td*1e6:7.1f} us (kernels {sum(v[0] for v in kd.values())/10*1e3:6.1f} us); medians {tc_med*1e6:.1f} / {td_med*1e6:.1f} us, slowest {tc_max*1e6:.0f} / {td_max*1e6:.0f} us; the engine's inflate call alone {tr_med*1e6:.1f} us")
 os.environ["ZNGAMD_TRACE"] = "1"

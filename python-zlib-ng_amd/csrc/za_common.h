@@ -36,6 +36,9 @@
 #define ZA_FLAG_CARRY   4u      // (set by the host) the unit's 32 KiB dictionary is the tail of the unit in front of it in the batch:
                                 // inside a run the chain tables are carried over instead of inserting the dictionary again
 #define ZA_FLAG_SEG2K   16u     // segments of 2 KiB whatever the unit's size (what the segment index of a dict-chained stream counts in: the threaded writer)
+#define ZA_FLAG_UNITS16K 32u    // (a block's flag, host only) the block is cut into units of 16 KiB instead of 128: one-shot calls of up to 128 KiB (r06), whose
+                                // latency is that of ONE wavefront walking its 64 segments -- eight wavefronts side by side, segments of 256 bytes
+#define ZA_SMALL_UNIT  16384u
 #define ZA_FLAG_RUNHEAD 8u      // (set by the host) first unit of a chain-kernel run: its dictionary IS inserted, its links are all in its own row
 // bits 8..11 of a unit's flags (set by the host, za_seg_shift_for): log2 of the unit's SEGMENT size.  A unit is always cut into at
 // most 64 segments (token boundaries are forced there: parse, dynamic programme and packer give a lane to each); a full unit's are

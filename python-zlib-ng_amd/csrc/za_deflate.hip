@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(64) void za_k_unit_crc(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 struct ZaPlanLds {
     uint32_t key[288];
-    uint32_t A[288];
+    __attribute__((aligned(16))) uint32_t A[288];
     uint32_t freq[320];
     uint8_t lens[320];
     uint16_t codes[320];
@@ -1671,23 +1671,33 @@ struct ZaPlanLds {
     int btype;
 };
 
-// rank-sort the non-zero symbols by (freq, index); all lanes take part.  Result in S.key[0..m).
+// rank-sort the non-zero symbols by (freq, index); all lanes take part.  Result in S.key[0..m).  The symbols in use are packed
+// to the front first (ballots), so that a rank costs m comparisons instead of nsym (r06: a call of 1 KiB uses 50 of the 286
+// literal/length symbols, a unit of text 120; the comparisons were 19 of the kernel's 105 us), four keys per LDS read.
 __device__ void za_sort_syms(ZaPlanLds &S, const uint32_t *freq, int nsym)
 {
     const int lane = za_lane();
     __syncthreads();
-    for (int i = lane; i < 288; i += 64) S.A[i] = (i < nsym && freq[i]) ? ((freq[i] << 9) | (uint32_t)i) : 0u;
-    __syncthreads();
     int m = 0;
-    for (int i = lane; i < nsym; i += 64) {
-        const uint32_t k = S.A[i];
-        if (!k) continue;
+    for (int base = 0; base < nsym; base += 64) {
+        const int i = base + lane;
+        const uint32_t k = (i < nsym && freq[i]) ? ((freq[i] << 9) | (uint32_t)i) : 0u;
+        const unsigned long long nz = __ballot(k != 0u);
+        if (k) S.A[m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u))] = k;
+        m += (int)__builtin_popcountll(nz);
+    }
+    __syncthreads();
+    for (int idx = lane; idx < m; idx += 64) {
+        const uint32_t k = S.A[idx];
         int rank = 0;
-        for (int j = 0; j < nsym; j++) { const uint32_t o = S.A[j]; rank += (o != 0u && o < k); }
+        int j = 0;
+        for (; j + 4 <= m; j += 4) {
+            const uint4 o = *(const uint4 *)&S.A[j];
+            rank += (o.x < k) + (o.y < k) + (o.z < k) + (o.w < k);
+        }
+        for (; j < m; j++) rank += S.A[j] < k;
         S.key[rank] = k;
     }
-    for (int j = lane; j < nsym; j += 64) m += (S.A[j] != 0u);
-    for (int d = 32; d >= 1; d >>= 1) m += __shfl_xor(m, d, 64);
     __syncthreads();
     if (lane == 0) S.m = m;
     __syncthreads();
@@ -1857,6 +1867,73 @@ __device__ void za_lengths_wave(ZaPlanLds &S, int nsym, int limit, uint8_t *lens
     __syncthreads();
 }
 
+// The same lengths for an alphabet of at most 32 symbols (the code-length code's 19) without a single LDS round trip inside the
+// algorithm: the array lives in ONE register across the lanes (lane i holds A[i]); every index is wave-uniform, so a read is a
+// v_readlane, a write a compare and a select, and the control flow scalar.  (Lane 0 alone, through LDS: 15 us of the plan kernel's 105.)
+__device__ void za_lengths_small(ZaPlanLds &S, int nsym, int limit, uint8_t *lens)
+{
+    const int lane = za_lane();
+    __syncthreads();
+    const int m = __builtin_amdgcn_readfirstlane(S.m);
+    for (int i = lane; i < nsym; i += 64) lens[i] = 0;
+    __syncthreads();
+    if (m == 0) return;
+    if (m == 1) { if (lane == 0) lens[S.key[0] & 511u] = 1; __syncthreads(); return; }
+    const uint32_t mykey = lane < m ? S.key[lane] : 0u;
+    uint32_t Av = mykey >> 9;
+    auto RD = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)Av, i); };
+    auto WR = [&](int i, uint32_t v) { Av = lane == i ? v : Av; };
+    int root = 0, leaf = 2, next;
+    WR(0, RD(0) + RD(1));
+    for (next = 1; next < m - 1; next++) {
+        uint32_t w;
+        if (leaf >= m || RD(root) < RD(leaf)) { w = RD(root); WR(root, (uint32_t)next); root++; }
+        else { w = RD(leaf); leaf++; }
+        if (leaf >= m || (root < next && RD(root) < RD(leaf))) { w += RD(root); WR(root, (uint32_t)next); root++; }
+        else { w += RD(leaf); leaf++; }
+        WR(next, w);
+    }
+    WR(m - 2, 0u);
+    for (next = m - 3; next >= 0; next--) WR(next, RD((int)RD(next)) + 1u);
+    int avbl = 1, used = 0, dpth = 0;
+    root = m - 2; next = m - 1;
+    while (avbl > 0 && dpth < 64) {
+        while (root >= 0 && (int)RD(root) == dpth) { used++; root--; }
+        while (avbl > used && next >= 0) { WR(next, (uint32_t)dpth); next--; avbl--; }
+        if (next < 0) break;
+        avbl = 2 * used; dpth++; used = 0;
+    }
+    // Av: the depth of leaf `lane` (rank order).  Leaves per depth, cut at the limit: lane d holds cnt[d]
+    const bool in = lane < m;
+    const bool over = __ballot(in && (int)Av > limit) != 0ull;
+    const int dcl = (int)Av > limit ? limit : (int)Av;
+    uint32_t Cv = 0;
+    for (int d = 1; d <= limit; d++) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(in && dcl == d));
+        Cv = lane == d ? c : Cv;
+    }
+    auto RC = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)Cv, i); };
+    auto WC = [&](int i, uint32_t v) { Cv = lane == i ? v : Cv; };
+    if (over) {
+        uint32_t total = 0;
+        for (int i = 1; i <= limit; i++) total += RC(i) << (limit - i);
+        // every step removes one unit of the Kraft sum; the guard only bounds a corrupted state
+        for (int guard = 0; total != (1u << limit) && guard < (1 << 17); guard++) {
+            WC(limit, RC(limit) - 1u);
+            for (int i = limit - 1; i > 0; i--)
+                if (RC(i)) { WC(i, RC(i) - 1u); WC(i + 1, RC(i + 1) + 2u); break; }
+            total--;
+        }
+    }
+    if (in) {
+        uint32_t acc = 0;
+        int len = 1;
+        for (int l = limit; l >= 1; l--) { acc += RC(l); if ((uint32_t)lane < acc) { len = l; break; } }
+        lens[mykey & 511u] = (uint8_t)len;
+    }
+    __syncthreads();
+}
+
 // lane 0 only: canonical codes, bit-reversed for LSB-first emission
 __device__ void za_canon_serial(const uint8_t *lens, int n, uint16_t *codes, uint32_t *scratch32 /* 32 dwords of LDS */)
 {
@@ -1931,6 +2008,12 @@ __constant__ uint8_t za_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 // bytes per unit) and the unit's EXACT compressed size to unit_len (header + histogram x (code length + extra bits) + end of
 // block + marker: everything that decides it is here), so that one prefix sum gives every unit its offset in the stream and the
 // packer writes it there -- no slots, no gather pass.
+#ifdef ZA_PLAN_STATS
+__device__ unsigned long long za_plan_stat[16];   // profiling build only: clocks of the plan kernel's phases (lane 0 of unit 0), [15] = launches
+#define ZA_PLAN_T(i) do { if (lane == 0 && blockIdx.x == 0) { const unsigned long long t_ = clock64(); za_plan_stat[i] += t_ - pt_; pt_ = t_; } } while (0)
+#else
+#define ZA_PLAN_T(i) do { } while (0)
+#endif
 #define ZA_HDR_STRIDE 640u      // bytes of header buffer per unit: the longest dynamic header is 3 + 14 + 57 + 316 x 14 bits = 563 bytes
 __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units, const uint32_t *__restrict__ hist_ws,
                                                 uint32_t *__restrict__ code_ws, ZaPlan *__restrict__ plan_ws,
@@ -1955,6 +2038,10 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         }
         return;
     }
+#ifdef ZA_PLAN_STATS
+    unsigned long long pt_ = clock64();
+    if (lane == 0 && blockIdx.x == 0) za_plan_stat[15] += 1;
+#endif
     const uint32_t *hist = hist_ws + (size_t)blockIdx.x * ZA_HIST_STRIDE;
     for (int i = lane; i < 320; i += 64) S.freq[i] = hist[i];
     __syncthreads();
@@ -1966,14 +2053,18 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
     }
     __syncthreads();
     // lit/len tree
+    ZA_PLAN_T(0);
     za_sort_syms(S, S.freq, 286);
+    ZA_PLAN_T(1);
     za_lengths_wave(S, 286, ZA_LIMIT_L, S.lens);
+    ZA_PLAN_T(2);
     if (lane < 2) S.lens[286 + lane] = 0;
     // distance tree
     za_sort_syms(S, S.freq + 288, 30);
-    za_lengths_wave(S, 30, ZA_LIMIT_D, S.lens + 288);
+    za_lengths_small(S, 30, ZA_LIMIT_D, S.lens + 288);           // (30 symbols: one register across the lanes)
     if (lane < 2) S.lens[318 + lane] = 0;
     __syncthreads();
+    ZA_PLAN_T(3);
 
     // canonical codes and the exact data costs: by all lanes (lane 0 alone walked 600 symbols through LDS, one round trip each)
     za_canon_wave(S.lens, 286, S.codes, S.A);
@@ -1993,6 +2084,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         cost_df += f * (uint32_t)(5 + ex);
     }
     for (int d = 32; d >= 1; d >>= 1) { cost_dd += __shfl_xor(cost_dd, d, 64); cost_df += __shfl_xor(cost_df, d, 64); }
+    ZA_PLAN_T(4);
     // the code-length sequence of the header: hlit literal/length lengths, then hdist distance lengths (copied by all lanes)
     int hlit, hdist;
     {
@@ -2008,97 +2100,157 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         if (lane < hdist) S.seq[hlit + lane] = S.lens[288 + lane];
         __syncthreads();
     }
-    if (lane == 0) {
-        // run-length encode the code lengths (tokens: sym | extra<<8)
-        const int nseq = hlit + hdist;
-        int nt = 0, i = 0;
-        while (i < nseq) {
-            const int v = S.seq[i];
-            int run = 1;
-            while (i + run < nseq && S.seq[i + run] == v) run++;
-            i += run;
-            if (v == 0) {
-                while (run >= 3) {
-                    if (run >= 11) { const int r = run > 138 ? 138 : run; S.cltok[nt++] = (uint16_t)(18 | ((r - 11) << 8)); run -= r; }
-                    else { S.cltok[nt++] = (uint16_t)(17 | ((run - 3) << 8)); run = 0; }
-                }
-                while (run-- > 0) S.cltok[nt++] = 0;
-            } else {
-                S.cltok[nt++] = (uint16_t)v; run--;
-                while (run >= 3) { const int r = run > 6 ? 6 : run; S.cltok[nt++] = (uint16_t)(16 | ((r - 3) << 8)); run -= r; }
-                while (run-- > 0) S.cltok[nt++] = (uint16_t)v;
-            }
+    // Run-length encoding of the code lengths (tokens: sym | extra << 8), by all lanes (r06; lane 0 alone took 31 us for it, every
+    // entry an LDS round trip): the first entry of every run works out its run's tokens in closed form -- a run of zeros is
+    // 138s, then one 18 / 17 for a rest of 3 or more, else the rest as literals; any other value is itself once, then 6s, then
+    // one 16 for a rest of 3 or more, else literals -- and a prefix sum over the runs' token counts gives them their places.
+    const int nseq = hlit + hdist;
+    int nt = 0;
+    {
+        if (lane < 19) S.clf[lane] = 0;
+        uint32_t vv[5];
+        unsigned long long st[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = lane + 64 * k;
+            vv[k] = i < nseq ? S.seq[i] : 0xFFu;
+            const uint32_t pv = (i > 0 && i < nseq) ? S.seq[i - 1] : 0xFEu;
+            st[k] = __ballot(i < nseq && vv[k] != pv);
         }
-        for (int k = 0; k < 19; k++) S.clf[k] = 0;
-        for (int k = 0; k < nt; k++) S.clf[S.cltok[k] & 0xFF]++;
-        // code-length alphabet: 19 symbols, insertion sort is enough
-        int m = 0;
-        for (int k = 0; k < 19; k++) if (S.clf[k]) {
-            const uint32_t key = (S.clf[k] << 9) | (uint32_t)k;
-            int j = m++;
-            while (j > 0 && S.key[j - 1] > key) { S.key[j] = S.key[j - 1]; j--; }
-            S.key[j] = key;
-        }
-        S.m = m;
-        za_lengths_serial(S, 19, 7, S.cl_lens);
-        za_canon_serial(S.cl_lens, 19, S.cl_codes, S.A + 192);
-        int hclen = 19; while (hclen > 4 && S.cl_lens[za_cl_order[hclen - 1]] == 0) hclen--;
-        // exact costs
-        const unsigned long long data_dyn = cost_dd, data_fix = cost_df;        // (at most 131 072 tokens of at most 48 bits: 32 bits hold the sums)
-        unsigned long long hdr_dyn = 3 + 5 + 5 + 4 + 3ull * (unsigned)hclen;
-        for (int k = 0; k < nt; k++) {
-            const int s = S.cltok[k] & 0xFF;
-            hdr_dyn += S.cl_lens[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0);
-        }
-        if (flat) hdr_dyn = 3 + 5 + 5 + 4 + 3 * 19 + 4ull * (unsigned)(hlit + hdist);
-        const unsigned long long cost_dyn = hdr_dyn + data_dyn, cost_fix = 3 + data_fix;
-        const unsigned long long nchunks = ((unsigned long long)n + 65534ull) / 65535ull;
-        const unsigned long long cost_sto = 8ull * ((unsigned long long)n + 5ull * nchunks);
-        unsigned long long bestc = cost_dyn; int btype = 2;
-        if (cost_fix <= bestc) { bestc = cost_fix; btype = 1; }
-        if (cost_sto <= bestc) { bestc = cost_sto; btype = 0; }
-        S.btype = btype;                                       // (a fixed block's code table is filled in by all lanes below)
-        plan.btype = (uint32_t)btype;
-        if (unit_len) {
-            // the unit's size, exactly: what the packer will write (it checks)
-            const unsigned long long bits = btype == 2 ? cost_dyn : cost_fix;       // header + tokens + end of block
-            const unsigned long long endbit = bits + (final ? 0ull : 3ull);
-            unit_len[blockIdx.x] = btype == 0 ? (uint32_t)n + 5u * (uint32_t)nchunks + (final ? 0u : 5u)
-                                              : (uint32_t)((endbit + 7ull) >> 3) + (final ? 0u : 4u);
-        }
-        if (btype != 0) {
-            ZaBitW w;
-            w.out = hdr_ws ? (uint32_t *)(hdr_ws + (size_t)blockIdx.x * ZA_HDR_STRIDE) : (uint32_t *)(out + (size_t)blockIdx.x * out_stride);
-            w.cap_words = hdr_ws ? ZA_HDR_STRIDE / 4 : out_stride / 4; w.w = 0; w.acc = 0; w.nb = 0; w.ovf = false;
-            w.put((uint32_t)final | ((uint32_t)btype << 1), 3);
-            if (btype == 2 && flat) {
-                // flat form: the code-length code is the 4-bit code of the symbols 0..15 (code(s) = s), no run lengths
-                w.put((uint32_t)(hlit - 257), 5);
-                w.put((uint32_t)(hdist - 1), 5);
-                w.put(15u, 4);
-                for (int k = 0; k < 19; k++) w.put(za_cl_order[k] < 16 ? 4u : 0u, 3);
-                for (int k = 0; k < hlit + hdist; k++) {
-                    const uint32_t v = k < hlit ? S.lens[k] : S.lens[288 + k - hlit];
-                    w.put(((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3), 4);
-                }
-            } else if (btype == 2) {
-                w.put((uint32_t)(hlit - 257), 5);
-                w.put((uint32_t)(hdist - 1), 5);
-                w.put((uint32_t)(hclen - 4), 4);
-                for (int k = 0; k < hclen; k++) w.put(S.cl_lens[za_cl_order[k]], 3);
-                for (int k = 0; k < nt; k++) {
-                    const int s = S.cltok[k] & 0xFF, ex = S.cltok[k] >> 8;
-                    w.put(S.cl_codes[s], S.cl_lens[s]);
-                    if (s == 16) w.put((uint32_t)ex, 2);
-                    else if (s == 17) w.put((uint32_t)ex, 3);
-                    else if (s == 18) w.put((uint32_t)ex, 7);
+        __syncthreads();                                            // (the counters are clear)
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = lane + 64 * k;
+            const bool start = ((st[k] >> lane) & 1ull) != 0ull;
+            // the next run's first entry: behind me in my own group of 64, or the first of a later group, or the end
+            int later = nseq;
+#pragma unroll
+            for (int k2 = 4; k2 > k; k2--) if (st[k2]) later = 64 * k2 + (int)__builtin_ctzll(st[k2]);
+            const unsigned long long behind = lane == 63 ? 0ull : st[k] >> (lane + 1);
+            const int nxt = behind ? i + 1 + (int)__builtin_ctzll(behind) : later;
+            const int run = nxt - i;
+            const uint32_t v = vv[k];
+            int q, rem, cnt;
+            if (v == 0u) { q = run / 138; rem = run - 138 * q; cnt = q + (rem >= 3 ? 1 : rem); }
+            else { q = (run - 1) / 6; rem = run - 1 - 6 * q; cnt = 1 + q + (rem >= 3 ? 1 : rem); }
+            const uint32_t c = start ? (uint32_t)cnt : 0u;
+            const uint32_t incl = za_wave_incl_scan(c);
+            if (start) {
+                int o = nt + (int)(incl - c);
+                if (v == 0u) {
+                    for (int j = 0; j < q; j++) S.cltok[o++] = (uint16_t)(18u | (127u << 8));
+                    if (rem >= 11) S.cltok[o++] = (uint16_t)(18u | ((uint32_t)(rem - 11) << 8));
+                    else if (rem >= 3) S.cltok[o++] = (uint16_t)(17u | ((uint32_t)(rem - 3) << 8));
+                    else for (int j = 0; j < rem; j++) S.cltok[o++] = 0;
+                    if (q + (rem >= 11)) atomicAdd(&S.clf[18], (uint32_t)(q + (rem >= 11)));
+                    if (rem >= 3 && rem < 11) atomicAdd(&S.clf[17], 1u);
+                    if (rem < 3 && rem) atomicAdd(&S.clf[0], (uint32_t)rem);
+                } else {
+                    S.cltok[o++] = (uint16_t)v;
+                    for (int j = 0; j < q; j++) S.cltok[o++] = (uint16_t)(16u | (3u << 8));
+                    if (rem >= 3) S.cltok[o++] = (uint16_t)(16u | ((uint32_t)(rem - 3) << 8));
+                    else for (int j = 0; j < rem; j++) S.cltok[o++] = (uint16_t)v;
+                    atomicAdd(&S.clf[v], 1u + (uint32_t)(rem < 3 ? rem : 0));
+                    if (q + (rem >= 3)) atomicAdd(&S.clf[16], (uint32_t)(q + (rem >= 3)));
                 }
             }
-            w.finish();
-            plan.header_bits = w.bits();
+            nt += (int)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        plan_ws[blockIdx.x] = plan;
+        __syncthreads();
     }
+    ZA_PLAN_T(5);
+    // the code-length alphabet: 19 symbols, ranked by (count, index) with the keys in registers (lane = symbol)
+    {
+        const uint32_t key = (lane < 19 && S.clf[lane]) ? ((S.clf[lane] << 9) | (uint32_t)lane) : 0u;
+        const int m = (int)__builtin_popcountll(__ballot(key != 0u));
+        int rank = 0;
+        for (int j = 0; j < 19; j++) { const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j); rank += (kj != 0u && kj < key); }
+        if (key) S.key[rank] = key;
+        if (lane == 0) S.m = m;
+    }
+    za_lengths_small(S, 19, 7, S.cl_lens);
+    za_canon_wave(S.cl_lens, 19, S.cl_codes, S.A + 192);
+    int hclen;
+    {
+        const unsigned long long nzc = __ballot(lane < 19 && S.cl_lens[za_cl_order[lane < 19 ? lane : 0]] != 0);
+        hclen = nzc ? 64 - (int)__builtin_clzll(nzc) : 0;
+        hclen = hclen < 4 ? 4 : hclen;
+    }
+    ZA_PLAN_T(6);
+    // exact costs (every lane ends up with the sums)
+    uint32_t tokbits = 0;
+    for (int k = lane; k < nt; k += 64) {
+        const int sy = S.cltok[k] & 0xFF;
+        tokbits += (uint32_t)S.cl_lens[sy] + (sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u);
+    }
+    for (int d = 32; d >= 1; d >>= 1) tokbits += __shfl_xor(tokbits, d, 64);
+    const unsigned long long data_dyn = cost_dd, data_fix = cost_df;        // (at most 131 072 tokens of at most 48 bits: 32 bits hold the sums)
+    unsigned long long hdr_dyn = 3 + 5 + 5 + 4 + 3ull * (unsigned)hclen + tokbits;
+    if (flat) hdr_dyn = 3 + 5 + 5 + 4 + 3 * 19 + 4ull * (unsigned)(hlit + hdist);
+    const unsigned long long cost_dyn = hdr_dyn + data_dyn, cost_fix = 3 + data_fix;
+    const unsigned long long nchunks = ((unsigned long long)n + 65534ull) / 65535ull;
+    const unsigned long long cost_sto = 8ull * ((unsigned long long)n + 5ull * nchunks);
+    unsigned long long bestc = cost_dyn; int btype = 2;
+    if (cost_fix <= bestc) { bestc = cost_fix; btype = 1; }
+    if (cost_sto <= bestc) { bestc = cost_sto; btype = 0; }
+    ZA_PLAN_T(7);
+    plan.btype = (uint32_t)btype;
+    if (unit_len && lane == 0) {
+        // the unit's size, exactly: what the packer will write (it checks)
+        const unsigned long long bits = btype == 2 ? cost_dyn : cost_fix;       // header + tokens + end of block
+        const unsigned long long endbit = bits + (final ? 0ull : 3ull);
+        unit_len[blockIdx.x] = btype == 0 ? (uint32_t)n + 5u * (uint32_t)nchunks + (final ? 0u : 5u)
+                                          : (uint32_t)((endbit + 7ull) >> 3) + (final ? 0u : 4u);
+    }
+    if (btype != 0) {
+        // The header's bits, by all lanes: every field knows its place (the code-length tokens' from a prefix sum over their
+        // sizes) and is ORed into a zeroed image in LDS, whose dwords then leave together (lane 0 alone: 13 us).
+        uint32_t *img = S.A;                                       // 160 dwords (ZA_HDR_STRIDE bytes); S.A + 192 .. 224 was the canonical codes' scratch
+        uint32_t *dst = hdr_ws ? (uint32_t *)(hdr_ws + (size_t)blockIdx.x * ZA_HDR_STRIDE) : (uint32_t *)(out + (size_t)blockIdx.x * out_stride);
+        const uint32_t cap_words = hdr_ws ? ZA_HDR_STRIDE / 4 : out_stride / 4;
+        __syncthreads();
+        for (int i = lane; i < (int)(ZA_HDR_STRIDE / 4); i += 64) img[i] = 0;
+        __syncthreads();
+        auto put = [&](uint32_t v, uint32_t pos, uint32_t len) {     // len <= 17 bits at bit `pos`
+            const uint32_t wd = pos >> 5, sh = pos & 31u;
+            atomicOr(&img[wd], v << sh);
+            if (sh + len > 32u) atomicOr(&img[wd + 1], v >> (32u - sh));
+        };
+        uint32_t hbits = 3;
+        if (btype == 2) {
+            const uint32_t hc = flat ? 19u : (uint32_t)hclen;
+            if (lane == 0) put((uint32_t)final | (2u << 1) | ((uint32_t)(hlit - 257) << 3) | ((uint32_t)(hdist - 1) << 8) | ((hc - 4u) << 13), 0u, 17u);
+            if (lane < (int)hc) put(flat ? (za_cl_order[lane] < 16 ? 4u : 0u) : (uint32_t)S.cl_lens[za_cl_order[lane]], 17u + 3u * (uint32_t)lane, 3u);
+            hbits = 17u + 3u * hc;
+            if (flat) {
+                // flat form: the code-length code is the 4-bit code of the symbols 0..15 (code(s) = s), no run lengths
+                for (int k = lane; k < nseq; k += 64) {
+                    const uint32_t v = S.seq[k];
+                    put(((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3), hbits + 4u * (uint32_t)k, 4u);
+                }
+                hbits += 4u * (uint32_t)nseq;
+            } else {
+                for (int base = 0; base < nt; base += 64) {
+                    const int k = base + lane;
+                    uint32_t val = 0, len = 0;
+                    if (k < nt) {
+                        const uint32_t sy = S.cltok[k] & 0xFFu, ex = S.cltok[k] >> 8;
+                        const uint32_t cl = S.cl_lens[sy];
+                        val = (uint32_t)S.cl_codes[sy] | (ex << cl);
+                        len = cl + (sy == 16u ? 2u : sy == 17u ? 3u : sy == 18u ? 7u : 0u);
+                    }
+                    const uint32_t incl = za_wave_incl_scan(len);
+                    if (k < nt) put(val, hbits + incl - len, len);
+                    hbits += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+            }
+        } else if (lane == 0) put((uint32_t)final | (1u << 1), 0u, 3u);
+        __syncthreads();
+        for (uint32_t i = (uint32_t)lane; i < (hbits + 31u) / 32u && i < cap_words; i += 64u) dst[i] = img[i];
+        plan.header_bits = hbits;
+    }
+    if (lane == 0) { S.btype = btype; plan_ws[blockIdx.x] = plan; }
+    ZA_PLAN_T(8);
     __syncthreads();
     if (S.btype == 1) {
         // the fixed code (RFC 1951 3.2.6), bit-reversed for LSB-first emission: lane 0 alone walked 600 LDS round trips for it,
@@ -2116,6 +2268,7 @@ __global__ __launch_bounds__(64) void za_k_plan(const ZaUnit *__restrict__ units
         __syncthreads();
     }
     for (int i = lane; i < 320; i += 64) code_out[i] = (uint32_t)S.codes[i] | ((uint32_t)S.lens[i] << 16);
+    ZA_PLAN_T(9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2354,15 +2507,16 @@ __global__ __launch_bounds__(256) void za_k_gather(const uint8_t *__restrict__ s
 __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict__ out_len, uint32_t n, uint32_t extra,
                                                      uint64_t base, uint64_t *__restrict__ dst_off,
                                                      uint64_t *total, const ZaUnit *__restrict__ units,
-                                                     const uint64_t *d_base = nullptr)      // (+ *d_base: the total of the launches in front; may BE `total`: no __restrict__ on either)
+                                                     const uint64_t *d_base = nullptr,      // (+ *d_base: the total of the launches in front; may BE `total`: no __restrict__ on either)
+                                                     int running = 0)                       // the total continues d_base's (a first launch passes no d_base and starts it)
 {
     if (d_base) base += *d_base;
     auto ext = [&](uint32_t i) -> unsigned long long {
         return (unsigned long long)extra + (units ? 4ull * ((units[i].in_len + (1u << ZA_CHUNK_SHIFT) - 1u) >> ZA_CHUNK_SHIFT) : 0ull);
     };
     __shared__ unsigned long long part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;          // (64 threads for the few units of a small call: thread 0 walks `nth` partial sums)
+    const uint32_t per = (n + nth - 1u) / nth;
     const uint32_t b = tid * per, e = (b + per < n) ? b + per : n;
     unsigned long long s = 0;
     for (uint32_t i = b; i < e; i++) s += (unsigned long long)out_len[i] + ext(i);
@@ -2370,10 +2524,12 @@ __global__ __launch_bounds__(1024) void za_k_offsets(const uint32_t *__restrict_
     __syncthreads();
     if (tid == 0) {
         unsigned long long run = base;
-        for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-        *total = d_base ? run : run - base;
+        const uint32_t used = per ? (n + per - 1u) / per : 0u;    // threads that hold anything
+        for (uint32_t i = 0; i < used; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        *total = (d_base || running) ? run : run - base;
     }
     __syncthreads();
+    if (b >= n) return;
     unsigned long long run = part[tid];
     for (uint32_t i = b; i < e; i++) { dst_off[i] = run; run += (unsigned long long)out_len[i] + ext(i); }
 }

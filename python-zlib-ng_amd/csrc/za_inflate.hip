@@ -206,6 +206,14 @@ __constant__ uint8_t za_i_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 
 // Parse a fixed or dynamic block header at `bitpos` (uniform across the wave) and build the decode
 // tables.  Returns ZA_I_OK / ZA_I_DATA / ZA_I_INPUT; advances bitpos past the header.
+#ifdef ZA_PS_STATS
+__device__ unsigned long long za_ps_stat[32];     // profiling build (profiles/ps_stats.sh): 0..15 the sweeps' counters, 16: rounds of the counting passes (as the wave runs them), 17: their core clock cycles, 18: tokens counted, 20..24: phases of a dynamic header
+#define ZA_STAT_ADD(i, v) do { if (za_lane() == 0) atomicAdd(&za_ps_stat[i], (unsigned long long)(v)); } while (0)
+#define ZA_STAT_T() wall_clock64()
+#else
+#define ZA_STAT_ADD(i, v) do { } while (0)
+#define ZA_STAT_T() 0ull
+#endif
 #define ZA_HDR_DW 148     // dwords of LDS that hold a whole dynamic header behind its three counts: 57 + 316 * 14 bits, + alignment and look-ahead
 template <typename TT>
 __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bitpos, int type, TT &T, int *scratch /*2 ints LDS*/,
@@ -221,6 +229,8 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         return ZA_I_OK;
     }
     if (bitpos + 14 > in_bits) return ZA_I_INPUT;
+    unsigned long long tph = ZA_STAT_T();
+#define ZA_HDR_T(i) do { const unsigned long long t_ = ZA_STAT_T(); ZA_STAT_ADD(i, t_ - tph); tph = t_; } while (0)
     uint64_t bits = za_peek(in, bitpos);
     const int nlen = (int)(bits & 31u) + 257, ndist = (int)((bits >> 5) & 31u) + 1, ncode = (int)((bits >> 10) & 15u) + 4;
     bitpos += 14;
@@ -248,16 +258,67 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         const uint64_t lo = ((uint64_t)hb[w + 1] << 32) | hb[w];
         return sh ? ((lo >> sh) | ((uint64_t)hb[w + 2] << (64 - sh))) : lo;
     };
-    if (lane == 0) {
-        uint64_t bp = bitpos;
-        for (int i = 0; i < ncode; i++) { T.lens[za_i_cl_order[i]] = (uint8_t)(peek(bp) & 7u); bp += 3; }
-    }
+    if (lane < ncode) T.lens[za_i_cl_order[lane]] = (uint8_t)(peek(bitpos + 3ull * (unsigned)lane) & 7u);      // (a lane per 3-bit field)
     bitpos += 3ull * (unsigned)ncode;
+    ZA_HDR_T(20);
     // code-length code: tables go to the distance slots for now (7-bit LUT)
     int st = za_build_table(T.lens, 19, T.cnt_d, T.sym_d, T.lut_d, 7, &scratch[0], &scratch[1]);
+    ZA_HDR_T(21);
     if (st != 0) return ZA_I_DATA;                       // must be complete
-    // decode nlen + ndist code lengths (serial, lane 0), result in T.lens[32..] then moved
+    // decode nlen + ndist code lengths, result in T.lens[0..] then moved
     __syncthreads();
+    int err = ZA_I_OK, adv = 0;
+    if (hb) {
+        // A chain of dependent decodes -- but nothing in it needs LDS (r06): the staged header lies in three registers across the
+        // lanes and the 7-bit table of the code-length code in two, every position is wave-uniform, so a window of the stream is
+        // two v_readlane and a scalar shift, a look-up one v_readlane, and the loop runs on the scalar unit; the lengths are written
+        // as they come (a run by as many lanes as it is long).  Lane 0 alone, three LDS round trips per symbol: 35 of the 60 us a
+        // dynamic header took -- the whole latency of a small stream's first block.
+        uint32_t hv[3], lutv[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; hv[k] = i < ZA_HDR_DW ? hb[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 2; k++) lutv[k] = T.lut_d[lane + 64 * k];
+        auto rdh = [&](uint32_t w) -> uint32_t {
+            const uint32_t r = w >> 6;
+            const uint32_t v = r == 0u ? hv[0] : r == 1u ? hv[1] : hv[2];
+            return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(w & 63u));
+        };
+        uint64_t bp = bitpos;
+        int idx = 0;
+        uint32_t prev = 0;
+        uint8_t *L = T.lens;           // from index 0: the 19 code-length lengths are no longer needed (their table is in registers now)
+        const int ntot = nlen + ndist;
+        while (idx < ntot) {
+            if (bp > in_bits) { err = ZA_I_INPUT; break; }
+            const uint32_t rel = (uint32_t)(bp - hbyte * 8ull), w = rel >> 5, sh = rel & 31u;
+            const uint64_t lo = ((uint64_t)rdh(w + 1u) << 32) | rdh(w);
+            const uint32_t b = (uint32_t)(lo >> sh);                 // 32 bits of the stream: a code and its extra bits take 14 at most
+            const uint32_t li = b & 127u;
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)(li < 64u ? lutv[0] : lutv[1]), (int)(li & 63u));
+            if (!e) { err = ZA_I_DATA; break; }                      // (the code-length code has no code longer than its table)
+            const int sy = (int)(e >> 4), l = (int)(e & 15u);
+            bp += (unsigned)l;
+            if (bp > in_bits) { err = ZA_I_INPUT; break; }
+            if (sy < 16) { if (lane == 0) L[idx] = (uint8_t)sy; idx++; prev = (uint32_t)sy; }
+            else {
+                int rep; uint32_t val = 0;
+                const uint32_t x = b >> l;
+                if (sy == 16) { if (idx == 0) { err = ZA_I_DATA; break; } val = prev; rep = 3 + (int)(x & 3u); bp += 2; }
+                else if (sy == 17) { rep = 3 + (int)(x & 7u); bp += 3; }
+                else { rep = 11 + (int)(x & 127u); bp += 7; }
+                if (bp > in_bits) { err = ZA_I_INPUT; break; }
+                if (idx + rep > ntot) { err = ZA_I_DATA; break; }
+                for (int j = lane; j < rep; j += 64) L[idx + j] = (uint8_t)val;
+                idx += rep;
+                prev = val;
+            }
+        }
+        adv = (int)(bp - bitpos);
+        __syncthreads();
+        if (err == ZA_I_OK && L[256] == 0) err = ZA_I_DATA;          // missing end-of-block
+        __syncthreads();
+    } else {
     if (lane == 0) {
         uint64_t bp = bitpos;
         int idx = 0, err = ZA_I_OK;
@@ -289,11 +350,13 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         scratch[1] = (int)(bp - bitpos);
     }
     __syncthreads();
-    const int err = scratch[0];
-    const int adv = scratch[1];
+    err = scratch[0];
+    adv = scratch[1];
     __syncthreads();
+    }
     if (err != ZA_I_OK) return err;
     bitpos += (unsigned)adv;
+    ZA_HDR_T(22);
     // distance lengths first (they sit after the literal/length ones), into lens[288..]
     if (lane < 32) {
         const uint8_t v = lane < ndist ? T.lens[nlen + lane] : (uint8_t)0;
@@ -305,11 +368,14 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
     int maxl;
     st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, TT::kLBits, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
     maxl = scratch[1];
+    ZA_HDR_T(23);
     if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
     st = za_build_table(T.lens + 288, ndist, T.cnt_d, T.sym_d, T.lut_d, TT::kDBits, &scratch[0], &scratch[1], T.fst_d, T.idx_d);
     maxl = scratch[1];
+    ZA_HDR_T(24);
     if (st < 0 || (st > 0 && maxl != 1)) return ZA_I_DATA;
     return ZA_I_OK;
+#undef ZA_HDR_T
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,14 +402,6 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 #endif
 #ifndef ZA_PS_LIT_GROUPS
 #define ZA_PS_LIT_GROUPS 1           // ... this many times, then the token behind them
-#endif
-#ifdef ZA_PS_STATS
-__device__ unsigned long long za_ps_stat[32];     // 16: rounds of the counting passes (as the wave runs them), 17: their core clock cycles, 18: tokens counted
-#define ZA_STAT_ADD(i, v) do { if (za_lane() == 0) atomicAdd(&za_ps_stat[i], (unsigned long long)(v)); } while (0)
-#define ZA_STAT_T() wall_clock64()
-#else
-#define ZA_STAT_ADD(i, v) do { } while (0)
-#define ZA_STAT_T() 0ull
 #endif
 // LDS of the sweeps, sized per kernel: BITS = longest sub-sequence (bits per lane), Q = matches of one sweep.  The single-
 // stream kernel (one wavefront on the whole GPU) takes long sub-sequences, 1024 bits, which re-synchronise in fewer passes;
@@ -879,7 +937,10 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     if (MODE != 1 && ring_stale) {
                         // the last RING symbols go back into the LDS ring (positions before the start: dictionary / markers)
                         __threadfence_block();
-                        for (uint32_t i = (uint32_t)lane; i < (uint32_t)RING; i += 64) {
+                        // (MODE 0: nothing can refer to what lies in front of the dictionary -- a stream of 1 KiB refills 1 KiB, not 32)
+                        uint32_t i0 = 0;
+                        if (MODE == 0 && op + (uint64_t)dict_len < (uint64_t)RING) i0 = (uint32_t)((uint64_t)RING - op - (uint64_t)dict_len) & ~63u;
+                        for (uint32_t i = i0 + (uint32_t)lane; i < (uint32_t)RING; i += 64) {
                             const long long q = (long long)op - (long long)RING + (long long)i;
                             SymT v;
                             if (q >= 0) v = out[q];

@@ -99,6 +99,9 @@ struct zngamd_ctx {
     uint64_t paths[4] = {0, 0, 0, 0};            // members decoded per path, see zngamd_decode_paths
     uint64_t indexed_units = 0;                  // units decoded with a writer's index (zngamd_indexed_units)
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // pinned host staging for device-to-host results (grow-only)
+    uint8_t *h_up = nullptr; size_t h_up_cap = 0;            // pinned host staging for small uploads (r06): the input of a small call, the unit / run tables
+    uint8_t *h_tab = nullptr; size_t h_tab_cap = 0;
+    hipEvent_t ev_up = nullptr, ev_tab = nullptr; bool up_busy = false, tab_busy = false;      // behind the last copy out of either: a buffer is written again only once that copy has run
     hipEvent_t ev_copy[2] = {nullptr, nullptr};              // ends of the staged device-to-host pieces
     bool prof = false; std::vector<EvPair> evs; std::vector<hipEvent_t> pool;
     double ms[ZNGAMD_K_COUNT] = {0}; uint64_t launches[ZNGAMD_K_COUNT] = {0};
@@ -190,7 +193,8 @@ try {
     {   // tables of the indexed-member decoder's CRC-32: [0, 1024) slice-by-4; [1024, 1152) the raw state advanced over 2 016 zero
         // bytes (what the other 63 lanes hold of a 2 KiB segment), one 16-entry table per nibble of the state; [1152, 1280)
         // x^(8 * 32 k) mod P for k < 128
-        std::vector<uint32_t> s4(1280);
+        // [1280, 2304) and [2304, 2817): the checksum kernel's multipliers (za_checksum.hip)
+        std::vector<uint32_t> s4(ZA_CK_TABS);
         for (int i = 0; i < 256; i++) s4[i] = tab[i];
         for (int t = 1; t < 4; t++) for (int i = 0; i < 256; i++) s4[256 * t + i] = (s4[256 * (t - 1) + i] >> 8) ^ tab[s4[256 * (t - 1) + i] & 0xFF];
         uint32_t x32 = 0x00800000u;                               // x^8 -> x^(8*32): squared five times
@@ -199,6 +203,15 @@ try {
         for (int k = 0; k < 128; k++) { s4[1152 + k] = xs; xs = za_multmodp(xs, x32); }
         const uint32_t x2016 = s4[1152 + 63];                     // x^(8 * 2016)
         for (int k = 0; k < 8; k++) for (uint32_t v = 0; v < 16; v++) s4[1024 + 16 * k + v] = za_multmodp(x2016, v << (4 * k));
+        {
+            uint32_t xt = 0x80000000u;                            // x^(8 t), t <= 512
+            for (int t = 0; t <= 512; t++) { s4[ZA_CK_XT + t] = xt; xt = za_multmodp(xt, 0x00800000u); }
+            for (int j = 0; j < 4; j++) {                         // x^(8 * (64 << j) * k), k < 256
+                const uint32_t step = s4[ZA_CK_XT + (64 << j)];
+                uint32_t xk = 0x80000000u;
+                for (int k = 0; k < 256; k++) { s4[ZA_CK_XS + 256 * j + k] = xk; xk = za_multmodp(xk, step); }
+            }
+        }
         if (hipMalloc((void **)&c->d_crc_slice4, s4.size() * 4) != hipSuccess ||
             hipMemcpy(c->d_crc_slice4, s4.data(), s4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             zngamd_ctx_destroy(c); return ZNGAMD_E_HIP;
@@ -221,6 +234,10 @@ void zngamd_ctx_destroy(zngamd_ctx *c)
     c->ccand.release(); c->csurv.release(); c->cres.release(); c->cchunks.release(); c->out16.release(); c->ccomp.release(); c->winbuf.release(); c->uarea.release();
     c->st_off.release(); c->runs.release(); c->ck.release(); c->matchq.release(); c->cands.release(); c->members.release(); c->mstatus.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_up) (void)hipHostFree(c->h_up);
+    if (c->h_tab) (void)hipHostFree(c->h_tab);
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
     for (auto &e : c->ev_copy) if (e) (void)hipEventDestroy(e);
     if (c->d_crc_table) (void)hipFree(c->d_crc_table);
     if (c->d_x8k) (void)hipFree(c->d_x8k);
@@ -336,7 +353,7 @@ uint32_t zngamd_crc32_combine_many(uint32_t crc, const uint32_t *crcs, const uin
 // run the checksum kernel over a device buffer and fold the per-span partials
 // In two halves, so that a caller with kernels of its own to run can put them between the two and wait once: checksum_launch
 // enqueues the kernel and the copy of its partial results, checksum_fold (behind a synchronisation of the stream) folds them.
-static int checksum_launch(zngamd_ctx *c, const uint8_t *d, uint64_t n, bool want_adler, std::vector<ZaCkPart> &parts)
+static int checksum_launch(zngamd_ctx *c, const uint8_t *d, uint64_t n, bool want_crc, bool want_adler, std::vector<ZaCkPart> &parts)
 {
     parts.clear();
     if (n == 0) return ZNGAMD_OK;
@@ -345,7 +362,7 @@ static int checksum_launch(zngamd_ctx *c, const uint8_t *d, uint64_t n, bool wan
     HIPCHK(c, c->ck.ensure(nspan));
     {
         ProfScope ps(c, ZNGAMD_K_OTHER);
-        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(64), 0, c->stream, d, n, c->d_crc_slice4, c->d_x8k, c->ck.p, want_adler ? 1 : 0);
+        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(256), 0, c->stream, d, n, c->d_crc_slice4, c->ck.p, want_crc ? 1 : 0, want_adler ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     parts.resize(nspan);
@@ -383,18 +400,45 @@ static int checksum_dev(zngamd_ctx *c, const uint8_t *d, uint64_t n, uint32_t *c
     if (n == 0) return ZNGAMD_OK;
     PhaseClock pc(c, "checksum of a device buffer");
     std::vector<ZaCkPart> parts;
-    const int r = checksum_launch(c, d, n, adler_io != nullptr, parts);
+    const int r = checksum_launch(c, d, n, crc_io != nullptr, adler_io != nullptr, parts);
     if (r) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     checksum_fold(parts, crc_io, adler_io);
     return ZNGAMD_OK;
 }
 
+// a grow-only pinned buffer (uploads from pinned memory are queued and return; from pageable memory the call stages them itself
+// and waits -- 15 to 30 us per copy of a small call)
+static int pinned_ensure(zngamd_ctx *c, uint8_t **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return ZNGAMD_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(c, hipHostMalloc((void **)p, want, hipHostMallocDefault));
+    *cap = want;
+    return ZNGAMD_OK;
+}
+
+#define ZNGAMD_SMALL_UP (1u << 20)       // inputs up to this size travel through the pinned upload buffer (one queued copy, the 64 zero bytes behind the input included)
 static int stage_in(zngamd_ctx *c, const uint8_t *in, uint64_t n, uint64_t pad_front = 0)
 {
     PhaseClock pc(c, "stage_in (host -> device)");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, c->st_in.ensure(pad_front + n + 64));
+    if (n <= ZNGAMD_SMALL_UP) {
+        // (nearly every call ends behind a synchronisation of the stream, but one that failed half way may have left its copy queued)
+        if (!c->ev_up) HIPCHK(c, hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+        if (c->up_busy) { HIPCHK(c, hipEventSynchronize(c->ev_up)); c->up_busy = false; }
+        const int r = pinned_ensure(c, &c->h_up, &c->h_up_cap, n + 64);
+        if (r) return r;
+        if (n) memcpy(c->h_up, in, n);
+        memset(c->h_up + n, 0, 64);
+        HIPCHK(c, hipMemcpyAsync(c->st_in.p + pad_front, c->h_up, n + 64, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_up, c->stream));
+        c->up_busy = true;
+        return ZNGAMD_OK;
+    }
     if (n) HIPCHK(c, hipMemcpyAsync(c->st_in.p + pad_front, in, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->st_in.p + pad_front + n, 0, 64, c->stream));
     return ZNGAMD_OK;
@@ -441,7 +485,8 @@ try {
 // ---------------------------------------------------------------------------------------------
 int zngamd_level_ok(int level) { return level >= -1 && level <= 9; }
 
-static uint32_t units_of(const zngamd_block &b) { return b.len == 0 ? 1u : (uint32_t)(((uint64_t)b.len + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT); }
+static uint32_t unit_size_of(const zngamd_block &b) { return (b.flags & ZNGAMD_FLAG_UNITS16K) ? ZA_SMALL_UNIT : (uint32_t)ZA_MAX_UNIT; }
+static uint32_t units_of(const zngamd_block &b) { const uint64_t U = unit_size_of(b); return b.len == 0 ? 1u : (uint32_t)(((uint64_t)b.len + U - 1) / U); }
 
 uint32_t zngamd_count_units(const zngamd_block *blocks, uint32_t n_blocks)
 {
@@ -457,11 +502,12 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
         const zngamd_block &B = blocks[b];
         if (B.dict_len > ZA_WIN || B.dict_len > B.off || B.off + B.len > in_len) return fail(c, ZNGAMD_E_ARG, "block outside the input buffer");
         const uint32_t nu = units_of(B);
+        const uint64_t U = unit_size_of(B);
         for (uint32_t k = 0; k < nu; k++) {
             ZaUnit u;
-            const uint64_t rel = (uint64_t)k * ZA_MAX_UNIT;
+            const uint64_t rel = (uint64_t)k * U;
             u.in_off = B.off + rel;
-            u.in_len = (uint32_t)std::min<uint64_t>(ZA_MAX_UNIT, B.len - rel);
+            u.in_len = (uint32_t)std::min<uint64_t>(U, B.len - rel);
             u.dict_len = (uint32_t)std::min<uint64_t>(ZA_WIN, (uint64_t)B.dict_len + rel);
             u.flags = (B.flags & (ZNGAMD_FLAG_FLATHDR | ZNGAMD_FLAG_SEG2K)) | ((k == nu - 1) ? (B.flags & ZNGAMD_FLAG_FINAL) : 0u);
             u.flags |= (uint32_t)za_seg_shift_for(u.in_len, u.flags) << 8;       // the unit's segment size (za_common.h: small units take small segments)
@@ -479,7 +525,8 @@ static int build_units(zngamd_ctx *c, const zngamd_block *blocks, uint32_t n_blo
 
 // launch the five deflate kernels over all units (in chunks that bound the workspace)
 // `packed` set: no slots -- the plan kernel sizes every unit exactly, a prefix sum places it, the packer writes it there
-struct PackedDst { uint8_t *d_dst = nullptr; uint64_t cap = 0; uint64_t *d_unit_off = nullptr; };
+struct PackedDst { uint8_t *d_dst = nullptr; uint64_t cap = 0; uint64_t *d_unit_off = nullptr;
+                   uint64_t *d_total = nullptr; uint32_t *d_status = nullptr; };      // (optional) where the stream's size and the units' pack status go: a caller that fetches all results with one copy
 static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len, const std::vector<ZaUnit> &hu, int level,
                              uint8_t *d_slots, uint32_t *d_unit_len, uint32_t *d_unit_crc, int max_dist = ZA_WIN,
                              const PackedDst *packed = nullptr)
@@ -497,7 +544,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         // context on this one meets)
         const size_t held = c->links.cap * 2 + c->best.cap * 4 + c->tok.cap * 4 + c->best_keep.cap * 4;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        if (ch > 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {       // (a driver call: tens of microseconds, and a small call has nothing to halve)
             auto need = [&](uint32_t k) { return (size_t)k * (ntab * ZA_PREV_STRIDE * 2 + ZA_BEST_STRIDE * 4 + (c->debug_keep ? (ZA_BEST_STRIDE + ZA_TOK_STRIDE) * 4 : 0) + 8192); };
             while (ch > 64 && need(ch) > held && need(ch) - held > free_b - free_b / 16) ch = (ch + 1) / 2;
         }
@@ -527,8 +574,10 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         HIPCHK(c, c->hdr.ensure((size_t)ch * ZA_HDR_STRIDE));
         d_offs = packed->d_unit_off;
         if (!d_offs) { HIPCHK(c, c->st_off.ensure(n)); d_offs = c->st_off.p; }
-        HIPCHK(c, hipMemsetAsync(d_run_total, 0, 8, c->stream));
+        if (packed->d_total) d_run_total = packed->d_total;
+        // (no memset of the running total: the first launch's prefix sum starts from nothing and writes it)
     }
+    uint32_t *d_status = (packed && packed->d_status) ? packed->d_status : c->status.p;
     // Runs of the chain kernel: one workgroup walks a run of consecutive units and carries its tables from unit to unit where
     // the next unit's dictionary is the tail of the one before (ZA_FLAG_CARRY); a run costs its first unit's dictionary
     // again, so longer runs save more (a quarter of the positions at most) -- but workgroups are handed out in order, and a
@@ -556,9 +605,25 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
             run_start.push_back(m);                                  // (the runs of one launch: starts relative to the launch, then its end)
         }
         HIPCHK(c, c->runs.ensure(run_start.size()));
+        if (n <= 4096) {
+            // a small table travels from pinned memory: two queued copies and no wait (r06: a call whose shape differs from the
+            // last one's paid 40 us for the two staged copies and the synchronisation)
+            const size_t rb = run_start.size() * 4, ub = (size_t)n * sizeof(ZaUnit);
+            if (!c->ev_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming));
+            if (c->tab_busy) { HIPCHK(c, hipEventSynchronize(c->ev_tab)); c->tab_busy = false; }
+            const int rp = pinned_ensure(c, &c->h_tab, &c->h_tab_cap, rb + ub);
+            if (rp) return rp;
+            memcpy(c->h_tab, hv.data(), ub);
+            memcpy(c->h_tab + ub, run_start.data(), rb);
+            HIPCHK(c, hipMemcpyAsync(c->units.p, c->h_tab, ub, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->runs.p, c->h_tab + ub, rb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_tab, c->stream));
+            c->tab_busy = true;
+        } else {
         HIPCHK(c, hipMemcpyAsync(c->runs.p, run_start.data(), run_start.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->units.p, hv.data(), (size_t)n * sizeof(ZaUnit), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));                  // (hv and run_start are locals)
+        }
         c->last_hu.swap(hv);
         c->plan_runs.swap(run_start);
         c->plan_in = hu; c->plan_ch = ch;
@@ -609,12 +674,12 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
               hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
                                  (uint8_t *)nullptr, 0u, level, c->hdr.p, d_unit_len + c0); }
             { ProfScope ps(c, ZNGAMD_K_GATHER);          // (what is left of the gather: the prefix sum)
-              hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(1024), 0, c->stream, d_unit_len + c0, m, 0u, 0ull, d_offs + c0, d_run_total,
-                                 (const ZaUnit *)nullptr, (const uint64_t *)d_run_total); }
+              hipLaunchKernelGGL(za_k_offsets, dim3(1), dim3(m <= 64 ? 64 : 1024), 0, c->stream, d_unit_len + c0, m, 0u, 0ull, d_offs + c0, d_run_total,
+                                 (const ZaUnit *)nullptr, c0 ? (const uint64_t *)d_run_total : (const uint64_t *)nullptr, 1); }
             { ProfScope ps(c, ZNGAMD_K_PACK);
               hipLaunchKernelGGL(za_k_pack, dim3(m), dim3(64), 0, c->stream, d_in, du, c->tok_p, c->segtok.p, c->codes.p, c->plan.p,
                                  c->segbits.p + (size_t)c0 * ZA_SEGB_STRIDE, c->cidx.p + (size_t)c0 * ZA_CIDX_STRIDE, packed->d_dst,
-                                 0u, d_unit_len + c0, c->status.p + c0, (const uint64_t *)(d_offs + c0), packed->cap, (const uint8_t *)c->hdr.p); }
+                                 0u, d_unit_len + c0, d_status + c0, (const uint64_t *)(d_offs + c0), packed->cap, (const uint8_t *)c->hdr.p); }
         } else {
         { ProfScope ps(c, ZNGAMD_K_PLAN);
           hipLaunchKernelGGL(za_k_plan, dim3(m), dim3(64), 0, c->stream, du, c->hist.p, c->codes.p, c->plan.p,
@@ -803,56 +868,72 @@ static int d2h_payload(zngamd_ctx *c, uint8_t *dst, const uint8_t *src_dev, uint
     return ZNGAMD_OK;
 }
 
+// (optional) a checksum of the staged input worked out beside the deflate kernels; its partial results travel with theirs
+struct CkReq { bool want_crc = false, want_adler = false; std::vector<ZaCkPart> parts; };
+
 static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks, int level,
                                std::vector<ZaUnit> &hu, std::vector<uint32_t> &ulen, std::vector<uint32_t> &ucrc,
                                const uint8_t **packed, int max_dist = ZA_WIN,
-                               uint8_t *direct_out = nullptr, uint64_t direct_cap = 0, uint64_t *direct_len = nullptr)
+                               uint8_t *direct_out = nullptr, uint64_t direct_cap = 0, uint64_t *direct_len = nullptr, CkReq *ck = nullptr)
 {
     int r;
     { PhaseClock pc(nullptr, "build_units"); r = build_units(c, blocks, n_blocks, in_len, hu); }
     if (r) return r;
     const uint32_t n = (uint32_t)hu.size();
-    HIPCHK(c, c->st_len.ensure(n)); HIPCHK(c, c->st_crc.ensure(n));
     // Packed: every unit's size is planned before it is packed and the packer writes at its final offset (no slots, no gather).
     // A unit is never larger than its stored form: its bytes + 5 per stored chunk of 65 535 + an empty stored block behind it.
     uint64_t bound = 64;
     for (const ZaUnit &u : hu) bound += (uint64_t)u.in_len + 32u;
-    HIPCHK(c, c->st_out.ensure(bound));
-    PackedDst pd; pd.d_dst = c->st_out.p; pd.cap = bound; pd.d_unit_off = nullptr;
+    // Everything the host wants back lies in ONE device buffer, the results in front of the stream -- the stream's size, the units'
+    // sizes, CRCs and pack status, the checksum kernel's partial sums -- so that a small call fetches results and bytes with one
+    // copy (r06: five copies of a few bytes each, staged one after the other, cost a small call 60 us):
+    //   [0, 16) size of the stream | [16, ..) n sizes | n CRCs | n status words | checksum parts | (to a multiple of 256) the stream
+    const uint64_t nspan = ck ? (in_len + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT : 0;
+    const uint64_t o_len = 16, o_crc = o_len + 4ull * n, o_st = o_crc + 4ull * n, o_ck = (o_st + 4ull * n + 15) & ~15ull;
+    const uint64_t head = (o_ck + nspan * sizeof(ZaCkPart) + 255) & ~255ull;
+    HIPCHK(c, c->st_out.ensure(head + bound));
+    uint8_t *d_head = c->st_out.p;
+    PackedDst pd; pd.d_dst = d_head + head; pd.cap = bound; pd.d_unit_off = nullptr;
+    pd.d_total = (uint64_t *)d_head; pd.d_status = (uint32_t *)(d_head + o_st);
+    if (ck && nspan) {
+        // the container's checksum: its kernel goes out in front of the deflate kernels and is waited for with them
+        ProfScope ps(c, ZNGAMD_K_OTHER);
+        hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(256), 0, c->stream, (const uint8_t *)c->st_in.p, in_len, c->d_crc_slice4,
+                           (ZaCkPart *)(d_head + o_ck), ck->want_crc ? 1 : 0, ck->want_adler ? 1 : 0);
+    }
     { PhaseClock pc(c, "deflate kernels");
-      r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, nullptr, c->st_len.p, c->st_crc.p, max_dist, &pd); }
+      r = deflate_units_dev(c, c->st_in.p, in_len, hu, level, nullptr, (uint32_t *)(d_head + o_len), (uint32_t *)(d_head + o_crc), max_dist, &pd); }
     if (r) return r;
     const bool direct = direct_out != nullptr;
-    ulen.resize(n); ucrc.resize(n);
-    std::vector<uint32_t> st(n);
-    uint64_t total = 0;
-    const uint64_t *d_run_total = (const uint64_t *)((const uint8_t *)c->d_small + 224);
-    // One round trip for the sizes, and for a small result the bytes as well (its upper bound travels: the size is not known yet)
+    // One round trip for the results, and for a small stream the bytes as well (its upper bound travels: the size is not known yet)
     const uint64_t EAGER = 512u << 10;
     uint8_t *stage = nullptr;
     const bool eager = bound <= EAGER;
-    if (eager) { int rs = host_stage(c, bound, &stage); if (rs) return rs; }
+    { int rs = host_stage(c, head + (eager ? bound : 0), &stage); if (rs) return rs; }
     {
         PhaseClock pc(c, "results to the host");
-        HIPCHK(c, hipMemcpyAsync(&total, d_run_total, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(ulen.data(), c->st_len.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(ucrc.data(), c->st_crc.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, n * 4ull, hipMemcpyDeviceToHost, c->stream));
-        if (eager) HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, bound, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(stage, d_head, head + (eager ? bound : 0), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    c->up_busy = false; c->tab_busy = false;                       // (the stream has drained: the upload buffers are free)
     prof_collect(c);
+    uint64_t total = 0;
+    memcpy(&total, stage, 8);
+    ulen.resize(n); ucrc.resize(n);
+    if (n) { memcpy(ulen.data(), stage + o_len, 4ull * n); memcpy(ucrc.data(), stage + o_crc, 4ull * n); }
+    const uint32_t *st = (const uint32_t *)(stage + o_st);
     for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_HIP, "packed deflate: a unit's size differs from its plan");
     if (total > bound) return fail(c, ZNGAMD_E_HIP, "packed deflate: stream larger than its bound");
+    if (ck) { ck->parts.resize(nspan); if (nspan) memcpy(ck->parts.data(), stage + o_ck, nspan * sizeof(ZaCkPart)); }
     // one-shot callers take the packed stream straight into their buffer (no intermediate copy)
     if (direct) { *direct_len = total; if (total > direct_cap) return fail(c, ZNGAMD_BUF_ERROR, "output buffer too small"); }
     if (eager) {
-        if (direct) memcpy(direct_out, stage, total); else *packed = stage;
+        if (direct) memcpy(direct_out, stage + head, total); else *packed = stage + head;
         return ZNGAMD_OK;
     }
     if (!direct) { int rs = host_stage(c, total, &stage); if (rs) return rs; *packed = stage; }
-    if (total && !direct) { HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, total, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-    if (total && direct) { const int rc_ = d2h_payload(c, direct_out, c->st_out.p, total); if (rc_) return rc_; HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    if (total && !direct) { HIPCHK(c, hipMemcpyAsync(stage, pd.d_dst, total, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    if (total && direct) { const int rc_ = d2h_payload(c, direct_out, pd.d_dst, total); if (rc_) return rc_; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return ZNGAMD_OK;
 }
 
@@ -904,8 +985,8 @@ try {
     if (r == ZNGAMD_BUF_ERROR && !hu.empty()) {
         // the packed stream does not fit: because a block outgrew its cap (an overflow, reported like the per-block form does),
         // or because the caller's buffer is simply too small (ZNGAMD_BUF_ERROR, *total = the size needed)
-        ulen.resize(hu.size());
-        HIPCHK(c, hipMemcpy(ulen.data(), c->st_len.p, hu.size() * 4ull, hipMemcpyDeviceToHost));
+        // (the units' sizes came back with the results: deflate_host_common fills `ulen` before it looks at the caller's room)
+        if (ulen.size() != hu.size()) return r;
         bool any = false;
         size_t u2 = 0;
         for (uint32_t b = 0; b < n_blocks; b++) {
@@ -946,15 +1027,16 @@ try {
     int r = stage_in(c, in, in_len);
     if (r) return r;
     zngamd_block B; B.off = 0; B.len = (uint32_t)in_len; B.dict_len = 0; B.flags = ZNGAMD_FLAG_FINAL; B.reserved = 0;
+    // a call of up to one unit's size is cut into units of 16 KiB (oracle: za_o_deflate_stream): eight wavefronts instead of one
+    if (in_len <= ZA_MAX_UNIT) B.flags |= ZNGAMD_FLAG_UNITS16K;
     std::vector<ZaUnit> hu; std::vector<uint32_t> ulen, ucrc; const uint8_t *packed = nullptr;
     if (window_bits < 9 || window_bits > 15) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
-    // the zlib container's Adler-32: its kernel goes out in front of the deflate kernels and is waited for with them
-    std::vector<ZaCkPart> ck_parts;
-    if (adler) { r = checksum_launch(c, c->st_in.p, in_len, true, ck_parts); if (r) return r; }
-    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, &packed, 1 << window_bits, out, out_cap, out_len);
-    if (r) { (void)hipStreamSynchronize(c->stream); return r; }       // (ck_parts is a local the copy may still be writing)
+    // the zlib container's Adler-32: its kernel goes out in front of the deflate kernels and its sums come back with their results
+    CkReq ck; ck.want_adler = adler != nullptr;
+    r = deflate_host_common(c, in_len, &B, 1, level, hu, ulen, ucrc, &packed, 1 << window_bits, out, out_cap, out_len, adler ? &ck : nullptr);
+    if (r) { (void)hipStreamSynchronize(c->stream); return r; }
     if (crc) { uint32_t v = 0; for (size_t u = 0; u < hu.size(); u++) v = u ? zngamd_crc32_combine(v, ucrc[u], hu[u].in_len) : ucrc[u]; *crc = v; }
-    if (adler) { uint32_t a = 1; checksum_fold(ck_parts, nullptr, &a); *adler = a; }
+    if (adler) { uint32_t a = 1; checksum_fold(ck.parts, nullptr, &a); *adler = a; }
     return ZNGAMD_OK;
 } ZA_ABI_GUARD
 
@@ -1087,6 +1169,47 @@ try {
     int r = stage_in(c, in, in_len, front);
     if (r) return r;
     if (dict_len) HIPCHK(c, hipMemcpyAsync(c->st_in.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+    if (in_len < (1u << 16) && out_cap <= (512u << 10)) {
+        // A small call (r06): the decoder, the checksum kernel -- which takes the output's length from where the decoder left it --
+        // and ONE copy that brings result, checksum parts and the bytes up to the caller's limit, behind one synchronisation (the
+        // result, the parts and the payload each had a round trip of their own: 60 of a 1 KiB call's 330 us).
+        const uint64_t head = 256;                                   // [0, 40) the decoder's result | [64, 128) checksum parts of up to four spans | the output
+        const uint64_t nspan = (crc || adler) ? (out_cap + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT : 0;
+        HIPCHK(c, c->st_out.ensure(head + out_cap + 64));
+        ZaInfResult *dres = (ZaInfResult *)c->st_out.p;
+        { ProfScope ps(c, ZNGAMD_K_INFLATE);
+          hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
+                             c->st_out.p + head, out_cap, dres); }
+        if (nspan) {
+            ProfScope ps(c, ZNGAMD_K_OTHER);
+            hipLaunchKernelGGL(za_k_checksum, dim3((uint32_t)nspan), dim3(256), 0, c->stream, (const uint8_t *)(c->st_out.p + head), out_cap, c->d_crc_slice4,
+                               (ZaCkPart *)(c->st_out.p + 64), crc ? 1 : 0, adler ? 1 : 0, (const uint64_t *)&dres->out_len);
+        }
+        HIPCHK(c, hipGetLastError());
+        uint8_t *stage = nullptr;
+        r = host_stage(c, head + out_cap, &stage);
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(stage, c->st_out.p, head + out_cap, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->up_busy = false;
+        prof_collect(c);
+        ZaInfResult res;
+        memcpy(&res, stage, sizeof res);
+        c->paths[ZNGAMD_PATH_SEQUENTIAL]++;
+        *out_len = res.out_len;
+        if (in_used) *in_used = (res.in_bits + 7) >> 3;
+        if (nspan) {
+            std::vector<ZaCkPart> parts(nspan);
+            memcpy(parts.data(), stage + 64, nspan * sizeof(ZaCkPart));
+            uint32_t cv = 0, av = 1;
+            checksum_fold(parts, crc ? &cv : nullptr, adler ? &av : nullptr);
+            if (crc) *crc = cv;
+            if (adler) *adler = av;
+        }
+        if (res.out_len) memcpy(out, stage + head, res.out_len <= out_cap ? res.out_len : out_cap);
+        if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
+        return map_status(res.status);
+    }
     HIPCHK(c, c->st_out.ensure(out_cap + 64));
     ZaInfResult res;
     bool chunked = false;
@@ -2609,6 +2732,15 @@ try {
 
 #include "zng_stream.hip"
 
+#ifdef ZA_PLAN_STATS
+// profiling build only: the plan kernel's phase clocks (za_deflate.hip), read and cleared
+extern "C" int zngamd_debug_plan_stats(unsigned long long *out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(za_plan_stat), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(za_plan_stat), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef ZA_CH_STATS
 // profiling build only: the chain kernel's clocks (za_deflate.hip), read and cleared
 extern "C" int zngamd_debug_ch_stats(unsigned long long *out32)

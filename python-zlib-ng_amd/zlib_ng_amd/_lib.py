@@ -28,7 +28,7 @@ UNIT_MAX = 131072
 SLOT_STRIDE = 131136
 SEG = 2048
 INDEX_STRIDE = 68        # ZNGAMD_INDEX_STRIDE
-FLAG_FINAL, FLAG_FLATHDR, FLAG_SEG2K = 1, 2, 16
+FLAG_FINAL, FLAG_FLATHDR, FLAG_SEG2K, FLAG_UNITS16K = 1, 2, 16, 32
 # The writer's segment index in a FILE (r06): behind the data member, EMPTY gzip members (header with FEXTRA, `03 00`, zero CRC and
 # ISIZE) whose 'Z','A' subfield holds: version 3, kind 1, the number of records (u16), the first record's unit number (u32), then
 # records of 138 bytes -- a unit's compressed bytes (u32, sync marker included), its output bytes (u32), 65 x u16: the bit offset of
@@ -610,7 +610,7 @@ class Context:
         written into the result object itself, around the bytes the engine puts there: no second copy of the payload."""
         p, keep = _addr(data)
         n = memoryview(data).nbytes
-        cap = n + (n // UNIT_MAX + 1) * 64 + 64
+        cap = n + (n // 16384 + 1) * 16 + 192          # (a call of up to 128 KiB is cut into units of 16 KiB: 10 bytes each at worst, stored)
         room = len(prefix) + (8 if trailer is not None else 0)
         out = _Out(cap + room)
         base = out.addr().value
