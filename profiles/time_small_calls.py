@@ -12,6 +12,8 @@ for size in (1 << 10, 16 << 10, 64 << 10):
         ts = []
         for _ in range(n):
             t = time.perf_counter(); f(x); ts.append(time.perf_counter() - t)
+        slow = max(range(n), key=lambda i: ts[i])
+        if ts[slow] > 4 * sorted(ts)[n // 2]: print(f"   (call {slow} of {n} took {ts[slow]*1e6:.0f} us; the three before it {[round(x*1e6) for x in ts[max(0,slow-3):slow]]})")
         ts.sort()
         return sum(ts) / n, ts[n // 2], ts[-1]
     tc, tc_med, tc_max = lap(zlib_ng.compress, d)

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
 // 40960 positions (u16 ring) and the input bytes of the last 65536 positions (byte ring), both indexed
 // by the absolute position P = 32768 + p.  A tile of 4096 positions is staged per barrier; every
 // position of the tile is then searched in parallel with LDS traffic only.
+#ifndef ZA_SEARCH_CONSEC
+#define ZA_SEARCH_CONSEC 1         // levels 1-6: a thread takes four CONSECUTIVE positions of a tile (0: positions 1 024 apart, as until r06 -- see the tile loop)
+#endif
 #ifndef ZA_STATS_FOLD
 #define ZA_STATS_FOLD 0            // 1: the dynamic programme's cost statistics taken inside the search of levels 4-6 (measured, lost: see the kernel)
 #endif
@@ -653,8 +656,23 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
         *(uint4 *)(lds + a) = make_uint4(oq.x, oq.y, oq.z, oq.w);
     };
     uint32_t nlkb[ZA_SEARCH_TILE / ZA_SEARCH_THREADS], nlkc[ZA_SEARCH_TILE / ZA_SEARCH_THREADS];
+    constexpr bool CONSEC = !FULL && ZA_SEARCH_CONSEC && !ZA_OWN_STAGE && !ZA_STATS_FOLD;
+    uint2 nob = make_uint2(0u, 0u), noc = make_uint2(0u, 0u);     // (CONSEC) my four positions' links of the next tile as they were loaded: taken apart a tile later
     auto load_own_links = [&](int tile_base) {
         if (ZA_OWN_STAGE) { own_load(tile_base); return; }
+        if (CONSEC) {
+            // four consecutive links of a table are ONE 8-byte load (a position behind the unit's end reads the unit's last links,
+            // and is never searched; the load may reach three entries past the unit's links: inside the row)
+            const int p = tile_base + 4 * tid;
+            const uint32_t off = 2u * (uint32_t)(p < n ? p : (n - 1) & ~3);
+#ifdef ZA_ABL_NO_LINKLOADS
+            nob = make_uint2(0x00010001u, 0x00010001u); noc = nob;
+#else
+            if (n > 0) { const ZaU2u t = *(const ZaU2u *)((const uint8_t *)linkb + off); nob.x = t.x; nob.y = t.y; }
+            if (USEC && n > 0) { const ZaU2u t = *(const ZaU2u *)((const uint8_t *)linkc + off); noc.x = t.x; noc.y = t.y; }
+#endif
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
             const int p = tile_base + k * ZA_SEARCH_THREADS + tid;
@@ -678,6 +696,16 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
     int res_base = -1;                                             // tile whose results wait in res[], -1: none
     auto flush_results = [&]() {
         if (res_base < 0) return;
+        if (CONSEC) {
+            const int p = res_base + 4 * tid;                         // four consecutive entries: one 16-byte store
+            if (p + 4 <= n) *(uint4 *)(best + p) = make_uint4(res[0], res[1], res[2], res[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (p + k < n) best[p + k] = res[k];
+            }
+            res_base = -1;
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++) {
             const int p = res_base + k * ZA_SEARCH_THREADS + tid;
@@ -719,6 +747,9 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 const uint32_t a = own_area(base) + 2u * (uint32_t)(k * ZA_SEARCH_THREADS + tid);
                 lkb[k] = *(const uint16_t *)(lds + (a & 0xFFFFu));
                 lkc[k] = USEC ? (uint32_t)*(const uint16_t *)(lds + ((a + 8192u) & 0xFFFFu)) : 0u;
+            } else if (CONSEC) {
+                lkb[k] = ((k < 2 ? nob.x : nob.y) >> (16 * (k & 1))) & 0xFFFFu;
+                lkc[k] = ((k < 2 ? noc.x : noc.y) >> (16 * (k & 1))) & 0xFFFFu;
             } else { lkb[k] = nlkb[k]; lkc[k] = nlkc[k]; }
             asm volatile("" : "+v"(lkb[k]), "+v"(lkc[k]) : : "memory");       // (here and now: nothing is moved across)
         }
@@ -912,7 +943,7 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             batch(left < 64u ? left : 64u);
         }
         } else {
-        uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + tid)) % ZA_RING;      // ring slot of my position, moved on by 1 024 per round
+        uint32_t slot = (goff + (uint32_t)(ZA_WIN + base + (CONSEC ? 4 * tid : tid))) % ZA_RING;      // ring slot of my (first) position, moved on by 1 024 per round (CONSEC: a multiple of four, like the ring's size -- my four slots do not wrap)
         // my four positions' own links in tables B and C are what was fetched a tile ago (lkb / lkc); the next tile's are asked for now
         load_own_links(base + ZA_SEARCH_TILE);
         // (the statistics' loads go out BEHIND the point where last tile's loads are used: the compiler's wait there, across the
@@ -922,13 +953,34 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
 #ifndef ZA_SEARCH_KUNROLL
 #define ZA_SEARCH_KUNROLL 4              // the four positions of a thread per tile as straight code (18.9 against 19.4 ms per 4 GiB at level 6)
 #endif
+        // (r06, ZA_SEARCH_CONSEC) A thread's four positions of a tile are CONSECUTIVE ones, 4 tid .. 4 tid + 3 (until now tid, tid +
+        // 1 024, ...): what a position needs of its own -- its 16 bytes, its link in the ring, its links in tables B and C, its
+        // segment's end -- comes in once for the four: five aligned dwords instead of twenty (a run's positions are multiples of
+        // four where the tile's are: the four byte offsets are constants, the first needs no alignment at all), one 8-byte LDS read
+        // of the ring instead of four 2-byte ones, one 8-byte load per table instead of four 2-byte ones, one 16-byte store of the
+        // entries instead of four -- vector-memory instructions are what this kernel's waves queue for.
+        const int p0c = base + 4 * tid;
+        const uint32_t P0c = goff + (uint32_t)(ZA_WIN + p0c);
+        uint32_t cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0, cm4 = 0;
+        uint2 cdq = make_uint2(0u, 0u);
+        int cseg_end = 0;
+        if (CONSEC && p0c < n) {
+            const uint32_t w = (P0c & (ZA_BYTES - 1)) >> 2;
+            cm0 = win32[w]; cm1 = win32[w + 1]; cm2 = win32[w + 2]; cm3 = win32[w + 3]; cm4 = win32[w + 4];
+            cdq = *(const uint2 *)(lds + RING_B0 + 2u * slot);
+            cseg_end = ((p0c >> sshift) + 1) << sshift;                 // (segments are 32 bytes at least: the four share one)
+            if (cseg_end > n) cseg_end = n;
+        }
 #pragma unroll
-        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
-            const int p = base + k * ZA_SEARCH_THREADS + tid;
+        for (int k = 0; k < ZA_SEARCH_TILE / ZA_SEARCH_THREADS; k++, slot = CONSEC ? slot : slot + ZA_SEARCH_THREADS >= ZA_RING ? slot + ZA_SEARCH_THREADS - ZA_RING : slot + ZA_SEARCH_THREADS) {
+            const int p = CONSEC ? p0c + k : base + k * ZA_SEARCH_THREADS + tid;
             res[k] = 0u;
             if (p >= n) continue;
-            int seg_end = ((p >> sshift) + 1) << sshift;
-            if (seg_end > n) seg_end = n;
+            int seg_end = cseg_end;
+            if (!CONSEC) {
+                seg_end = ((p >> sshift) + 1) << sshift;
+                if (seg_end > n) seg_end = n;
+            }
             int maxlen = seg_end - p;
             if (maxlen > ZA_MAX_MATCH) maxlen = ZA_MAX_MATCH;
             // the result: distance - 1 (bits 0..14) | length (bits 15..23); the position's own byte travels in the top byte
@@ -937,7 +989,13 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
             // my first 16 bytes stay in registers; every candidate's first 16 bytes are compared
             // against them without branches (this also plays the role of zlib's quick-reject byte)
             uint32_t me0, me1, me2, me3;
-            {   // five aligned dwords and one shift amount (the ring has mirrored pad dwords behind its end)
+            if (CONSEC) {
+                if (k == 0) { me0 = cm0; me1 = cm1; me2 = cm2; me3 = cm3; }
+                else {
+                    me0 = __builtin_amdgcn_alignbyte(cm1, cm0, (uint32_t)k); me1 = __builtin_amdgcn_alignbyte(cm2, cm1, (uint32_t)k);
+                    me2 = __builtin_amdgcn_alignbyte(cm3, cm2, (uint32_t)k); me3 = __builtin_amdgcn_alignbyte(cm4, cm3, (uint32_t)k);
+                }
+            } else {   // five aligned dwords and one shift amount (the ring has mirrored pad dwords behind its end)
                 const uint32_t idx = P & (ZA_BYTES - 1), w = idx >> 2, sh = idx & 3u;
                 const uint32_t m0 = win32[w], m1 = win32[w + 1], m2 = win32[w + 2], m3 = win32[w + 3], m4 = win32[w + 4];
                 me0 = __builtin_amdgcn_alignbyte(m1, m0, sh); me1 = __builtin_amdgcn_alignbyte(m2, m1, sh);
@@ -948,8 +1006,8 @@ __global__ __launch_bounds__(ZA_SEARCH_THREADS) void za_k_search(const uint8_t *
                 const int nice = L.nice < cap ? L.nice : cap;
                 int best_len = ZA_MIN_MATCH - 1, best_dist = 0;
                 uint32_t q = P;
-                uint32_t qb = RING_B0 + 2u * slot;                           // LDS byte address of q's link, kept incrementally
-                uint32_t d = *(const uint16_t *)(lds + qb);
+                uint32_t qb = RING_B0 + 2u * (CONSEC ? slot + (uint32_t)k : slot);   // LDS byte address of q's link, kept incrementally
+                uint32_t d = CONSEC ? ((k < 2 ? cdq.x : cdq.y) >> (16 * (k & 1))) & 0xFFFFu : (uint32_t)*(const uint16_t *)(lds + qb);
                 int depth = STEPS > 0 ? STEPS : L.chain;
 #pragma unroll
                 while (depth-- > 0) {
