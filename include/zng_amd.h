@@ -55,11 +55,11 @@ typedef struct zngamd_ctx zngamd_ctx;
                                          (what zngamd_gzip_members* writes; any inflater reads it as an ordinary dynamic header) */
 #define ZNGAMD_FLAG_SEG2K      16u    /* segments of 2 KiB whatever the block's size (small blocks take smaller ones otherwise): what the
                                        * segment index of a dict-chained stream is counted in (zngamd_deflate_index) */
-/* window of the stream the blocks belong to: match distances stay within 2^bits (deflateInit2's windowBits 9..15).
- * Taken from the FIRST block of a call and applied to all of them; 0 = 15. */
 #define ZNGAMD_FLAG_UNITS16K   32u    /* the block is cut into units of 16 KiB (deflate blocks of their own, each with the 32 KiB before it as
                                         its dictionary) instead of 128 KiB: latency before size -- what zngamd_deflate_stream does by itself for
-                                        inputs of up to 128 KiB (r06; +0.2 .. 1.2 % of compressed size, a 64 KiB call 970 -> 560 us) */
+                                        inputs of up to 128 KiB (r06; +0.2 .. 1.2 % of compressed size, a 64 KiB call 970 -> 435 us) */
+/* window of the stream the blocks belong to: match distances stay within 2^bits (deflateInit2's windowBits 9..15).
+ * Taken from the FIRST block of a call and applied to all of them; 0 = 15. */
 #define ZNGAMD_FLAG_WBITS(bits) (((uint32_t)(bits) & 15u) << 8)
 
 #define ZNGAMD_UNIT_MAX        131072u  /* largest span one kernel unit covers */

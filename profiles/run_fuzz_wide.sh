@@ -23,5 +23,9 @@ for seed in $((S+1)) $((S+2)); do
   timeout -k 10 280 python3 profiles/fuzz_indexed_chain.py $seed 120 > $OUT/indexed_$seed.txt 2>&1 || { echo "indexed chain $seed failed"; tail -3 $OUT/indexed_$seed.txt; exit 1; }
   tail -1 $OUT/indexed_$seed.txt
 done
+for seed in $((S+1)) $((S+2)); do
+  timeout -k 10 280 python3 profiles/fuzz_small_calls.py $seed 400 > $OUT/small_$seed.txt 2>&1 || { echo "small calls $seed failed"; tail -3 $OUT/small_$seed.txt; exit 1; }
+  tail -1 $OUT/small_$seed.txt
+done
 timeout -k 10 280 python3 profiles/fuzz_reader_windows.py $((S+1)) 30 > $OUT/reader_401.txt 2>&1 || { echo "reader windows failed"; tail -3 $OUT/reader_401.txt; exit 1; }
 tail -1 $OUT/reader_401.txt

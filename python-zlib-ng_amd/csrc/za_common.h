@@ -43,7 +43,7 @@
 // bits 8..11 of a unit's flags (set by the host, za_seg_shift_for): log2 of the unit's SEGMENT size.  A unit is always cut into at
 // most 64 segments (token boundaries are forced there: parse, dynamic programme and packer give a lane to each); a full unit's are
 // 2 KiB, the units of small calls get smaller ones -- 32 bytes at least -- so that a call of a few KiB is not ONE lane walking
-// 2 048 positions (the latency of zlib_ng.compress(16 KiB): 1.4 ms -> 0.3).  Indexed members always use 2 KiB (their index's grain).
+// 2 048 positions (zlib_ng.compress of 16 KiB: 850 -> 625 us in r05, 377 us with r06's host path; profiles/time_small_calls.py).  Indexed members always use 2 KiB (their index's grain).
 #define ZA_UNIT_SEG_SHIFT(flags) ((int)(((flags) >> 8) & 15u))
 #define ZA_LIMIT_L     10       // longest literal/length code the encoder emits: one 2^10-entry table decodes every symbol
 #define ZA_LIMIT_D     9        // longest distance code

@@ -137,36 +137,43 @@ __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_
             for (int l = 1; l <= 15; l++) { fst[l] = (uint16_t)first; idx[l] = (uint16_t)index; index += c[l]; first = (first + c[l]) << 1; }
         }
     }
+    // (r06) The first-level table is filled BY SYMBOL: a symbol of length l <= lut_bits owns the 2^(lut_bits - l) entries whose low l
+    // bits are its code in stream order (the code's bits reversed), and a lane learns its symbols' codes where it places them --
+    // first code of the length + the symbol's rank among its length's symbols.  Until r06 every lane decoded its share of the
+    // ENTRIES bit by bit (ten dependent steps and an LDS read per entry, sixteen entries a lane for the 10-bit table): 8 of the
+    // 16 us the literal/length table of a dynamic header took.
+    uint32_t ecode[5] = {0u, 0u, 0u, 0u, 0u};
     if (st >= 0) {
         const unsigned long long below = (1ull << lane) - 1ull;
-        int base = 0;
+        int base = 0, first = 0;
 #pragma unroll
         for (int l = 1; l <= 15; l++) {
+            first = (first + c[l - 1]) << 1;                     // first code of length l (c[0] = 0)
             if (c[l]) {
+                const int idx_l = base;
 #pragma unroll
                 for (int b = 0; b < 5; b++) {
                     const unsigned long long m = __ballot(L[b] == l);
-                    if (L[b] == l) sym[base + __popcll(m & below)] = (uint16_t)(b * 64 + lane);
+                    if (L[b] == l) {
+                        const int pos = base + __popcll(m & below);
+                        sym[pos] = (uint16_t)(b * 64 + lane);
+                        ecode[b] = __brev((uint32_t)(first + (pos - idx_l))) >> (32 - l);
+                    }
                     base += __popcll(m);
                 }
             }
         }
+        for (int e = lane; e < (1 << lut_bits); e += 64) lut[e] = 0;      // (entries of longer codes, and of an incomplete code's gaps, stay 0)
     }
     __syncthreads();
     if (st >= 0) {
-        // LUT entry for the low lut_bits bits e: canonical decode with the counts in registers
-        for (int e = lane; e < (1 << lut_bits); e += 64) {
-            uint32_t v = (uint32_t)e, r = 0;
-            int code = 0, first = 0, index = 0;
 #pragma unroll
-            for (int l = 1; l <= 10; l++) {
-                if (l <= lut_bits && r == 0) {
-                    code |= (int)(v & 1u); v >>= 1;
-                    if (code - c[l] < first) r = ((uint32_t)sym[index + (code - first)] << 4) | (uint32_t)l;
-                    index += c[l]; first += c[l]; first <<= 1; code <<= 1;
-                }
+        for (int b = 0; b < 5; b++) {
+            const int l = L[b];
+            if (l != 0 && l <= lut_bits) {
+                const uint16_t entry = (uint16_t)(((uint32_t)(b * 64 + lane) << 4) | (uint32_t)l);
+                for (uint32_t e = ecode[b]; e < (1u << lut_bits); e += 1u << l) lut[e] = entry;
             }
-            lut[e] = (uint16_t)r;
         }
     }
     __syncthreads();

@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_stream_objects.py", 301, 40),
     ("fuzz_reader_windows.py", 1, 6),
     ("fuzz_indexed_chain.py", 3, 25),        # the writer's segment index: units of every kind and size decoded side by side, files through writer and readers
+    ("fuzz_small_calls.py", 5, 40),          # the one-shot calls' small paths: 16 KiB units, one-copy results, checksums beside the kernels, the small inflate path
     ("fuzz_long_matches.py", 11, 30),        # zero runs, periods and sparse bytes at levels 4-9: the dynamic programme's long-match path, multi-unit batches
 ])
 def test_fuzz_script_smallest_seed(script, seed, cases):
