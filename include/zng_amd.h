@@ -296,6 +296,13 @@ int zngamd_index_create(zngamd_ctx *ctx, uint32_t n_units, const uint32_t *unit_
                         const uint32_t *rows, void **handle);
 void zngamd_index_destroy(void *handle);
 int zngamd_deflate_index(zngamd_ctx *ctx, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows);
+/* zngamd_deflate_blocks_packed and zngamd_deflate_index of ITS units in one call (n_units = zngamd_count_units(blocks, n_blocks)):
+ * what a writer that shares its context with other threads calls -- between two calls another thread's deflate could slip, and
+ * zngamd_deflate_index answers for the context's last deflate call, whoever made it.  Replaces, with the index, the writer
+ * thread's join of its blocks (gzip_ng_threaded.py:382-398). */
+int zngamd_deflate_blocks_packed_indexed(zngamd_ctx *ctx, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                                         int level, uint8_t *out, uint64_t out_cap, uint64_t block_cap, uint32_t *out_len, uint32_t *crc,
+                                         uint64_t *total, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows);
 int zngamd_gunzip_stream(zngamd_ctx *ctx, zngamd_gz_state *st, const uint8_t *in, uint64_t in_len, int last,
                          uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint32_t *n_members,
                          uint64_t *in_consumed);

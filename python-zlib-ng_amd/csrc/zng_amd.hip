@@ -80,6 +80,7 @@ struct zngamd_ctx {
     DevBuf<uint16_t> links; DevBuf<uint32_t> best, tok, segtok, hist, codes; DevBuf<ZaPlan> plan;
     uint16_t *prev_p = nullptr, *linkb_p = nullptr, *linkc_p = nullptr; uint32_t *tok_p = nullptr;     // where the current chunk size puts the tables inside `links`, and the token words (inside `links` too unless zngamd_debug_keep asked for all stages to stay)
     bool debug_keep = false, last_kept = false; DevBuf<uint32_t> best_keep, dpcost;
+    std::vector<uint32_t> last_ulen_host; bool last_ulen_on_host = false;      // ... and on the host, where the call fetched them with its results (the device copy lies in a staging buffer that an inflate call of another thread may give back)
     const uint32_t *last_unit_len = nullptr;     // the last deflate call's per-unit compressed sizes (device; the caller's array or a staging buffer of this context)     // zngamd_debug_keep: the search results as they were before the dynamic programme, its cost tables
     // per call
     DevBuf<ZaUnit> units; DevBuf<uint32_t> segbits, cidx, status, runs;
@@ -691,7 +692,7 @@ static int deflate_units_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_len
         }
         HIPCHK(c, hipGetLastError());
     }
-    c->last_units = n; c->last_single_chunk = (n <= ch); c->last_kept = c->debug_keep; c->last_unit_len = d_unit_len;
+    c->last_units = n; c->last_single_chunk = (n <= ch); c->last_kept = c->debug_keep; c->last_unit_len = d_unit_len; c->last_ulen_on_host = false;
     return ZNGAMD_OK;
 }
 
@@ -921,6 +922,7 @@ static int deflate_host_common(zngamd_ctx *c, uint64_t in_len, const zngamd_bloc
     memcpy(&total, stage, 8);
     ulen.resize(n); ucrc.resize(n);
     if (n) { memcpy(ulen.data(), stage + o_len, 4ull * n); memcpy(ucrc.data(), stage + o_crc, 4ull * n); }
+    c->last_ulen_host = ulen; c->last_ulen_on_host = true;
     const uint32_t *st = (const uint32_t *)(stage + o_st);
     for (uint32_t i = 0; i < n; i++) if (st[i]) return fail(c, ZNGAMD_E_HIP, "packed deflate: a unit's size differs from its plan");
     if (total > bound) return fail(c, ZNGAMD_E_HIP, "packed deflate: stream larger than its bound");
@@ -969,12 +971,9 @@ try {
     return ret;
 } ZA_ABI_GUARD
 
-int zngamd_deflate_blocks_packed(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
-                                 int level, uint8_t *out, uint64_t out_cap, uint64_t block_cap, uint32_t *out_len, uint32_t *crc, uint64_t *total)
-try {
-    if (!c || (!in && in_len) || (!blocks && n_blocks) || !out || !out_len || !crc || !total) return ZNGAMD_E_ARG;
-    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
-    std::lock_guard<std::mutex> g(c->mu);
+static int deflate_blocks_packed_locked(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                                        int level, uint8_t *out, uint64_t out_cap, uint64_t block_cap, uint32_t *out_len, uint32_t *crc, uint64_t *total)
+{
     *total = 0;
     int r = stage_in(c, in, in_len);
     if (r) return r;
@@ -1015,6 +1014,32 @@ try {
     }
     if (ret) c->err = "Compressed output exceeds buffer size";
     return ret;
+}
+
+int zngamd_deflate_blocks_packed(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                                 int level, uint8_t *out, uint64_t out_cap, uint64_t block_cap, uint32_t *out_len, uint32_t *crc, uint64_t *total)
+try {
+    if (!c || (!in && in_len) || (!blocks && n_blocks) || !out || !out_len || !crc || !total) return ZNGAMD_E_ARG;
+    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    std::lock_guard<std::mutex> g(c->mu);
+    return deflate_blocks_packed_locked(c, in, in_len, blocks, n_blocks, level, out, out_cap, block_cap, out_len, crc, total);
+} ZA_ABI_GUARD
+
+static int deflate_index_locked(zngamd_ctx *c, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows);
+// The packed call and the segment index of ITS units in one: a context shared by several writer threads would otherwise have to
+// keep them from slipping a deflate call of their own between a thread's two calls (zngamd_deflate_index answers for the
+// context's last deflate call, whoever made it).
+int zngamd_deflate_blocks_packed_indexed(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, const zngamd_block *blocks, uint32_t n_blocks,
+                                         int level, uint8_t *out, uint64_t out_cap, uint64_t block_cap, uint32_t *out_len, uint32_t *crc, uint64_t *total,
+                                         uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows)
+try {
+    if (!c || (!in && in_len) || (!blocks && n_blocks) || !out || !out_len || !crc || !total || !unit_in_len || !unit_out_len || !rows) return ZNGAMD_E_ARG;
+    if (!zngamd_level_ok(level)) return fail(c, ZNGAMD_STREAM_ERROR, "Bad compression level");
+    if (n_units != zngamd_count_units(blocks, n_blocks)) return fail(c, ZNGAMD_E_ARG, "n_units is not what zngamd_count_units says for these blocks");
+    std::lock_guard<std::mutex> g(c->mu);
+    const int r = deflate_blocks_packed_locked(c, in, in_len, blocks, n_blocks, level, out, out_cap, block_cap, out_len, crc, total);
+    if (r) return r;
+    return deflate_index_locked(c, n_units, unit_in_len, unit_out_len, rows);
 } ZA_ABI_GUARD
 
 int zngamd_deflate_stream(zngamd_ctx *c, const uint8_t *in, uint64_t in_len, int level, int window_bits, uint8_t *out,
@@ -1583,18 +1608,25 @@ void zngamd_index_destroy(void *handle)
     delete ix;
 }
 // the index of the context's last deflate call on the HOST, with the units' sizes (what a writer keeps for its file's trailing members)
+static int deflate_index_locked(zngamd_ctx *c, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows)
+{
+    if (n_units == 0) return ZNGAMD_OK;
+    const bool on_host = c->last_ulen_on_host && c->last_ulen_host.size() == n_units;
+    if (n_units != c->last_units || !c->cidx.p || (!on_host && !c->last_unit_len) || c->last_hu.size() != n_units) return fail(c, ZNGAMD_E_ARG, "the index is that of the context's last deflate call: its unit count differs");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(rows, c->cidx.p, (size_t)n_units * ZA_CIDX_STRIDE * 4, hipMemcpyDeviceToHost, c->stream));
+    if (on_host) memcpy(unit_in_len, c->last_ulen_host.data(), (size_t)n_units * 4);
+    else HIPCHK(c, hipMemcpyAsync(unit_in_len, c->last_unit_len, (size_t)n_units * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t u = 0; u < n_units; u++) unit_out_len[u] = c->last_hu[u].in_len;
+    return ZNGAMD_OK;
+}
+
 int zngamd_deflate_index(zngamd_ctx *c, uint32_t n_units, uint32_t *unit_in_len, uint32_t *unit_out_len, uint32_t *rows)
 try {
     if (!c || !unit_in_len || !unit_out_len || !rows) return ZNGAMD_E_ARG;
     std::lock_guard<std::mutex> g(c->mu);
-    if (n_units == 0) return ZNGAMD_OK;
-    if (n_units != c->last_units || !c->cidx.p || !c->last_unit_len || c->last_hu.size() != n_units) return fail(c, ZNGAMD_E_ARG, "the index is that of the context's last deflate call: its unit count differs");
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(rows, c->cidx.p, (size_t)n_units * ZA_CIDX_STRIDE * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(unit_in_len, c->last_unit_len, (size_t)n_units * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (uint32_t u = 0; u < n_units; u++) unit_out_len[u] = c->last_hu[u].in_len;
-    return ZNGAMD_OK;
+    return deflate_index_locked(c, n_units, unit_in_len, unit_out_len, rows);
 } ZA_ABI_GUARD
 
 int zngamd_crc32_fold_dev(zngamd_ctx *c, const uint32_t *d_crcs, uint32_t n, uint64_t each_len, uint64_t last_len, uint32_t *crc)

@@ -55,7 +55,7 @@ SYMBOLS = [
     "zngamd_comm_unique_id", "zngamd_comm_create", "zngamd_comm_destroy", "zngamd_comm_last_error", "zngamd_comm_count", "zngamd_comm_layout",
     "zngamd_comm_allgather_stream", "zngamd_comm_offsets", "zngamd_comm_wait", "zngamd_comm_barrier", "zngamd_comm_max_f64",
     "zngamd_gunzip", "zngamd_gunzip_partial", "zngamd_gunzip_stream", "zngamd_gzip_members", "zngamd_gzip_members_dev", "zngamd_profiling",
-    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_deflate_index_dev", "zngamd_inflate_units_indexed_dev", "zngamd_index_create", "zngamd_index_destroy", "zngamd_deflate_index", "zngamd_indexed_units", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
+    "zngamd_kernel_times", "zngamd_kernel_class_count", "zngamd_abi", "zngamd_decode_paths", "zngamd_deflate_index_dev", "zngamd_inflate_units_indexed_dev", "zngamd_index_create", "zngamd_index_destroy", "zngamd_deflate_index", "zngamd_deflate_blocks_packed_indexed", "zngamd_indexed_units", "zngamd_debug_fetch", "zngamd_debug_keep", "zngamd_d2d", "zngamd_dmemset", "zngamd_mem_info",
 ]
 
 
@@ -115,6 +115,9 @@ def load():
                                             u8p, C.c_uint64, u32p, u32p]
         L.zngamd_deflate_blocks_packed.argtypes = [vp, u8p, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
                                                    u8p, C.c_uint64, C.c_uint64, u32p, u32p, C.POINTER(C.c_uint64)]
+        L.zngamd_deflate_blocks_packed_indexed.argtypes = [vp, u8p, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
+                                                           u8p, C.c_uint64, C.c_uint64, u32p, u32p, C.POINTER(C.c_uint64),
+                                                           C.c_uint32, vp, vp, vp]
         L.zngamd_count_units.argtypes = [C.POINTER(Block), C.c_uint32]
         L.zngamd_count_units.restype = C.c_uint32
         L.zngamd_deflate_blocks_dev.argtypes = [vp, vp, C.c_uint64, C.POINTER(Block), C.c_uint32, C.c_int,
@@ -553,14 +556,17 @@ class Context:
         return self.L.zngamd_crc32_combine(crc1 & 0xFFFFFFFF, crc2 & 0xFFFFFFFF, len2)
 
     # ---- deflate
-    def deflate_blocks(self, buf, blocks, level, out_cap, joined=False, into=None):
+    def deflate_blocks(self, buf, blocks, level, out_cap, joined=False, into=None, index=False):
         """blocks: list of (off, len, dict_len, flags), or a table made by block_table() (a writer whose batches have the
         same shape makes it once).  -> (list of bytes|None, list of crc, overflowed); with joined=True the first element is
         ONE object, the blocks' outputs back to back (a writer that only concatenates them saves the allocation and release
         of one object per block) and a list of lengths is appended to the result: the engine copies the packed stream
         straight into it (zngamd_deflate_blocks_packed).  `into` (joined only): a bytearray of at least n * out_cap bytes
         that takes the output -- the result is then a memoryview of its filled part (a writer that keeps two of them
-        writes into warm memory; a fresh object costs a page fault per 4 KiB)."""
+        writes into warm memory; a fresh object costs a page fault per 4 KiB).  `index` (joined only): the segment-index records
+        of the call's units come back as a fifth element (None after an overflow) -- from the SAME engine call
+        (zngamd_deflate_blocks_packed_indexed): a context that several writer threads share answers zngamd_deflate_index for its
+        last deflate call, whoever made it."""
         arr, n = blocks if isinstance(blocks, tuple) and len(blocks) == 2 and isinstance(blocks[0], C.Array) else block_table(blocks)
         p, keep = _addr(buf)
         lens = (C.c_uint32 * max(n, 1))()
@@ -568,20 +574,30 @@ class Context:
         need = max(n, 1) * out_cap
         if joined:
             total = C.c_uint64(0)
+            if index:
+                nu = int(self.L.zngamd_count_units(arr, n))
+                uin = np.empty(max(nu, 1), np.uint32); uout = np.empty(max(nu, 1), np.uint32); rows = np.empty((max(nu, 1), INDEX_STRIDE), np.uint32)
+                tail = (nu, uin.ctypes.data_as(C.c_void_p), uout.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p))
+                call = self.L.zngamd_deflate_blocks_packed_indexed
+            else:
+                tail = ()
+                call = self.L.zngamd_deflate_blocks_packed
             if into is not None and len(into) >= need:
                 anchor = C.c_char.from_buffer(into)
-                r = self.L.zngamd_deflate_blocks_packed(self.h, p, memoryview(buf).nbytes, arr, n, level,
-                                                        C.cast(C.addressof(anchor), C.c_void_p), len(into), out_cap,
-                                                        C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p), C.byref(total))
+                r = call(self.h, p, memoryview(buf).nbytes, arr, n, level,
+                         C.cast(C.addressof(anchor), C.c_void_p), len(into), out_cap,
+                         C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p), C.byref(total), *tail)
                 del anchor
                 self._chk(r, (OK, E_OVERFLOW))
                 res = None if r == E_OVERFLOW else memoryview(into)[:total.value]
             else:
                 out = _Out(need)
-                r = self.L.zngamd_deflate_blocks_packed(self.h, p, memoryview(buf).nbytes, arr, n, level, out.addr(), need, out_cap,
-                                                        C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p), C.byref(total))
+                r = call(self.h, p, memoryview(buf).nbytes, arr, n, level, out.addr(), need, out_cap,
+                         C.cast(lens, C.c_void_p), C.cast(crcs, C.c_void_p), C.byref(total), *tail)
                 self._chk(r, (OK, E_OVERFLOW))
                 res = None if r == E_OVERFLOW else out.take(total.value)
+            if index:
+                return res, list(crcs[:n]), r == E_OVERFLOW, list(lens[:n]), (None if r == E_OVERFLOW else self._index_records(nu, uin[:nu], uout[:nu], rows[:nu]))
             return res, list(crcs[:n]), r == E_OVERFLOW, list(lens[:n])
         # The per-block outputs land in a buffer that lives with the context: device-to-host copies into memory that has
         # been touched (and registered by the runtime) before run several times faster than into fresh pages.  The lock
@@ -767,6 +783,10 @@ class Context:
         uin = np.empty(nu, np.uint32); uout = np.empty(nu, np.uint32); rows = np.empty((nu, INDEX_STRIDE), np.uint32)
         self._chk(self.L.zngamd_deflate_index(self.h, nu, uin.ctypes.data_as(C.c_void_p), uout.ctypes.data_as(C.c_void_p),
                                               rows.ctypes.data_as(C.c_void_p)))
+        return self._index_records(nu, uin, uout, rows)
+
+    @staticmethod
+    def _index_records(nu, uin, uout, rows):
         rec = np.zeros(nu, _index_rec_dtype())
         rec["in_len"], rec["out_len"] = uin, uout
         nseg = (uout.astype(np.int64) + 2047) >> 11
@@ -855,10 +875,10 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=Non
     # `index` (a list, or None): the batch's segment-index records are appended to it, in unit order (Context.deflate_index_records
     # of every range, taken right behind the range's engine call on its own context)
     def one():
-        r = ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into)
-        if index is not None and not r[2]:
-            index.append(ctxs[0].deflate_index_records(table if table is not None else blocks))
-        return r
+        r = ctxs[0].deflate_blocks(buf, table if table is not None else blocks, level, out_cap, joined=True, into=into, index=index is not None)
+        if index is not None and r[4] is not None:
+            index.append(r[4])
+        return r[:4]
     if g <= 1 or sys.is_finalizing():      # (no new threads while the interpreter shuts down)
         return one()
     total = sum(b[1] for b in blocks)
@@ -885,9 +905,10 @@ def deflate_blocks_multi(ctxs, buf, blocks, level, out_cap, into=None, table=Non
             lo = min(o - d for o, _, d, _ in sub)
             hi = max(o + ln for o, ln, _, _ in sub)
             rel = [(o - lo, ln, d, f) for o, ln, d, f in sub]
-            parts[j] = ctxs[j].deflate_blocks(mv[lo:hi], rel, level, out_cap, joined=True)
-            if index is not None and not parts[j][2]:
-                recs[j] = ctxs[j].deflate_index_records(rel)
+            r = ctxs[j].deflate_blocks(mv[lo:hi], rel, level, out_cap, joined=True, index=index is not None)
+            parts[j] = r[:4]
+            if index is not None:
+                recs[j] = r[4]
         except BaseException as exc:                      # raised in the caller's thread below
             errs.append(exc)
     ths = [threading.Thread(target=run, args=(j,), name=f"zng-amd-gpu{j}") for j in range(1, len(parts))]

@@ -238,3 +238,30 @@ def test_seg2k_units_match_the_oracle(ctx):
     plain, _, _ = ctx.deflate_blocks(data, [(o, n, d, 0) for o, n, d, _ in blocks], 6, 40000)
     assert zlib.decompressobj(-15).decompress(b"".join(outs) + b"\x03\x00") == data
     assert plain != outs                       # (small units cut otherwise: the flag changes their tokens)
+
+
+def test_two_writers_on_one_context_keep_their_own_index(ctx):
+    """Two threaded writers at work at once share the process's context: a batch's segment-index records must be those of ITS
+    engine call (zngamd_deflate_blocks_packed_indexed), not of whichever call the context made last."""
+    import gzip
+    import io
+    import threading
+    from zlib_ng_amd import gzip_ng_threaded as T
+    datas = [_mix(43 * B + 1001, 61), _mix(43 * B + 1001, 67), _mix(37 * B + 5, 71)]      # (two of the same shape: a foreign index of the same unit count would go unnoticed by a count check)
+    blobs = [None] * len(datas)
+
+    def work(i):
+        bio = io.BytesIO()
+        with T.open(bio, "wb", block_size=B, threads=1) as f:
+            for o in range(0, len(datas[i]), 3 * B + 17):       # small writes: many batches per file, so that the writers' engine calls interleave
+                f.write(datas[i][o:o + 3 * B + 17])
+        blobs[i] = bio.getvalue()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(datas))]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    for i, data in enumerate(datas):
+        assert gzip.decompress(blobs[i]) == data
+        ctx.L.zngamd_indexed_units(ctx.h, 1)
+        with T.open(io.BytesIO(blobs[i]), "rb") as f:
+            assert f.read() == data
+        assert ctx.L.zngamd_indexed_units(ctx.h, 1) > 0       # ... and it was the index that decoded it
