@@ -259,8 +259,13 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
 #ifdef ZA_CH_STATS
             const unsigned long long T0 = clock64();
 #endif
+#ifdef ZA_ABL_CH_HALFREADS
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g += 2) { const uint32_t t = *(const uint32_t *)&hb[64 * g + 2 * (lane >> 1)]; hh[g] = t & 0xFFFCu; hh[g + 1] = (t >> 16) & 0xFFFCu; }      // (timing only: the offsets two at a time)
+#else
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) hh[g] = hb[64 * g + lane];
+#endif
 #ifdef ZA_CH_STATS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long T1 = clock64();
@@ -299,8 +304,13 @@ __global__ __launch_bounds__(256) void za_k_chains(const uint8_t *__restrict__ i
                 }
             }
 #endif
+#ifdef ZA_ABL_CH_HALFWRITES
+#pragma unroll
+            for (int g = 0; g < ZA_CH_GROUP; g += 2) ob[64 * g + lane] = old[g] + old[g + 1];       // (timing only: half the inserting wave's writes)
+#else
 #pragma unroll
             for (int g = 0; g < ZA_CH_GROUP; g++) ob[64 * g + lane] = old[g];
+#endif
 #ifdef ZA_CH_STATS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             st_ph[0] += T1 - T0; st_ph[1] += T2 - T1; st_ph[2] += clock64() - T2; st_ph[3] += 1;
