@@ -426,7 +426,15 @@ struct ZaParBufT {
 };
 
 // returns the number of lanes whose sub-sequences were decoded (0: nothing done, position untouched)
-template <int MODE, typename SymT, typename PB, typename TT>
+// what orders a wave's stores of output symbols in front of its later loads of them: a fence that waits for memory -- or, where
+// `out` is an LDS image (OLDS: za_k_inflate_serial_small), nothing but the compiler's order: one wave's LDS accesses execute in order
+template <bool OLDS> __device__ __forceinline__ void za_out_fence()
+{
+    if (OLDS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __threadfence_block();
+}
+
+template <int MODE, typename SymT, typename PB, typename TT, bool OLDS = false>
 __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
                             SymT *__restrict__ out, uint64_t out_cap, const TT &T, PB *P,
                             uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob)
@@ -685,7 +693,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             for (int sft = 32; sft; sft >>= 1) { const uint32_t ov = (uint32_t)__shfl_xor((int)fv, sft, 64); fv = ov > fv ? ov : fv; }
             if (fv > *far_io) *far_io = fv;
         }
-        __threadfence_block();                  // literals (global) and the queue (LDS) are visible to the whole wave
+        za_out_fence<OLDS>();                   // literals (global) and the queue (LDS) are visible to the whole wave
         __builtin_amdgcn_wave_barrier();
         ZA_STAT_ADD(4, ZA_STAT_T() - t1);
         const unsigned long long t2 = ZA_STAT_T();
@@ -810,7 +818,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
                         }
                     }
                 }
-                __threadfence_block();
+                za_out_fence<OLDS>();
                 done = done || ready;
                 pending = __ballot(!done);
                 ZA_STAT_ADD(14, 1);
@@ -841,7 +849,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 #define ZA_I_SYNC 2
 // MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
 // start), RING symbols in LDS; older sources are read back from `out` (written many rounds ago) or are markers.
-template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>, typename TT = ZaInfTabs>
+template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>, typename TT = ZaInfTabs, bool OLDS = false>
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       SymT *__restrict__ out, uint64_t out_cap,
@@ -925,7 +933,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             while (!eob && status == ZA_I_OK) {
                 if (P != nullptr) {
                     if (par_wait == 0) {
-                        const int got = za_par_sweep<MODE, SymT, PB>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
+                        const int got = za_par_sweep<MODE, SymT, PB, TT, OLDS>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
                                                                      max_back ? &far : nullptr, eob);
                         ibase = ~0ull;                                   // the staging area was used by the sweep
                         // A sweep that kept few lanes (the passes had not settled, the queue was full) is followed by another sweep
@@ -943,7 +951,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                     } else par_wait--;
                     if (MODE != 1 && ring_stale) {
                         // the last RING symbols go back into the LDS ring (positions before the start: dictionary / markers)
-                        __threadfence_block();
+                        za_out_fence<OLDS>();
                         // (MODE 0: nothing can refer to what lies in front of the dictionary -- a stream of 1 KiB refills 1 KiB, not 32)
                         uint32_t i0 = 0;
                         if (MODE == 0 && op + (uint64_t)dict_len < (uint64_t)RING) i0 = (uint32_t)((uint64_t)RING - op - (uint64_t)dict_len) & ~63u;
@@ -1214,6 +1222,38 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
                                                          0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
     if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
+}
+
+// The same decoder for a SMALL stream (r06): the output is assembled in LDS and leaves in one coalesced pass at the end.  On a
+// lone wavefront every round of the sweeps' match resolution was a load and a store round trip to memory behind a fence
+// (1.15 us a round, 400 of a 64 KiB stream's 1 100 us), every literal of the storing pass and of the sequential rounds a store
+// to memory, the ring refill behind a sweep a read-back of it: with `out` in LDS they are LDS round trips.  The image holds
+// ZA_SMALL_IMG bytes; a stream that produces more comes back as "output full" with exactly that many, and the host runs the
+// ordinary kernel (zngamd_inflate_raw's small path).
+#ifndef ZA_SMALL_IMG
+#define ZA_SMALL_IMG 98304
+#endif
+__global__ __launch_bounds__(64) void za_k_inflate_serial_small(const uint8_t *__restrict__ in, uint64_t in_len, uint32_t start_bit,
+                                                                const uint8_t *__restrict__ dict, uint32_t dict_len,
+                                                                uint8_t *__restrict__ out, uint64_t out_cap,
+                                                                ZaInfResult *__restrict__ res)
+{
+    __shared__ ZaInfTabs T;
+    __shared__ uint8_t win[ZA_WIN];
+    __shared__ int scratch[2];
+    __shared__ ZaParBufT<1024, 3072> P;
+    __shared__ __attribute__((aligned(16))) uint8_t img[ZA_SMALL_IMG];
+    uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
+    const uint64_t cap = out_cap < (uint64_t)ZA_SMALL_IMG ? out_cap : (uint64_t)ZA_SMALL_IMG;
+    const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>, ZaInfTabs, true>(in, in_len, dict, dict_len, img, cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
+                                                         0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
+    __syncthreads();
+    const int lane = za_lane();
+    for (uint64_t i = 16ull * (uint64_t)lane; i < op; i += 1024ull) {
+        if (i + 16ull <= op) { const uint4 v = *(const uint4 *)(img + i); ZaU4u t = {v.x, v.y, v.z, v.w}; *(ZaU4u *)(out + i) = t; }
+        else for (uint64_t k = i; k < op; k++) out[k] = img[k];
+    }
+    if (lane == 0) { res->status = status; res->pad = (uint32_t)ZA_SMALL_IMG; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1202,8 +1202,14 @@ try {
         const uint64_t nspan = (crc || adler) ? (out_cap + ZA_MAX_UNIT - 1) / ZA_MAX_UNIT : 0;
         HIPCHK(c, c->st_out.ensure(head + out_cap + 64));
         ZaInfResult *dres = (ZaInfResult *)c->st_out.p;
+        // (the output is assembled in LDS by za_k_inflate_serial_small; a stream that outgrows the image -- ZA_SMALL_IMG bytes --
+        // comes back as "output full" at exactly that size and goes to the ordinary kernel: second == true)
+        static const bool no_img = getenv("ZNGAMD_NO_SMALL_IMAGE") != nullptr;
+        for (int second = no_img ? 1 : 0; second < 2; second++) {
         { ProfScope ps(c, ZNGAMD_K_INFLATE);
-          hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
+          if (second) hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
+                             c->st_out.p + head, out_cap, dres);
+          else hipLaunchKernelGGL(za_k_inflate_serial_small, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
                              c->st_out.p + head, out_cap, dres); }
         if (nspan) {
             ProfScope ps(c, ZNGAMD_K_OTHER);
@@ -1220,6 +1226,7 @@ try {
         prof_collect(c);
         ZaInfResult res;
         memcpy(&res, stage, sizeof res);
+        if (!second && res.status == ZA_I_OUTFULL && res.out_len == (uint64_t)ZA_SMALL_IMG && out_cap > (uint64_t)ZA_SMALL_IMG) continue;      // the image was full, the caller's buffer is not
         c->paths[ZNGAMD_PATH_SEQUENTIAL]++;
         *out_len = res.out_len;
         if (in_used) *in_used = (res.in_bits + 7) >> 3;
@@ -1234,6 +1241,8 @@ try {
         if (res.out_len) memcpy(out, stage + head, res.out_len <= out_cap ? res.out_len : out_cap);
         if (res.status == ZA_I_DATA) c->err = "invalid deflate data";
         return map_status(res.status);
+        }
+        return fail(c, ZNGAMD_E_HIP, "small inflate: no result");       // (not reached: the second pass always returns)
     }
     HIPCHK(c, c->st_out.ensure(out_cap + 64));
     ZaInfResult res;
