@@ -54,6 +54,15 @@ struct ZaInfTabsT {
 };
 using ZaInfTabs = ZaInfTabsT<ZA_LUT_L_BITS, ZA_LUT_D_BITS>;
 
+// Every kernel that builds decode tables or runs the sequential decoder is ONE wavefront per workgroup (or, r06, lets one of its
+// wavefronts do so while another works beside it: za_k_inflate_serial_small): what orders the wave's LDS traffic is a fence and a
+// wave barrier -- no s_barrier, which would wait for wavefronts that never come.
+__device__ __forceinline__ void za_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct ZaInfResult {
     int32_t status; uint32_t pad;
     uint64_t out_len;
@@ -104,7 +113,7 @@ __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_
                               int *shared_status, int *shared_maxlen, uint16_t *fst = nullptr, uint16_t *idx = nullptr)
 {
     const int lane = za_lane();
-    __syncthreads();
+    za_wave_sync();
     int L[5];
 #pragma unroll
     for (int b = 0; b < 5; b++) { const int i = b * 64 + lane; L[b] = i < n ? (int)lens[i] : 0; }
@@ -165,7 +174,7 @@ __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_
         }
         for (int e = lane; e < (1 << lut_bits); e += 64) lut[e] = 0;      // (entries of longer codes, and of an incomplete code's gaps, stay 0)
     }
-    __syncthreads();
+    za_wave_sync();
     if (st >= 0) {
 #pragma unroll
         for (int b = 0; b < 5; b++) {
@@ -176,7 +185,7 @@ __device__ int za_build_table(const uint8_t *lens, int n, uint16_t *cnt, uint16_
             }
         }
     }
-    __syncthreads();
+    za_wave_sync();
     return st;
 }
 
@@ -228,7 +237,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
 {
     const int lane = za_lane();
     if (type == 1) {
-        __syncthreads();
+        za_wave_sync();
         for (int i = lane; i < 320; i += 64)
             T.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : i < 318 ? 5 : 0);
         za_build_table(T.lens, 288, T.cnt_l, T.sym_l, T.lut_l, TT::kLBits, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
@@ -243,7 +252,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
     bitpos += 14;
     if (nlen > 286 || ndist > 30) return ZA_I_DATA;
     if (bitpos + 3ull * (unsigned)ncode > in_bits) return ZA_I_INPUT;
-    __syncthreads();
+    za_wave_sync();
     if (lane < 19) T.lens[lane] = 0;
     // The code lengths are decoded by one lane, one dependent read per symbol: from LDS that is a fraction of a microsecond
     // for the whole header, from memory about a microsecond per symbol.
@@ -258,7 +267,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
             hb[i] = v;
         }
     }
-    __syncthreads();
+    za_wave_sync();
     auto peek = [&](uint64_t bp) -> uint64_t {
         if (!hb) return za_peek(in, bp);
         const uint32_t rel = (uint32_t)(bp - hbyte * 8ull), w = rel >> 5, sh = rel & 31u;
@@ -273,7 +282,7 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
     ZA_HDR_T(21);
     if (st != 0) return ZA_I_DATA;                       // must be complete
     // decode nlen + ndist code lengths, result in T.lens[0..] then moved
-    __syncthreads();
+    za_wave_sync();
     int err = ZA_I_OK, adv = 0;
     if (hb) {
         // A chain of dependent decodes -- but nothing in it needs LDS (r06): the staged header lies in three registers across the
@@ -322,9 +331,9 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
             }
         }
         adv = (int)(bp - bitpos);
-        __syncthreads();
+        za_wave_sync();
         if (err == ZA_I_OK && L[256] == 0) err = ZA_I_DATA;          // missing end-of-block
-        __syncthreads();
+        za_wave_sync();
     } else {
     if (lane == 0) {
         uint64_t bp = bitpos;
@@ -356,10 +365,10 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         scratch[0] = err;
         scratch[1] = (int)(bp - bitpos);
     }
-    __syncthreads();
+    za_wave_sync();
     err = scratch[0];
     adv = scratch[1];
-    __syncthreads();
+    za_wave_sync();
     }
     if (err != ZA_I_OK) return err;
     bitpos += (unsigned)adv;
@@ -369,9 +378,9 @@ __device__ int za_read_tables(const uint8_t *in, uint64_t in_bits, uint64_t &bit
         const uint8_t v = lane < ndist ? T.lens[nlen + lane] : (uint8_t)0;
         T.lens[288 + lane] = v;
     }
-    __syncthreads();
+    za_wave_sync();
     for (int i = nlen + lane; i < 288; i += 64) T.lens[i] = 0;
-    __syncthreads();
+    za_wave_sync();
     int maxl;
     st = za_build_table(T.lens, nlen, T.cnt_l, T.sym_l, T.lut_l, TT::kLBits, &scratch[0], &scratch[1], T.fst_l, T.idx_l);
     maxl = scratch[1];
@@ -434,13 +443,31 @@ template <bool OLDS> __device__ __forceinline__ void za_out_fence()
     else __threadfence_block();
 }
 
-template <int MODE, typename SymT, typename PB, typename TT, bool OLDS = false>
+// (r06, za_k_inflate_serial_small) A SECOND wavefront runs the counting passes of the NEXT sweep while the first one stores and
+// resolves the current one -- a sweep's passes need nothing of the sweep in front of it but where it ended.  ROLE 0: everything
+// on the calling wave (all other kernels); ROLE 1: the main wave -- takes over the helper's result where it has one for this very
+// position, asks for the next sweep in front of its storing pass and waits for it behind the resolution; ROLE 2: the helper --
+// staging and counting passes into the buffer it was told, results to H, nothing else.  The two talk through LDS words (go /
+// done sequence numbers); the second staging area lives in H.
+struct ZaSweepHelp {
+    uint32_t stage2[64 * 1024 / 32 + 8];
+    uint32_t start[64], endp[64], cnt[64], nm[64];
+    int st[64];
+    uint64_t bitpos;            // what the result below is for
+    uint32_t valid, buf;        // a result is there; the staging area it lies in (0: P->stage, 1: stage2)
+    int nvalid, its;
+    uint64_t req_bitpos; uint32_t req_buf, cmd;      // request: 1 run, 2 exit
+    uint32_t go, done;          // sequence numbers
+};
+
+template <int MODE, typename SymT, typename PB, typename TT, bool OLDS = false, int ROLE = 0>
 __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
                             SymT *__restrict__ out, uint64_t out_cap, const TT &T, PB *P,
-                            uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob)
+                            uint64_t &bitpos, uint64_t &op, uint32_t hist, uint32_t *far_io, bool &eob, ZaSweepHelp *H = nullptr)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
+    if (ROLE == 2) H->valid = 0u;                 // (uniform: every early return below leaves "no result")
     // Near the end of the input fewer lanes take part (L of them, sub-sequences of ZA_PS_MINBITS bits) instead of none: the last
     // 520 bytes of every member went through the sequential rounds, 65 of them (ZA_PS_SHORT_TAIL_LANES: the fewest lanes worth a sweep).
 #ifndef ZA_PS_SHORT_TAIL_LANES
@@ -454,13 +481,22 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
     const uint64_t sbyte = (bitpos >> 3) & ~3ull;
     const uint32_t b0 = (uint32_t)(bitpos - sbyte * 8ull);                 // 0..31
     const uint32_t ndw = ((b0 + L * S + 48u) >> 5) + 5u;                    // fits the staging area: a lane reads up to 64 bits ahead
+    bool pre = false;                                                       // (ROLE 1) the helper has counted this very sweep
+    uint32_t cur_buf = 0;                                                   // the staging area this sweep's bytes lie in
+    if (ROLE == 1) {
+        pre = H->valid != 0u && H->bitpos == bitpos;
+        cur_buf = pre ? H->buf : 0u;
+    }
+    if (ROLE == 2) cur_buf = H->req_buf;
+    uint32_t *const stg = cur_buf ? H->stage2 : P->stage;
     __builtin_amdgcn_wave_barrier();
+    if (!pre)
     for (uint32_t i = (uint32_t)lane; i < ndw; i += 64) {
         const uint64_t o = sbyte + 4ull * i;
         uint32_t v = 0;
         if (o + 4 <= in_len + 8) v = za_ld32(in + o);                       // the buffer is padded by >= 8 bytes
         else for (int k = 0; k < 4; k++) if (o + (unsigned)k < in_len + 8) v |= (uint32_t)in[o + (unsigned)k] << (8 * k);
-        P->stage[i] = v;
+        stg[i] = v;
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -477,11 +513,11 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         int s = 0, fr = -(1 << 30);
         uint32_t w = from >> 5;
         const uint32_t sh0 = from & 31u;
-        uint64_t bb = ((((uint64_t)P->stage[w + 1]) << 32) | (uint64_t)P->stage[w]) >> sh0;
+        uint64_t bb = ((((uint64_t)stg[w + 1]) << 32) | (uint64_t)stg[w]) >> sh0;
         uint32_t nb = 64u - sh0;
         w += 2;
         while (bp < lim) {
-            if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
+            if (nb <= 32u) { bb |= (uint64_t)stg[w] << nb; nb += 32u; w++; }
             uint32_t e = T.lut_l[(uint32_t)bb & ((1u << TT::kLBits) - 1u)];
             if (!e) e = za_long_decode((uint32_t)bb, T.cnt_l, T.fst_l, T.idx_l, T.sym_l, TT::kLBits + 1);
             if (!e) { s = 2; break; }
@@ -500,7 +536,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             len += (int)((uint32_t)(bb >> used) & ((1u << nx) - 1u));
             used += (uint32_t)nx;
             bp += used; bb >>= used; nb -= used;
-            if (nb <= 32u) { bb |= (uint64_t)P->stage[w] << nb; nb += 32u; w++; }
+            if (nb <= 32u) { bb |= (uint64_t)stg[w] << nb; nb += 32u; w++; }
             e = T.lut_d[(uint32_t)bb & ((1u << TT::kDBits) - 1u)];
             if (!e) e = za_long_decode((uint32_t)bb, T.cnt_d, T.fst_d, T.idx_d, T.sym_d, TT::kDBits + 1);
             const int ds = (int)(e >> 4);
@@ -558,7 +594,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
             wave_rounds++;
 #endif
             const uint32_t w = bp >> 5, sh = bp & 31u;
-            const uint32_t d0 = P->stage[w], d1 = P->stage[w + 1], d2 = P->stage[w + 2], d3 = P->stage[w + 3], d4 = P->stage[w + 4];
+            const uint32_t d0 = stg[w], d1 = stg[w + 1], d2 = stg[w + 2], d3 = stg[w + 3], d4 = stg[w + 4];
             const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
             const uint32_t h2 = __builtin_amdgcn_alignbit(d3, d2, sh), h3 = __builtin_amdgcn_alignbit(d4, d3, sh);
             const uint32_t room = lim - bp;                                 // > 0
@@ -629,6 +665,12 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
     int nvalid = (int)L;
     const unsigned long long t0 = ZA_STAT_T();
     int its = 0;
+    if (pre) {
+        // the helper's passes over this sweep: every lane's start, end, counts and state as its own passes would have left them
+        start = H->start[lane]; endp = H->endp[lane]; cnt = H->cnt[lane]; nm = H->nm[lane]; st = H->st[lane];
+        nvalid = H->nvalid; its = H->its;
+        H->valid = 0u;
+    } else
     for (int it = 1;; it++) {
         its = it;
         if (dirty) {
@@ -649,7 +691,12 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         if (!chm) break;
         if (it >= PB::kMaxIt) { nvalid = __builtin_ctzll(chm); break; }
     }
-    ZA_STAT_ADD(0, 1); ZA_STAT_ADD(2, its); ZA_STAT_ADD(3, ZA_STAT_T() - t0); ZA_STAT_ADD(13, nvalid);
+    if (ROLE == 2) {
+        H->start[lane] = start; H->endp[lane] = endp; H->cnt[lane] = cnt; H->nm[lane] = nm; H->st[lane] = st;
+        H->nvalid = nvalid; H->its = its; H->bitpos = bitpos; H->buf = cur_buf; H->valid = 1u;       // (uniform stores)
+        return 1;
+    }
+    ZA_STAT_ADD(0, 1); ZA_STAT_ADD(2, its); ZA_STAT_ADD(3, pre ? 0ull : ZA_STAT_T() - t0); ZA_STAT_ADD(13, nvalid);
     // the chain ends at the first lane that did not run to its limit
     bool eob_hit = false;
     {
@@ -682,12 +729,28 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)cinc, nvalid - 1);
     const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)minc, nvalid - 1);
     const uint32_t last_end = (uint32_t)__builtin_amdgcn_readlane((int)endp, nvalid - 1);
+    bool posted = false;
+    uint32_t seq = 0;
+    auto wait_helper = [&]() {
+        if (ROLE == 1 && posted) {
+            while (__hip_atomic_load(&H->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+            posted = false;
+        }
+    };
+    if (ROLE == 1 && !eob_hit) {
+        // the next sweep starts where this one ends: the helper counts it while this wave stores and resolves
+        H->req_bitpos = sbyte * 8ull + (uint64_t)last_end; H->req_buf = cur_buf ^ 1u; H->cmd = 1u;
+        seq = H->go + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&H->go, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        posted = true;
+    }
     if (MODE != 1) {
         const unsigned long long t1 = ZA_STAT_T();
         if (act) run(true, start, lim, op + (uint64_t)base, base, qb);
         // a distance before the history is an error of the stream: nothing is committed, the sequential rounds find and
         // report it (what the storing pass wrote lies behind `op` and is overwritten)
-        if (__ballot(bad_dist)) { ZA_STAT_ADD(6, 1); return 0; }
+        if (__ballot(bad_dist)) { ZA_STAT_ADD(6, 1); wait_helper(); if (ROLE == 1) H->valid = 0u; return 0; }
         if (far_io) {
             uint32_t fv = far_seen;
             for (int sft = 32; sft; sft >>= 1) { const uint32_t ov = (uint32_t)__shfl_xor((int)fv, sft, 64); fv = ov > fv ? ov : fv; }
@@ -827,6 +890,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
         ZA_STAT_ADD(5, ZA_STAT_T() - t2);
     }
     ZA_STAT_ADD(11, total); ZA_STAT_ADD(12, eob_hit ? 1 : 0); ZA_STAT_ADD(15, M);
+    wait_helper();
     op += (uint64_t)total;
     bitpos = sbyte * 8ull + (uint64_t)last_end;
     if (eob_hit) eob = true;
@@ -849,7 +913,7 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
 #define ZA_I_SYNC 2
 // MODE 0: bytes, 32 KiB ring in LDS.  MODE 1: count only.  MODE 2: 16-bit symbols (markers for bytes before the
 // start), RING symbols in LDS; older sources are read back from `out` (written many rounds ago) or are markers.
-template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>, typename TT = ZaInfTabs, bool OLDS = false>
+template <int MODE, typename SymT, int RING = ZA_WIN, typename PB = ZaParBufT<1024, 3072>, typename TT = ZaInfTabs, bool OLDS = false, bool HELPED = false>
 __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t in_len,
                                       const uint8_t *__restrict__ dict, uint32_t dict_len,
                                       SymT *__restrict__ out, uint64_t out_cap,
@@ -857,7 +921,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                                       uint32_t start_bit = 0, uint64_t *blk_bits = nullptr, uint64_t *blk_out = nullptr,
                                       uint32_t hist = 0xFFFFFFFFu, bool stop_at_sync = false, uint32_t *max_back = nullptr,
                                       const uint64_t *__restrict__ stops = nullptr, uint32_t nstops = 0, uint64_t abs_bit0 = 0,
-                                      PB *P = nullptr)
+                                      PB *P = nullptr, ZaSweepHelp *H = nullptr)
 {
     const int lane = za_lane();
     const uint64_t in_bits = in_len * 8ull;
@@ -878,7 +942,7 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
         if (q >= 0) return out[q];
         return MODE == 2 ? (SymT)(256u + (uint32_t)(ZA_WIN + q)) : (SymT)dict[(long long)dict_len + q];
     };
-    __syncthreads();
+    za_wave_sync();
 
     for (;;) {
         cp_bits = bitpos; cp_out = op;          // a decoder can restart here with the last 32 KiB of output as dictionary
@@ -933,8 +997,8 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
             while (!eob && status == ZA_I_OK) {
                 if (P != nullptr) {
                     if (par_wait == 0) {
-                        const int got = za_par_sweep<MODE, SymT, PB, TT, OLDS>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
-                                                                     max_back ? &far : nullptr, eob);
+                        const int got = za_par_sweep<MODE, SymT, PB, TT, OLDS, HELPED ? 1 : 0>(in, in_len, dict, dict_len, out, out_cap, T, P, bitpos, op, hist,
+                                                                     max_back ? &far : nullptr, eob, H);
                         ibase = ~0ull;                                   // the staging area was used by the sweep
                         // A sweep that kept few lanes (the passes had not settled, the queue was full) is followed by another sweep
                         // at once; only the second such sweep in a row sends the decoder to 32 sequential rounds (data on which the
@@ -945,8 +1009,10 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
                             ring_stale = true;
                             if (got < 16 && !eob) { if (++short_run >= 2) par_wait = 32; }
                             else short_run = 0;
+                            if (HELPED && (eob || par_wait != 0)) H->valid = 0u;      // (no sweep follows at once: the staging areas are the sequential rounds' and the header's)
                             continue;
                         }
+                        if (HELPED) H->valid = 0u;
                         par_wait = 32;
                     } else par_wait--;
                     if (MODE != 1 && ring_stale) {
@@ -1231,24 +1297,45 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
 // ZA_SMALL_IMG bytes; a stream that produces more comes back as "output full" with exactly that many, and the host runs the
 // ordinary kernel (zngamd_inflate_raw's small path).
 #ifndef ZA_SMALL_IMG
-#define ZA_SMALL_IMG 98304
+#define ZA_SMALL_IMG 86016        // (84 KiB: with the helper's staging area the kernel takes 155 of the CU's 160 KiB)
 #endif
-__global__ __launch_bounds__(64) void za_k_inflate_serial_small(const uint8_t *__restrict__ in, uint64_t in_len, uint32_t start_bit,
-                                                                const uint8_t *__restrict__ dict, uint32_t dict_len,
-                                                                uint8_t *__restrict__ out, uint64_t out_cap,
-                                                                ZaInfResult *__restrict__ res)
+__global__ __launch_bounds__(128) void za_k_inflate_serial_small(const uint8_t *__restrict__ in, uint64_t in_len, uint32_t start_bit,
+                                                                 const uint8_t *__restrict__ dict, uint32_t dict_len,
+                                                                 uint8_t *__restrict__ out, uint64_t out_cap,
+                                                                 ZaInfResult *__restrict__ res)
 {
     __shared__ ZaInfTabs T;
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
     __shared__ ZaParBufT<1024, 3072> P;
+    __shared__ ZaSweepHelp H;
     __shared__ __attribute__((aligned(16))) uint8_t img[ZA_SMALL_IMG];
-    uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
     const uint64_t cap = out_cap < (uint64_t)ZA_SMALL_IMG ? out_cap : (uint64_t)ZA_SMALL_IMG;
-    const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>, ZaInfTabs, true>(in, in_len, dict, dict_len, img, cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
-                                                         0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
-    __syncthreads();
     const int lane = za_lane();
+    if (threadIdx.x < 64 && lane == 0) { H.valid = 0u; H.go = 0u; H.done = 0u; H.cmd = 0u; }
+    __syncthreads();                                               // (the one barrier both waves meet)
+    if (threadIdx.x >= 64) {
+        // the helper: counting passes of the sweep it is asked for, into the staging area it is told, until it is sent home
+        uint32_t seen = 0;
+        for (;;) {
+            while (__hip_atomic_load(&H.go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seen) __builtin_amdgcn_s_sleep(1);
+            seen++;
+            if (H.cmd == 2u) break;
+            uint64_t bp = H.req_bitpos, opd = 0;
+            bool eobd = false;
+            (void)za_par_sweep<0, uint8_t, ZaParBufT<1024, 3072>, ZaInfTabs, true, 2>(in, in_len, dict, dict_len, img, cap, T, &P, bp, opd, dict_len, nullptr, eobd, &H);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&H.done, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
+    const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>, ZaInfTabs, true, true>(in, in_len, dict, dict_len, img, cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
+                                                         0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P, &H);
+    H.cmd = 2u;                                                    // the helper goes home
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&H.go, H.go + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    za_wave_sync();
     for (uint64_t i = 16ull * (uint64_t)lane; i < op; i += 1024ull) {
         if (i + 16ull <= op) { const uint4 v = *(const uint4 *)(img + i); ZaU4u t = {v.x, v.y, v.z, v.w}; *(ZaU4u *)(out + i) = t; }
         else for (uint64_t k = i; k < op; k++) out[k] = img[k];

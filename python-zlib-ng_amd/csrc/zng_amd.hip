@@ -1209,7 +1209,7 @@ try {
         { ProfScope ps(c, ZNGAMD_K_INFLATE);
           if (second) hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
                              c->st_out.p + head, out_cap, dres);
-          else hipLaunchKernelGGL(za_k_inflate_serial_small, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
+          else hipLaunchKernelGGL(za_k_inflate_serial_small, dim3(1), dim3(128), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
                              c->st_out.p + head, out_cap, dres); }
         if (nspan) {
             ProfScope ps(c, ZNGAMD_K_OTHER);
