@@ -4,5 +4,5 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 export ZNGAMD_CHUNK_UNITS=32768 ZNGAMD_UNIT_BATCH=32768
-PASSES="sq fetch write sq2" timeout -k 10 1100 bash profiles/run_pmc.sh r06i > gpurun_out/pmc_r06i.log 2>&1
-tail -5 gpurun_out/pmc_r06i.log
+PASSES="sq fetch write sq2" timeout -k 10 1100 bash profiles/run_pmc.sh r06j > gpurun_out/pmc_r06j.log 2>&1
+tail -5 gpurun_out/pmc_r06j.log
