@@ -897,6 +897,31 @@ __device__ int za_par_sweep(const uint8_t *__restrict__ in, uint64_t in_len, con
     return nvalid;
 }
 
+// the helper wavefront's life (ROLE 2): the counting passes of the sweep it is asked for, into the staging area it is told, until it is sent home
+template <typename SymT, typename PB, typename TT, bool OLDS>
+__device__ void za_sweep_helper_loop(const uint8_t *__restrict__ in, uint64_t in_len, const uint8_t *__restrict__ dict, uint32_t dict_len,
+                                     SymT *__restrict__ out, uint64_t out_cap, const TT &T, PB *P, ZaSweepHelp *H)
+{
+    uint32_t seen = 0;
+    for (;;) {
+        while (__hip_atomic_load(&H->go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seen) __builtin_amdgcn_s_sleep(1);
+        seen++;
+        if (H->cmd == 2u) break;
+        uint64_t bp = H->req_bitpos, opd = 0;
+        bool eobd = false;
+        (void)za_par_sweep<0, SymT, PB, TT, OLDS, 2>(in, in_len, dict, dict_len, out, out_cap, T, P, bp, opd, dict_len, nullptr, eobd, H);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&H->done, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// ... and the main wave sending it home (no request is open: every sweep waits for its helper before it returns)
+__device__ __forceinline__ void za_sweep_helper_exit(ZaSweepHelp *H)
+{
+    H->cmd = 2u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&H->go, H->go + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ------------------------------------------------------------------------------------------------
 // sequential decoder: one wave per stream
 // ------------------------------------------------------------------------------------------------
@@ -1275,7 +1300,9 @@ __device__ int za_inflate_serial_core(const uint8_t *__restrict__ in, uint64_t i
 }
 
 
-__global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len, uint32_t start_bit,
+// (r06) two wavefronts: the second one counts the next sweep while the first stores and resolves the current one (ZaSweepHelp)
+#define ZA_SERIAL_THREADS 128
+__global__ __launch_bounds__(ZA_SERIAL_THREADS) void za_k_inflate_serial(const uint8_t *__restrict__ in, uint64_t in_len, uint32_t start_bit,
                                                           const uint8_t *__restrict__ dict, uint32_t dict_len,
                                                           uint8_t *__restrict__ out, uint64_t out_cap,
                                                           ZaInfResult *__restrict__ res)
@@ -1284,9 +1311,17 @@ __global__ __launch_bounds__(64) void za_k_inflate_serial(const uint8_t *__restr
     __shared__ uint8_t win[ZA_WIN];
     __shared__ int scratch[2];
     __shared__ ZaParBufT<1024, 3072> P;
+    __shared__ ZaSweepHelp H;
+    if (threadIdx.x == 0) { H.valid = 0u; H.go = 0u; H.done = 0u; H.cmd = 0u; }
+    __syncthreads();                                               // (the one barrier both waves meet)
+    if (threadIdx.x >= 64) {
+        za_sweep_helper_loop<uint8_t, ZaParBufT<1024, 3072>, ZaInfTabs, false>(in, in_len, dict, dict_len, out, out_cap, T, &P, &H);
+        return;
+    }
     uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
-    const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
-                                                         0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P);
+    const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>, ZaInfTabs, false, true>(in, in_len, dict, dict_len, out, out_cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
+                                                         0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P, &H);
+    za_sweep_helper_exit(&H);
     if (za_lane() == 0) { res->status = status; res->pad = 0; res->out_len = op; res->in_bits = bits; res->block_bits = cpb; res->block_out = cpo; }
 }
 
@@ -1315,26 +1350,13 @@ __global__ __launch_bounds__(128) void za_k_inflate_serial_small(const uint8_t *
     if (threadIdx.x < 64 && lane == 0) { H.valid = 0u; H.go = 0u; H.done = 0u; H.cmd = 0u; }
     __syncthreads();                                               // (the one barrier both waves meet)
     if (threadIdx.x >= 64) {
-        // the helper: counting passes of the sweep it is asked for, into the staging area it is told, until it is sent home
-        uint32_t seen = 0;
-        for (;;) {
-            while (__hip_atomic_load(&H.go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seen) __builtin_amdgcn_s_sleep(1);
-            seen++;
-            if (H.cmd == 2u) break;
-            uint64_t bp = H.req_bitpos, opd = 0;
-            bool eobd = false;
-            (void)za_par_sweep<0, uint8_t, ZaParBufT<1024, 3072>, ZaInfTabs, true, 2>(in, in_len, dict, dict_len, img, cap, T, &P, bp, opd, dict_len, nullptr, eobd, &H);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __hip_atomic_store(&H.done, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        za_sweep_helper_loop<uint8_t, ZaParBufT<1024, 3072>, ZaInfTabs, true>(in, in_len, dict, dict_len, img, cap, T, &P, &H);
         return;
     }
     uint64_t bits = 0, op = 0, cpb = 0, cpo = 0;
     const int status = za_inflate_serial_core<0, uint8_t, ZA_WIN, ZaParBufT<1024, 3072>, ZaInfTabs, true, true>(in, in_len, dict, dict_len, img, cap, T, win, scratch, P.stage, bits, op, start_bit, &cpb, &cpo,
                                                          0xFFFFFFFFu, false, nullptr, nullptr, 0, 0, &P, &H);
-    H.cmd = 2u;                                                    // the helper goes home
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __hip_atomic_store(&H.go, H.go + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    za_sweep_helper_exit(&H);
     za_wave_sync();
     for (uint64_t i = 16ull * (uint64_t)lane; i < op; i += 1024ull) {
         if (i + 16ull <= op) { const uint4 v = *(const uint4 *)(img + i); ZaU4u t = {v.x, v.y, v.z, v.w}; *(ZaU4u *)(out + i) = t; }

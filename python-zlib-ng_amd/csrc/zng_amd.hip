@@ -1140,7 +1140,7 @@ static int inflate_serial_dev(zngamd_ctx *c, const uint8_t *d_in, uint64_t in_le
 {
     ZaInfResult *dres = (ZaInfResult *)((uint8_t *)c->d_small + 64);
     { ProfScope ps(c, ZNGAMD_K_INFLATE);
-      hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, d_in, in_len, start_bit, d_dict, dict_len, d_out, out_cap, dres); }
+      hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(ZA_SERIAL_THREADS), 0, c->stream, d_in, in_len, start_bit, d_dict, dict_len, d_out, out_cap, dres); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hres, dres, sizeof(ZaInfResult), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1207,7 +1207,7 @@ try {
         static const bool no_img = getenv("ZNGAMD_NO_SMALL_IMAGE") != nullptr;
         for (int second = no_img ? 1 : 0; second < 2; second++) {
         { ProfScope ps(c, ZNGAMD_K_INFLATE);
-          if (second) hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
+          if (second) hipLaunchKernelGGL(za_k_inflate_serial, dim3(1), dim3(ZA_SERIAL_THREADS), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
                              c->st_out.p + head, out_cap, dres);
           else hipLaunchKernelGGL(za_k_inflate_serial_small, dim3(1), dim3(128), 0, c->stream, (const uint8_t *)(c->st_in.p + front), in_len, 0u, (const uint8_t *)c->st_in.p, dict_len,
                              c->st_out.p + head, out_cap, dres); }
