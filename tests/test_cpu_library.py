@@ -318,3 +318,53 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     for rank in (0, 1):
         assert f"rank {rank} of 2 needs a GPU" in r.stderr
         assert any(f"rank {rank} (pid" in ln and "exited with 2" in ln for ln in r.stderr.splitlines())
+
+
+def test_index_members_round_trip_and_are_skipped_by_any_gzip_reader():
+    """The file format of the writer's segment index (host logic, no GPU): empty gzip members with a 'ZA' FEXTRA subfield and a
+    locator behind ONE data member -- what _lib.index_members writes, _lib.parse_index_tail finds from the file's end, and the
+    system gzip reads as nothing at all."""
+    import gzip
+    import io
+    import struct
+    import zlib
+    import numpy as np
+    from zlib_ng_amd import _lib
+    rng = np.random.default_rng(7)
+    nu = 2 * _lib.INDEX_PER_MEMBER + 13                      # three index members
+    rec = np.zeros(nu, _lib._index_rec_dtype())
+    rec["out_len"] = 131072
+    rec["out_len"][-1] = 5000
+    rec["in_len"] = rng.integers(100, 60000, nu)
+    e = rng.integers(1, 2000, (nu, 65)).astype(np.uint16)
+    nseg = (rec["out_len"].astype(np.int64) + 2047) >> 11
+    e[np.arange(65)[None, :] > nseg[:, None]] = 0
+    e[5] = 0                                                 # a unit of stored blocks: all zeros
+    rec["e"] = e
+    payload = bytes(int(rec["in_len"].astype(np.int64).sum()))     # stands for the units' deflate bytes (never decoded here)
+    data_member = bytes.fromhex("1f8b0800" "00000000" "00ff") + payload + b"\x03\x00" + struct.pack("<II", 0, 0)
+    tail = _lib.index_members([rec[:1000], rec[1000:]], len(data_member))
+    plain = bytes.fromhex("1f8b0800" "00000000" "00ff" "0300" "00000000" "00000000")
+    for blob in (data_member + tail, data_member + tail + plain, b"x" * 777 + data_member + tail + plain):
+        start = len(blob) - len(data_member) - len(tail) - (len(plain) if blob.endswith(plain) else 0)
+        fp = io.BytesIO(blob)
+        fp.seek(3)
+        got = _lib.parse_index_tail(fp, start, len(blob))
+        assert fp.tell() == 3 and got is not None
+        uin, uout, rows = got
+        assert (uin == rec["in_len"]).all() and (uout == rec["out_len"]).all() and rows.shape == (nu, _lib.INDEX_STRIDE)
+        want = np.cumsum(e.astype(np.uint32), axis=1, dtype=np.uint32)
+        want[np.arange(65)[None, :] > nseg[:, None]] = 0
+        want[5] = 0
+        assert (rows[:, :65] == want).all()
+    # every index member and the locator are complete, empty gzip members: the system's reader sees no data in them
+    assert gzip.decompress(tail) == b"" and gzip.decompress(tail + plain) == b""
+    d = zlib.decompressobj(31)
+    assert d.decompress(tail[:tail.index(b"\x1f\x8b", 4)]) == b"" and d.eof
+    # any doubt and there is no index: a damaged locator, sizes that do not add up, a truncated file
+    blob = data_member + tail + plain
+    for at, what in ((len(blob) - 20 - 30, "locator"), (len(data_member) + 17, "record header")):
+        bad = bytearray(blob); bad[at] ^= 0x40
+        assert _lib.parse_index_tail(io.BytesIO(bytes(bad)), 0, len(bad)) is None, what
+    assert _lib.parse_index_tail(io.BytesIO(blob[:-25]), 0, len(blob) - 25) is None
+    assert _lib.parse_index_tail(io.BytesIO(b"y" + blob), 0, len(blob) + 1) is None      # the data member does not start where the caller says
