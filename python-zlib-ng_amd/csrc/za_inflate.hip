@@ -7,7 +7,9 @@
 //   za_k_inflate_serial   any RFC 1951 stream, one wavefront per stream: inside a Huffman block the 64 lanes
 //                         decode 64 self-synchronising sub-sequences at once (za_par_sweep); block headers,
 //                         stored blocks, the ends of the input / output and errors are handled by wave-uniform
-//                         sequential rounds (32 KiB history ring in LDS, copies done by all 64 lanes)
+//                         sequential rounds (32 KiB history ring in LDS, copies done by all 64 lanes); r06: a second
+//                         wavefront counts the NEXT sweep while the first stores and resolves the current one (ZaSweepHelp)
+//   za_k_inflate_serial_small   the same for the small one-shot calls: the output assembled in an LDS image
 //   za_k_scan_members     pass 1 of the two-pass scheme: coalesced sweep of the compressed stream
 //                         for this engine's indexed gzip members ('Z','A' FEXTRA subfield)
 //   za_k_inflate_members  pass 2: one wavefront per member, one lane per 2 KiB segment decodes its
